@@ -1,0 +1,122 @@
+"""Pin oracle/rat_m2_oracle.py to the vectors the real reference produced (tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as gc
+from oracle import rat_m2_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def oracle_config(case):
+    fields = orc.fields_from_specs(gc.feature_specs(case))
+    return orc.Config(fields=fields, embedding_dim=case["embedding_dim"], num_heads=case["num_heads"],
+                      dim_head=case["dim_head"], depth=case["depth"], scale_dim=case["scale_dim"],
+                      dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=case["batch_norm"],
+                      use_wide=case["use_wide"], embedding_regularizer=float(case["embedding_regularizer"] or 0.0),
+                      net_regularizer=float(case["net_regularizer"] or 0.0))
+
+
+def state_shapes(cfg):
+    """Full state_dict shapes = trainable tensors + BatchNorm buffers, in registration order."""
+    shapes = {}
+    for k, s in orc.parameter_shapes(cfg).items():
+        shapes[k] = s
+        if cfg.batch_norm and k.startswith("dnn.dnn.") and k.endswith(".bias") and len(s) == 1:
+            pos = int(k.split(".")[2])
+            layers, _ = orc.dnn_layout(cfg)
+            if any(bn == pos for _, bn in layers):
+                shapes["dnn.dnn.%d.running_mean" % pos] = s
+                shapes["dnn.dnn.%d.running_var" % pos] = s
+                shapes["dnn.dnn.%d.num_batches_tracked" % pos] = ()
+    return shapes
+
+
+def noise_gradient_tensors(cfg):
+    """Biases of a Linear that feeds BatchNorm: their true gradient is 0 (BN subtracts the batch mean), what
+    autograd returns is rounding noise, and Adam turns noise into +-lr steps.  They cannot be compared
+    after an optimizer step (and do not influence any output)."""
+    layers, _ = orc.dnn_layout(cfg)
+    return {"dnn.dnn.%d.bias" % lin for lin, bn in layers if bn is not None}
+
+
+def load_case(name):
+    case = gc.case_by_name(name)
+    cfg = oracle_config(case)
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    w = {k: torch.from_numpy(np.asarray(v)) for k, v in gc.make_weights(case, state_shapes(cfg)).items()}
+    X, y, _, _ = gc.make_inputs(case)
+    return case, cfg, gold, w, torch.from_numpy(X), torch.from_numpy(y)
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in gc.CASES])
+def test_param_inventory_matches_reference(name):
+    case, cfg, gold, w, X, y = load_case(name)
+    assert orc.count_parameters(cfg) == int(gold["param_count"])
+    ref_keys = sorted(k[len("init/"):].replace("#summary", "") for k in gold.files if k.startswith("init/"))
+    mine = sorted(k for k in state_shapes(cfg) if not k.startswith("query_proj"))
+    assert mine == ref_keys
+
+
+@pytest.mark.parametrize("kc", gc.KNOWN_COUNT_CASES, ids=lambda c: c["name"])
+def test_known_parameter_counts(kc):
+    """exps/RAT_m2/*/*.log 'Total number of parameters' (1337241 / 4714649 / 16970282)."""
+    assert orc.count_parameters(oracle_config(kc)) == kc["expected_params"]
+    counts = np.load(os.path.join(GOLD, "param_counts.npz"))
+    assert int(counts[kc["name"]]) == kc["expected_params"]
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in gc.CASES])
+def test_eval_forward(name):
+    case, cfg, gold, w, X, y = load_case(name)
+    with torch.no_grad():
+        yp = orc.forward(w, X, y, cfg, training=False).numpy()
+    np.testing.assert_allclose(yp, gold["eval/y_pred"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(y[:, :1].numpy().astype(np.float32), gold["eval/y_true"])
+    assert abs(orc.logloss(gold["eval/y_true"], yp) - float(gold["eval/logloss"])) < 1e-9 + 1e-6
+    if "eval/auc" in gold.files:
+        assert abs(orc.auc(gold["eval/y_true"], gold["eval/y_pred"]) - float(gold["eval/auc"])) < 1e-12
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in gc.CASES])
+def test_two_training_steps(name):
+    """loss, every gradient, the clip norm and the post-Adam weights of two consecutive iterations."""
+    case, cfg, gold, w, X, y = load_case(name)
+    state = {}
+    for step in (1, 2):
+        new_w, loss, y_pred, grads, gnorm = orc.train_step(w, X, y, cfg, state, step)
+        np.testing.assert_allclose(y_pred.numpy(), gold["train%d/y_pred" % step], rtol=0, atol=1e-6)
+        assert abs(float(loss) - float(gold["train%d/loss" % step])) < 1e-6
+        assert abs(float(gnorm) - float(gold["train%d/gnorm" % step])) < 1e-5 * max(1.0, float(gnorm))
+        seen = 0
+        for k, g in grads.items():
+            gc.check_summary(gold, "train%d/grad/%s" % (step, k), g.numpy(), rtol=2e-4, atol=2e-6)
+            seen += 1
+        assert seen == sum(1 for k in orc.parameter_shapes(cfg) if not k.startswith("query_proj"))
+        assert not any(k.startswith("query_proj") for k in grads)
+        for k, v in new_w.items():
+            if k.startswith("query_proj"):
+                assert torch.equal(v, w[k])
+                continue
+            if k in noise_gradient_tensors(cfg):
+                assert float((v - w[k]).abs().max()) <= 1.0001 * cfg.learning_rate
+                continue
+            # running_mean inherits momentum * (noise walk of the bias in front of it)
+            atol = 2e-6 if not k.endswith("running_mean") else 2e-6 + step * cfg.bn_momentum * cfg.learning_rate * 1.01
+            gc.check_summary(gold, "train%d/post/%s" % (step, k), v.numpy(), rtol=2e-4, atol=atol)
+        w = new_w
+    with torch.no_grad():
+        yp = orc.forward(w, X, y, cfg, training=False).numpy()
+    # with BN the eval output sees (bias walk - running_mean walk): up to ~2 steps * lr of logit noise per unit
+    np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=2e-3 if cfg.batch_norm else 2e-6)
+
+
+def test_float64_oracle_agrees_with_float32():
+    case, cfg, gold, w, X, y = load_case("kkbox_shape")
+    w64 = {k: (v.double() if v.is_floating_point() else v) for k, v in w.items()}
+    with torch.no_grad():
+        yp = orc.forward(w64, X, y, cfg, training=False).numpy()
+    np.testing.assert_allclose(yp, gold["eval/y_pred"], rtol=0, atol=2e-6)
