@@ -1,0 +1,147 @@
+/* rat_hip.h — C ABI of librat_hip.so: the MI355X (gfx950) hot path of RAT_m2.
+ *
+ * The reference (YushenLi807/WWW24-RAT) is pure Python on torch ATen and has no FFI; the drop-in boundary
+ * is its FuxiCTR model-plugin API (run_expid.py:75-76 -> fuxictr/pytorch/models/RAT_m2.py).  This header is
+ * what a ctypes binding inside that plugin calls instead of the ATen op sequences cited per entry point.
+ * All paths below are relative to /root/reference.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; the caller (PyTorch's allocator)
+ *    owns every buffer including workspaces; the library allocates and frees nothing;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), never synchronises the
+ *    device, is re-entrant and keeps no global mutable state (forward runs on the Python main thread,
+ *    backward on autograd's device thread);
+ *  - return value 0 = launched, negative = rejected (message via rat_last_error(), thread-local);
+ *  - all arithmetic is IEEE fp32; ids are int32; token grids are row-major [B][T][S][d]
+ *    (sample-in-batch, target||retrieved sample, label||field token, embedding dim).
+ */
+#ifndef RAT_HIP_H_
+#define RAT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAT_ABI_VERSION 1
+
+int rat_version(void);
+const char* rat_last_error(void);
+
+/* One feature field (fuxictr/features.py:46-57 feature_specs entry + its nn.Embedding,
+ * fuxictr/pytorch/layers/embedding.py:76-95).  `width` is the table's row length (embedding_dim, or 1 for
+ * the LR "wide" tables of fuxictr/pytorch/layers/shallow.py:23-45). */
+typedef struct RatField {
+    float* table;        /* [vocab][width] weights (forward) or gradient table (backward) */
+    int32_t col;         /* first input column (feature_specs[f]["index"]) */
+    int32_t ncols;       /* 1 for categorical, max_len for a MaskedSumPooling bag (sequence.py:32-38) */
+    int32_t vocab;
+    int32_t padding_idx; /* -1 = none; rows with this id receive no gradient (nn.Embedding padding_idx) */
+} RatField;
+
+/* ---- K1: token-grid assembly -------------------------------------------------------------------------
+ * replaces RAT_m2.forward lines 113-126 (RAT_m2.py): 3x EmbeddingLayer.forward (embedding.py:40-43,
+ * 158-178, 138-156), 2x label_embedding_layer, 3x torch.concat.
+ * idx [B][T][L] int32, label_ids [B][T] int32 (2 for the target row, the retrieved label otherwise),
+ * fields_dev: device array of nfields RatField, label_table [3][d], grid out [B][T][1+nfields][d]. */
+int rat_gather_fwd(const int32_t* idx, const int32_t* label_ids, const RatField* fields_dev, int nfields,
+                   const float* label_table, float* grid, int B, int T, int L, int d, void* stream);
+
+/* backward of the above (autograd's embedding_dense_backward + cat/stack backward, base_model.py:223).
+ * dgrid [B][T][S][d]; dflat (nullable) [B][nfields*d] = gradient of the DNN branch input X_emb.flatten(1)
+ * (RAT_m2.py:145-146), added onto the target rows; grad tables are ACCUMULATED into (caller zeroes them);
+ * dlabel_table [3][d] is accumulated too. */
+int rat_gather_bwd(const float* dgrid, const float* dflat, const int32_t* idx, const int32_t* label_ids,
+                   const RatField* grad_fields_dev, int nfields, float* dlabel_table,
+                   int B, int T, int L, int d, void* stream);
+
+/* ---- K2: attention phase of CrossIntraEncoderBlock --------------------------------------------------
+ * y = Attention(LayerNorm(x)) + x over groups of L tokens (RAT_m2.py:155-161, 176-202, 222-230).
+ * Sequence q in [0, nseq) owns tokens  tok(q, p) = (q / q_div) * hi_stride + (q % q_div) * lo_stride
+ * + p * pos_stride, p in [0, L)  (token units; a token is d floats).  Intra-sample attention over the
+ * grid: nseq=B*T, L=S, q_div=nseq, lo_stride=S, pos_stride=1.  Cross-sample: nseq=B*S, L=T, q_div=S,
+ * hi_stride=T*S, lo_stride=1, pos_stride=S — the reference's reshape/transpose/flatten copy
+ * (RAT_m2.py:226-227) becomes this addressing. */
+typedef struct RatSeqMap {
+    int64_t nseq;
+    int32_t L;
+    int64_t q_div, hi_stride, lo_stride, pos_stride;
+} RatSeqMap;
+
+typedef struct RatAttnParams {      /* HOST struct of device pointers; state_dict names under          */
+    float* ln_g;  /* [d]      encoder.encoder.<i>.<which>_attention.norm.weight                          */
+    float* ln_b;  /* [d]      ...norm.bias                                                               */
+    float* w_qkv; /* [3*h*dh][d]  ...fn.to_qkv.weight (no bias)                                          */
+    float* w_out; /* [d][h*dh]    ...fn.to_out.0.weight, NULL when heads==1 && dim_head==d (Identity)    */
+    float* b_out; /* [d]          ...fn.to_out.0.bias                                                    */
+} RatAttnParams;
+
+/* o_save [ntok][h*dh] and lse_save [ntok][h] (token-indexed like x) are written when non-NULL (training)
+ * and consumed by rat_attn_bwd. */
+int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
+                 const RatSeqMap* map_host, int d, int heads, int dim_head, float ln_eps, void* stream);
+
+size_t rat_attn_bwd_workspace(int d, int heads, int dim_head);
+/* dx = dL/dx (overwritten), grads_host->* overwritten with the batch-summed parameter gradients. */
+int rat_attn_bwd(const float* x, const float* dy, const float* o_save, const float* lse_save, float* dx,
+                 const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace,
+                 size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
+                 float ln_eps, void* stream);
+
+/* ---- K2 (cont.): FeedForward + residual, y = W2 gelu_erf(W1 x + b1) + b2 + x (RAT_m2.py:163-174, 232) */
+int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
+                int64_t ntok, int d, int hidden, void* stream);
+size_t rat_ffn_bwd_workspace(int d, int hidden);
+int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                size_t workspace_bytes, int64_t ntok, int d, int hidden, void* stream);
+
+/* ---- K3: prediction head -----------------------------------------------------------------------------
+ * Plain fp32 GEMM on MFMA for MLP_Layer's nn.Linear (deep.py:126-141) forward / dgrad / wgrad:
+ * C[M][N] = op(A) op(B) (+ bias[N]) (+ beta*C), row-major with leading dimensions, op = transpose flag. */
+int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+              float* C, int ldc, const float* bias, float beta, void* stream);
+
+/* BatchNorm1d (train: batch stats, biased var; running stats momentum update with unbiased var; eval:
+ * running stats) followed by ReLU — deep.py:128-132.  use_bn=0 -> ReLU only.  z,a [M][N]. */
+int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* save_mean, float* save_rstd, int M, int N, int training,
+                    int use_bn, float eps, float momentum, void* stream);
+/* a = the forward output (its sign is the ReLU mask); dgamma/dbeta overwritten */
+int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
+                    const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, int M, int N,
+                    int use_bn, void* stream);
+/* column sums of a [M][N] matrix (bias gradients) */
+int rat_colsum(const float* a, int lda, float* out, int M, int N, void* stream);
+
+/* logit = fc(cls) + dnn_out + sum_f lr_table_f[idx] ; y_pred = sigmoid(logit)  (RAT_m2.py:138-150,
+ * shallow.py:36-45); loss_sum += sum_b BCE(y_pred, y_true)/B with torch's log clamp at -100
+ * (torch_utils.py:51-63, base_model.py:74-77).  cls rows are read at cls + b*cls_stride (floats); idx rows of
+ * the TARGET sample at idx + b*idx_stride.  dnn_out / lr_fields_dev / loss_sum / y_true may be NULL. */
+int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* fc_w, const float* fc_b,
+                  const float* dnn_out, const RatField* lr_fields_dev, int nfields, const int32_t* idx,
+                  int64_t idx_stride, const float* y_true, float* y_pred, float* loss_sum, int B, int d,
+                  void* stream);
+/* dlogit[b] = gscale * (y_pred - y_true)/B ; dcls row b (written at dcls + b*dcls_stride) = dlogit*fc_w ;
+ * dfc_w, dfc_b and the LR grad tables are ACCUMULATED into (caller zeroes them). */
+int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride,
+                  const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
+                  float* dfc_b, const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx,
+                  int64_t idx_stride, float gscale, int B, int d, void* stream);
+
+/* ---- K4/K5: regulariser + clip_grad_norm_ + Adam over flat buffers -----------------------------------
+ * base_model.py:79-94,224-225; torch_utils.py:41-49,65-81.
+ * rat_l2_reg: for i<n: g[i] += lambda*w[i]; reg_out += (lambda/2)*sum w^2   (the "embedding_layer" tensors).
+ * rat_sumsq : norm_sq_out += sum g^2 (fp32 partials, fp64-free two-stage tree; caller zeroes the scalar).
+ * rat_clip_adam: coef = min(1, max_norm/(sqrt(*norm_sq)+1e-6)); g*=coef; Adam(lr,b1,b2,eps,step), in place. */
+int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, float* reg_out, void* stream);
+int rat_sumsq(const float* g, int64_t n, float* norm_sq_out, void* stream);
+int rat_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* norm_sq,
+                  float max_norm, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAT_HIP_H_ */

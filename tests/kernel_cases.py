@@ -1,0 +1,139 @@
+"""Shared helpers for the kernel parity tests (used with the host-emulation build on CPU and the HIP build on GPU)."""
+import numpy as np
+import torch
+
+from oracle import rat_m2_oracle as orc
+
+
+def rnd(rs, *shape, scale=1.0):
+    return torch.from_numpy((scale * rs.standard_normal(shape)).astype(np.float32))
+
+
+def attn_reference(x, ln_g, ln_b, w_qkv, w_out, b_out, heads, dh, mode):
+    """x: [B,T,S,d] float64/32 -> y same layout, via the oracle's attention()."""
+    B, T, S, d = x.shape
+    w = {"p.norm.weight": ln_g, "p.norm.bias": ln_b, "p.fn.to_qkv.weight": w_qkv}
+    if w_out is not None:
+        w["p.fn.to_out.0.weight"] = w_out
+        w["p.fn.to_out.0.bias"] = b_out
+    cfg = orc.Config(fields=[], embedding_dim=d, num_heads=heads, dim_head=dh)
+    if mode == "intra":
+        xi = x.reshape(B * T, S, d)
+        return (orc.attention(xi, w, "p.", cfg) + xi).reshape(B, T, S, d)
+    xc = x.transpose(1, 2).reshape(B * S, T, d)
+    return (orc.attention(xc, w, "p.", cfg) + xc).reshape(B, S, T, d).transpose(1, 2)
+
+
+def ffn_reference(x, w1, b1, w2, b2):
+    w = {"m.0.weight": w1, "m.0.bias": b1, "m.3.weight": w2, "m.3.bias": b2}
+    return orc.feed_forward(x, w, "m.") + x
+
+
+# ----------------------------------------------------------------------------- generic kernel checks
+from rat_amd import ops  # noqa: E402
+
+
+class F:
+    def __init__(self, col, ncols, vocab, padding_idx=None):
+        self.col, self.ncols, self.vocab, self.padding_idx = col, ncols, vocab, padding_idx
+
+
+def close(a, b, rtol, atol, msg=""):
+    np.testing.assert_allclose(a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+def check_gather(lib, dev, d, B=3, T=4):
+    rs = np.random.RandomState(0)
+    L = 5
+    fields = [F(0, 1, 7), F(1, 3, 6, padding_idx=5), F(4, 1, 9, padding_idx=8)]
+    tables = [rnd(rs, f.vocab, d) for f in fields]
+    tables[1][5] = 0
+    label_table = rnd(rs, 3, d)
+    idx = torch.stack([torch.from_numpy(rs.randint(0, [7, 6, 6, 6, 9][c], size=(B, T))) for c in range(L)], -1).int().contiguous()
+    labels = torch.from_numpy(rs.randint(0, 2, size=(B, T))).int()
+    labels[:, 0] = 2
+    dgrid = rnd(rs, B, T, 4, d)
+    dflat = rnd(rs, B, 3 * d)
+    # reference (CPU autograd)
+    tl = [t.clone().requires_grad_(True) for t in tables] + [label_table.clone().requires_grad_(True)]
+    e1 = torch.nn.functional.embedding(idx[..., 1:4].long(), tl[1], padding_idx=5).sum(-2)
+    e2 = torch.nn.functional.embedding(idx[..., 4].long(), tl[2], padding_idx=8)
+    ref = torch.stack([tl[3][labels.long()], tl[0][idx[..., 0].long()], e1, e2], dim=2)
+    ((ref * dgrid).sum() + (ref[:, 0, 1:].reshape(B, -1) * dflat).sum()).backward()
+    # device
+    tables_d = [t.to(dev) for t in tables]
+    label_d, idx_d, labels_d = label_table.to(dev), idx.to(dev), labels.to(dev)
+    ftab = ops.field_table(fields, tables_d, dev)
+    grid = ops.gather_fwd(idx_d, labels_d, ftab, 3, label_d, B, T, L, d, lib=lib)
+    assert torch.equal(grid.cpu(), ref.detach()), "gather must be bit-exact"
+    gtabs = [torch.zeros_like(t) for t in tables_d]
+    dlabel = torch.zeros(3, d, device=dev)
+    gftab = ops.field_table(fields, gtabs, dev)
+    ops.gather_bwd(dgrid.to(dev), dflat.to(dev), idx_d, labels_d, gftab, 3, dlabel, B, T, L, d, lib=lib)
+    for g, t in zip(gtabs + [dlabel], tl):
+        close(g, t.grad, 1e-5, 1e-6)
+
+
+def check_sgemm(lib, dev, ta, tb, M=70, N=37, K=29):
+    rs = np.random.RandomState(1)
+    A = rnd(rs, *((K, M) if ta else (M, K)))
+    Bm = rnd(rs, *((N, K) if tb else (K, N)))
+    bias = rnd(rs, N)
+    C = rnd(rs, M, N)
+    ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double() + 0.5 * C.double()
+    Cd = C.to(dev)
+    ops.sgemm(ta, tb, M, N, K, A.to(dev), A.shape[1], Bm.to(dev), Bm.shape[1], Cd, N, bias=bias.to(dev), beta=0.5, lib=lib)
+    close(Cd, ref, 1e-5, 1e-5 * max(1.0, K ** 0.5 / 5))
+
+
+def attn_weights(rs, d, heads, dh, proj):
+    inner = heads * dh
+    return (1 + 0.1 * rnd(rs, d), 0.1 * rnd(rs, d), rnd(rs, 3 * inner, d, scale=d ** -0.5),
+            rnd(rs, d, inner, scale=inner ** -0.5) if proj else None, 0.1 * rnd(rs, d) if proj else None)
+
+
+def check_attn(lib, dev, case, mode, seed=2):
+    B, T, S, d, heads, dh, proj = case
+    rs = np.random.RandomState(seed)
+    x = rnd(rs, B, T, S, d)
+    ws = attn_weights(rs, d, heads, dh, proj)
+    dy = rnd(rs, B, T, S, d)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) if w is not None else None for w in ws]
+    ref = attn_reference(xr, *wr, heads, dh, mode)
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    wd = [w.to(dev) if w is not None else None for w in ws]
+    params = ops.attn_params(*wd)
+    smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
+    y, o_save, lse = ops.attn_fwd(xd, params, smap, d, heads, dh, save=True, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    gs = [torch.zeros_like(w) if w is not None else None for w in wd]
+    grads = ops.attn_params(*gs)
+    dx, _ = ops.attn_bwd(xd, dyd, o_save, lse, params, grads, smap, d, heads, dh, lib=lib)
+    scale = max(1.0, (B * T * S) ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    for name, g, w in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, wr):
+        if w is not None:
+            close(g, w.grad, 1e-4, 1e-4 * scale, name)
+
+
+def check_ffn(lib, dev, ntok, d, hidden):
+    rs = np.random.RandomState(3)
+    x = rnd(rs, ntok, d)
+    ws = (rnd(rs, hidden, d, scale=d ** -0.5), 0.1 * rnd(rs, hidden), rnd(rs, d, hidden, scale=hidden ** -0.5), 0.1 * rnd(rs, d))
+    dy = rnd(rs, ntok, d)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    ref = ffn_reference(xr, *wr)
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    wd = [w.to(dev) for w in ws]
+    y = ops.ffn_fwd(xd, *wd, d, hidden, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    gs = [torch.zeros_like(w) for w in wd]
+    dx, _ = ops.ffn_bwd(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, lib=lib)
+    scale = max(1.0, ntok ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    for g, w in zip(gs, wr):
+        close(g, w.grad, 1e-4, 1e-4 * scale)

@@ -1,0 +1,47 @@
+"""CPU checks of the kernel SOURCES through the host-emulation build (tests/emu): the same .hip files compiled
+with g++ -DRAT_EMU, one OS thread per GPU thread.  They pin index arithmetic / LDS layouts / the MFMA lane maps
+against the oracle on tiny shapes without a GPU; tests/test_gpu_kernels.py (-m gpu) runs the same checks, and
+bigger ones, on the real HIP build."""
+import os
+import sys
+
+import pytest
+
+import kernel_cases as kc
+from rat_amd._lib import RatLib
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="session")
+def emu():
+    import build_emu
+    return RatLib(build_emu.build())
+
+
+@pytest.mark.parametrize("d", [8, 10])
+def test_gather_fwd_bwd(emu, d):
+    kc.check_gather(emu, "cpu", d)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_sgemm(emu, ta, tb):
+    kc.check_sgemm(emu, "cpu", ta, tb)
+
+
+ATTN_CASES = [  # B, T, S, d, heads, dh, project_out
+    (2, 3, 4, 8, 2, 4, True),
+    (1, 4, 5, 10, 2, 10, True),
+    (2, 2, 3, 8, 1, 8, False),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=str)
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attn_fwd_bwd(emu, case, mode):
+    kc.check_attn(emu, "cpu", case, mode)
+
+
+@pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128)])
+def test_ffn_fwd_bwd(emu, ntok, d, hidden):
+    kc.check_ffn(emu, "cpu", ntok, d, hidden)

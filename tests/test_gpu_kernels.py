@@ -1,0 +1,48 @@
+"""GPU parity tests of every C-ABI kernel against the oracle (float64 CPU) — run on the MI355X box with -m gpu."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rat_amd._lib import get_lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return get_lib()
+
+
+@pytest.mark.parametrize("d", [8, 10, 64])
+def test_gather_fwd_bwd(lib, d):
+    kc.check_gather(lib, "cuda", d)
+    kc.check_gather(lib, "cuda", d, B=37, T=11)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("shape", [(70, 37, 29), (512, 400, 1280), (4096, 1, 400), (400, 1280, 512)])
+def test_sgemm(lib, ta, tb, shape):
+    kc.check_sgemm(lib, "cuda", ta, tb, *shape)
+
+
+ATTN_CASES = [  # B, T, S, d, heads, dh, project_out
+    (2, 3, 4, 8, 2, 4, True),
+    (1, 4, 5, 10, 2, 10, True),
+    (2, 2, 3, 8, 1, 8, False),
+    (3, 11, 21, 64, 8, 10, True),       # north-star shape
+    (5, 6, 14, 40, 8, 10, True),        # KKBox config shape
+    (4, 31, 9, 10, 4, 10, True),        # Tmall-like: long cross sequences
+    (300, 6, 4, 10, 2, 10, True),       # ML-Tag config shape, many chunks per work-group
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES, ids=str)
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attn_fwd_bwd(lib, case, mode):
+    kc.check_attn(lib, "cuda", case, mode)
+
+
+@pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (100000, 64, 128), (5000, 40, 80)])
+def test_ffn_fwd_bwd(lib, ntok, d, hidden):
+    kc.check_ffn(lib, "cuda", ntok, d, hidden)

@@ -1,0 +1,364 @@
+// ffn.hip — K2b: the block MLP of CrossIntraEncoderBlock with its residual, forward and backward.
+//
+//   y = W2 gelu_erf(W1 x + b1) + b2 + x        (RAT_m2.py:163-174 FeedForward, RAT_m2.py:232; no LayerNorm in front)
+//
+// Token-wise, so the grid is treated as a flat [ntok][d] matrix.  A 512-thread work-group owns 64 tokens:
+// x tile and the hidden tile live in LDS, both GEMMs run on v_mfma_f32_16x16x4_f32 with the weights
+// streamed from L2 as B operands.  Backward recomputes the hidden activations, and keeps dW1 / dW2 in MFMA
+// accumulators across the work-group's chunk loop (per-work-group slab + fixed-order reduction).
+#include "rat_device.h"
+#include "../../include/rat_hip.h"
+
+namespace {
+
+constexpr int FFN_THREADS = 512;
+constexpr int FFN_WAVES = FFN_THREADS / 64;
+constexpr int FFN_ROWS = 64;
+constexpr int WSLOTS = 8;          // persistent tiles per wave for each of dW1, dW2  (H16/16 * D16/16 <= 64)
+
+struct FfnArgs {
+    const float* x;
+    const float* dy;
+    float* y;            // forward output / backward dx
+    const float* w1;     // [H][D]
+    const float* b1;
+    const float* w2;     // [D][H]
+    const float* b2;
+    float* slabs;
+    int64_t slab_stride;
+    int64_t ntok, nchunks;
+    int d, hidden;
+    int vec_x, vec_w1, vec_w2;
+};
+
+struct FfnGeom {
+    int D, H, D16, H16, ldx, ldh;
+    __host__ __device__ FfnGeom(int d, int hidden) {
+        D = d;
+        H = hidden;
+        D16 = (D + 15) / 16 * 16;
+        H16 = (H + 15) / 16 * 16;
+        ldx = D16 + 4;
+        ldh = H16 + 4;
+    }
+    size_t fwd_smem() const { return (size_t)FFN_ROWS * (ldx + ldh) * 4; }
+    size_t bwd_smem() const { return (size_t)FFN_ROWS * (2 * ldx + 2 * ldh) * 4; }
+    int64_t slab_floats() const { return 2 * (int64_t)H * D + H + D; }
+};
+
+__device__ __forceinline__ void ffn_load(float* tile, int ld, const float* src, int64_t tok0, int rows, int width, bool vec) {
+    if (vec) {
+        const int w4 = width >> 2;
+        for (int e = threadIdx.x; e < FFN_ROWS * w4; e += FFN_THREADS) {
+            const int r = e / w4, c4 = e - r * w4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows) v = *reinterpret_cast<const float4*>(src + (tok0 + r) * width + 4 * c4);
+            *reinterpret_cast<float4*>(tile + (size_t)r * ld + 4 * c4) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < FFN_ROWS * width; e += FFN_THREADS) {
+            const int r = e / width, c = e - r * width;
+            tile[(size_t)r * ld + c] = r < rows ? src[(tok0 + r) * width + c] : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void ffn_zero_cols(float* tile, int ld, int c0) {
+    const int w = ld - c0;
+    for (int e = threadIdx.x; e < FFN_ROWS * w; e += FFN_THREADS) tile[(size_t)(e / w) * ld + c0 + e % w] = 0.f;
+}
+
+// hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- h, gs <- gelu(h))
+template <int MODE>
+__device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
+                                           int mt_valid, int rows) {
+    const int ntn = g.H16 / 16;
+    const RatLdsRows A{xs, g.ldx};
+    const RatGlobalWnk Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
+    for (int nt = rat_wave(); nt < ntn; nt += FFN_WAVES) {
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][0] = rat_zero4();
+        rat_wave_gemm<4, 1>(acc, A, Bw, 0, nt, mt_valid, 1, g.D16 / 16);
+        const int col = rat_acc_col(nt);
+        if (col < g.H) {
+            const float bias = a.b1[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < mt_valid)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rat_acc_row(i, r);
+                        const float h = row < rows ? acc[i][0][r] + bias : 0.f;    // padding rows stay exactly 0
+                        if (MODE == 0) {
+                            hs[(size_t)row * g.ldh + col] = rat_gelu(h);
+                        } else {
+                            hs[(size_t)row * g.ldh + col] = h;
+                            gs[(size_t)row * g.ldh + col] = rat_gelu(h);
+                        }
+                    }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
+    RAT_DYN_SMEM(smem);
+    const FfnGeom g(a.d, a.hidden);
+    float* xs = reinterpret_cast<float*>(smem);
+    float* hs = xs + (size_t)FFN_ROWS * g.ldx;
+    ffn_zero_cols(xs, g.ldx, g.D);
+    ffn_zero_cols(hs, g.ldh, g.H);
+    __syncthreads();
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        const int64_t tok0 = chunk * FFN_ROWS;
+        const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
+        const int mt_valid = (rows + 15) / 16;
+        ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, a.vec_x != 0);
+        __syncthreads();
+        ffn_hidden<0>(a, g, xs, hs, nullptr, mt_valid, rows);
+        __syncthreads();
+        // y = gelu(h) W2^T + b2 + x
+        const int ntn = g.D16 / 16, mblocks = (mt_valid + 1) / 2, ntasks = mblocks * ntn;
+        const RatLdsRows A{hs, g.ldh};
+        const RatGlobalWnk Bw{a.w2, g.D, g.H, g.H, a.vec_w2 != 0};
+        for (int task = rat_wave(); task < ntasks; task += FFN_WAVES) {
+            const int mt0 = (task / ntn) * 2, nt = task % ntn;
+            const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
+            f32x4 acc[2][1];
+            acc[0][0] = acc[1][0] = rat_zero4();
+            rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.H16 / 16);
+            const int col = rat_acc_col(nt);
+            if (col < g.D) {
+                const float bias = a.b2[col];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    if (i < mtv)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = rat_acc_row(mt0 + i, r);
+                            if (row < rows) a.y[(tok0 + row) * g.D + col] = acc[i][0][r] + bias + xs[(size_t)row * g.ldx + col];
+                        }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
+    RAT_DYN_SMEM(smem);
+    const FfnGeom g(a.d, a.hidden);
+    const int D = g.D, H = g.H;
+    float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx] x
+    float* dys = xs + (size_t)FFN_ROWS * g.ldx;                 // [64][ldx] dL/dy
+    float* hs = dys + (size_t)FFN_ROWS * g.ldx;                 // [64][ldh] h = W1 x + b1
+    float* gs = hs + (size_t)FFN_ROWS * g.ldh;                  // [64][ldh] gelu(h), later dh
+
+    f32x4 acc1[WSLOTS], acc2[WSLOTS];                           // dW1 tiles (H16/16 x D16/16), dW2 tiles (D16/16 x H16/16)
+#pragma unroll
+    for (int s = 0; s < WSLOTS; ++s) acc1[s] = acc2[s] = rat_zero4();
+    float db1 = 0.f, db2 = 0.f;                                 // thread c owns column c (c < H resp. c < D)
+    const int t1n = g.D16 / 16, t1 = (g.H16 / 16) * t1n;
+    const int t2n = g.H16 / 16, t2 = (g.D16 / 16) * t2n;
+
+    ffn_zero_cols(xs, g.ldx, D);
+    ffn_zero_cols(dys, g.ldx, D);
+    ffn_zero_cols(hs, g.ldh, H);
+    ffn_zero_cols(gs, g.ldh, H);
+    __syncthreads();
+
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+        const int64_t tok0 = chunk * FFN_ROWS;
+        const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
+        const int mt_valid = (rows + 15) / 16;
+        ffn_load(xs, g.ldx, a.x, tok0, rows, D, a.vec_x != 0);
+        ffn_load(dys, g.ldx, a.dy, tok0, rows, D, a.vec_x != 0);
+        __syncthreads();
+        ffn_hidden<1>(a, g, xs, hs, gs, mt_valid, rows);
+        __syncthreads();
+        // dW2 += dy^T gelu(h) ; db2 += colsum(dy)
+        {
+            const RatLdsCols At{dys, g.ldx};
+            const RatLdsCols Bt{gs, g.ldh};
+#pragma unroll
+            for (int s = 0; s < WSLOTS; ++s) {
+                const int id = rat_wave() + FFN_WAVES * s;
+                if (id < t2) acc2[s] = rat_wave_gemm1(acc2[s], At, Bt, id / t2n, id % t2n, mt_valid);
+            }
+            if (threadIdx.x < D) {
+                float sacc = 0.f;
+                for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * g.ldx + threadIdx.x];
+                db2 += sacc;
+            }
+        }
+        __syncthreads();
+        // dh = (dy W2) * gelu'(h)  -> gs
+        {
+            const int ntn = g.H16 / 16;
+            const RatLdsRows A{dys, g.ldx};
+            const RatGlobalWkn Bw{a.w2, D, H, H};
+            for (int nt = rat_wave(); nt < ntn; nt += FFN_WAVES) {
+                f32x4 acc[4][1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][0] = rat_zero4();
+                rat_wave_gemm<4, 1>(acc, A, Bw, 0, nt, mt_valid, 1, g.D16 / 16);
+                const int col = rat_acc_col(nt);
+                if (col < H)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < mt_valid)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = rat_acc_row(i, r);
+                                const size_t o = (size_t)row * g.ldh + col;
+                                gs[o] = row < rows ? acc[i][0][r] * rat_gelu_grad(hs[o]) : 0.f;
+                            }
+            }
+        }
+        __syncthreads();
+        // dx = dh W1 + dy ; dW1 += dh^T x ; db1 += colsum(dh)
+        {
+            const int ntn = g.D16 / 16, mblocks = (mt_valid + 1) / 2, ntasks = mblocks * ntn;
+            const RatLdsRows A{gs, g.ldh};
+            const RatGlobalWkn Bw{a.w1, H, D, D};
+            for (int task = rat_wave(); task < ntasks; task += FFN_WAVES) {
+                const int mt0 = (task / ntn) * 2, nt = task % ntn;
+                const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
+                f32x4 acc[2][1];
+                acc[0][0] = acc[1][0] = rat_zero4();
+                rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.H16 / 16);
+                const int col = rat_acc_col(nt);
+                if (col < D)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        if (i < mtv)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int row = rat_acc_row(mt0 + i, r);
+                                if (row < rows) a.y[(tok0 + row) * D + col] = acc[i][0][r] + dys[(size_t)row * g.ldx + col];
+                            }
+            }
+            const RatLdsCols At{gs, g.ldh};
+            const RatLdsCols Bt{xs, g.ldx};
+#pragma unroll
+            for (int s = 0; s < WSLOTS; ++s) {
+                const int id = rat_wave() + FFN_WAVES * s;
+                if (id < t1) acc1[s] = rat_wave_gemm1(acc1[s], At, Bt, id / t1n, id % t1n, mt_valid);
+            }
+            if (threadIdx.x < H) {
+                float sacc = 0.f;
+                for (int r = 0; r < rows; ++r) sacc += gs[(size_t)r * g.ldh + threadIdx.x];
+                db1 += sacc;
+            }
+        }
+        __syncthreads();
+    }
+
+    // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+    float* s_w1 = slab;
+    float* s_w2 = s_w1 + (int64_t)H * D;
+    float* s_b1 = s_w2 + (int64_t)D * H;
+    float* s_b2 = s_b1 + H;
+#pragma unroll
+    for (int s = 0; s < WSLOTS; ++s) {
+        const int id = rat_wave() + FFN_WAVES * s;
+        if (id < t1) {
+            const int col = rat_acc_col(id % t1n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rat_acc_row(id / t1n, r);
+                if (row < H && col < D) s_w1[(int64_t)row * D + col] = acc1[s][r];
+            }
+        }
+        if (id < t2) {
+            const int col = rat_acc_col(id % t2n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rat_acc_row(id / t2n, r);
+                if (row < D && col < H) s_w2[(int64_t)row * H + col] = acc2[s][r];
+            }
+        }
+    }
+    if (threadIdx.x < H) s_b1[threadIdx.x] = db1;
+    if (threadIdx.x < D) s_b2[threadIdx.x] = db2;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int ffn_check(int64_t ntok, int d, int hidden, bool backward) {
+    RAT_REQUIRE(ntok > 0 && d > 0 && hidden > 0, "bad dims");
+    RAT_REQUIRE(d <= FFN_THREADS && hidden <= FFN_THREADS, "d / hidden above 512 not supported");
+    const FfnGeom g(d, hidden);
+    RAT_REQUIRE((backward ? g.bwd_smem() : g.fwd_smem()) <= 160 * 1024, "d*scale_dim too large for the LDS tile");
+    if (backward)
+        RAT_REQUIRE((g.H16 / 16) * (g.D16 / 16) <= WSLOTS * FFN_WAVES, "hidden x d exceeds the in-register dW accumulator budget");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
+                           int64_t ntok, int d, int hidden, void* stream) {
+    if (ffn_check(ntok, d, hidden, false)) return -1;
+    RAT_REQUIRE(x && y && w1 && b1 && w2 && b2, "null pointer");
+    FfnArgs a{};
+    a.x = x;
+    a.y = y;
+    a.w1 = w1;
+    a.b1 = b1;
+    a.w2 = w2;
+    a.b2 = b2;
+    a.ntok = ntok;
+    a.nchunks = (ntok + FFN_ROWS - 1) / FFN_ROWS;
+    a.d = d;
+    a.hidden = hidden;
+    a.vec_x = (d % 4 == 0) && aligned16(x);
+    a.vec_w1 = (d % 4 == 0) && aligned16(w1);
+    a.vec_w2 = (hidden % 4 == 0) && aligned16(w2);
+    const FfnGeom g(d, hidden);
+    const size_t smem = g.fwd_smem();
+    int per_cu = (int)((160 * 1024) / smem);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t blocks = a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu;
+    RAT_LAUNCH(ffn_fwd_kernel, (unsigned)blocks, FFN_THREADS, smem, stream, a);
+    return rat_check_launch("rat_ffn_fwd");
+}
+
+extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
+    const FfnGeom g(d, hidden);
+    return (size_t)256 * (size_t)g.slab_floats() * sizeof(float);
+}
+
+extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                           const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                           size_t workspace_bytes, int64_t ntok, int d, int hidden, void* stream) {
+    if (ffn_check(ntok, d, hidden, true)) return -1;
+    RAT_REQUIRE(x && dy && dx && w1 && b1 && w2 && b2 && dw1 && db1 && dw2 && db2 && workspace, "null pointer");
+    RAT_REQUIRE(workspace_bytes >= rat_ffn_bwd_workspace(d, hidden), "workspace too small");
+    FfnArgs a{};
+    a.x = x;
+    a.dy = dy;
+    a.y = dx;
+    a.w1 = w1;
+    a.b1 = b1;
+    a.w2 = w2;
+    a.b2 = b2;
+    a.ntok = ntok;
+    a.nchunks = (ntok + FFN_ROWS - 1) / FFN_ROWS;
+    a.d = d;
+    a.hidden = hidden;
+    a.vec_x = (d % 4 == 0) && aligned16(x) && aligned16(dy);
+    a.vec_w1 = (d % 4 == 0) && aligned16(w1);
+    a.vec_w2 = (hidden % 4 == 0) && aligned16(w2);
+    const FfnGeom g(d, hidden);
+    a.slabs = workspace;
+    a.slab_stride = g.slab_floats();
+    const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
+    RAT_LAUNCH(ffn_bwd_kernel, blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+    if (rat_check_launch("rat_ffn_bwd")) return -1;
+    float* outs[4] = {dw1, dw2, db1, db2};
+    const int64_t sizes[4] = {(int64_t)hidden * d, (int64_t)d * hidden, hidden, d};
+    const int64_t offs[4] = {0, (int64_t)hidden * d, 2 * (int64_t)hidden * d, 2 * (int64_t)hidden * d + hidden};
+    return rat_launch_reduce_slabs(workspace, blocks, a.slab_stride, outs, offs, sizes, 4, stream);
+}

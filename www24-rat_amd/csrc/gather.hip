@@ -1,0 +1,196 @@
+// gather.hip — K1: token-grid assembly (embedding gather + label tokens) and its backward scatter.
+//
+// Forward replaces RAT_m2.forward lines 113-126 of the reference (3x EmbeddingLayer.forward over F
+// nn.Embedding tables, 2x label_embedding_layer, 3x torch.concat): ONE pass that reads each embedding row
+// once with 16-byte coalesced loads and writes the [B][T][S][d] grid once.  HBM-bound; algorithmic bytes
+// per sample = T*F*d*4 (rows) + T*S*d*4 (grid) + T*L*4 (ids)  (SURVEY.md §8d).
+#include "rat_device.h"
+#include "../../include/rat_hip.h"
+
+namespace {
+
+constexpr int GATHER_THREADS = 256;
+constexpr int GATHER_ITEMS = 4;       // independent rows in flight per thread
+
+// vectorised path: d % 4 == 0, one item = one 16-byte piece of one grid row
+__global__ void __launch_bounds__(GATHER_THREADS)
+gather_fwd_vec_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ label_ids,
+                      const RatField* __restrict__ fields, const float* __restrict__ label_table,
+                      float* __restrict__ grid, int64_t nrows, int S, int L, int d) {
+    const int cpr = d >> 2;                                   // 16-byte pieces per row
+    const int64_t nitems = nrows * cpr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e0 < nitems; e0 += stride * GATHER_ITEMS) {
+        const float4* src[GATHER_ITEMS];
+        int extra[GATHER_ITEMS];                              // >0: bag field, number of extra ids to sum
+        const int32_t* idp[GATHER_ITEMS];
+        const float* tab[GATHER_ITEMS];
+        int vocab[GATHER_ITEMS];
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) {
+            const int64_t e = e0 + (int64_t)u * stride;
+            src[u] = nullptr;
+            extra[u] = 0;
+            idp[u] = nullptr;
+            tab[u] = nullptr;
+            vocab[u] = 1;
+            if (e < nitems) {
+                const int64_t row = e / cpr;
+                const int piece = (int)(e - row * cpr);
+                const int64_t bt = row / S;
+                const int s = (int)(row - bt * S);
+                if (s == 0) {
+                    src[u] = reinterpret_cast<const float4*>(label_table + (int64_t)label_ids[bt] * d) + piece;
+                } else {
+                    const RatField f = fields[s - 1];
+                    const int32_t* ids = idx + bt * L + f.col;
+                    int id = ids[0];
+                    id = id < 0 ? 0 : (id >= f.vocab ? f.vocab - 1 : id);
+                    src[u] = reinterpret_cast<const float4*>(f.table + (int64_t)id * d) + piece;
+                    extra[u] = f.ncols - 1;
+                    idp[u] = ids;
+                    tab[u] = f.table + piece * 4;
+                    vocab[u] = f.vocab;
+                }
+            }
+        }
+        float4 v[GATHER_ITEMS];
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) v[u] = src[u] ? *src[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) {
+            for (int j = 1; j <= extra[u]; ++j) {             // MaskedSumPooling bag (padding row is all-zero)
+                int id = idp[u][j];
+                id = id < 0 ? 0 : (id >= vocab[u] ? vocab[u] - 1 : id);
+                const float4 w = *reinterpret_cast<const float4*>(tab[u] + (int64_t)id * d);
+                v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) {
+            const int64_t e = e0 + (int64_t)u * stride;
+            if (e < nitems) reinterpret_cast<float4*>(grid)[e] = v[u];
+        }
+    }
+}
+
+// generic path: any d, one item = one float
+__global__ void __launch_bounds__(GATHER_THREADS)
+gather_fwd_scalar_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ label_ids,
+                         const RatField* __restrict__ fields, const float* __restrict__ label_table,
+                         float* __restrict__ grid, int64_t nrows, int S, int L, int d) {
+    const int64_t nitems = nrows * d;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nitems; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / d;
+        const int c = (int)(e - row * d);
+        const int64_t bt = row / S;
+        const int s = (int)(row - bt * S);
+        float v;
+        if (s == 0) {
+            v = label_table[(int64_t)label_ids[bt] * d + c];
+        } else {
+            const RatField f = fields[s - 1];
+            const int32_t* ids = idx + bt * L + f.col;
+            v = 0.f;
+            for (int j = 0; j < f.ncols; ++j) {
+                int id = ids[j];
+                id = id < 0 ? 0 : (id >= f.vocab ? f.vocab - 1 : id);
+                v += f.table[(int64_t)id * d + c];
+            }
+        }
+        grid[e] = v;
+    }
+}
+
+// backward: one lane per grid element; field rows -> fp32 atomics shaped as contiguous row segments
+// (a 64-lane wave covers one 256-byte row at d = 64: the full-rate atomic shape on gfx950).
+__global__ void __launch_bounds__(GATHER_THREADS)
+gather_bwd_fields_kernel(const float* __restrict__ dgrid, const float* __restrict__ dflat,
+                         const int32_t* __restrict__ idx, const RatField* __restrict__ gfields,
+                         int64_t nbt, int T, int S, int L, int d) {
+    const int F = S - 1;
+    const int64_t nitems = nbt * F * d;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nitems; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % d);
+        const int64_t r = e / d;
+        const int fi = (int)(r % F);
+        const int64_t bt = r / F;
+        float g = dgrid[((bt * S) + 1 + fi) * d + c];
+        if (dflat != nullptr && (bt % T) == 0) g += dflat[((bt / T) * F + fi) * d + c];
+        const RatField f = gfields[fi];
+        const int32_t* ids = idx + bt * L + f.col;
+        for (int j = 0; j < f.ncols; ++j) {
+            int id = ids[j];
+            id = id < 0 ? 0 : (id >= f.vocab ? f.vocab - 1 : id);
+            if (id != f.padding_idx) atomicAdd(f.table + (int64_t)id * d + c, g);
+        }
+    }
+}
+
+// label-token rows: only 3 destination rows -> reduce inside the block first (LDS), then 3*d atomics per block
+__global__ void __launch_bounds__(GATHER_THREADS)
+gather_bwd_label_kernel(const float* __restrict__ dgrid, const int32_t* __restrict__ label_ids,
+                        float* __restrict__ dlabel, int64_t nbt, int S, int d) {
+    RAT_DYN_SMEM(smem);
+    float* part = reinterpret_cast<float*>(smem);            // [3][d]
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) part[i] = 0.f;
+    __syncthreads();
+    const int64_t nitems = nbt * d;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nitems; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % d);
+        const int64_t bt = e / d;
+        int lab = label_ids[bt];
+        lab = lab < 0 ? 0 : (lab > 2 ? 2 : lab);
+        atomicAdd(&part[lab * d + c], dgrid[(bt * S) * d + c]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x)
+        if (part[i] != 0.f) atomicAdd(&dlabel[i], part[i]);
+}
+
+int pick_blocks(int64_t nitems, int per_thread) {
+    int64_t want = (nitems + (int64_t)GATHER_THREADS * per_thread - 1) / ((int64_t)GATHER_THREADS * per_thread);
+    if (want < 1) want = 1;
+    if (want > 2048) want = 2048;                             // 256 CUs x 8 blocks, grid-stride the rest
+    return (int)want;
+}
+
+}  // namespace
+
+extern "C" int rat_gather_fwd(const int32_t* idx, const int32_t* label_ids, const RatField* fields_dev, int nfields,
+                              const float* label_table, float* grid, int B, int T, int L, int d, void* stream) {
+    RAT_REQUIRE(B > 0 && T > 0 && L > 0 && d > 0 && nfields >= 0, "bad dims");
+    RAT_REQUIRE(idx && label_ids && label_table && grid && (fields_dev || nfields == 0), "null pointer");
+    const int S = nfields + 1;
+    const int64_t nrows = (int64_t)B * T * S;
+    const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(grid) | reinterpret_cast<uintptr_t>(label_table)) % 16 == 0);
+    if (vec) {
+        RAT_LAUNCH(gather_fwd_vec_kernel, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
+                   label_ids, fields_dev, label_table, grid, nrows, S, L, d);
+    } else {
+        RAT_LAUNCH(gather_fwd_scalar_kernel, pick_blocks(nrows * d, 4), GATHER_THREADS, 0, stream, idx, label_ids,
+                   fields_dev, label_table, grid, nrows, S, L, d);
+    }
+    return rat_check_launch("rat_gather_fwd");
+}
+
+extern "C" int rat_gather_bwd(const float* dgrid, const float* dflat, const int32_t* idx, const int32_t* label_ids,
+                              const RatField* grad_fields_dev, int nfields, float* dlabel_table, int B, int T, int L,
+                              int d, void* stream) {
+    RAT_REQUIRE(B > 0 && T > 0 && L > 0 && d > 0 && nfields >= 0, "bad dims");
+    RAT_REQUIRE(dgrid && idx && label_ids, "null pointer");
+    const int S = nfields + 1;
+    const int64_t nbt = (int64_t)B * T;
+    if (nfields > 0) {
+        RAT_REQUIRE(grad_fields_dev, "null grad field table");
+        RAT_LAUNCH(gather_bwd_fields_kernel, pick_blocks(nbt * nfields * d, 4), GATHER_THREADS, 0, stream, dgrid, dflat,
+                   idx, grad_fields_dev, nbt, T, S, L, d);
+    }
+    if (dlabel_table) {
+        int blocks = pick_blocks(nbt * d, 16);
+        if (blocks > 256) blocks = 256;
+        RAT_LAUNCH(gather_bwd_label_kernel, blocks, GATHER_THREADS, (size_t)3 * d * sizeof(float), stream, dgrid,
+                   label_ids, dlabel_table, nbt, S, d);
+    }
+    return rat_check_launch("rat_gather_bwd");
+}

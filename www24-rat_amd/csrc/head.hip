@@ -1,0 +1,246 @@
+// head.hip — K3: BatchNorm1d+ReLU, bias gradients, and the logit / sigmoid / BCE stage of the prediction head.
+//   MLP_Layer (fuxictr/pytorch/layers/deep.py:126-141), LR_Layer (shallow.py:36-45), RAT_m2.forward lines 138-150,
+//   BCE of get_loss_fn (torch_utils.py:51-63).
+#include "rat_device.h"
+#include "../../include/rat_hip.h"
+
+namespace {
+
+constexpr int HD_THREADS = 256;
+constexpr int HD_COLS = 32;                 // columns per block
+constexpr int HD_RG = HD_THREADS / HD_COLS; // row groups per block
+
+// sum over the HD_RG row groups of one column; result valid for every thread of that column
+__device__ __forceinline__ float col_reduce(float v, float* scratch) {
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    __syncthreads();
+    scratch[rg * HD_COLS + cg] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < HD_RG; ++r) s += scratch[r * HD_COLS + cg];
+    return s;
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_relu_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* save_mean, float* save_rstd, int M, int N,
+                   int training, int use_bn, float eps, float momentum) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int col = blockIdx.x * HD_COLS + cg;
+    const bool ok = col < N;
+    float mean = 0.f, rstd = 1.f, gam = 1.f, bet = 0.f;
+    if (use_bn) {
+        if (training) {
+            float s = 0.f;
+            if (ok) for (int m = rg; m < M; m += HD_RG) s += z[(size_t)m * N + col];
+            mean = col_reduce(s, scratch) / (float)M;
+            float v = 0.f;
+            if (ok) for (int m = rg; m < M; m += HD_RG) { const float t = z[(size_t)m * N + col] - mean; v += t * t; }
+            const float var = col_reduce(v, scratch) / (float)M;
+            rstd = 1.0f / sqrtf(var + eps);
+            if (ok && rg == 0) {
+                save_mean[col] = mean;
+                save_rstd[col] = rstd;
+                const float unbiased = M > 1 ? var * (float)M / (float)(M - 1) : var;
+                running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
+                running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+            }
+        } else if (ok) {
+            mean = running_mean[col];
+            rstd = 1.0f / sqrtf(running_var[col] + eps);
+        }
+        if (ok) { gam = gamma[col]; bet = beta[col]; }
+    }
+    if (ok)
+        for (int m = rg; m < M; m += HD_RG) {
+            const float y = (z[(size_t)m * N + col] - mean) * rstd * gam + bet;
+            a[(size_t)m * N + col] = y > 0.f ? y : 0.f;
+        }
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_relu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
+                   float* __restrict__ dz, const float* gamma, const float* save_mean, const float* save_rstd,
+                   float* dgamma, float* dbeta, int M, int N, int use_bn) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int col = blockIdx.x * HD_COLS + cg;
+    const bool ok = col < N;
+    if (!use_bn) {
+        if (ok) for (int m = rg; m < M; m += HD_RG) {
+            const size_t o = (size_t)m * N + col;
+            dz[o] = a[o] > 0.f ? da[o] : 0.f;
+        }
+        return;
+    }
+    const float mean = ok ? save_mean[col] : 0.f, rstd = ok ? save_rstd[col] : 1.f;
+    const float gam = ok ? gamma[col] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) for (int m = rg; m < M; m += HD_RG) {
+        const size_t o = (size_t)m * N + col;
+        const float xh = (z[o] - mean) * rstd;
+        const float g = a[o] > 0.f ? da[o] : 0.f;
+        s1 += g;
+        s2 += g * xh;
+    }
+    s1 = col_reduce(s1, scratch);
+    s2 = col_reduce(s2, scratch);
+    if (ok && rg == 0) { dgamma[col] = s2; dbeta[col] = s1; }
+    const float m1 = s1 / (float)M, m2 = s2 / (float)M;
+    if (ok) for (int m = rg; m < M; m += HD_RG) {
+        const size_t o = (size_t)m * N + col;
+        const float xh = (z[o] - mean) * rstd;
+        const float g = a[o] > 0.f ? da[o] : 0.f;
+        dz[o] = gam * rstd * (g - m1 - xh * m2);
+    }
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int col = blockIdx.x * HD_COLS + cg;
+    float s = 0.f;
+    if (col < N) for (int m = rg; m < M; m += HD_RG) s += a[(size_t)m * lda + col];
+    s = col_reduce(s, scratch);
+    if (col < N && rg == 0) out[col] = s;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch) {   // 256 threads
+    v = rat_group_sum<64>(v);
+    __syncthreads();
+    if (rat_lane() == 0) scratch[rat_wave()] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+logit_fwd_kernel(const float* __restrict__ cls, int64_t cls_stride, const float* fc_w, const float* fc_b,
+                 const float* dnn_out, const RatField* lr_fields, int nfields, const int32_t* idx, int64_t idx_stride,
+                 const float* y_true, float* y_pred, float* loss_sum, int B, int d) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float loss = 0.f;
+    if (b < B) {
+        float zl = fc_b[0];
+        const float* c = cls + (int64_t)b * cls_stride;
+        for (int k = 0; k < d; ++k) zl = fmaf(c[k], fc_w[k], zl);
+        if (dnn_out != nullptr) zl += dnn_out[b];
+        if (lr_fields != nullptr) {
+            float lr = 0.f;
+            for (int f = 0; f < nfields; ++f) {
+                const RatField fd = lr_fields[f];
+                const int32_t* ids = idx + (int64_t)b * idx_stride + fd.col;
+                for (int j = 0; j < fd.ncols; ++j) {
+                    int id = ids[j];
+                    id = id < 0 ? 0 : (id >= fd.vocab ? fd.vocab - 1 : id);
+                    lr += fd.table[id];
+                }
+            }
+            zl += lr;
+        }
+        const float p = 1.0f / (1.0f + expf(-zl));
+        y_pred[b] = p;
+        if (y_true != nullptr) {
+            const float t = y_true[b];
+            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
+            loss = -(t * lp + (1.0f - t) * l1p) / (float)B;
+        }
+    }
+    if (loss_sum != nullptr) {
+        const float s = block_sum(loss, scratch);
+        if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+    }
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ cls,
+                 int64_t cls_stride, const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
+                 float* dfc_b, const RatField* lr_grad_fields, int nfields, const int32_t* idx, int64_t idx_stride,
+                 float gscale, int B, int d) {
+    RAT_DYN_SMEM(smem);
+    float* part = reinterpret_cast<float*>(smem);             // [d + 1] block partials of dfc_w, dfc_b
+    for (int i = threadIdx.x; i <= d; i += blockDim.x) part[i] = 0.f;
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        const float dl = gscale * (y_pred[b] - y_true[b]) / (float)B;
+        dlogit[b] = dl;
+        const float* c = cls + (int64_t)b * cls_stride;
+        float* dc = dcls + (int64_t)b * dcls_stride;
+        for (int k = 0; k < d; ++k) {
+            dc[k] = dl * fc_w[k];
+            atomicAdd(&part[k], dl * c[k]);
+        }
+        atomicAdd(&part[d], dl);
+        if (lr_grad_fields != nullptr)
+            for (int f = 0; f < nfields; ++f) {
+                const RatField fd = lr_grad_fields[f];
+                const int32_t* ids = idx + (int64_t)b * idx_stride + fd.col;
+                for (int j = 0; j < fd.ncols; ++j) {
+                    int id = ids[j];
+                    id = id < 0 ? 0 : (id >= fd.vocab ? fd.vocab - 1 : id);
+                    if (id != fd.padding_idx) atomicAdd(fd.table + id, dl);
+                }
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += blockDim.x) atomicAdd(&dfc_w[i], part[i]);
+    if (threadIdx.x == 0) atomicAdd(dfc_b, part[d]);
+}
+
+}  // namespace
+
+extern "C" int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float* save_mean, float* save_rstd, int M, int N, int training,
+                               int use_bn, float eps, float momentum, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && a, "bad args");
+    if (use_bn) RAT_REQUIRE(gamma && beta && running_mean && running_var && (!training || (save_mean && save_rstd)), "null BN pointer");
+    RAT_LAUNCH(bn_relu_fwd_kernel, (N + HD_COLS - 1) / HD_COLS, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, gamma,
+               beta, running_mean, running_var, save_mean, save_rstd, M, N, training, use_bn, eps, momentum);
+    return rat_check_launch("rat_bn_relu_fwd");
+}
+
+extern "C" int rat_colsum(const float* a, int lda, float* out, int M, int N, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && a && out, "bad args");
+    RAT_LAUNCH(colsum_kernel, (N + HD_COLS - 1) / HD_COLS, HD_THREADS, HD_THREADS * sizeof(float), stream, a, lda, out, M, N);
+    return rat_check_launch("rat_colsum");
+}
+
+extern "C" int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* fc_w, const float* fc_b, const float* dnn_out,
+                             const RatField* lr_fields_dev, int nfields, const int32_t* idx, int64_t idx_stride,
+                             const float* y_true, float* y_pred, float* loss_sum, int B, int d, void* stream) {
+    RAT_REQUIRE(B > 0 && d > 0 && cls && fc_w && fc_b && y_pred, "bad args");
+    RAT_REQUIRE(lr_fields_dev == nullptr || idx != nullptr, "LR term needs idx");
+    RAT_LAUNCH(logit_fwd_kernel, (B + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 16 * sizeof(float), stream, cls, cls_stride,
+               fc_w, fc_b, dnn_out, lr_fields_dev, nfields, idx, idx_stride, y_true, y_pred, loss_sum, B, d);
+    return rat_check_launch("rat_logit_fwd");
+}
+
+extern "C" int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride,
+                             const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w, float* dfc_b,
+                             const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx, int64_t idx_stride,
+                             float gscale, int B, int d, void* stream) {
+    RAT_REQUIRE(B > 0 && d > 0 && y_pred && y_true && cls && fc_w && dlogit && dcls && dfc_w && dfc_b, "bad args");
+    RAT_REQUIRE(lr_grad_fields_dev == nullptr || idx != nullptr, "LR term needs idx");
+    RAT_LAUNCH(logit_bwd_kernel, (B + HD_THREADS - 1) / HD_THREADS, HD_THREADS, (size_t)(d + 1) * sizeof(float), stream,
+               y_pred, y_true, cls, cls_stride, fc_w, dlogit, dcls, dcls_stride, dfc_w, dfc_b, lr_grad_fields_dev, nfields,
+               idx, idx_stride, gscale, B, d);
+    return rat_check_launch("rat_logit_bwd");
+}
+
+extern "C" int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
+                               const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, int M, int N,
+                               int use_bn, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && a && da && dz, "bad args");
+    if (use_bn) RAT_REQUIRE(gamma && save_mean && save_rstd && dgamma && dbeta, "null BN pointer");
+    RAT_LAUNCH(bn_relu_bwd_kernel, (N + HD_COLS - 1) / HD_COLS, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, da, dz,
+               gamma, save_mean, save_rstd, dgamma, dbeta, M, N, use_bn);
+    return rat_check_launch("rat_bn_relu_bwd");
+}

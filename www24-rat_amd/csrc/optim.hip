@@ -1,0 +1,98 @@
+// optim.hip — K4/K5: L2 regulariser gradient, global grad-norm, and fused clip + Adam over flat fp32 buffers.
+//   BaseModel.add_regularization (fuxictr/pytorch/models/base_model.py:79-94, get_regularizer torch_utils.py:65-81),
+//   nn.utils.clip_grad_norm_(params, 10.) and Adam.step() (base_model.py:224-225, torch_utils.py:41-49).
+// HBM-bound streaming kernels: 16-byte accesses, grid-stride, <= 2048 blocks.
+#include "rat_device.h"
+#include "../../include/rat_hip.h"
+
+namespace {
+
+constexpr int OPT_THREADS = 256;
+
+__device__ __forceinline__ float opt_block_sum(float v, float* scratch) {
+    v = rat_group_sum<64>(v);
+    __syncthreads();
+    if (rat_lane() == 0) scratch[rat_wave()] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+l2_reg_kernel(const float* __restrict__ w, float* __restrict__ g, int64_t n, float lambda, float* reg_out) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wv = w[i];
+        g[i] += lambda * wv;
+        acc = fmaf(wv, wv, acc);
+    }
+    if (reg_out != nullptr) {
+        const float s = opt_block_sum(acc, scratch);
+        if (threadIdx.x == 0) atomicAdd(reg_out, 0.5f * lambda * s);
+    }
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        acc = fmaf(v, v, acc);
+    }
+    const float s = opt_block_sum(acc, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                 const float* norm_sq, float max_norm, float step_size, float beta1, float beta2, float eps,
+                 float inv_sqrt_bc2) {
+    float coef = 1.0f;
+    if (norm_sq != nullptr) {
+        coef = max_norm / (sqrtf(*norm_sq) + 1e-6f);
+        coef = coef < 1.0f ? coef : 1.0f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gv = g[i] * coef;
+        const float mv = beta1 * m[i] + (1.0f - beta1) * gv;
+        const float vv = beta2 * v[i] + (1.0f - beta2) * gv * gv;
+        m[i] = mv;
+        v[i] = vv;
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        w[i] -= step_size * mv / denom;
+    }
+}
+
+int opt_blocks(int64_t n) {
+    int64_t b = (n + OPT_THREADS * 4 - 1) / (OPT_THREADS * 4);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, float* reg_out, void* stream) {
+    RAT_REQUIRE(n > 0 && w && g, "bad args");
+    RAT_LAUNCH(l2_reg_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, w, g, n, lambda, reg_out);
+    return rat_check_launch("rat_l2_reg");
+}
+
+extern "C" int rat_sumsq(const float* g, int64_t n, float* norm_sq_out, void* stream) {
+    RAT_REQUIRE(n > 0 && g && norm_sq_out, "bad args");
+    RAT_LAUNCH(sumsq_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, g, n, norm_sq_out);
+    return rat_check_launch("rat_sumsq");
+}
+
+extern "C" int rat_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* norm_sq, float max_norm,
+                             float lr, float beta1, float beta2, float eps, int step, void* stream) {
+    RAT_REQUIRE(n > 0 && w && g && m && v && step >= 1, "bad args");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    RAT_LAUNCH(clip_adam_kernel, opt_blocks(n), OPT_THREADS, 0, stream, w, g, m, v, n, norm_sq, max_norm,
+               (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+    return rat_check_launch("rat_clip_adam");
+}

@@ -1,0 +1,189 @@
+// rat_device.h — device-side building blocks shared by the RAT_m2 kernels (gfx950 / CDNA4).
+//
+// Everything here is written for 64-lane wavefronts and the v_mfma_f32_16x16x4_f32 matrix instruction
+// (exact fp32, bit-identical to a k-ordered fmaf chain — which is what keeps the kernels inside the
+// reference's fp32 tolerance).  Lane maps (cdna_hip_programming.md §3):
+//     A: lane l holds A[i = l & 15][k = l >> 4]      B: lane l holds B[k = l >> 4][j = l & 15]
+//     C/D: col = l & 15, row = (l >> 4) * 4 + reg
+// The contraction index of one 16-wide "k-block" is permuted so that a lane's four values are CONTIGUOUS
+// in memory: MFMA step j of lane group g = l >> 4 consumes k = 16*kb + 4*g + j.  A and B use the same
+// permutation, so the sum is unchanged, and row-major operands are fetched with one 16-byte load.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef RAT_EMU
+#include "hip_emu.h"
+#define RAT_MFMA16(a, b, c) emu_mfma_f32_16x16x4f32((a), (b), (c))
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((vector_size(16)));
+#define RAT_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define RAT_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define RAT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#include <string>
+
+// ------------------------------------------------------------------------------------------- host side
+const char* rat_set_error(const std::string& msg);   // stores thread-local, returns c_str
+int rat_fail(const std::string& msg);                 // sets error, returns -1
+int rat_check_launch(const char* what);               // hipGetLastError -> 0 / -1
+
+#define RAT_REQUIRE(cond, msg)                  \
+    do {                                        \
+        if (!(cond)) return rat_fail(std::string(__func__) + ": " + (msg)); \
+    } while (0)
+
+static inline int rat_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------- device side
+#define RAT_WAVE 64
+
+__device__ __forceinline__ int rat_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ int rat_wave() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ f32x4 rat_zero4() {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+
+// sum over groups of `width` consecutive lanes (width a power of two <= 64); every lane gets the result
+template <int WIDTH>
+__device__ __forceinline__ float rat_group_sum(float v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float rat_gelu(float x) {          // nn.GELU() exact erf form
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float rat_gelu_grad(float x) {     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- MFMA operand fetchers.  Each returns the lane's 4 values of k-block `kb` for 16-row/col tile `tile`.
+// A[m][k] or B[n][k]-as-weights, row-major in LDS with the contraction index contiguous (16-byte reads).
+struct RatLdsRows {
+    const float* base;
+    int ld;                                   // floats, multiple of 4; base 16-byte aligned
+    __device__ __forceinline__ float4 operator()(int tile, int kb) const {
+        const int l = rat_lane();
+        return *reinterpret_cast<const float4*>(base + (size_t)(tile * 16 + (l & 15)) * ld + kb * 16 + 4 * (l >> 4));
+    }
+};
+// operand stored with the contraction index as the ROW of an LDS tile: X[k][m] (token-contraction GEMMs)
+struct RatLdsCols {
+    const float* base;
+    int ld;
+    __device__ __forceinline__ float4 operator()(int tile, int kb) const {
+        const int l = rat_lane();
+        const float* p = base + (size_t)(kb * 16 + 4 * (l >> 4)) * ld + tile * 16 + (l & 15);
+        return make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
+    }
+};
+// nn.Linear weight W[N][K] in global memory used as B[k][n] = W[n][k]  (y = x W^T)
+struct RatGlobalWnk {
+    const float* w;
+    int N, K, ld;
+    bool vec;                                 // K % 4 == 0 && ld % 4 == 0 && 16-byte aligned base
+    __device__ __forceinline__ float4 operator()(int tile, int kb) const {
+        const int l = rat_lane();
+        const int n = tile * 16 + (l & 15);
+        const int k = kb * 16 + 4 * (l >> 4);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            const float* p = w + (size_t)n * ld + k;
+            if (vec && k + 3 < K) {
+                r = *reinterpret_cast<const float4*>(p);
+            } else {
+                if (k + 0 < K) r.x = p[0];
+                if (k + 1 < K) r.y = p[1];
+                if (k + 2 < K) r.z = p[2];
+                if (k + 3 < K) r.w = p[3];
+            }
+        }
+        return r;
+    }
+};
+// weight W[K][N] in global memory used as B[k][n] = W[k][n]  (dx = dy W)
+struct RatGlobalWkn {
+    const float* w;
+    int K, N, ld;
+    __device__ __forceinline__ float4 operator()(int tile, int kb) const {
+        const int l = rat_lane();
+        const int n = tile * 16 + (l & 15);
+        const int k = kb * 16 + 4 * (l >> 4);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            const float* p = w + (size_t)k * ld + n;
+            if (k + 0 < K) r.x = p[0];
+            if (k + 1 < K) r.y = p[(size_t)ld];
+            if (k + 2 < K) r.z = p[(size_t)2 * ld];
+            if (k + 3 < K) r.w = p[(size_t)3 * ld];
+        }
+        return r;
+    }
+};
+
+// acc[i][j] += A(tile mt0+i) * B(tile nt0+j) over kblocks 16-wide k-blocks; tiles beyond mt_valid/nb_valid
+// are skipped (wave-uniform).  All 64 lanes of the wave must call this together.
+template <int MT, int NB, class AF, class BF>
+__device__ __forceinline__ void rat_wave_gemm(f32x4 (&acc)[MT][NB], const AF& af, const BF& bf, int mt0, int nt0,
+                                              int mt_valid, int nb_valid, int kblocks) {
+    for (int kb = 0; kb < kblocks; ++kb) {
+        float4 a[MT], b[NB];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = (i < mt_valid) ? af(mt0 + i, kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[j] = (j < nb_valid) ? bf(nt0 + j, kb) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (i < mt_valid && j < nb_valid) acc[i][j] = RAT_MFMA16(a[i].x, b[j].x, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (i < mt_valid && j < nb_valid) acc[i][j] = RAT_MFMA16(a[i].y, b[j].y, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (i < mt_valid && j < nb_valid) acc[i][j] = RAT_MFMA16(a[i].z, b[j].z, acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+                if (i < mt_valid && j < nb_valid) acc[i][j] = RAT_MFMA16(a[i].w, b[j].w, acc[i][j]);
+    }
+}
+
+// single-tile variant for the persistent weight-gradient accumulators
+template <class AF, class BF>
+__device__ __forceinline__ f32x4 rat_wave_gemm1(f32x4 acc, const AF& af, const BF& bf, int mt, int nt, int kblocks) {
+    for (int kb = 0; kb < kblocks; ++kb) {
+        const float4 a = af(mt, kb);
+        const float4 b = bf(nt, kb);
+        acc = RAT_MFMA16(a.x, b.x, acc);
+        acc = RAT_MFMA16(a.y, b.y, acc);
+        acc = RAT_MFMA16(a.z, b.z, acc);
+        acc = RAT_MFMA16(a.w, b.w, acc);
+    }
+    return acc;
+}
+
+// row/col of accumulator register r of a 16x16 tile
+__device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 16 + (rat_lane() >> 4) * 4 + r; }
+__device__ __forceinline__ int rat_acc_col(int tile_n) { return tile_n * 16 + (rat_lane() & 15); }
+
+// sum the persistent-gradient slabs of all work-groups: out[p] = sum_wg slab[wg][p], fixed order
+__global__ void rat_reduce_slabs_kernel(const float* slabs, int nslabs, int64_t stride, float* out, int64_t n);
+int rat_launch_reduce_slabs(const float* slabs, int nslabs, int64_t stride, float* const* outs_host,
+                            const int64_t* offsets, const int64_t* sizes, int nouts, void* stream);

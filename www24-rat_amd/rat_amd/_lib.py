@@ -1,0 +1,100 @@
+"""ctypes binding of librat_hip.so (include/rat_hip.h).
+
+The product path has exactly one implementation: the HIP library built by ``www24-rat_amd/build.py``.  If it is
+missing or fails to load, importing/using the ops raises — there is no CPU or eager-PyTorch fallback.
+(``tests/emu`` may hand a host-emulation build of the same kernel sources to ``RatLib`` directly; nothing in this
+package does.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
+ABI_VERSION = 1
+
+
+class RatField(Structure):
+    _fields_ = [("table", c_void_p), ("col", c_int32), ("ncols", c_int32), ("vocab", c_int32), ("padding_idx", c_int32)]
+
+
+class RatSeqMap(Structure):
+    _fields_ = [("nseq", c_int64), ("L", c_int32), ("q_div", c_int64), ("hi_stride", c_int64), ("lo_stride", c_int64),
+                ("pos_stride", c_int64)]
+
+
+class RatAttnParams(Structure):
+    _fields_ = [("ln_g", c_void_p), ("ln_b", c_void_p), ("w_qkv", c_void_p), ("w_out", c_void_p), ("b_out", c_void_p)]
+
+
+class RatError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_SIGNATURES = {
+    "rat_version": (c_int, []),
+    "rat_last_error": (c_char_p, []),
+    "rat_gather_fwd": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "rat_gather_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "rat_attn_fwd": (c_int, [_P, _P, _P, _P, POINTER(RatAttnParams), POINTER(RatSeqMap), c_int, c_int, c_int, c_float, _P]),
+    "rat_attn_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "rat_attn_bwd": (c_int, [_P, _P, _P, _P, _P, POINTER(RatAttnParams), POINTER(RatAttnParams), _P, c_size_t,
+                             POINTER(RatSeqMap), c_int, c_int, c_int, c_float, _P]),
+    "rat_ffn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "rat_ffn_bwd_workspace": (c_size_t, [c_int, c_int]),
+    "rat_ffn_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, _P]),
+    "rat_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P]),
+    "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
+    "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "rat_colsum": (c_int, [_P, c_int, _P, c_int, c_int, _P]),
+    "rat_logit_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, _P, _P, _P, c_int, c_int, _P]),
+    "rat_logit_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, c_int, _P, c_int64, c_float, c_int,
+                              c_int, _P]),
+    "rat_l2_reg": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
+    "rat_sumsq": (c_int, [_P, c_int64, _P, _P]),
+    "rat_clip_adam": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class RatLib:
+    """A loaded librat_hip.so with typed entry points; ``call(name, *args)`` raises RatError on a negative return."""
+
+    def __init__(self, path=None):
+        self.path = path or os.environ.get("RAT_HIP_LIBRARY", DEFAULT_LIB)
+        if not os.path.exists(self.path):
+            raise RatError("librat_hip.so not found at %s — build it with `python www24-rat_amd/build.py` "
+                           "(hipcc --offload-arch=gfx950).  There is no fallback path." % self.path)
+        self.cdll = ctypes.CDLL(self.path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.cdll, name)          # AttributeError if the library does not export the symbol
+            fn.restype = res
+            fn.argtypes = args
+        v = self.cdll.rat_version()
+        if v != ABI_VERSION:
+            raise RatError("librat_hip.so ABI version %d != expected %d" % (v, ABI_VERSION))
+
+    def last_error(self):
+        msg = self.cdll.rat_last_error()
+        return msg.decode() if msg else ""
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise RatError("%s failed (%d): %s" % (name, rc, self.last_error()))
+
+    def size(self, name, *args):
+        return int(getattr(self.cdll, name)(*args))
+
+
+_default = None
+
+
+def get_lib():
+    """The process-wide HIP library (loaded after torch so that it binds to torch's HIP runtime)."""
+    global _default
+    if _default is None:
+        import torch  # noqa: F401  (loads libamdhip64 first; librat_hip.so then resolves against the same runtime)
+        _default = RatLib()
+    return _default

@@ -1,0 +1,190 @@
+"""Tensor-level wrappers over the C ABI (include/rat_hip.h).  No arithmetic happens here: every function checks
+layout/dtype, takes raw ``data_ptr()``s plus the current HIP stream and calls into librat_hip.so.
+
+``lib`` defaults to the process-wide HIP library; tests may pass another ``RatLib`` (the host-emulation build).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import RatAttnParams, RatSeqMap, get_lib
+
+FIELD_DTYPE = np.dtype([("table", "<u8"), ("col", "<i4"), ("ncols", "<i4"), ("vocab", "<i4"), ("padding_idx", "<i4")])
+assert FIELD_DTYPE.itemsize == 24
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+
+
+def field_table(fields, tables, device):
+    """Device array of RatField records.  fields: objects with .col/.ncols/.vocab/.padding_idx; tables: tensors."""
+    arr = np.zeros(len(fields), dtype=FIELD_DTYPE)
+    for i, (f, t) in enumerate(zip(fields, tables)):
+        _chk(t, name="table")
+        arr[i] = (t.data_ptr(), f.col, f.ncols, f.vocab, -1 if f.padding_idx is None else f.padding_idx)
+    raw = torch.from_numpy(arr.view(np.uint8).copy())
+    return raw.to(device)
+
+
+def intra_map(B, T, S):
+    return RatSeqMap(nseq=B * T, L=S, q_div=B * T, hi_stride=0, lo_stride=S, pos_stride=1)
+
+
+def cross_map(B, T, S):
+    return RatSeqMap(nseq=B * S, L=T, q_div=S, hi_stride=T * S, lo_stride=1, pos_stride=S)
+
+
+def attn_params(ln_g, ln_b, w_qkv, w_out, b_out):
+    for t in (ln_g, ln_b, w_qkv, w_out, b_out):
+        _chk(t, name="attention parameter")
+    return RatAttnParams(ln_g.data_ptr(), ln_b.data_ptr(), w_qkv.data_ptr(),
+                         w_out.data_ptr() if w_out is not None else None,
+                         b_out.data_ptr() if b_out is not None else None)
+
+
+# ----------------------------------------------------------------------------- K1
+def gather_fwd(idx, label_ids, ftab, nfields, label_table, B, T, L, d, lib=None):
+    lib = lib or get_lib()
+    _chk(idx, torch.int32, "idx"), _chk(label_ids, torch.int32, "label_ids"), _chk(label_table, name="label_table")
+    grid = torch.empty((B, T, nfields + 1, d), dtype=torch.float32, device=idx.device)
+    lib.call("rat_gather_fwd", _p(idx), _p(label_ids), _p(ftab), nfields, _p(label_table), _p(grid), B, T, L, d, _stream(idx))
+    return grid
+
+
+def gather_bwd(dgrid, dflat, idx, label_ids, gftab, nfields, dlabel_table, B, T, L, d, lib=None):
+    lib = lib or get_lib()
+    _chk(dgrid, name="dgrid"), _chk(dflat, name="dflat"), _chk(dlabel_table, name="dlabel_table")
+    lib.call("rat_gather_bwd", _p(dgrid), _p(dflat), _p(idx), _p(label_ids), _p(gftab), nfields, _p(dlabel_table),
+             B, T, L, d, _stream(dgrid))
+
+
+# ----------------------------------------------------------------------------- K2
+def attn_fwd(x, params, seqmap, d, heads, dim_head, save=False, eps=1e-5, out=None, lib=None):
+    lib = lib or get_lib()
+    _chk(x, name="x")
+    y = out if out is not None else torch.empty_like(x)
+    ntok = x.numel() // d
+    o_save = lse = None
+    if save:
+        o_save = torch.empty((ntok, heads * dim_head), dtype=torch.float32, device=x.device)
+        lse = torch.empty((ntok, heads), dtype=torch.float32, device=x.device)
+    lib.call("rat_attn_fwd", _p(x), _p(y), _p(o_save), _p(lse), ctypes.byref(params), ctypes.byref(seqmap), d, heads,
+             dim_head, eps, _stream(x))
+    return y, o_save, lse
+
+
+def attn_bwd(x, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=1e-5, workspace=None, lib=None):
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy, name="dy")
+    need = lib.size("rat_attn_bwd_workspace", d, heads, dim_head)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    lib.call("rat_attn_bwd", _p(x), _p(dy), _p(o_save), _p(lse), _p(dx), ctypes.byref(params), ctypes.byref(grads),
+             _p(workspace), workspace.numel() * 4, ctypes.byref(seqmap), d, heads, dim_head, eps, _stream(x))
+    return dx, workspace
+
+
+def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, lib=None):
+    lib = lib or get_lib()
+    _chk(x, name="x")
+    y = out if out is not None else torch.empty_like(x)
+    lib.call("rat_ffn_fwd", _p(x), _p(y), _p(w1), _p(b1), _p(w2), _p(b2), x.numel() // d, d, hidden, _stream(x))
+    return y
+
+
+def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None, lib=None):
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy, name="dy")
+    need = lib.size("rat_ffn_bwd_workspace", d, hidden)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    lib.call("rat_ffn_bwd", _p(x), _p(dy), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2), _p(db2),
+             _p(workspace), workspace.numel() * 4, x.numel() // d, d, hidden, _stream(x))
+    return dx, workspace
+
+
+# ----------------------------------------------------------------------------- K3
+def sgemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, beta=0.0, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_sgemm", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta), _stream(C))
+
+
+def bn_relu_fwd(z, gamma, beta, running_mean, running_var, training, use_bn, eps=1e-5, momentum=0.1, lib=None):
+    lib = lib or get_lib()
+    _chk(z, name="z")
+    M, N = z.shape
+    a = torch.empty_like(z)
+    save_mean = save_rstd = None
+    if use_bn and training:
+        save_mean = torch.empty(N, dtype=torch.float32, device=z.device)
+        save_rstd = torch.empty(N, dtype=torch.float32, device=z.device)
+    lib.call("rat_bn_relu_fwd", _p(z), _p(a), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(save_mean),
+             _p(save_rstd), M, N, int(training), int(use_bn), eps, momentum, _stream(z))
+    return a, save_mean, save_rstd
+
+
+def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, lib=None):
+    lib = lib or get_lib()
+    M, N = z.shape
+    dz = torch.empty_like(z)
+    lib.call("rat_bn_relu_bwd", _p(z), _p(a), _p(da), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd), _p(dgamma), _p(dbeta),
+             M, N, int(use_bn), _stream(z))
+    return dz
+
+
+def colsum(a, lda, out, M, N, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_colsum", _p(a), lda, _p(out), M, N, _stream(out))
+
+
+def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_stride, y_true, loss_sum, B, d, lib=None):
+    lib = lib or get_lib()
+    y_pred = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
+    lib.call("rat_logit_fwd", _p(cls), cls_stride, _p(fc_w), _p(fc_b), _p(dnn_out), _p(lr_ftab), nfields, _p(idx),
+             idx_stride, _p(y_true), _p(y_pred), _p(loss_sum), B, d, _stream(fc_w))
+    return y_pred
+
+
+def logit_bwd(y_pred, y_true, cls, cls_stride, fc_w, dcls, dcls_stride, dfc_w, dfc_b, lr_gftab, nfields, idx, idx_stride,
+              gscale, B, d, lib=None):
+    lib = lib or get_lib()
+    dlogit = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
+    lib.call("rat_logit_bwd", _p(y_pred), _p(y_true), _p(cls), cls_stride, _p(fc_w), _p(dlogit), _p(dcls), dcls_stride,
+             _p(dfc_w), _p(dfc_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), B, d, _stream(fc_w))
+    return dlogit
+
+
+# ----------------------------------------------------------------------------- K4 / K5
+def l2_reg(w, g, lam, reg_out, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_l2_reg", _p(w), _p(g), w.numel(), float(lam), _p(reg_out), _stream(w))
+
+
+def sumsq(g, out, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_sumsq", _p(g), g.numel(), _p(out), _stream(g))
+
+
+def clip_adam(w, g, m, v, norm_sq, max_norm, lr, beta1, beta2, eps, step, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_clip_adam", _p(w), _p(g), _p(m), _p(v), w.numel(), _p(norm_sq), float(max_norm), float(lr), float(beta1),
+             float(beta2), float(eps), int(step), _stream(w))
