@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — training samples/sec of the RAT_m2 hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of BaseModel.train_one_epoch on one synthetic batch that is already
+resident in HBM: zero_grad -> forward -> BCE(+L2) -> backward -> [all-reduce] -> clip_grad_norm(10) -> Adam.
+Workload at every N: BASELINE.json configs[1] (F=20 fields, 1M-row vocab, K=10 retrieved, d=64, batch 4096 PER GPU,
+weak scaling), KKBox hyper-parameters for what BASELINE.json leaves open.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "www24-rat_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, exact fp32
+PEAK_HBM_GBS = 8000.0             # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="synthetic_F20_V1M_K10_d64_B4096")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=256)
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of every C-ABI launch on torch's current stream (the stream the kernels are launched on)."""
+
+    def __init__(self, lib):
+        self.lib, self.inner, self.records, self.enabled = lib, lib.call, [], False
+        lib.call = self._call
+
+    def _call(self, name, *args):
+        if not self.enabled:
+            return self.inner(name, *args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        self.inner(name, *args)
+        e.record()
+        self.records.append((name, self._tag(name, args), s, e))
+
+    @staticmethod
+    def _tag(name, args):
+        if name in ("rat_attn_fwd", "rat_attn_bwd"):
+            smap = args[5 if name == "rat_attn_fwd" else 9]._obj
+            return "L%d" % smap.L
+        return ""
+
+    def summary(self, steps):
+        out = {}
+        for name, tag, s, e in self.records:
+            d = out.setdefault((name, tag), [0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+        return {k: dict(launches_per_step=v[0] / steps, avg_ms=v[1] / v[0], ms_per_step=v[1] / steps) for k, v in out.items()}
+
+
+def algorithmic_work(spec):
+    """FLOPs / bytes per LAUNCH of each hot kernel (padded MFMA lanes and recompute do not count;
+    backward = 2x forward)."""
+    B, F, K, d = spec["batch"], spec["F"], spec["K"], spec["d"]
+    T, S = K + 1, F + 1
+    I, H = spec["num_heads"] * spec["dim_head"], d * spec["scale_dim"]
+    tok = B * T * S
+    work = {}
+    for L in (S, T):
+        f = tok * (8 * d * I + 4 * I * L)
+        work[("rat_attn_fwd", "L%d" % L)] = ("mfma", f)
+        work[("rat_attn_bwd", "L%d" % L)] = ("mfma", 2 * f)
+    work[("rat_ffn_fwd", "")] = ("mfma", tok * 4 * d * H)
+    work[("rat_ffn_bwd", "")] = ("mfma", 2 * tok * 4 * d * H)
+    work[("rat_gather_fwd", "")] = ("hbm", B * (T * F * d * 4 + T * S * d * 4 + T * F * 4))
+    work[("rat_gather_bwd", "")] = ("hbm", B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4))
+    return work
+
+
+def cpu_baseline(spec, fm, batch_size, seed):
+    """The oracle (a port: oracle/rat_m2_oracle.py, pinned to the reference's golden vectors) timed on this box's host
+    cores on a bounded sample of the same workload: full training steps at a reduced batch."""
+    from oracle import rat_m2_oracle as orc
+    from rat_amd import synthetic
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = orc.Config(fields=orc.fields_from_specs(fm.feature_specs), embedding_dim=spec["d"], num_heads=spec["num_heads"],
+                     dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
+                     dnn_hidden_units=tuple(spec["dnn_hidden_units"]), batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],
+                     embedding_regularizer=0.0005, learning_rate=spec["learning_rate"])
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+    for name, shp in orc.parameter_shapes(cfg).items():         # reference-like init scales
+        if len(shp) == 2 and "embedding_layer" in name:
+            w[name] = torch.randn(shp, generator=g) * (1.0 if name.startswith("label") else 1e-4)
+        elif len(shp) == 2:
+            w[name] = torch.randn(shp, generator=g) * (2.0 / (shp[0] + shp[1])) ** 0.5
+        elif name.endswith("norm.weight") or (name.startswith("dnn.") and name.endswith("weight")):
+            w[name] = torch.ones(shp)
+        else:
+            w[name] = torch.zeros(shp)
+    layers, _ = orc.dnn_layout(cfg)
+    for _, bn in layers:
+        if bn is not None:
+            n = w["dnn.dnn.%d.weight" % bn].shape[0]
+            w["dnn.dnn.%d.running_mean" % bn] = torch.zeros(n)
+            w["dnn.dnn.%d.running_var" % bn] = torch.ones(n)
+            w["dnn.dnn.%d.num_batches_tracked" % bn] = torch.zeros((), dtype=torch.int64)
+    X, y, _, _ = synthetic.make_batch(spec, fm, seed=seed, batch=batch_size)
+    state = {}
+    w, *_ = orc.train_step(w, X, y, cfg, state, 1)                    # warm-up
+    t0 = time.perf_counter()
+    nsteps = 2
+    for s in range(nsteps):
+        w, *_ = orc.train_step(w, X, y, cfg, state, 2 + s)
+    dt = time.perf_counter() - t0
+    return dict(value=batch_size * nsteps / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d full training steps (fwd+loss+bwd+clip+Adam) of the CPU oracle at batch %d of the same workload "
+                       "(F=%d, K=%d, d=%d, %d-row vocab), %d torch threads" % (nsteps, batch_size, spec["F"], spec["K"], spec["d"],
+                                                                                spec["total_vocab"], torch.get_num_threads()))
+
+
+def main():
+    args = parse()
+    import torch.distributed as dist
+    from rat_amd import synthetic
+    from rat_amd.base_model import seed_everything
+    from rat_amd.model import RAT_m2
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    spec = synthetic.WORKLOADS[args.workload]
+    fm = synthetic.feature_map_for(args.workload, spec)
+    seed_everything(2021)
+    model = RAT_m2(fm, **synthetic.model_kwargs(spec, gpu=local_rank))
+    batch = synthetic.make_batch(spec, fm, seed=1000 + rank, device=model.device)
+    model.train()
+    timer = KernelTimer(model._lib)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step(batch)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        B = spec["batch"]
+        ksum = timer.summary(args.steps)
+        work = algorithmic_work(spec)
+        kernels = []
+        for key, st in sorted(ksum.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+            row = dict(kernel=key[0] + (":" + key[1] if key[1] else ""), launches_per_step=round(st["launches_per_step"], 2),
+                       avg_ms=round(st["avg_ms"], 4), ms_per_step=round(st["ms_per_step"], 4))
+            if key in work:
+                bound, amount = work[key]
+                if bound == "mfma":
+                    row.update(bound="mfma", achieved=round(amount / (st["avg_ms"] * 1e-3) / 1e12, 3), unit="TFLOP/s")
+                else:
+                    row.update(bound="hbm", achieved=round(amount / (st["avg_ms"] * 1e-3) / 1e9, 1), unit="GB/s")
+            kernels.append(row)
+        # dominant kernel = the C-ABI entry point with the most time per step (all its launches, both attention phases pooled)
+        pooled = {}
+        for key, st in ksum.items():
+            p = pooled.setdefault(key[0], dict(ms=0.0, n=0.0, amount=0.0, bound=None))
+            p["ms"] += st["ms_per_step"]
+            p["n"] += st["launches_per_step"]
+            if key in work:
+                p["bound"] = work[key][0]
+                p["amount"] += work[key][1] * st["launches_per_step"]
+        dom_name, dom = max(((k, v) for k, v in pooled.items() if v["bound"]), key=lambda kv: kv[1]["ms"])
+        avg_s = dom["ms"] / dom["n"] * 1e-3
+        per_launch = dom["amount"] / dom["n"]
+        if dom["bound"] == "mfma":
+            achieved, peak, unit = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        roofline = dict(kernel=dom_name, bound=dom["bound"], achieved=round(achieved, 3), peak=peak, unit=unit,
+                        frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(avg_s * 1e3, 4),
+                        launches_per_step=round(dom["n"], 2))
+        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64", value=round(B * world * args.steps / elapsed, 1),
+                      unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                      ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+                      dtype="f32", data="synthetic",
+                      config=dict(workload=args.workload, fields=spec["F"], vocab_rows=spec["total_vocab"], retrieved=spec["K"],
+                                  embedding_dim=spec["d"], batch_per_gpu=B, global_batch=B * world, heads=spec["num_heads"],
+                                  dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
+                                  dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam",
+                                  parallelism="dp%d" % world),
+                      roofline=roofline, kernels=kernels)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(spec, fm, args.cpu_batch, seed=1000)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

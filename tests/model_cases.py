@@ -1,0 +1,103 @@
+"""Model-level parity checks shared by the CPU (emulation) and GPU test files."""
+import os
+
+import numpy as np
+import torch
+
+import golden_cases as gc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build_model(case, gpu=-1, seed=None, **overrides):
+    from rat_amd.base_model import seed_everything
+    from rat_amd.features import FeatureMap
+    from rat_amd.model import RAT_m2
+    fm = FeatureMap.from_specs(case["name"], gc.feature_specs(case))
+    kw = gc.model_kwargs(case)
+    kw["gpu"] = gpu
+    kw["model_root"] = "/tmp/rat_amd_models/"
+    kw.update(overrides)
+    if seed is not None:
+        seed_everything(seed)
+    return RAT_m2(fm, **kw)
+
+
+def load_weights(model, case):
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = gc.make_weights(case, shapes)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in w.items()})
+
+
+def batch_of(case):
+    X, y, rv, rl = gc.make_inputs(case)
+    return (torch.from_numpy(X), torch.from_numpy(y), torch.from_numpy(rv), torch.from_numpy(rl))
+
+
+def noise_tensors(model):
+    """biases of a Linear feeding BatchNorm (true gradient 0; see tests/test_oracle_golden.py)."""
+    return {"dnn.dnn.%d.bias" % lin for lin, bn, _ in model._dnn_layers if bn is not None}
+
+
+def check_init(name, gpu):
+    case = gc.case_by_name(name)
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model = build_model(case, gpu=gpu, seed=case["init_seed"])
+    sd = model.state_dict()
+    assert int(gold["param_count"]) == model.count_parameters()
+    keys = [k for k in sd if not k.startswith("query_proj")]
+    assert sorted(keys) == sorted(k[len("init/"):].replace("#summary", "") for k in gold.files if k.startswith("init/"))
+    for k in keys:
+        gc.check_summary(gold, "init/" + k, sd[k].detach().cpu().numpy(), rtol=0, atol=0)
+
+
+def check_eval(name, gpu):
+    case = gc.case_by_name(name)
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model = build_model(case, gpu=gpu, seed=1)
+    load_weights(model, case)
+    model.eval()
+    with torch.no_grad():
+        out = model.forward(batch_of(case))
+    np.testing.assert_allclose(out["y_pred"].cpu().numpy(), gold["eval/y_pred"], rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(out["y_true"].cpu().numpy(), gold["eval/y_true"])
+
+
+def check_training(name, gpu):
+    case = gc.case_by_name(name)
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model = build_model(case, gpu=gpu, seed=1)
+    load_weights(model, case)
+    batch = batch_of(case)
+    model.train()
+    noise = noise_tensors(model)
+    for step in (1, 2):
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.optimizer.zero_grad()
+        loss = model.get_total_loss(batch)
+        assert abs(float(loss) - float(gold["train%d/loss" % step])) < 2e-6
+        loss.backward()
+        n = 0
+        for k, p in model.named_parameters():
+            if k.startswith("query_proj"):
+                assert p.grad is None
+                continue
+            gc.check_summary(gold, "train%d/grad/%s" % (step, k), p.grad.detach().cpu().numpy(), rtol=3e-4, atol=3e-6)
+            n += 1
+        assert n == sum(1 for k in gold.files if k.startswith("train%d/grad/" % step))
+        norm_sq = model.optimizer.clip_and_step(10.0)
+        gn = float(torch.sqrt(norm_sq)[0])
+        assert abs(gn - float(gold["train%d/gnorm" % step])) < 1e-5 * max(1.0, gn)
+        for k, v in model.state_dict().items():
+            if k.startswith("query_proj"):
+                assert torch.equal(v, before[k])
+                continue
+            if k in noise:
+                assert float((v - before[k]).abs().max()) <= 1.0001e-3
+                continue
+            atol = 3e-6 if not k.endswith("running_mean") else 3e-6 + step * 0.1 * 1e-3 * 1.01
+            gc.check_summary(gold, "train%d/post/%s" % (step, k), v.detach().cpu().numpy(), rtol=3e-4, atol=atol)
+    model.eval()
+    with torch.no_grad():
+        yp = model.forward(batch)["y_pred"].cpu().numpy()
+    np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=2e-3 if case["batch_norm"] else 3e-6)

@@ -45,3 +45,18 @@ def test_attn_fwd_bwd(emu, case, mode):
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128)])
 def test_ffn_fwd_bwd(emu, ntok, d, hidden):
     kc.check_ffn(emu, "cpu", ntok, d, hidden)
+
+
+@pytest.mark.parametrize("use_bn", [True, False])
+def test_bn_relu_colsum(emu, use_bn):
+    kc.check_bn_relu(emu, "cpu", 37, 40, use_bn)
+    kc.check_bn_relu(emu, "cpu", 9, 5, use_bn)
+
+
+@pytest.mark.parametrize("with_dnn,with_lr", [(True, True), (False, False)])
+def test_logit_fwd_bwd(emu, with_dnn, with_lr):
+    kc.check_logit(emu, "cpu", 9, 8, with_dnn, with_lr)
+
+
+def test_l2_sumsq_clip_adam(emu):
+    kc.check_optim(emu, "cpu", 777)

@@ -46,3 +46,18 @@ def test_attn_fwd_bwd(lib, case, mode):
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (100000, 64, 128), (5000, 40, 80)])
 def test_ffn_fwd_bwd(lib, ntok, d, hidden):
     kc.check_ffn(lib, "cuda", ntok, d, hidden)
+
+
+@pytest.mark.parametrize("use_bn", [True, False])
+def test_bn_relu_colsum(lib, use_bn):
+    kc.check_bn_relu(lib, "cuda", 4096, 400, use_bn)
+    kc.check_bn_relu(lib, "cuda", 9, 5, use_bn)
+
+
+@pytest.mark.parametrize("with_dnn,with_lr", [(True, True), (False, False)])
+def test_logit_fwd_bwd(lib, with_dnn, with_lr):
+    kc.check_logit(lib, "cuda", 1000, 64, with_dnn, with_lr)
+
+
+def test_l2_sumsq_clip_adam(lib):
+    kc.check_optim(lib, "cuda", 1000003)

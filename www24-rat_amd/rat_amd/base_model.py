@@ -1,0 +1,294 @@
+"""BaseModel — the training-loop surface the reference's driver calls (run_expid.py:75-102), re-hosted on the HIP
+hot path.  Same public methods, kwargs, log lines and checkpoint format as fuxictr/pytorch/models/base_model.py
+(cited per method); the arithmetic (loss, regulariser, clipping, Adam) runs in librat_hip.so over flat buffers.
+"""
+import logging
+import os
+import re
+
+import numpy as np
+import torch
+from torch import nn
+
+from .metrics import evaluate_metrics
+
+
+def get_device(gpu=-1):
+    """torch_utils.py:34-39."""
+    if gpu >= 0 and torch.cuda.is_available():
+        return torch.device("cuda:%d" % gpu)
+    return torch.device("cpu")
+
+
+def seed_everything(seed=1029):
+    """torch_utils.py:26-32."""
+    import random
+    random.seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+
+
+def parse_regularizer(reg):
+    """get_regularizer (torch_utils.py:65-81) restricted to what the HIP path implements: a float or "l2(x)"."""
+    if not reg:
+        return 0.0
+    if isinstance(reg, (int, float)):
+        return float(reg)
+    if isinstance(reg, str) and reg.startswith("l2("):
+        return float(reg.rstrip(")").split("(")[-1])
+    raise NotImplementedError("regularizer=%r: only l2 is implemented on the HIP path" % (reg,))
+
+
+class Monitor:
+    """fuxictr/utils.py:94-104."""
+
+    def __init__(self, kv):
+        self.kv_pairs = {kv: 1} if isinstance(kv, str) else kv
+
+    def get_value(self, logs):
+        return sum(logs.get(k, 0) * v for k, v in self.kv_pairs.items())
+
+
+class BaseModel(nn.Module):
+    def __init__(self, feature_map, model_id="BaseModel", gpu=-1, monitor="AUC", save_best_only=True,
+                 monitor_mode="max", patience=2, every_x_epochs=1, embedding_regularizer=None, net_regularizer=None,
+                 reduce_lr_on_plateau=True, embedding_initializer="torch.nn.init.normal_(std=1e-4)",
+                 retrieval_augmented=False, retrieval_configs=None, **kwargs):
+        super().__init__()
+        self.device = get_device(gpu)
+        self._monitor = Monitor(kv=monitor)
+        self._monitor_mode = monitor_mode
+        self._patience = patience
+        self._every_x_epochs = every_x_epochs
+        self._save_best_only = save_best_only
+        self._embedding_regularizer = embedding_regularizer
+        self._net_regularizer = net_regularizer
+        self._reduce_lr_on_plateau = reduce_lr_on_plateau
+        self._embedding_initializer = embedding_initializer
+        self._retrieval_augmented = retrieval_augmented
+        if retrieval_augmented:
+            assert retrieval_configs is not None, \
+                "retrieval-augmented mode requires a dataset with retrieval configurations"
+            self._labelwise_retrieval = retrieval_configs["label_wise"]
+        self._feature_map = feature_map
+        self.model_id = model_id
+        self.model_dir = os.path.join(kwargs["model_root"], feature_map.dataset_id)
+        self.checkpoint = os.path.abspath(os.path.join(self.model_dir, self.model_id + ".model"))
+        self._validation_metrics = kwargs["metrics"]
+        self._verbose = kwargs["verbose"]
+        self._max_gradient_norm = 10.0
+
+    # ---- compile / loss ------------------------------------------------------------------------------
+    def compile(self, optimizer, loss, lr):
+        """base_model.py:70-72.  "adam" selects the fused HIP clip+Adam; the loss must be BCE."""
+        from .optim import FusedClipAdam
+        if not (isinstance(optimizer, str) and optimizer.lower() == "adam"):
+            raise NotImplementedError("optimizer=%r: the HIP path implements Adam (every shipped config)" % (optimizer,))
+        if loss not in ("bce", "binary_crossentropy", "binary_cross_entropy"):
+            raise NotImplementedError("loss=%r: the HIP path implements binary cross-entropy" % (loss,))
+        self.optimizer = FusedClipAdam(self, lr=lr)
+        self.loss_fn = "binary_cross_entropy"
+
+    def add_loss(self, inputs, reduction="mean"):
+        """base_model.py:74-77."""
+        assert reduction == "mean"
+        return self._loss_terms(inputs, with_reg=False)[1]
+
+    def add_regularization(self):
+        """base_model.py:79-94: (lambda/2)*||W||^2 over the "embedding_layer" tensors (and net_regularizer over the rest)."""
+        return self._regularization_value()
+
+    def get_total_loss(self, inputs):
+        """base_model.py:97-99: BCE + regulariser, one autograd node whose backward is the HIP backward pass."""
+        _, loss, reg = self._loss_terms(inputs, with_reg=True)
+        total = loss + reg
+        world = self._world_size()
+        return total / world if world > 1 else total
+
+    # ---- init ----------------------------------------------------------------------------------------
+    def reset_parameters(self):
+        """base_model.py:101-123: N(0, std) on every nn.Embedding that lives in an nn.ModuleDict (all rows but
+        the last when a padding row exists), xavier_normal_ + zero bias on every nn.Linear.  Visiting order is
+        nn.Module.apply's, so the RNG stream matches the reference's for an identical module tree."""
+        init = self._embedding_initializer
+        std = None
+        if init is not None:
+            m = re.fullmatch(r"torch\.nn\.init\.normal_\(std=([0-9.eE+-]+)\)", init.replace(" ", ""))
+            if m is None:
+                raise NotImplementedError("embedding_initializer={} is not supported.".format(init))
+            std = float(m.group(1))
+
+        def visit(mod):
+            if type(mod) == nn.ModuleDict:
+                for _, v in mod.items():
+                    if type(v) == nn.Embedding and std is not None:
+                        target = v.weight[0:-1, :] if v.padding_idx is not None else v.weight
+                        torch.nn.init.normal_(target, std=std)
+            if type(mod) == nn.Linear:
+                nn.init.xavier_normal_(mod.weight)
+                if mod.bias is not None:
+                    mod.bias.data.fill_(0)
+        with torch.no_grad():
+            self.apply(visit)
+
+    def inputs_to_device(self, inputs):
+        """base_model.py:125-139 — kept for API compatibility; the HIP path uses _prepare_batch instead."""
+        if self._retrieval_augmented:
+            X, y, retrieved_values, retrieved_lens = inputs
+            self.batch_size = y.size(0)
+            return (X.to(self.device), y.float().unsqueeze(-1).to(self.device), retrieved_values.to(self.device),
+                    retrieved_lens.int().to(self.device))
+        X, y = inputs
+        self.batch_size = y.size(0)
+        return X.to(self.device), y.float().unsqueeze(-1).to(self.device)
+
+    def model_to_device(self):
+        self.to(device=self.device)
+        self._after_device_move()
+
+    # ---- fit -----------------------------------------------------------------------------------------
+    def on_batch_end(self, batch, logs={}):
+        self._total_batches += 1
+        if (batch + 1) % self._every_x_batches == 0 or (batch + 1) % self._batches_per_epoch == 0:
+            epoch = round(float(self._total_batches) / self._batches_per_epoch, 2)
+            val_logs = self.evaluate_generator(self.valid_gen)
+            self.checkpoint_and_earlystop(epoch, val_logs)
+            self.train()
+            logging.info("--- {}/{} batches finished ---".format(batch + 1, self._batches_per_epoch))
+
+    def lr_decay(self, factor=0.1, min_lr=1e-6):
+        reduced_lr = None
+        for group in self.optimizer.param_groups:
+            reduced_lr = max(group["lr"] * factor, min_lr)
+            group["lr"] = reduced_lr
+        return reduced_lr
+
+    def checkpoint_and_earlystop(self, epoch, logs, min_delta=1e-6):
+        value = self._monitor.get_value(logs)
+        worse = (value > self._best_metric - min_delta) if self._monitor_mode == "min" else \
+                (value < self._best_metric + min_delta)
+        if worse:
+            self._stopping_steps += 1
+            logging.info("Monitor({}) STOP: {:.6f} !".format(self._monitor_mode, value))
+            if self._reduce_lr_on_plateau:
+                logging.info("Reduce learning rate on plateau: {:.6f}".format(self.lr_decay()))
+        else:
+            self._stopping_steps = 0
+            self._best_metric = value
+            if self._save_best_only:
+                logging.info("Save best model: monitor({}): {:.6f}".format(self._monitor_mode, value))
+                self.save_weights(self.checkpoint)
+        if self._stopping_steps * self._every_x_epochs >= self._patience:
+            self._stop_training = True
+            logging.info("Early stopping at epoch={:g}".format(epoch))
+        if not self._save_best_only:
+            self.save_weights(self.checkpoint)
+
+    def fit_generator(self, data_generator, epochs=1, validation_data=None, verbose=0, max_gradient_norm=10., **kwargs):
+        """base_model.py:181-211."""
+        self.valid_gen = validation_data
+        self._max_gradient_norm = max_gradient_norm
+        self._best_metric = np.inf if self._monitor_mode == "min" else -np.inf
+        self._stopping_steps = 0
+        self._total_batches = 0
+        self._batches_per_epoch = len(data_generator)
+        self._every_x_batches = int(np.ceil(self._every_x_epochs * self._batches_per_epoch))
+        self._stop_training = False
+        self._verbose = verbose
+        logging.info("Start training: {} batches/epoch".format(self._batches_per_epoch))
+        logging.info("************ Epoch=1 start ************")
+        for epoch in range(epochs):
+            epoch_loss = self.train_one_epoch(data_generator, epoch)
+            logging.info("Train loss: {:.6f}".format(epoch_loss))
+            if self._stop_training:
+                break
+            logging.info("************ Epoch={} end ************".format(epoch + 1))
+        logging.info("Training finished.")
+
+    def train_step(self, batch_data):
+        """One iteration of base_model.py:220-226: zero_grad -> loss -> backward -> clip(10.) -> Adam.
+        Returns the (device) loss tensor; no host synchronisation."""
+        self.optimizer.zero_grad()
+        loss = self.get_total_loss(batch_data)
+        loss.backward()
+        self._exchange_gradients()
+        self.optimizer.clip_and_step(self._max_gradient_norm)
+        return loss.detach()
+
+    def train_one_epoch(self, data_generator, epoch):
+        self.train()
+        running = torch.zeros((), device=self.device)
+        for batch_index, batch_data in enumerate(data_generator):
+            running += self.train_step(batch_data) * self._world_size()
+            if self.valid_gen is not None:
+                self.on_batch_end(batch_index)
+            else:
+                self._total_batches += 1
+            if self._stop_training:
+                break
+        return float(running.item()) / self._batches_per_epoch
+
+    # ---- eval ----------------------------------------------------------------------------------------
+    def evaluate_generator(self, data_generator):
+        """base_model.py:232-247."""
+        self.eval()
+        preds, trues = [], []
+        with torch.no_grad():
+            for batch_data in data_generator:
+                out = self.forward(batch_data)
+                preds.append(out["y_pred"])
+                trues.append(out["y_true"])
+        y_pred = torch.cat(preds).double().cpu().numpy().reshape(-1)
+        y_true = torch.cat(trues).double().cpu().numpy().reshape(-1)
+        return self.evaluate_metrics(y_true, y_pred, self._validation_metrics)
+
+    def evaluate_metrics(self, y_true, y_pred, metrics):
+        return evaluate_metrics(y_true, y_pred, metrics)
+
+    def predict_generator(self, data_generator):
+        """base_model.py:252-273."""
+        self.eval()
+        preds = []
+        with torch.no_grad():
+            for batch_data in data_generator:
+                assert batch_data[0].ndim == 3, "retrieval augmented mode requires input_shape like [Bx(1+K)xF]"
+                preds.append(self.forward(batch_data)["y_pred"])
+        return torch.cat(preds).double().cpu().numpy().reshape(-1)
+
+    def save_weights(self, checkpoint):
+        os.makedirs(os.path.dirname(os.path.abspath(checkpoint)), exist_ok=True)
+        torch.save(self.state_dict(), checkpoint)
+
+    def load_weights(self, checkpoint):
+        state = torch.load(checkpoint, map_location="cpu")
+        self.load_state_dict(state)          # copies in place: the flat parameter buffer stays intact
+
+    def get_output_activation(self, task="binary_classification"):
+        if task == "binary_classification":
+            return nn.Sigmoid()
+        raise NotImplementedError("task={} is not supported.".format(task))
+
+    def count_parameters(self, count_embedding=True):
+        """base_model.py:294-301."""
+        total = 0
+        for name, p in self.named_parameters():
+            if not count_embedding and "embedding" in name:
+                continue
+            if p.requires_grad:
+                total += p.numel()
+        logging.info("Total number of parameters: {}.".format(total))
+        return total
+
+    # ---- hooks the concrete model fills in -----------------------------------------------------------
+    def _after_device_move(self):
+        pass
+
+    def _world_size(self):
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _exchange_gradients(self):
+        pass

@@ -1,0 +1,458 @@
+"""RAT_m2 — the reference's default model (fuxictr/pytorch/models/RAT_m2.py:28-152) as a FuxiCTR model plugin
+whose forward/backward is the hand-written HIP path of librat_hip.so.
+
+What is kept from the reference (so that it drops in):
+  * the constructor signature and every kwarg the shipped configs pass (RAT_m2.py:29-56, base_model.py:32-46);
+  * the module tree, hence the ``state_dict`` keys/shapes (checkpoints load both ways) and, because modules are
+    created and re-initialised in the same order, the same initial weights under the same seed;
+  * ``forward(inputs) -> {"y_true": [B,1], "y_pred": [B,1]}`` on the DataLoader's 4-tuple
+    (fuxictr/pytorch/data_generator.py:66-78) and the BaseModel training surface.
+What is different: the torch modules below only HOLD parameters — none of their ``forward`` methods is ever called.
+All parameters with a gradient live in ONE flat fp32 buffer (tables first), the whole forward+backward is a single
+autograd node, and its backward fills one flat gradient buffer that the fused clip+Adam consumes.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import get_lib
+from .base_model import BaseModel, parse_regularizer
+from .features import field_infos
+
+
+# ------------------------------------------------------------------------------------ parameter containers
+class _EmbeddingDict(nn.Module):
+    """EmbeddingDictLayer's parameters (fuxictr/pytorch/layers/embedding.py:46-95): one nn.Embedding per field."""
+
+    def __init__(self, feature_map, width):
+        super().__init__()
+        self.embedding_layer = nn.ModuleDict()
+        for name, spec in feature_map.feature_specs.items():
+            if spec.get("embedding_dim", width) != width and width != 1:
+                raise NotImplementedError("per-field embedding_dim is outside the RAT_m2 hot path")
+            if spec["type"] == "categorical":
+                pad = spec.get("padding_idx", None)
+            elif spec["type"] == "sequence":
+                pad = spec["vocab_size"] - 1
+            else:
+                raise NotImplementedError("feature type %r is outside the RAT_m2 hot path" % spec["type"])
+            self.embedding_layer[name] = nn.Embedding(spec["vocab_size"], width, padding_idx=pad)
+
+
+class _EmbeddingLayer(nn.Module):
+    def __init__(self, feature_map, width):
+        super().__init__()
+        self.embedding_layer = _EmbeddingDict(feature_map, width)
+
+
+class _LRLayer(nn.Module):
+    """LR_Layer with use_bias=False (shallow.py:23-34, RAT_m2.py:85-86)."""
+
+    def __init__(self, feature_map):
+        super().__init__()
+        self.bias = None
+        self.embedding_layer = _EmbeddingLayer(feature_map, 1)
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, heads, dim_head, dropout):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.dim_head = heads, dim_head
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        project_out = not (heads == 1 and dim_head == dim)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
+
+
+class _PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+class _FeedForward(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(0.0), nn.Linear(hidden, dim), nn.Dropout(0.0))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, dim_head, dropout, hidden):
+        super().__init__()
+        self.cross_attention = _PreNorm(dim, _Attention(dim, heads, dim_head, dropout))
+        self.intra_attention = _PreNorm(dim, _Attention(dim, heads, dim_head, dropout))
+        self.mlp = _FeedForward(dim, hidden)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, dim, heads, dim_head, dropout, depth, hidden):
+        super().__init__()
+        self.encoder = nn.ModuleList([_Block(dim, heads, dim_head, dropout, hidden) for _ in range(depth)])
+
+
+class _MLP(nn.Module):
+    """MLP_Layer's module list (deep.py:108-139): [Linear, (BatchNorm1d), act, (Dropout)]* + Linear(.,1)."""
+
+    def __init__(self, input_dim, hidden_units, activation, dropout, batch_norm):
+        super().__init__()
+        if not isinstance(activation, str) or activation.lower() != "relu":
+            raise NotImplementedError("dnn_activations=%r: the HIP head fuses ReLU (every shipped config)" % (activation,))
+        rates = dropout if isinstance(dropout, list) else [dropout] * len(hidden_units)
+        mods = []
+        widths = [input_dim] + list(hidden_units)
+        for j in range(len(widths) - 1):
+            mods.append(nn.Linear(widths[j], widths[j + 1], bias=True))
+            if batch_norm:
+                mods.append(nn.BatchNorm1d(widths[j + 1]))
+            mods.append(nn.ReLU())
+            if rates[j] > 0:
+                mods.append(nn.Dropout(p=rates[j]))
+        mods.append(nn.Linear(widths[-1], 1, bias=True))
+        self.dnn = nn.Sequential(*mods)
+
+
+# ------------------------------------------------------------------------------------ the autograd node
+class _RATFunction(torch.autograd.Function):
+    """forward = K1 -> depth x (intra attn, cross attn, FFN) -> head -> sigmoid/BCE (+ L2 value);
+    backward = the same chain reversed, writing every parameter gradient into one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, model, batch, with_reg, *params):
+        y_pred, loss, reg, saved = model._run_forward(batch, save=True, with_reg=with_reg)
+        ctx.model, ctx.saved_state, ctx.with_reg = model, saved, with_reg
+        ctx.mark_non_differentiable(y_pred)
+        return y_pred, loss, reg
+
+    @staticmethod
+    def backward(ctx, _g_pred, g_loss, g_reg):
+        grads = ctx.model._run_backward(ctx.saved_state, float(g_loss), float(g_reg) if ctx.with_reg else 0.0)
+        ctx.saved_state = None
+        return (None, None, None) + tuple(grads)
+
+
+class RAT_m2(BaseModel):
+    def __init__(self, feature_map, model_id="RAT_m2", gpu=-1, task="binary_classification", learning_rate=1e-3,
+                 embedding_dim=10, dnn_hidden_units=[64, 64, 64], dnn_activations="ReLU", attention_layers=2,
+                 num_heads=1, attention_dim=8, net_dropout=0, batch_norm=False, layer_norm=False, use_scale=False,
+                 use_wide=False, use_residual=True, embedding_regularizer=None, net_regularizer=None, depth=4, heads=4,
+                 pool="cls", dim_head=10, dropout=0., emb_dropout=0., scale_dim=4, **kwargs):
+        super().__init__(feature_map, model_id=model_id, gpu=gpu, embedding_regularizer=embedding_regularizer,
+                         net_regularizer=net_regularizer, **kwargs)
+        if dropout and dropout > 0:
+            raise NotImplementedError("attention dropout > 0 is not implemented (every shipped config uses 0)")
+        d, nf = embedding_dim, feature_map.num_fields
+        self._cfg = dict(d=d, heads=num_heads, dh=dim_head, depth=depth, hidden=d * scale_dim, nf=nf,
+                         batch_norm=bool(batch_norm), use_wide=bool(use_wide), emb_dropout=float(emb_dropout),
+                         net_dropout=net_dropout, lam_emb=parse_regularizer(embedding_regularizer),
+                         lam_net=parse_regularizer(net_regularizer))
+        self._fields = field_infos(feature_map)
+        # --- module tree in the reference's registration order (RAT_m2.py:63-98) -------------------------
+        self.embedding_layer = _EmbeddingLayer(feature_map, d)
+        self.label_embedding_layer = nn.Embedding(num_embeddings=3, embedding_dim=d)
+        self.query_proj = nn.Linear(d * nf, d * nf)           # dead in the reference too (RAT_m2.py:66-67), kept for state_dict
+        self.query_dropout = nn.Dropout(net_dropout) if (not isinstance(net_dropout, list) and net_dropout > 0) else None
+        kwargs["retrieval_configs"]["topK"]                    # the reference requires the key (RAT_m2.py:73)
+        torch.randn(1, 1, d)                                   # `space_token` (RAT_m2.py:74): unregistered, but it advances the RNG
+        self.encoder = _Encoder(d, num_heads, dim_head, dropout, depth, d * scale_dim)
+        self.dropout = nn.Dropout(emb_dropout)
+        self.lr_layer = _LRLayer(feature_map) if use_wide else None
+        self.dnn = _MLP(d * nf, dnn_hidden_units, dnn_activations, net_dropout, batch_norm) if dnn_hidden_units else None
+        self.fc = nn.Linear(d, 1)
+        self.output_activation = self.get_output_activation(task)
+        self._flat = None
+        self._lib = None
+        self._last_gflat = None
+        self._ws = {}
+        self.compile(kwargs["optimizer"], loss=kwargs["loss"], lr=learning_rate)
+        self.reset_parameters()
+        self.model_to_device()
+
+    # ------------------------------------------------------------------------------ flat parameter buffer
+    def _trainable(self):
+        """(name, param) of every tensor that receives a gradient, "embedding_layer" tensors first."""
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad and not n.startswith("query_proj")]
+        emb = [(n, p) for n, p in named if "embedding_layer" in n]
+        rest = [(n, p) for n, p in named if "embedding_layer" not in n]
+        return emb, rest
+
+    def _after_device_move(self):
+        """Re-home every trainable tensor into one flat buffer (16-byte aligned slots) and cache kernel descriptors."""
+        emb, rest = self._trainable()
+        offsets, off = OrderedDict(), 0
+        for n, p in emb:
+            offsets[n] = off
+            off += (p.numel() + 3) // 4 * 4
+        self._n_emb = off
+        for n, p in rest:
+            offsets[n] = off
+            off += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for n, p in emb + rest:
+                view = flat[offsets[n]:offsets[n] + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+        self._flat, self._offsets, self._order = flat, offsets, [n for n, _ in emb + rest]
+        self._params = OrderedDict(emb + rest)
+        self._lib = get_lib() if self._lib is None else self._lib
+        self._build_descriptors()
+
+    def _p(self, name):
+        return self._params[name].data
+
+    def _build_descriptors(self):
+        c, dev = self._cfg, self.device
+        emb_prefix = "embedding_layer.embedding_layer.embedding_layer."
+        self._tables = [self._p(emb_prefix + f.name + ".weight") for f in self._fields]
+        self._ftab = ops.field_table(self._fields, self._tables, dev)
+        if c["use_wide"]:
+            lr_prefix = "lr_layer.embedding_layer.embedding_layer.embedding_layer."
+            self._lr_tables = [self._p(lr_prefix + f.name + ".weight") for f in self._fields]
+            self._lr_ftab = ops.field_table(self._fields, self._lr_tables, dev)
+        else:
+            self._lr_tables, self._lr_ftab = None, None
+        self._blocks = []
+        for i in range(c["depth"]):
+            blk = {}
+            for which in ("intra", "cross"):
+                p = "encoder.encoder.%d.%s_attention." % (i, which)
+                has_out = (p + "fn.to_out.0.weight") in self._params
+                names = [p + "norm.weight", p + "norm.bias", p + "fn.to_qkv.weight",
+                         p + "fn.to_out.0.weight" if has_out else None, p + "fn.to_out.0.bias" if has_out else None]
+                blk[which] = (names, ops.attn_params(*[self._p(n) if n else None for n in names]))
+            p = "encoder.encoder.%d.mlp.net." % i
+            blk["ffn"] = [p + "0.weight", p + "0.bias", p + "3.weight", p + "3.bias"]
+            self._blocks.append(blk)
+        # DNN head layout: [(linear_idx, bn_idx or None, dropout_p)], out linear idx
+        self._dnn_layers, self._dnn_out = [], None
+        if self.dnn is not None:
+            mods = list(self.dnn.dnn)
+            j = 0
+            while j < len(mods) - 1:
+                lin, bn, pdrop = j, None, 0.0
+                j += 1
+                if isinstance(mods[j], nn.BatchNorm1d):
+                    bn = j
+                    j += 1
+                j += 1                                        # ReLU
+                if j < len(mods) and isinstance(mods[j], nn.Dropout):
+                    pdrop = mods[j].p
+                    j += 1
+                self._dnn_layers.append((lin, bn, pdrop))
+            self._dnn_out = len(mods) - 1
+
+    def _gflat_view(self, gflat, name):
+        p = self._params[name]
+        o = self._offsets[name]
+        return gflat[o:o + p.numel()].view_as(p)
+
+    def _gather_flat_grad(self):
+        """The flat gradient the last backward produced, or one assembled from p.grad if autograd copied them."""
+        g = self._last_gflat
+        names = self._order
+        if g is not None and all(self._params[n].grad is not None and
+                                 self._params[n].grad.data_ptr() == g.data_ptr() + 4 * self._offsets[n] for n in names):
+            return g
+        if all(self._params[n].grad is None for n in names):
+            return None
+        g = torch.zeros_like(self._flat)
+        for n in names:
+            if self._params[n].grad is not None:
+                self._gflat_view(g, n).copy_(self._params[n].grad)
+        return g
+
+    def _exchange_gradients(self):
+        """Data parallelism: ONE all-reduce (RCCL over xGMI) of the whole flat gradient bucket."""
+        import torch.distributed as dist
+        if self._world_size() > 1:
+            g = self._gather_flat_grad()
+            if g is not None:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                if g is not self._last_gflat:
+                    for n in self._order:
+                        self._params[n].grad = self._gflat_view(g, n)
+                    self._last_gflat = g
+
+    # ------------------------------------------------------------------------------ batch plumbing
+    def _prepare_batch(self, inputs):
+        """inputs_to_device (base_model.py:125-133) + the slicing of RAT_m2.forward lines 110-116: ids become int32
+        once, on the host side of the boundary; the target row's label token is id 2."""
+        X, y = inputs[0], inputs[1]
+        if len(inputs) >= 4:
+            assert inputs[3].ndim == 1, "RIM does not support label-wise retrieval-enhanced training"
+        assert X.ndim == 3, "retrieval augmented mode requires input_shape like [Bx(1+K)xF]"
+        idx = X.to(torch.int32) if X.dtype != torch.int32 else X
+        labels = y.to(torch.int32).clone()
+        labels[:, 0] = 2
+        y_true = y[:, 0].to(torch.float32)
+        dev = self.device
+        return (idx.contiguous().to(dev, non_blocking=True), labels.contiguous().to(dev, non_blocking=True),
+                y_true.contiguous().to(dev, non_blocking=True))
+
+    # ------------------------------------------------------------------------------ public forward
+    def forward(self, inputs):
+        """RAT_m2.forward (RAT_m2.py:104-152)."""
+        batch = self._prepare_batch(inputs)
+        self.batch_size = batch[0].shape[0]
+        if torch.is_grad_enabled() and self.training:
+            y_pred, _, _ = _RATFunction.apply(self, batch, False, *[self._params[n] for n in self._order])
+        else:
+            y_pred, _, _, _ = self._run_forward(batch, save=False, with_reg=False)
+        return {"y_true": batch[2].unsqueeze(-1), "y_pred": y_pred}
+
+    def _loss_terms(self, inputs, with_reg):
+        batch = self._prepare_batch(inputs)
+        self.batch_size = batch[0].shape[0]
+        if torch.is_grad_enabled():
+            y_pred, loss, reg = _RATFunction.apply(self, batch, with_reg, *[self._params[n] for n in self._order])
+        else:
+            y_pred, loss, reg, _ = self._run_forward(batch, save=False, with_reg=with_reg)
+        return y_pred, loss, reg
+
+    def _regularization_value(self):
+        c = self._cfg
+        reg = torch.zeros(1, dtype=torch.float32, device=self.device)
+        if c["lam_emb"] > 0 and self._n_emb > 0:
+            ops.sumsq(self._flat[:self._n_emb], reg, lib=self._lib)
+            reg = reg * (0.5 * c["lam_emb"])
+        if c["lam_net"] > 0:
+            rest = torch.zeros(1, dtype=torch.float32, device=self.device)
+            ops.sumsq(self._flat[self._n_emb:], rest, lib=self._lib)
+            reg = reg + rest * (0.5 * c["lam_net"])
+        return reg[0]
+
+    # ------------------------------------------------------------------------------ the HIP pipeline
+    def _run_forward(self, batch, save, with_reg):
+        c, lib = self._cfg, self._lib
+        idx, labels, y_true = batch
+        B, T, L = idx.shape
+        d, F, H, heads, dh = c["d"], c["nf"], c["hidden"], c["heads"], c["dh"]
+        S = F + 1
+        training = self.training
+        if training and (c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers)):
+            raise NotImplementedError("emb_dropout / net_dropout > 0 in training mode is not implemented yet")
+        x0 = ops.gather_fwd(idx, labels, self._ftab, F, self._p("label_embedding_layer.weight"), B, T, L, d, lib=lib)
+        saved = {"batch": batch, "dims": (B, T, L, S), "blocks": [], "dnn": []}
+        # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
+        dnn_out = None
+        if self.dnn is not None:
+            mods = self.dnn.dnn
+            a_prev, lda, K = x0[:, 0, 1:, :], T * S * d, F * d
+            for lin, bn, _ in self._dnn_layers:
+                W, bvec = mods[lin].weight.data, mods[lin].bias.data
+                N = W.shape[0]
+                z = torch.empty((B, N), dtype=torch.float32, device=x0.device)
+                ops.sgemm(0, 1, B, N, K, a_prev, lda, W, K, z, N, bias=bvec, lib=lib)
+                if bn is not None:
+                    m = mods[bn]
+                    a, sm, sr = ops.bn_relu_fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
+                                                eps=m.eps, momentum=m.momentum, lib=lib)
+                    if training:
+                        m.num_batches_tracked += 1
+                else:
+                    a, sm, sr = ops.bn_relu_fwd(z, None, None, None, None, training, False, lib=lib)
+                if save:
+                    saved["dnn"].append((a_prev, lda, K, z, a, sm, sr))
+                a_prev, lda, K = a, N, N
+            W, bvec = mods[self._dnn_out].weight.data, mods[self._dnn_out].bias.data
+            dnn_out = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
+            ops.sgemm(0, 1, B, 1, K, a_prev, lda, W, K, dnn_out, 1, bias=bvec, lib=lib)
+            if save:
+                saved["dnn_last"] = (a_prev, lda, K)
+        # ---- encoder: depth x (intra attention, cross attention, FFN), each with its residual
+        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        x = x0
+        for bi, blk in enumerate(self._blocks):
+            inplace = (not save) and bi > 0                    # eval: x0 must survive (DNN input), later grids are reused
+            xa, o1, l1 = ops.attn_fwd(x, blk["intra"][1], imap, d, heads, dh, save=save, out=x if inplace else None, lib=lib)
+            xb, o2, l2 = ops.attn_fwd(xa, blk["cross"][1], cmap, d, heads, dh, save=save, out=xa if not save else None, lib=lib)
+            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+            xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, lib=lib)
+            if save:
+                saved["blocks"].append((x, o1, l1, xa, o2, l2, xb))
+            x = xc
+        # ---- logit = fc(cls) + dnn + wide ; sigmoid ; BCE
+        loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
+        y_pred = ops.logit_fwd(x, T * S * d, self.fc.weight.data, self.fc.bias.data, dnn_out, self._lr_ftab, F, idx, T * L,
+                               y_true, loss, B, d, lib=lib)
+        reg = self._regularization_value() if with_reg else torch.zeros((), dtype=torch.float32, device=x0.device)
+        if save:
+            saved["x_final"], saved["y_pred"] = x, y_pred
+        return y_pred, loss[0], reg, saved
+
+    def _workspace(self, key, nbytes):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() * 4 < nbytes:
+            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _run_backward(self, saved, g_loss, g_reg):
+        c, lib = self._cfg, self._lib
+        idx, labels, y_true = saved["batch"]
+        B, T, L, S = saved["dims"]
+        d, F, H, heads, dh = c["d"], c["nf"], c["hidden"], c["heads"], c["dh"]
+        dev = self._flat.device
+        gflat = torch.zeros_like(self._flat)
+        G = lambda name: self._gflat_view(gflat, name)          # noqa: E731
+        x_final, y_pred = saved["x_final"], saved["y_pred"]
+        # ---- head
+        dx = torch.zeros_like(x_final)
+        lr_gftab = None
+        if c["use_wide"]:
+            lr_prefix = "lr_layer.embedding_layer.embedding_layer.embedding_layer."
+            lr_gftab = ops.field_table(self._fields, [G(lr_prefix + f.name + ".weight") for f in self._fields], dev)
+        dlogit = ops.logit_bwd(y_pred, y_true, x_final, T * S * d, self.fc.weight.data, dx, T * S * d, G("fc.weight"),
+                               G("fc.bias"), lr_gftab, F, idx, T * L, g_loss, B, d, lib=lib)
+        dflat = None
+        if self.dnn is not None:
+            mods = self.dnn.dnn
+            pre = "dnn.dnn.%d." % self._dnn_out
+            a_prev, lda, K = saved["dnn_last"]
+            W = mods[self._dnn_out].weight.data
+            ops.sgemm(1, 0, 1, K, B, dlogit, 1, a_prev, lda, G(pre + "weight"), K, lib=lib)       # dW = dlogit^T a
+            ops.colsum(dlogit, 1, G(pre + "bias"), B, 1, lib=lib)
+            da = torch.empty((B, K), dtype=torch.float32, device=dev)
+            ops.sgemm(0, 0, B, K, 1, dlogit, 1, W, K, da, K, lib=lib)                             # da = dlogit W
+            for (lin, bn, _), (a_in, lda_in, K_in, z, a, sm, sr) in zip(reversed(self._dnn_layers), reversed(saved["dnn"])):
+                N = z.shape[1]
+                if bn is not None:
+                    m = mods[bn]
+                    dz = ops.bn_relu_bwd(z, a, da, m.weight.data, sm, sr, G("dnn.dnn.%d.weight" % bn), G("dnn.dnn.%d.bias" % bn),
+                                         True, lib=lib)
+                else:
+                    dz = ops.bn_relu_bwd(z, a, da, None, None, None, None, None, False, lib=lib)
+                pre = "dnn.dnn.%d." % lin
+                ops.sgemm(1, 0, N, K_in, B, dz, N, a_in, lda_in, G(pre + "weight"), K_in, lib=lib)  # dW = dz^T a_in
+                ops.colsum(dz, N, G(pre + "bias"), B, N, lib=lib)
+                da = torch.empty((B, K_in), dtype=torch.float32, device=dev)
+                ops.sgemm(0, 0, B, K_in, N, dz, N, mods[lin].weight.data, K_in, da, K_in, lib=lib)   # da_in = dz W
+            dflat = da                                                                             # [B, F*d]
+        # ---- encoder, reversed
+        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
+        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
+        for blk, (x_in, o1, l1, xa, o2, l2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
+            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+            gw = [G(n) for n in blk["ffn"]]
+            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, lib=lib)
+            for which, xin, o, l, smap in (("cross", xa, o2, l2, cmap), ("intra", x_in, o1, l1, imap)):
+                names, params = blk[which]
+                grads = ops.attn_params(*[G(n) if n else None for n in names])
+                dx, _ = ops.attn_bwd(xin, dx, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+        # ---- embedding tables
+        emb_prefix = "embedding_layer.embedding_layer.embedding_layer."
+        gftab = ops.field_table(self._fields, [G(emb_prefix + f.name + ".weight") for f in self._fields], dev)
+        ops.gather_bwd(dx, dflat, idx, labels, gftab, F, G("label_embedding_layer.weight"), B, T, L, d, lib=lib)
+        # ---- L2 regulariser gradient (base_model.py:79-94): lambda * W on the "embedding_layer" tensors
+        if g_reg != 0.0:
+            if c["lam_emb"] > 0 and self._n_emb > 0:
+                ops.l2_reg(self._flat[:self._n_emb], gflat[:self._n_emb], c["lam_emb"] * g_reg, None, lib=lib)
+            if c["lam_net"] > 0:
+                ops.l2_reg(self._flat[self._n_emb:], gflat[self._n_emb:], c["lam_net"] * g_reg, None, lib=lib)
+        self._last_gflat = gflat
+        return [self._gflat_view(gflat, n) for n in self._order]

@@ -1,0 +1,59 @@
+"""Deterministic synthetic workloads shaped like BASELINE.json's configs: uniform ids per field,
+Bernoulli(0.5) labels, reference init rules under seed_everything(2021).  No dataset is available offline."""
+from collections import OrderedDict
+
+import torch
+
+from .features import FeatureMap
+
+KKBOX_HYPER = dict(num_heads=8, dim_head=10, depth=4, scale_dim=2, dnn_hidden_units=[400, 400, 400], batch_norm=True,
+                   use_wide=True, learning_rate=1e-3)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the single-GPU configuration the metric is quoted on
+    "synthetic_F20_V1M_K10_d64_B4096": dict(F=20, total_vocab=1_000_000, K=10, d=64, batch=4096, **KKBOX_HYPER),
+    # BASELINE.json configs[0] shape (CPU-runnable plumbing case)
+    "mltag_like_K10_d16_B256": dict(F=3, total_vocab=90_000, K=10, d=16, batch=256, num_heads=2, dim_head=10, depth=4,
+                                    scale_dim=4, dnn_hidden_units=[400, 400, 400], batch_norm=False, use_wide=True,
+                                    learning_rate=1e-3),
+    # tiny: smoke / CI
+    "tiny": dict(F=5, total_vocab=500, K=3, d=16, batch=32, num_heads=2, dim_head=10, depth=2, scale_dim=2,
+                 dnn_hidden_units=[32, 16], batch_norm=True, use_wide=True, learning_rate=1e-3),
+}
+
+
+def feature_map_for(name, spec):
+    vocab = spec["total_vocab"] // spec["F"]
+    specs = OrderedDict()
+    for i in range(spec["F"]):
+        specs["c%02d" % i] = {"source": "", "type": "categorical", "vocab_size": vocab, "index": i}
+    return FeatureMap.from_specs(name, specs)
+
+
+def model_kwargs(spec, gpu, embedding_regularizer=0.0005, model_root="/tmp/rat_amd_models/"):
+    return dict(model_id="RAT_m2_bench", gpu=gpu, task="binary_classification", learning_rate=spec["learning_rate"],
+                embedding_dim=spec["d"], dnn_hidden_units=list(spec["dnn_hidden_units"]), dnn_activations="relu",
+                num_heads=spec["num_heads"], dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
+                dropout=0.0, emb_dropout=0.0, net_dropout=0, batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],
+                embedding_regularizer=embedding_regularizer, net_regularizer=0, retrieval_augmented=True,
+                retrieval_configs={"topK": spec["K"], "label_wise": False}, model_root=model_root,
+                metrics=["AUC", "logloss"], verbose=0, optimizer="adam", loss="binary_crossentropy", monitor="AUC",
+                monitor_mode="max", patience=2, every_x_epochs=1, save_best_only=True, seed=2021)
+
+
+def make_batch(spec, feature_map, seed=0, batch=None, device=None, as_float64=True):
+    """The DataLoader 4-tuple (data_generator.py:66-78).  With ``device`` set, ids are handed over as int32 tensors
+    already resident in HBM (what bench.py times); otherwise float64 host tensors exactly like the reference's."""
+    B = batch or spec["batch"]
+    T = spec["K"] + 1
+    g = torch.Generator().manual_seed(seed)
+    cols = [torch.randint(0, s["vocab_size"], (B, T, 1), generator=g) for s in feature_map.feature_specs.values()]
+    X = torch.cat(cols, dim=-1)
+    y = torch.randint(0, 2, (B, T), generator=g)
+    rv = torch.rand(B, T - 1, generator=g, dtype=torch.float64)
+    rl = torch.full((B,), T - 1, dtype=torch.int64)
+    if device is not None:
+        return (X.to(torch.int32).to(device), y.to(torch.float32).to(device), rv.to(device), rl.to(device))
+    if as_float64:
+        return (X.to(torch.float64), y.to(torch.float64), rv, rl)
+    return (X, y, rv, rl)
