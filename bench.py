@@ -94,7 +94,8 @@ def cpu_baseline(spec, fm, batch_size, seed):
     cores on a bounded sample of the same workload: full training steps at a reduced batch."""
     from oracle import rat_m2_oracle as orc
     from rat_amd import synthetic
-    torch.set_num_threads(os.cpu_count() or 1)
+    # many-core hosts thrash on these small ops with one thread per core; 32 threads is where the oracle peaks
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cfg = orc.Config(fields=orc.fields_from_specs(fm.feature_specs), embedding_dim=spec["d"], num_heads=spec["num_heads"],
                      dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
                      dnn_hidden_units=tuple(spec["dnn_hidden_units"]), batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],

@@ -141,6 +141,11 @@ int rat_sumsq(const float* g, int64_t n, float* norm_sq_out, void* stream);
 int rat_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* norm_sq,
                   float max_norm, float lr, float beta1, float beta2, float eps, int step, void* stream);
 
+/* Inverted dropout (nn.Dropout; RAT_m2.py:83,135 emb_dropout, deep.py:133-134 net_dropout): y = keep(seed,i) ? x/(1-p) : 0
+ * with a counter-based mask, so the backward pass calls the same function on the gradient with the same seed.
+ * In place (y == x) is allowed. */
+int rat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Experiment entry with the reference's command line (run_expid.py:27-115 of the reference):
+
+    python run_expid.py --config ./configs/RAT_m2/kkbox_x1 --expid RAT_m2_kkbox_x1_10fold_retrieval --gpu 0
+
+load config -> feature_map.json -> batch sources -> ``getattr(models, params["model"])(feature_map, **params)`` ->
+fit_generator -> load best checkpoint -> evaluate on valid/test -> append one CSV result line.  The model class is this
+repo's HIP-backed plugin.  Preprocessing (CSV -> ids) and BM25 retrieval are offline steps outside the hot path: the
+data directory must already hold ``feature_map.json``, ``{train,valid,test}.{h5|npz}`` and
+``retrieval_{K}_{split}.{h5|npz}``; with ``--synthetic N`` a structured synthetic dataset of N training rows shaped
+like the feature map (or like the named bench workload when no feature map exists) is generated instead.
+"""
+import argparse
+import datetime
+import gc
+import logging
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.realpath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "www24-rat_amd"))
+
+import rat_amd  # noqa: E402
+from rat_amd import data as rat_data  # noqa: E402
+from rat_amd import models, synthetic  # noqa: E402
+from rat_amd.base_model import seed_everything  # noqa: E402
+from rat_amd.config import load_config, print_to_json, print_to_list, set_logger  # noqa: E402
+from rat_amd.features import FeatureMap  # noqa: E402
+
+
+def _find(data_dir, stem):
+    for ext in (".npz", ".h5"):
+        p = os.path.join(data_dir, stem + ext)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def build_sources(params, feature_map, synthetic_rows):
+    topk = params["retrieval_configs"]["topK"]
+    bs = params["batch_size"]
+    if synthetic_rows:
+        out = {}
+        for split, n, seed in (("train", synthetic_rows, 1), ("valid", max(synthetic_rows // 8, bs), 2),
+                               ("test", max(synthetic_rows // 8, bs), 3)):
+            data, idx, val, lens = rat_data.synthetic_split(feature_map, n, topk, seed)
+            out[split] = rat_data.RetrievalBatches(data, data, idx, val, lens, bs, shuffle=(split == "train") and params.get("shuffle", True),
+                                                   seed=params.get("seed", 0))
+        return out["train"], out["valid"], out["test"]
+    data_dir = os.path.join(params["data_root"], params["dataset_id"])
+    out = []
+    for split in ("train", "valid", "test"):
+        dpath, rpath = _find(data_dir, split), _find(data_dir, "retrieval_%d_%s" % (topk, split))
+        if dpath is None or rpath is None:
+            raise RuntimeError("missing %s / retrieval_%d_%s under %s (pre-computed offline by the reference's "
+                               "build_dataset + BM25 retrieval, or pass --synthetic N)" % (split, topk, split, data_dir))
+        pool = _find(data_dir, "retrieval_pool") if split != "train" or "fold" not in params["retrieval_configs"].get("split_type", "") else None
+        out.append(rat_data.batches_from_files(dpath, rpath, bs, pool_path=pool, shuffle=(split == "train") and params.get("shuffle", True),
+                                               seed=params.get("seed", 0)))
+    return out
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--version", type=str, default="pytorch", help="The model version.")
+    parser.add_argument("--config", type=str, default="../configs/", help="The config directory.")
+    parser.add_argument("--expid", type=str, default="FM_test", help="The experiment id to run.")
+    parser.add_argument("--gpu", type=int, default=-1, help="The gpu index, -1 for cpu")
+    parser.add_argument("--synthetic", type=int, default=0, help="generate N synthetic training rows instead of reading data")
+    parser.add_argument("--epochs", type=int, default=None, help="override the config's epochs")
+    args = vars(parser.parse_args(argv))
+    params = load_config(args["config"], args["expid"])
+    params["gpu"], params["version"] = args["gpu"], args["version"]
+    if args["epochs"] is not None:
+        params["epochs"] = args["epochs"]
+    set_logger(params)
+    logging.info(print_to_json(params))
+    seed_everything(seed=params["seed"])
+
+    data_dir = os.path.join(params["data_root"], params["dataset_id"])
+    feature_map = FeatureMap(params["dataset_id"], data_dir, params["version"])
+    json_file = os.path.join(data_dir, "feature_map.json")
+    if os.path.exists(json_file):
+        feature_map.load(json_file)
+    elif args["synthetic"]:
+        spec = synthetic.WORKLOADS["tiny"]
+        feature_map = synthetic.feature_map_for(params["dataset_id"], spec)
+    else:
+        raise RuntimeError("feature_map not exist!")
+    train_gen, valid_gen, test_gen = build_sources(params, feature_map, args["synthetic"])
+
+    model_class = getattr(models, params["model"])
+    model = model_class(feature_map, **params)
+    model.count_parameters()
+    model.fit_generator(train_gen, validation_data=valid_gen, **params)
+
+    logging.info("Load best model: {}".format(model.checkpoint))
+    model.load_weights(model.checkpoint)
+    logging.info("****** Validation evaluation ******")
+    valid_result = model.evaluate_generator(valid_gen)
+    del train_gen, valid_gen
+    gc.collect()
+    logging.info("******** Test evaluation ********")
+    test_result = model.evaluate_generator(test_gen) if test_gen else {}
+
+    result_file = os.path.join(params["model_root"], params["dataset_id"], params["model_id"] + ".csv")
+    with open(result_file, "a+") as fw:
+        fw.write(" {},[command] python {},[exp_id] {},[dataset_id] {},[train] {},[val] {},[test] {}\n".format(
+            datetime.datetime.now().strftime("%Y%m%d-%H%M%S"), " ".join(sys.argv), args["expid"], params["dataset_id"],
+            "N.A.", print_to_list(valid_result), print_to_list(test_result)))
+    return valid_result, test_result
+
+
+if __name__ == "__main__":
+    main()

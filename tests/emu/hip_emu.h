@@ -40,6 +40,7 @@ typedef int hipError_t;
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __restrict__
+#define __shared__ static
 
 namespace emu {
 struct Block {

@@ -33,6 +33,7 @@ ATTN_CASES = [  # B, T, S, d, heads, dh, project_out
     (2, 3, 4, 8, 2, 4, True),
     (1, 4, 5, 10, 2, 10, True),
     (2, 2, 3, 8, 1, 8, False),
+    (1, 3, 4, 16, 8, 10, True),      # served by the compiled fast shape <TD=16, TDH=10>
 ]
 
 

@@ -38,3 +38,45 @@ def test_eval_forward(name):
 @pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj"])
 def test_two_training_steps(name):
     mc.check_training(name, gpu=-1)
+
+
+def test_dropout_training_is_consistent():
+    """emb_dropout / net_dropout > 0: masks are counter-based, so (a) the backward pass re-derives the forward's mask —
+    checked by a finite-difference probe of one embedding row through the whole model — and (b) eval ignores dropout."""
+    import rat_amd.ops as ops
+    case = dict(gc.case_by_name("tiny_seq_bn"))
+    case["batch_norm"] = False
+    model = mc.build_model(case, gpu=-1, seed=1, emb_dropout=0.3, net_dropout=0.25)
+    mc.load_weights(model, case)
+    batch = mc.batch_of(case)
+    model.eval()
+    with torch.no_grad():
+        ref = mc.build_model(case, gpu=-1, seed=1)
+        mc.load_weights(ref, case)
+        ref.eval()
+        assert torch.equal(model.forward(batch)["y_pred"], ref.forward(batch)["y_pred"])
+    model.train()
+    torch.manual_seed(123)
+    loss = model.get_total_loss(batch)
+    loss.backward()
+    name = "embedding_layer.embedding_layer.embedding_layer.a.weight"
+    p = dict(model.named_parameters())[name]
+    g = p.grad.clone()
+    row = int(batch[0][0, 0, 0])
+    eps = 1e-2
+    vals = []
+    for sgn in (+1, -1):
+        with torch.no_grad():
+            p.data[row, 3] += sgn * eps
+        torch.manual_seed(123)                       # same dropout seeds -> same masks
+        with torch.no_grad():
+            vals.append(float(model.get_total_loss(batch)))
+        with torch.no_grad():
+            p.data[row, 3] -= sgn * eps
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - float(g[row, 3])) < 5e-3 * max(1.0, abs(fd)), (fd, float(g[row, 3]))
+    # the mask really drops ~p of the elements and rescales the rest
+    x = torch.ones(100000)
+    y = ops.dropout(x, 0.3, 77)
+    kept = float((y != 0).float().mean())
+    assert abs(kept - 0.7) < 0.01 and abs(float(y.max()) - 1 / 0.7) < 1e-6

@@ -11,25 +11,31 @@
 // rows = floor(64/L) whole sequences, staged in LDS:
 //     xs  [64][D16+4]   LayerNorm'ed tokens (A operand of the QKV projection, 16-byte row reads)
 //     qkv [64][3I16+4]  projection output; the softmax(QK^T)V result overwrites the Q columns in place
-// The projections run on v_mfma_f32_16x16x4_f32 with the weights streamed from L2 as B operands; the
-// (L x L x dh) attention core of a sequence-head is far too small and ragged for a 16x16 MFMA tile at fp32
-// (fp32 MFMA peak == fp32 VALU peak on gfx950, and an 11x11x10 problem fills 39 % of a padded tile), so it
-// runs on the VALU, one lane per (sequence, head, query) with an online softmax.
+// The projections run on v_mfma_f32_16x16x4_f32 with the weights streamed from L2 as B operands (one k-block
+// ahead of the MFMAs); the (L x L x dh) attention core of a sequence-head is far too small and ragged for a
+// 16x16 MFMA tile at fp32 (fp32 MFMA peak == fp32 VALU peak on gfx950, and an 11x11x10 problem fills 39 % of a
+// padded tile), so it runs on the VALU, one lane per (sequence, head, query) with an online softmax.
 // Backward recomputes LayerNorm and QKV from x, re-derives P from the saved log-sum-exp, and keeps every
 // weight gradient in MFMA accumulators across the work-group's whole chunk loop (written once per launch
 // to a per-work-group slab, then summed in fixed order => deterministic).
+//
+// Two code paths from ONE source: template <TD, TDH>.  TD > 0 ("fast"): embedding_dim == TD and heads*dim_head
+// are multiples of 16, dim_head == TDH, 16-byte aligned pointers — every bounds guard compiles away and loops
+// over d / dim_head unroll.  TD == 0: any shape within the limits below, guarded loads, zero-padded tiles.
 #include "rat_device.h"
 #include "../../include/rat_hip.h"
+
+#include <initializer_list>
 
 namespace {
 
 constexpr int ATT_THREADS = 512;
 constexpr int ATT_WAVES = ATT_THREADS / 64;
 constexpr int ATT_ROWS = 64;
+constexpr int ATT_MT = ATT_ROWS / 16;
 constexpr int DH_MAX = 16;        // dim_head <= 16 (every shipped config uses 10)
 constexpr int QSLOTS = 8;         // persistent dW_qkv tiles per wave  (3I16/16 * D16/16 <= 64)
 constexpr int OSLOTS = 4;         // persistent dW_out tiles per wave  (D16/16 * I16/16 <= 32)
-constexpr int LN_COLS = 16;       // columns per lane in the 8-lanes-per-row LayerNorm passes (d <= 128)
 
 struct AttnArgs {
     const float* x;
@@ -88,7 +94,7 @@ __device__ __forceinline__ void map_rows(const AttnArgs& a, int64_t chunk, int64
     }
 }
 
-// load D floats per row from a token-indexed global array into an LDS tile (padding rows -> 0)
+// load `width` floats per row from a token-indexed global array into an LDS tile (padding rows -> 0)
 __device__ __forceinline__ void load_rows(float* tile, int ld, const float* src, const int64_t* rowtok, int width,
                                           bool vec) {
     if (vec) {
@@ -114,77 +120,127 @@ __device__ __forceinline__ void zero_cols(float* tile, int ld, int c0) {   // ti
     for (int e = threadIdx.x; e < ATT_ROWS * w; e += ATT_THREADS) tile[(size_t)(e / w) * ld + c0 + e % w] = 0.f;
 }
 
-// in-place LayerNorm of the valid rows of xs (8 lanes per row); optionally keeps mean / rstd
+// in-place LayerNorm of the valid rows of xs (8 lanes per row, COLS columns each); optionally keeps mean / rstd
+template <int COLS>
 __device__ __forceinline__ void layer_norm_rows(float* xs, int ld, int D, int rows, const float* g, const float* b,
                                                 float eps, float* mu_out, float* rs_out) {
     const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
     float* xr = xs + (size_t)r * ld;
+    float xv[COLS];
     float s = 0.f;
-    for (int c = sub; c < D; c += 8) s += xr[c];
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) {
+        const int c = sub + 8 * k;
+        xv[k] = c < D ? xr[c] : 0.f;
+        s += xv[k];
+    }
     const float mean = rat_group_sum<8>(s) / (float)D;
     float v = 0.f;
-    for (int c = sub; c < D; c += 8) {
-        const float t = xr[c] - mean;
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) {
+        const float t = (sub + 8 * k < D) ? xv[k] - mean : 0.f;
         v += t * t;
     }
     const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / (float)D + eps);
-    if (r < rows)
-        for (int c = sub; c < D; c += 8) xr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+    if (r < rows) {
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) {
+            const int c = sub + 8 * k;
+            if (c < D) xr[c] = (xv[k] - mean) * rstd * g[c] + b[c];
+        }
+    }
     if (mu_out != nullptr && sub == 0) {
         mu_out[r] = mean;
         rs_out[r] = rstd;
     }
 }
 
-// qkv[rows][0:3I] = xs W_qkv^T   (each wave: all M tiles x 2 N tiles per task)
-__device__ __forceinline__ void qkv_projection(const AttnArgs& a, const AttnGeom& g, const float* xs, float* qkv,
-                                               int mt_valid) {
-    const int ntn = g.Q16 / 16, ntasks = (ntn + 1) / 2;
-    const RatLdsRows A{xs, g.ldx};
-    const RatGlobalWnk Bw{a.w_qkv, g.Q3, g.D, g.D, a.vec_wqkv != 0};
-    for (int task = rat_wave(); task < ntasks; task += ATT_WAVES) {
-        f32x4 acc[4][2];
+// per-head vectors of the attention core: compile-time dim_head (8-byte LDS accesses) or runtime <= DH_MAX
+template <int TDH>
+struct HeadVec {
+    static constexpr int N = TDH > 0 ? TDH : DH_MAX;
+    float v[N];
+    __device__ __forceinline__ void load(const float* p, int dh) {
+        if (TDH > 0 && TDH % 2 == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = rat_zero4();
-        const int nt0 = task * 2;
-        const int nbv = ntn - nt0 < 2 ? ntn - nt0 : 2;
-        rat_wave_gemm<4, 2>(acc, A, Bw, 0, nt0, mt_valid, nbv, g.D16 / 16);
+            for (int c = 0; c < N; c += 2) {
+                const float2 t = *reinterpret_cast<const float2*>(p + c);
+                v[c] = t.x;
+                v[c + 1] = t.y;
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (i < mt_valid && j < nbv) {
-                    const int col = rat_acc_col(nt0 + j);
-                    if (col < g.Q3)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(i, r) * g.ldq + col] = acc[i][j][r];
-                }
+            for (int c = 0; c < N; ++c) v[c] = (TDH > 0 || c < dh) ? p[c] : 0.f;
+        }
     }
-}
+    __device__ __forceinline__ void store(float* p, int dh, float scale) const {
+        if (TDH > 0 && TDH % 2 == 0) {
+#pragma unroll
+            for (int c = 0; c < N; c += 2) *reinterpret_cast<float2*>(p + c) = make_float2(v[c] * scale, v[c + 1] * scale);
+        } else {
+#pragma unroll
+            for (int c = 0; c < N; ++c)
+                if (TDH > 0 || c < dh) p[c] = v[c] * scale;
+        }
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = 0.f;
+    }
+    __device__ __forceinline__ float dot(const HeadVec& o) const {       // padded lanes are 0 on both sides
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < N; ++c) s = fmaf(v[c], o.v[c], s);
+        return s;
+    }
+    __device__ __forceinline__ void axpy(float a, const HeadVec& x) {    // v += a * x
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = fmaf(a, x.v[c], v[c]);
+    }
+    __device__ __forceinline__ void scale_axpy(float s, float a, const HeadVec& x) {   // v = v * s + a * x
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = fmaf(a, x.v[c], v[c] * s);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ forward
+template <int TD, int TDH>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
+    constexpr bool FAST = TD > 0;
+    constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
     RAT_DYN_SMEM(smem);
-    const AttnGeom g(a.d, a.heads, a.dh);
+    const AttnGeom g(FAST ? TD : a.d, a.heads, FAST && TDH > 0 ? TDH : a.dh);
     float* xs = reinterpret_cast<float*>(smem);
     float* qkv = xs + (size_t)ATT_ROWS * g.ldx;
     int64_t* rowtok = reinterpret_cast<int64_t*>(qkv + (size_t)ATT_ROWS * g.ldq);
-    const int L = a.L, D = g.D, I = g.I, dh = a.dh;
+    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh;
+    const int ldx = g.ldx, ldq = g.ldq;
 
-    zero_cols(xs, g.ldx, D);
-    zero_cols(qkv, g.ldq, g.Q3);
+    zero_cols(xs, ldx, D);
+    zero_cols(qkv, ldq, g.Q3);
     __syncthreads();
 
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         int nsq, rows;
         map_rows(a, chunk, rowtok, nsq, rows);
         __syncthreads();
-        load_rows(xs, g.ldx, a.x, rowtok, D, a.vec_x != 0);
+        load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
         __syncthreads();
-        layer_norm_rows(xs, g.ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
+        layer_norm_rows<COLS>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
-        qkv_projection(a, g, xs, qkv, mt_valid);
+
+        // Q|K|V = LN(x) W_qkv^T  -> qkv[rows][0:3I]
+        {
+            const RatLdsRows A{xs, ldx};
+            const RatGlobalWnkT<!FAST> Bw{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0};
+            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
+                if (FAST || col < g.Q3)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * ldq + col] = acc[r];
+            });
+        }
         __syncthreads();
 
         // softmax(Q K^T * scale) V, one lane per (sequence, head, query); result replaces Q in place
@@ -194,76 +250,55 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             const int h = (task / L) % a.heads;
             const int sq = task / (L * a.heads);
             const int row_i = sq * L + i;
-            float* qp = qkv + (size_t)row_i * g.ldq + h * dh;
-            float q[DH_MAX], o[DH_MAX];
-#pragma unroll
-            for (int c = 0; c < DH_MAX; ++c) {
-                q[c] = c < dh ? qp[c] : 0.f;
-                o[c] = 0.f;
-            }
+            float* qp = qkv + (size_t)row_i * ldq + h * dh;
+            HeadVec<TDH> q, o, kv;
+            q.load(qp, dh);
+            o.zero();
             float m = -INFINITY, l = 0.f;
+            const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh;
             for (int j = 0; j < L; ++j) {
-                const float* kp = qkv + (size_t)(sq * L + j) * g.ldq + I + h * dh;
-                const float* vp = kp + I;
-                float s = 0.f;
-#pragma unroll
-                for (int c = 0; c < DH_MAX; ++c)
-                    if (c < dh) s = fmaf(q[c], kp[c], s);
-                s *= a.scale;
+                const float* kp = kbase + (size_t)j * ldq;
+                kv.load(kp, dh);
+                const float s = q.dot(kv) * a.scale;
                 const float mn = fmaxf(m, s);
                 const float corr = expf(m - mn);
                 const float p = expf(s - mn);
                 l = l * corr + p;
-#pragma unroll
-                for (int c = 0; c < DH_MAX; ++c)
-                    if (c < dh) o[c] = fmaf(p, vp[c], o[c] * corr);
+                kv.load(kp + I, dh);
+                o.scale_axpy(corr, p, kv);
                 m = mn;
             }
             const float inv = 1.0f / l;
+            o.store(qp, dh, inv);
             const int64_t tok = rowtok[row_i];
-#pragma unroll
-            for (int c = 0; c < DH_MAX; ++c)
-                if (c < dh) {
-                    const float ov = o[c] * inv;
-                    qp[c] = ov;
-                    if (a.o_save != nullptr) a.o_save[tok * I + h * dh + c] = ov;
-                }
+            if (a.o_save != nullptr) o.store(a.o_save + tok * I + h * dh, dh, inv);
             if (a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + logf(l);
         }
         __syncthreads();
 
         // y = O W_out^T + b_out + x   (or y = O + x when Attention has no output projection)
         if (a.w_out != nullptr) {
-            const int ntn = g.D16 / 16, mblocks = (mt_valid + 1) / 2, ntasks2 = mblocks * ntn;
-            const RatLdsRows A{qkv, g.ldq};
-            const RatGlobalWnk Bw{a.w_out, D, I, I, a.vec_wout != 0};
-            for (int task = rat_wave(); task < ntasks2; task += ATT_WAVES) {
-                const int mt0 = (task / ntn) * 2, nt = task % ntn;
-                const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
-                f32x4 acc[2][1];
-                acc[0][0] = acc[1][0] = rat_zero4();
-                rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.I16 / 16);
+            const RatLdsRows A{qkv, ldq};
+            const RatGlobalWnkT<!FAST> Bw{a.w_out, D, I, I, a.vec_wout != 0};
+            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.D16 / 16, g.I16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
-                if (col < D) {
+                if (FAST || col < D) {
                     const float bias = a.b_out[col];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        if (i < mtv)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rat_acc_row(mt0 + i, r);
-                                if (row < rows) {
-                                    const int64_t tok = rowtok[row];
-                                    a.y[tok * D + col] = acc[i][0][r] + bias + a.x[tok * D + col];
-                                }
-                            }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rat_acc_row(mt, r);
+                        if (row < rows) {
+                            const int64_t tok = rowtok[row];
+                            a.y[tok * D + col] = acc[r] + bias + a.x[tok * D + col];
+                        }
+                    }
                 }
-            }
+            });
         } else {
             for (int e = threadIdx.x; e < rows * D; e += ATT_THREADS) {
                 const int r = e / D, c = e - r * D;
                 const int64_t tok = rowtok[r];
-                a.y[tok * D + c] = qkv[(size_t)r * g.ldq + c] + a.x[tok * D + c];
+                a.y[tok * D + c] = qkv[(size_t)r * ldq + c] + a.x[tok * D + c];
             }
         }
         __syncthreads();
@@ -271,16 +306,20 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- backward
+template <int TD, int TDH>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
+    constexpr bool FAST = TD > 0;
+    constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
     RAT_DYN_SMEM(smem);
-    const AttnGeom g(a.d, a.heads, a.dh);
-    const int L = a.L, D = g.D, I = g.I, dh = a.dh, H = a.heads;
+    const AttnGeom g(FAST ? TD : a.d, a.heads, FAST && TDH > 0 ? TDH : a.dh);
+    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = a.heads;
+    const int ldx = g.ldx, ldq = g.ldq, ldt = g.ldt;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx]  LayerNorm(x)
-    float* dys = xs + (size_t)ATT_ROWS * g.ldx;                 // [64][ldx]  dL/dy
-    float* qkv = dys + (size_t)ATT_ROWS * g.ldx;                // [64][ldq]  Q|K|V, later dQ|dK|dV
-    float* ob = qkv + (size_t)ATT_ROWS * g.ldq;                 // [64][ldt]  O, later dQ
-    float* dob = ob + (size_t)ATT_ROWS * g.ldt;                 // [64][ldt]  dO, later d(LayerNorm out)
-    float* mu = dob + (size_t)ATT_ROWS * g.ldt;                 // [64]
+    float* dys = xs + (size_t)ATT_ROWS * ldx;                   // [64][ldx]  dL/dy
+    float* qkv = dys + (size_t)ATT_ROWS * ldx;                  // [64][ldq]  Q|K|V, later dQ|dK|dV
+    float* ob = qkv + (size_t)ATT_ROWS * ldq;                   // [64][ldt]  O, later dQ
+    float* dob = ob + (size_t)ATT_ROWS * ldt;                   // [64][ldt]  dO, later d(LayerNorm out)
+    float* mu = dob + (size_t)ATT_ROWS * ldt;                   // [64]
     float* rs = mu + ATT_ROWS;                                  // [64]
     float* lses = rs + ATT_ROWS;                                // [64][H]
     float* dlt = lses + (size_t)ATT_ROWS * H;                   // [64][H]   rowsum(dO * O)
@@ -293,60 +332,60 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     for (int s = 0; s < QSLOTS; ++s) accq[s] = rat_zero4();
 #pragma unroll
     for (int s = 0; s < OSLOTS; ++s) acco[s] = rat_zero4();
-    float dgam[LN_COLS], dbet[LN_COLS];
+    float dgam[COLS], dbet[COLS];
 #pragma unroll
-    for (int k = 0; k < LN_COLS; ++k) dgam[k] = dbet[k] = 0.f;
+    for (int k = 0; k < COLS; ++k) dgam[k] = dbet[k] = 0.f;
     float dbo = 0.f;
     const int q_tn = g.D16 / 16, q_tiles = (g.Q16 / 16) * q_tn;       // dW_qkv tiles: (3I16/16) x (D16/16)
     const int o_tn = g.I16 / 16, o_tiles = (g.D16 / 16) * o_tn;       // dW_out tiles: (D16/16) x (I16/16)
 
-    zero_cols(xs, g.ldx, D);
-    zero_cols(dys, g.ldx, D);
-    zero_cols(qkv, g.ldq, g.Q3);
-    zero_cols(ob, g.ldt, 0);
-    zero_cols(dob, g.ldt, 0);
+    zero_cols(xs, ldx, D);
+    zero_cols(dys, ldx, D);
+    zero_cols(qkv, ldq, g.Q3);
+    zero_cols(ob, ldt, 0);
+    zero_cols(dob, ldt, 0);
     __syncthreads();
 
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         int nsq, rows;
         map_rows(a, chunk, rowtok, nsq, rows);
         __syncthreads();
-        load_rows(xs, g.ldx, a.x, rowtok, D, a.vec_x != 0);
-        load_rows(dys, g.ldx, a.dy, rowtok, D, a.vec_x != 0);
-        load_rows(ob, g.ldt, a.o_save, rowtok, I, (I % 4) == 0 && a.vec_x != 0);
+        load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
+        load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0);
+        load_rows(ob, ldt, a.o_save, rowtok, I, FAST || ((I % 4) == 0 && a.vec_x != 0));
         for (int e = threadIdx.x; e < ATT_ROWS * H; e += ATT_THREADS) {
             const int64_t tok = rowtok[e / H];
             lses[e] = tok >= 0 ? a.lse_save[tok * H + e % H] : 0.f;
         }
         __syncthreads();
-        layer_norm_rows(xs, g.ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
+        layer_norm_rows<COLS>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
 
         // (1) recompute Q|K|V
-        qkv_projection(a, g, xs, qkv, mt_valid);
-        // (2) dO = dy W_out  (dob[rows][0:I])
-        if (has_out) {
-            const int ntn = g.I16 / 16, mblocks = (mt_valid + 1) / 2, ntasks = mblocks * ntn;
-            const RatLdsRows A{dys, g.ldx};
-            const RatGlobalWkn Bw{a.w_out, D, I, I};
-            for (int task = rat_wave(); task < ntasks; task += ATT_WAVES) {
-                const int mt0 = (task / ntn) * 2, nt = task % ntn;
-                const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
-                f32x4 acc[2][1];
-                acc[0][0] = acc[1][0] = rat_zero4();
-                rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.D16 / 16);
+        {
+            const RatLdsRows A{xs, ldx};
+            const RatGlobalWnkT<!FAST> Bw{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0};
+            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
-                if (col < I)
+                if (FAST || col < g.Q3)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        if (i < mtv)
+                    for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * ldq + col] = acc[r];
+            });
+        }
+        if (has_out) {
+            // (2) dO = dy W_out  (dob[rows][0:I])
+            const RatLdsRows A{dys, ldx};
+            const RatGlobalWknT<!FAST> Bw{a.w_out, D, I, I};
+            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.I16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
+                if (FAST || col < I)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt0 + i, r) * g.ldt + col] = acc[i][0][r];
-            }
+                    for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
+            });
             // (3) dW_out += dy^T O ; db_out += colsum(dy)
-            const RatLdsCols At{dys, g.ldx};
-            const RatLdsCols Bt{ob, g.ldt};
+            const RatLdsCols At{dys, ldx};
+            const RatLdsCols Bt{ob, ldt};
 #pragma unroll
             for (int s = 0; s < OSLOTS; ++s) {
                 const int id = rat_wave() + ATT_WAVES * s;
@@ -354,13 +393,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
             if (threadIdx.x < D) {
                 float sacc = 0.f;
-                for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * g.ldx + threadIdx.x];
+                for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * ldx + threadIdx.x];
                 dbo += sacc;
             }
         } else {
             for (int e = threadIdx.x; e < ATT_ROWS * D; e += ATT_THREADS) {
                 const int r = e / D, c = e - r * D;
-                dob[(size_t)r * g.ldt + c] = dys[(size_t)r * g.ldx + c];
+                dob[(size_t)r * ldt + c] = dys[(size_t)r * ldx + c];
             }
         }
         __syncthreads();
@@ -372,39 +411,25 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             const int h = (task / L) % H;
             const int sq = task / (L * H);
             const int row_i = sq * L + i;
-            const float* qp = qkv + (size_t)row_i * g.ldq + h * dh;
-            const float* dop = dob + (size_t)row_i * g.ldt + h * dh;
-            float* op = ob + (size_t)row_i * g.ldt + h * dh;
-            float q[DH_MAX], go[DH_MAX], dq[DH_MAX];
-            float delta = 0.f;
-#pragma unroll
-            for (int c = 0; c < DH_MAX; ++c) {
-                q[c] = c < dh ? qp[c] : 0.f;
-                go[c] = c < dh ? dop[c] : 0.f;
-                dq[c] = 0.f;
-                if (c < dh) delta = fmaf(go[c], op[c], delta);
-            }
+            float* op = ob + (size_t)row_i * ldt + h * dh;
+            HeadVec<TDH> q, go, dq, kv;
+            q.load(qkv + (size_t)row_i * ldq + h * dh, dh);
+            go.load(dob + (size_t)row_i * ldt + h * dh, dh);
+            kv.load(op, dh);
+            const float delta = go.dot(kv);
+            dq.zero();
             dlt[row_i * H + h] = delta;
             const float lse = lses[row_i * H + h];
+            const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh;
             for (int j = 0; j < L; ++j) {
-                const float* kp = qkv + (size_t)(sq * L + j) * g.ldq + I + h * dh;
-                const float* vp = kp + I;
-                float s = 0.f, dp = 0.f;
-#pragma unroll
-                for (int c = 0; c < DH_MAX; ++c)
-                    if (c < dh) {
-                        s = fmaf(q[c], kp[c], s);
-                        dp = fmaf(go[c], vp[c], dp);
-                    }
-                const float p = expf(s * a.scale - lse);
-                const float ds = p * (dp - delta);
-#pragma unroll
-                for (int c = 0; c < DH_MAX; ++c)
-                    if (c < dh) dq[c] = fmaf(ds, kp[c], dq[c]);
+                const float* kp = kbase + (size_t)j * ldq;
+                kv.load(kp + I, dh);
+                const float dp = go.dot(kv);
+                kv.load(kp, dh);
+                const float p = expf(q.dot(kv) * a.scale - lse);
+                dq.axpy(p * (dp - delta), kv);
             }
-#pragma unroll
-            for (int c = 0; c < DH_MAX; ++c)
-                if (c < dh) op[c] = dq[c] * a.scale;
+            dq.store(op, dh, a.scale);
         }
         __syncthreads();
         // pass 2: one lane per key row -> dK, dV (written over K, V)
@@ -412,71 +437,54 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             const int j = task % L;
             const int h = (task / L) % H;
             const int sq = task / (L * H);
-            float* kp = qkv + (size_t)(sq * L + j) * g.ldq + I + h * dh;
-            float* vp = kp + I;
-            float kk[DH_MAX], vv[DH_MAX], dk[DH_MAX], dv[DH_MAX];
-#pragma unroll
-            for (int c = 0; c < DH_MAX; ++c) {
-                kk[c] = c < dh ? kp[c] : 0.f;
-                vv[c] = c < dh ? vp[c] : 0.f;
-                dk[c] = dv[c] = 0.f;
-            }
+            float* kp = qkv + (size_t)(sq * L + j) * ldq + I + h * dh;
+            HeadVec<TDH> kk, vv, dk, dv, t;
+            kk.load(kp, dh);
+            vv.load(kp + I, dh);
+            dk.zero();
+            dv.zero();
             for (int i = 0; i < L; ++i) {
                 const int row_i = sq * L + i;
-                const float* qp = qkv + (size_t)row_i * g.ldq + h * dh;
-                const float* dop = dob + (size_t)row_i * g.ldt + h * dh;
-                float s = 0.f, dp = 0.f;
-#pragma unroll
-                for (int c = 0; c < DH_MAX; ++c)
-                    if (c < dh) {
-                        s = fmaf(qp[c], kk[c], s);
-                        dp = fmaf(dop[c], vv[c], dp);
-                    }
-                const float p = expf(s * a.scale - lses[row_i * H + h]);
-                const float ds = p * (dp - dlt[row_i * H + h]);
-#pragma unroll
-                for (int c = 0; c < DH_MAX; ++c)
-                    if (c < dh) {
-                        dk[c] = fmaf(ds, qp[c], dk[c]);
-                        dv[c] = fmaf(p, dop[c], dv[c]);
-                    }
+                t.load(dob + (size_t)row_i * ldt + h * dh, dh);
+                const float dp = t.dot(vv);
+                const float lse = lses[row_i * H + h], delta = dlt[row_i * H + h];
+                HeadVec<TDH> qv;
+                qv.load(qkv + (size_t)row_i * ldq + h * dh, dh);
+                const float p = expf(qv.dot(kk) * a.scale - lse);
+                dv.axpy(p, t);
+                dk.axpy(p * (dp - delta), qv);
             }
-#pragma unroll
-            for (int c = 0; c < DH_MAX; ++c)
-                if (c < dh) {
-                    kp[c] = dk[c] * a.scale;
-                    vp[c] = dv[c];
-                }
+            dk.store(kp, dh, a.scale);
+            dv.store(kp + I, dh, 1.0f);
         }
         __syncthreads();
         // dQ (in ob) -> Q columns of qkv: qkv now holds d[Q|K|V]
-        for (int e = threadIdx.x; e < rows * I; e += ATT_THREADS) {
-            const int r = e / I, c = e - r * I;
-            qkv[(size_t)r * g.ldq + c] = ob[(size_t)r * g.ldt + c];
+        if (FAST) {
+            const int w4 = I >> 2;
+            for (int e = threadIdx.x; e < ATT_ROWS * w4; e += ATT_THREADS) {
+                const int r = e / w4, c4 = e - r * w4;
+                *reinterpret_cast<float4*>(qkv + (size_t)r * ldq + 4 * c4) = *reinterpret_cast<const float4*>(ob + (size_t)r * ldt + 4 * c4);
+            }
+        } else {
+            for (int e = threadIdx.x; e < rows * I; e += ATT_THREADS) {
+                const int r = e / I, c = e - r * I;
+                qkv[(size_t)r * ldq + c] = ob[(size_t)r * ldt + c];
+            }
         }
         __syncthreads();
 
         // (5) d(LN out) = dQKV W_qkv -> dob[rows][0:D] ; (6) dW_qkv += dQKV^T LN(x)
         {
-            const int ntn = g.D16 / 16, mblocks = (mt_valid + 1) / 2, ntasks2 = mblocks * ntn;
-            const RatLdsRows A{qkv, g.ldq};
-            const RatGlobalWkn Bw{a.w_qkv, g.Q3, D, D};
-            for (int task = rat_wave(); task < ntasks2; task += ATT_WAVES) {
-                const int mt0 = (task / ntn) * 2, nt = task % ntn;
-                const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
-                f32x4 acc[2][1];
-                acc[0][0] = acc[1][0] = rat_zero4();
-                rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.Q16 / 16);
+            const RatLdsRows A{qkv, ldq};
+            const RatGlobalWknT<!FAST> Bw{a.w_qkv, g.Q3, D, D};
+            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
-                if (col < D)
+                if (FAST || col < D)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        if (i < mtv)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt0 + i, r) * g.ldt + col] = acc[i][0][r];
-            }
-            const RatLdsCols At{qkv, g.ldq};
-            const RatLdsCols Bt{xs, g.ldx};
+                    for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
+            });
+            const RatLdsCols At{qkv, ldq};
+            const RatLdsCols Bt{xs, ldx};
 #pragma unroll
             for (int s = 0; s < QSLOTS; ++s) {
                 const int id = rat_wave() + ATT_WAVES * s;
@@ -491,16 +499,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             const bool valid = r < rows;
             const int64_t tok = rowtok[r];
             const float mean = mu[r], rstd = rs[r];
-            float xh[LN_COLS], gg[LN_COLS];
+            float xh[COLS], gg[COLS];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < LN_COLS; ++k) {
+            for (int k = 0; k < COLS; ++k) {
                 const int c = sub + 8 * k;
                 xh[k] = 0.f;
                 gg[k] = 0.f;
                 if (c < D && valid) {
                     xh[k] = (a.x[tok * D + c] - mean) * rstd;
-                    gg[k] = dob[(size_t)r * g.ldt + c];
+                    gg[k] = dob[(size_t)r * ldt + c];
                     const float gw = gg[k] * a.ln_g[c];
                     s1 += gw;
                     s2 += gw * xh[k];
@@ -509,11 +517,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             s1 = rat_group_sum<8>(s1) / (float)D;
             s2 = rat_group_sum<8>(s2) / (float)D;
 #pragma unroll
-            for (int k = 0; k < LN_COLS; ++k) {
+            for (int k = 0; k < COLS; ++k) {
                 const int c = sub + 8 * k;
                 if (c < D && valid) {
                     const float gw = gg[k] * a.ln_g[c];
-                    a.y[tok * D + c] = dys[(size_t)r * g.ldx + c] + rstd * (gw - s1 - xh[k] * s2);
+                    a.y[tok * D + c] = dys[(size_t)r * ldx + c] + rstd * (gw - s1 - xh[k] * s2);
                     dgam[k] += gg[k] * xh[k];
                     dbet[k] += gg[k];
                 }
@@ -561,26 +569,26 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     {
         const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
 #pragma unroll
-        for (int k = 0; k < LN_COLS; ++k) {
+        for (int k = 0; k < COLS; ++k) {
             const int c = sub + 8 * k;
-            if (c < D) red[(size_t)r * g.ldx + c] = dgam[k];
+            if (c < D) red[(size_t)r * ldx + c] = dgam[k];
         }
         __syncthreads();
         if (threadIdx.x < D) {
             float sacc = 0.f;
-            for (int rr = 0; rr < ATT_ROWS; ++rr) sacc += red[(size_t)rr * g.ldx + threadIdx.x];
+            for (int rr = 0; rr < ATT_ROWS; ++rr) sacc += red[(size_t)rr * ldx + threadIdx.x];
             s_gam[threadIdx.x] = sacc;
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < LN_COLS; ++k) {
+        for (int k = 0; k < COLS; ++k) {
             const int c = sub + 8 * k;
-            if (c < D) red[(size_t)r * g.ldx + c] = dbet[k];
+            if (c < D) red[(size_t)r * ldx + c] = dbet[k];
         }
         __syncthreads();
         if (threadIdx.x < D) {
             float sacc = 0.f;
-            for (int rr = 0; rr < ATT_ROWS; ++rr) sacc += red[(size_t)rr * g.ldx + threadIdx.x];
+            for (int rr = 0; rr < ATT_ROWS; ++rr) sacc += red[(size_t)rr * ldx + threadIdx.x];
             s_bet[threadIdx.x] = sacc;
         }
     }
@@ -590,7 +598,7 @@ int check_dims(const RatSeqMap* map, int d, int heads, int dim_head, bool backwa
     RAT_REQUIRE(map != nullptr, "null seq map");
     RAT_REQUIRE(d > 0 && heads > 0 && dim_head > 0, "bad dims");
     RAT_REQUIRE(dim_head <= DH_MAX, "dim_head > 16 is not supported by this kernel");
-    RAT_REQUIRE(d <= 8 * LN_COLS, "embedding_dim > 128 is not supported by this kernel");
+    RAT_REQUIRE(d <= 128, "embedding_dim > 128 is not supported by this kernel");
     RAT_REQUIRE(map->L >= 1 && map->L <= ATT_ROWS, "sequence length (K+1 or F+1) must be in [1, 64]");
     RAT_REQUIRE(map->nseq >= 1 && map->q_div >= 1, "bad seq map");
     const AttnGeom g(d, heads, dim_head);
@@ -632,6 +640,15 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
     a.vec_wout = (I % 4 == 0) && aligned16(w->w_out);
 }
 
+// which compiled fast shape (if any) serves these dimensions
+int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
+    if (a.dh != 10 || (a.heads * a.dh) % 16 != 0 || a.w_out == nullptr) return 0;
+    for (const void* p : ptrs)
+        if (p != nullptr && !aligned16(p)) return 0;
+    if (!aligned16(a.w_qkv) || !aligned16(a.w_out)) return 0;
+    return (a.d == 64 || a.d == 16) ? a.d : 0;
+}
+
 }  // namespace
 
 extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
@@ -649,12 +666,14 @@ extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_
     const AttnGeom g(d, heads, dim_head);
     const size_t smem = g.fwd_smem();
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
-    int64_t blocks = a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu;
-    RAT_LAUNCH(attn_fwd_kernel, (unsigned)blocks, ATT_THREADS, smem, stream, a);
+    const unsigned blocks = (unsigned)(a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu);
+    switch (fast_dim(a, {x, y, o_save})) {
+        case 64: RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a); break;
+        case 16: RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a); break;
+        default: RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a); break;
+    }
     return rat_check_launch("rat_attn_fwd");
 }
-
-static int attn_bwd_blocks(int64_t nchunks) { return (int)(nchunks < 256 ? nchunks : 256); }
 
 extern "C" size_t rat_attn_bwd_workspace(int d, int heads, int dim_head) {
     const AttnGeom g(d, heads, dim_head);
@@ -680,8 +699,13 @@ extern "C" int rat_attn_bwd(const float* x, const float* dy, const float* o_save
     const AttnGeom g(d, heads, dim_head);
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
-    const int blocks = attn_bwd_blocks(a.nchunks);
-    RAT_LAUNCH(attn_bwd_kernel, blocks, ATT_THREADS, g.bwd_smem(heads), stream, a);
+    const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
+    const size_t smem = g.bwd_smem(heads);
+    switch (fast_dim(a, {x, dy, o_save, dx})) {
+        case 64: RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a); break;
+        case 16: RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a); break;
+        default: RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a); break;
+    }
     if (rat_check_launch("rat_attn_bwd")) return -1;
     const int D = d, I = heads * dim_head;
     float* outs[5] = {grads_host->w_qkv, grads_host->w_out, grads_host->b_out, grads_host->ln_g, grads_host->ln_b};

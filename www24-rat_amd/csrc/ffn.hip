@@ -9,11 +9,14 @@
 #include "rat_device.h"
 #include "../../include/rat_hip.h"
 
+#include <initializer_list>
+
 namespace {
 
 constexpr int FFN_THREADS = 512;
 constexpr int FFN_WAVES = FFN_THREADS / 64;
 constexpr int FFN_ROWS = 64;
+constexpr int FFN_MT = FFN_ROWS / 16;
 constexpr int WSLOTS = 8;          // persistent tiles per wave for each of dW1, dW2  (H16/16 * D16/16 <= 64)
 
 struct FfnArgs {
@@ -69,41 +72,35 @@ __device__ __forceinline__ void ffn_zero_cols(float* tile, int ld, int c0) {
 }
 
 // hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- h, gs <- gelu(h))
-template <int MODE>
+template <bool FAST, int MODE>
 __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
                                            int mt_valid, int rows) {
-    const int ntn = g.H16 / 16;
     const RatLdsRows A{xs, g.ldx};
-    const RatGlobalWnk Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
-    for (int nt = rat_wave(); nt < ntn; nt += FFN_WAVES) {
-        f32x4 acc[4][1];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][0] = rat_zero4();
-        rat_wave_gemm<4, 1>(acc, A, Bw, 0, nt, mt_valid, 1, g.D16 / 16);
+    const RatGlobalWnkT<!FAST> Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
+    rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
         const int col = rat_acc_col(nt);
-        if (col < g.H) {
+        if (FAST || col < g.H) {
             const float bias = a.b1[col];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < mt_valid)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rat_acc_row(i, r);
-                        const float h = row < rows ? acc[i][0][r] + bias : 0.f;    // padding rows stay exactly 0
-                        if (MODE == 0) {
-                            hs[(size_t)row * g.ldh + col] = rat_gelu(h);
-                        } else {
-                            hs[(size_t)row * g.ldh + col] = h;
-                            gs[(size_t)row * g.ldh + col] = rat_gelu(h);
-                        }
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const int row = rat_acc_row(mt, r);
+                const float h = row < rows ? acc[r] + bias : 0.f;    // padding rows stay exactly 0
+                if (MODE == 0) {
+                    hs[(size_t)row * g.ldh + col] = rat_gelu(h);
+                } else {
+                    hs[(size_t)row * g.ldh + col] = h;
+                    gs[(size_t)row * g.ldh + col] = rat_gelu(h);
+                }
+            }
         }
-    }
+    });
 }
 
+template <int TD>
 __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
+    constexpr bool FAST = TD > 0;
     RAT_DYN_SMEM(smem);
-    const FfnGeom g(a.d, a.hidden);
+    const FfnGeom g(FAST ? TD : a.d, a.hidden);
     float* xs = reinterpret_cast<float*>(smem);
     float* hs = xs + (size_t)FFN_ROWS * g.ldx;
     ffn_zero_cols(xs, g.ldx, g.D);
@@ -113,40 +110,35 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         const int64_t tok0 = chunk * FFN_ROWS;
         const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
         const int mt_valid = (rows + 15) / 16;
-        ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, a.vec_x != 0);
+        ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, FAST || a.vec_x != 0);
         __syncthreads();
-        ffn_hidden<0>(a, g, xs, hs, nullptr, mt_valid, rows);
+        ffn_hidden<FAST, 0>(a, g, xs, hs, nullptr, mt_valid, rows);
         __syncthreads();
         // y = gelu(h) W2^T + b2 + x
-        const int ntn = g.D16 / 16, mblocks = (mt_valid + 1) / 2, ntasks = mblocks * ntn;
-        const RatLdsRows A{hs, g.ldh};
-        const RatGlobalWnk Bw{a.w2, g.D, g.H, g.H, a.vec_w2 != 0};
-        for (int task = rat_wave(); task < ntasks; task += FFN_WAVES) {
-            const int mt0 = (task / ntn) * 2, nt = task % ntn;
-            const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
-            f32x4 acc[2][1];
-            acc[0][0] = acc[1][0] = rat_zero4();
-            rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.H16 / 16);
-            const int col = rat_acc_col(nt);
-            if (col < g.D) {
-                const float bias = a.b2[col];
+        {
+            const RatLdsRows A{hs, g.ldh};
+            const RatGlobalWnkT<!FAST> Bw{a.w2, g.D, g.H, g.H, a.vec_w2 != 0};
+            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
+                if (FAST || col < g.D) {
+                    const float bias = a.b2[col];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    if (i < mtv)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = rat_acc_row(mt0 + i, r);
-                            if (row < rows) a.y[(tok0 + row) * g.D + col] = acc[i][0][r] + bias + xs[(size_t)row * g.ldx + col];
-                        }
-            }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rat_acc_row(mt, r);
+                        if (row < rows) a.y[(tok0 + row) * g.D + col] = acc[r] + bias + xs[(size_t)row * g.ldx + col];
+                    }
+                }
+            });
         }
         __syncthreads();
     }
 }
 
+template <int TD>
 __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
+    constexpr bool FAST = TD > 0;
     RAT_DYN_SMEM(smem);
-    const FfnGeom g(a.d, a.hidden);
+    const FfnGeom g(FAST ? TD : a.d, a.hidden);
     const int D = g.D, H = g.H;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx] x
     float* dys = xs + (size_t)FFN_ROWS * g.ldx;                 // [64][ldx] dL/dy
@@ -170,10 +162,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         const int64_t tok0 = chunk * FFN_ROWS;
         const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
         const int mt_valid = (rows + 15) / 16;
-        ffn_load(xs, g.ldx, a.x, tok0, rows, D, a.vec_x != 0);
-        ffn_load(dys, g.ldx, a.dy, tok0, rows, D, a.vec_x != 0);
+        ffn_load(xs, g.ldx, a.x, tok0, rows, D, FAST || a.vec_x != 0);
+        ffn_load(dys, g.ldx, a.dy, tok0, rows, D, FAST || a.vec_x != 0);
         __syncthreads();
-        ffn_hidden<1>(a, g, xs, hs, gs, mt_valid, rows);
+        ffn_hidden<FAST, 1>(a, g, xs, hs, gs, mt_valid, rows);
         __syncthreads();
         // dW2 += dy^T gelu(h) ; db2 += colsum(dy)
         {
@@ -193,50 +185,33 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         __syncthreads();
         // dh = (dy W2) * gelu'(h)  -> gs
         {
-            const int ntn = g.H16 / 16;
             const RatLdsRows A{dys, g.ldx};
-            const RatGlobalWkn Bw{a.w2, D, H, H};
-            for (int nt = rat_wave(); nt < ntn; nt += FFN_WAVES) {
-                f32x4 acc[4][1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][0] = rat_zero4();
-                rat_wave_gemm<4, 1>(acc, A, Bw, 0, nt, mt_valid, 1, g.D16 / 16);
+            const RatGlobalWknT<!FAST> Bw{a.w2, D, H, H};
+            rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
-                if (col < H)
+                if (FAST || col < H)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (i < mt_valid)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rat_acc_row(i, r);
-                                const size_t o = (size_t)row * g.ldh + col;
-                                gs[o] = row < rows ? acc[i][0][r] * rat_gelu_grad(hs[o]) : 0.f;
-                            }
-            }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rat_acc_row(mt, r);
+                        const size_t o = (size_t)row * g.ldh + col;
+                        gs[o] = row < rows ? acc[r] * rat_gelu_grad(hs[o]) : 0.f;
+                    }
+            });
         }
         __syncthreads();
         // dx = dh W1 + dy ; dW1 += dh^T x ; db1 += colsum(dh)
         {
-            const int ntn = g.D16 / 16, mblocks = (mt_valid + 1) / 2, ntasks = mblocks * ntn;
             const RatLdsRows A{gs, g.ldh};
-            const RatGlobalWkn Bw{a.w1, H, D, D};
-            for (int task = rat_wave(); task < ntasks; task += FFN_WAVES) {
-                const int mt0 = (task / ntn) * 2, nt = task % ntn;
-                const int mtv = mt_valid - mt0 < 2 ? mt_valid - mt0 : 2;
-                f32x4 acc[2][1];
-                acc[0][0] = acc[1][0] = rat_zero4();
-                rat_wave_gemm<2, 1>(acc, A, Bw, mt0, nt, mtv, 1, g.H16 / 16);
+            const RatGlobalWknT<!FAST> Bw{a.w1, H, D, D};
+            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
-                if (col < D)
+                if (FAST || col < D)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        if (i < mtv)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rat_acc_row(mt0 + i, r);
-                                if (row < rows) a.y[(tok0 + row) * D + col] = acc[i][0][r] + dys[(size_t)row * g.ldx + col];
-                            }
-            }
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = rat_acc_row(mt, r);
+                        if (row < rows) a.y[(tok0 + row) * D + col] = acc[r] + dys[(size_t)row * g.ldx + col];
+                    }
+            });
             const RatLdsCols At{gs, g.ldh};
             const RatLdsCols Bt{xs, g.ldx};
 #pragma unroll
@@ -285,6 +260,14 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int ffn_fast_dim(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
+    if (a.hidden % 16 != 0) return 0;
+    for (const void* p : ptrs)
+        if (!aligned16(p)) return 0;
+    if (!aligned16(a.w1) || !aligned16(a.w2)) return 0;
+    return (a.d == 64 || a.d == 16) ? a.d : 0;
+}
+
 int ffn_check(int64_t ntok, int d, int hidden, bool backward) {
     RAT_REQUIRE(ntok > 0 && d > 0 && hidden > 0, "bad dims");
     RAT_REQUIRE(d <= FFN_THREADS && hidden <= FFN_THREADS, "d / hidden above 512 not supported");
@@ -321,7 +304,11 @@ extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const floa
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     const int64_t blocks = a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu;
-    RAT_LAUNCH(ffn_fwd_kernel, (unsigned)blocks, FFN_THREADS, smem, stream, a);
+    switch (ffn_fast_dim(a, {x, y})) {
+        case 64: RAT_LAUNCH((ffn_fwd_kernel<64>), (unsigned)blocks, FFN_THREADS, smem, stream, a); break;
+        case 16: RAT_LAUNCH((ffn_fwd_kernel<16>), (unsigned)blocks, FFN_THREADS, smem, stream, a); break;
+        default: RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, smem, stream, a); break;
+    }
     return rat_check_launch("rat_ffn_fwd");
 }
 
@@ -355,7 +342,11 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
-    RAT_LAUNCH(ffn_bwd_kernel, blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+    switch (ffn_fast_dim(a, {x, dy, dx})) {
+        case 64: RAT_LAUNCH((ffn_bwd_kernel<64>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
+        case 16: RAT_LAUNCH((ffn_bwd_kernel<16>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
+        default: RAT_LAUNCH((ffn_bwd_kernel<0>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
+    }
     if (rat_check_launch("rat_ffn_bwd")) return -1;
     float* outs[4] = {dw1, dw2, db1, db2};
     const int64_t sizes[4] = {(int64_t)hidden * d, (int64_t)d * hidden, hidden, d};

@@ -96,3 +96,30 @@ extern "C" int rat_clip_adam(float* w, const float* g, float* m, float* v, int64
                (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
     return rat_check_launch("rat_clip_adam");
 }
+
+// ---- inverted dropout with a counter-based generator (nn.Dropout of RAT_m2.py:83,135 `emb_dropout` and deep.py:133-134
+// `net_dropout`).  mask(i) depends only on (seed, i), so backward re-derives it instead of storing it:
+// y[i] = keep(seed, i) ? x[i] / (1 - p) : 0.  torch's Philox stream cannot be matched bit for bit; parity for p > 0 is
+// statistical (SURVEY.md §7 hard part 5).
+namespace {
+__device__ __forceinline__ uint32_t rat_hash32(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);          // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint32_t threshold, float scale, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = rat_hash32(seed, (uint64_t)i) >= threshold ? x[i] * scale : 0.f;
+}
+}  // namespace
+
+extern "C" int rat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+    RAT_REQUIRE(n > 0 && x && y && p >= 0.f && p < 1.f, "bad args");
+    const uint32_t threshold = (uint32_t)((double)p * 4294967296.0);
+    RAT_LAUNCH(dropout_kernel, opt_blocks(n), OPT_THREADS, 0, stream, x, y, n, threshold, 1.0f / (1.0f - p), seed);
+    return rat_check_launch("rat_dropout");
+}

@@ -21,23 +21,57 @@ int rat_check_launch(const char* what) {
 extern "C" int rat_version(void) { return RAT_ABI_VERSION; }
 extern "C" const char* rat_last_error(void) { return g_last_error.c_str(); }
 
-// out[p] = sum over slabs (fixed order => bitwise reproducible for a fixed grid)
-__global__ void rat_reduce_slabs_kernel(const float* slabs, int nslabs, int64_t stride, float* out, int64_t n) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int w = 0; w < nslabs; ++w) s += slabs[(int64_t)w * stride + p];
-        out[p] = s;
+// out[p] = sum over slabs in a fixed order => bitwise reproducible for a fixed grid.  One launch covers all the
+// parameter tensors of a backward kernel: 64 parameters x 4 slab-quarters per 256-thread block (coalesced across
+// parameters), quarters combined through LDS in a fixed order.
+struct RatReduceArgs {
+    const float* slabs;
+    int nslabs;
+    int64_t stride;
+    int nouts;
+    float* out[8];
+    int64_t off[8];
+    int64_t size[8];
+    int64_t first_block[9];     // block range of each output
+};
+
+__global__ void __launch_bounds__(256) rat_reduce_slabs_kernel(RatReduceArgs r) {
+    __shared__ float part[256];
+    int o = 0;
+    while (o + 1 < r.nouts && (int64_t)blockIdx.x >= r.first_block[o + 1]) ++o;
+    const int lane_p = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int64_t p = ((int64_t)blockIdx.x - r.first_block[o]) * 64 + lane_p;
+    float s = 0.f;
+    if (p < r.size[o]) {
+        const int per = (r.nslabs + 3) / 4;
+        const int w0 = quarter * per, w1 = (w0 + per < r.nslabs) ? w0 + per : r.nslabs;
+        const float* src = r.slabs + r.off[o] + p;
+        for (int w = w0; w < w1; ++w) s += src[(int64_t)w * r.stride];
     }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (quarter == 0 && p < r.size[o]) r.out[o][p] = ((part[lane_p] + part[64 + lane_p]) + part[128 + lane_p]) + part[192 + lane_p];
 }
 
 int rat_launch_reduce_slabs(const float* slabs, int nslabs, int64_t stride, float* const* outs_host,
                             const int64_t* offsets, const int64_t* sizes, int nouts, void* stream) {
+    RatReduceArgs r{};
+    r.slabs = slabs;
+    r.nslabs = nslabs;
+    r.stride = stride;
+    int64_t blocks = 0;
     for (int i = 0; i < nouts; ++i) {
         if (!outs_host[i] || sizes[i] <= 0) continue;
-        int blocks = (int)((sizes[i] + 255) / 256);
-        if (blocks > 1024) blocks = 1024;
-        RAT_LAUNCH(rat_reduce_slabs_kernel, blocks, 256, 0, stream, slabs + offsets[i], nslabs, stride, outs_host[i],
-                   sizes[i]);
+        if (r.nouts >= 8) return rat_fail("rat_reduce_slabs: too many outputs");
+        r.out[r.nouts] = outs_host[i];
+        r.off[r.nouts] = offsets[i];
+        r.size[r.nouts] = sizes[i];
+        r.first_block[r.nouts] = blocks;
+        blocks += (sizes[i] + 63) / 64;
+        ++r.nouts;
     }
+    if (r.nouts == 0) return 0;
+    r.first_block[r.nouts] = blocks;
+    RAT_LAUNCH(rat_reduce_slabs_kernel, (unsigned)blocks, 256, 0, stream, r);
     return rat_check_launch("rat_reduce_slabs");
 }

@@ -87,18 +87,21 @@ struct RatLdsCols {
         return make_float4(p[0], p[ld], p[2 * ld], p[3 * ld]);
     }
 };
-// nn.Linear weight W[N][K] in global memory used as B[k][n] = W[n][k]  (y = x W^T)
-struct RatGlobalWnk {
+// nn.Linear weight W[N][K] in global memory used as B[k][n] = W[n][k]  (y = x W^T).
+// GUARD=false: N, K multiples of 16, ld % 4 == 0, 16-byte aligned base -> one unguarded 16-byte load.
+template <bool GUARD>
+struct RatGlobalWnkT {
     const float* w;
     int N, K, ld;
-    bool vec;                                 // K % 4 == 0 && ld % 4 == 0 && 16-byte aligned base
+    bool vec;                                 // (GUARD only) K % 4 == 0 && ld % 4 == 0 && 16-byte aligned base
     __device__ __forceinline__ float4 operator()(int tile, int kb) const {
         const int l = rat_lane();
         const int n = tile * 16 + (l & 15);
         const int k = kb * 16 + 4 * (l >> 4);
+        const float* p = w + (size_t)n * ld + k;
+        if (!GUARD) return *reinterpret_cast<const float4*>(p);
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < N) {
-            const float* p = w + (size_t)n * ld + k;
             if (vec && k + 3 < K) {
                 r = *reinterpret_cast<const float4*>(p);
             } else {
@@ -111,17 +114,20 @@ struct RatGlobalWnk {
         return r;
     }
 };
+typedef RatGlobalWnkT<true> RatGlobalWnk;
 // weight W[K][N] in global memory used as B[k][n] = W[k][n]  (dx = dy W)
-struct RatGlobalWkn {
+template <bool GUARD>
+struct RatGlobalWknT {
     const float* w;
     int K, N, ld;
     __device__ __forceinline__ float4 operator()(int tile, int kb) const {
         const int l = rat_lane();
         const int n = tile * 16 + (l & 15);
         const int k = kb * 16 + 4 * (l >> 4);
+        const float* p = w + (size_t)k * ld + n;
+        if (!GUARD) return make_float4(p[0], p[(size_t)ld], p[(size_t)2 * ld], p[(size_t)3 * ld]);
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < N) {
-            const float* p = w + (size_t)k * ld + n;
             if (k + 0 < K) r.x = p[0];
             if (k + 1 < K) r.y = p[(size_t)ld];
             if (k + 2 < K) r.z = p[(size_t)2 * ld];
@@ -130,6 +136,30 @@ struct RatGlobalWkn {
         return r;
     }
 };
+typedef RatGlobalWknT<true> RatGlobalWkn;
+
+// acc[i] += A(tile mt0+i) * B(tile nt) for i < MT, every tile valid, B fetched one k-block ahead (the B operand
+// comes from global memory / L2; the next fragment is in flight while the current one feeds the MFMAs).
+template <int MT, class AF, class BF>
+__device__ __forceinline__ void rat_wave_gemm_col(f32x4 (&acc)[MT], const AF& af, const BF& bf, int mt0, int nt,
+                                                  int kblocks) {
+    float4 bn = bf(nt, 0);
+    for (int kb = 0; kb < kblocks; ++kb) {
+        const float4 b = bn;
+        bn = bf(nt, kb + 1 < kblocks ? kb + 1 : kb);
+        float4 a[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = af(mt0 + i, kb);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].x, b.x, acc[i]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].y, b.y, acc[i]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].z, b.z, acc[i]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].w, b.w, acc[i]);
+    }
+}
 
 // acc[i][j] += A(tile mt0+i) * B(tile nt0+j) over kblocks 16-wide k-blocks; tiles beyond mt_valid/nb_valid
 // are skipped (wave-uniform).  All 64 lanes of the wave must call this together.
@@ -165,6 +195,36 @@ __device__ __forceinline__ void rat_wave_gemm(f32x4 (&acc)[MT][NB], const AF& af
     }
 }
 
+// C[MTILES*16 rows][n_tiles*16] = A (LDS rows) x B (weights in L2) as 16x16 tiles; tasks = (M block of MT tiles) x (N tile),
+// dealt round-robin to the NWAVES waves; epi(mt, nt, acc) consumes each finished tile.
+// FAST: all M tiles are always computed (padding rows are zero), no validity predicates, B one k-block ahead.
+template <bool FAST, int MT, int NWAVES, int MTILES, class AF, class BF, class Epi>
+__device__ __forceinline__ void rat_gemm_phase(const AF& A, const BF& Bw, int mt_valid, int n_tiles, int kblocks, const Epi& epi) {
+    constexpr int MBLOCKS = MTILES / MT;
+    const int ntasks = MBLOCKS * n_tiles;
+    for (int task = rat_wave(); task < ntasks; task += NWAVES) {
+        const int mt0 = (task / n_tiles) * MT, nt = task % n_tiles;
+        if (!FAST && mt0 >= mt_valid) continue;
+        if (FAST) {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = rat_zero4();
+            rat_wave_gemm_col<MT>(acc, A, Bw, mt0, nt, kblocks);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) epi(mt0 + i, nt, acc[i]);
+        } else {
+            f32x4 acc[MT][1];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i][0] = rat_zero4();
+            const int mtv = mt_valid - mt0 < MT ? mt_valid - mt0 : MT;
+            rat_wave_gemm<MT, 1>(acc, A, Bw, mt0, nt, mtv, 1, kblocks);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (i < mtv) epi(mt0 + i, nt, acc[i][0]);
+        }
+    }
+}
+
 // single-tile variant for the persistent weight-gradient accumulators
 template <class AF, class BF>
 __device__ __forceinline__ f32x4 rat_wave_gemm1(f32x4 acc, const AF& af, const BF& bf, int mt, int nt, int kblocks) {
@@ -184,6 +244,5 @@ __device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 
 __device__ __forceinline__ int rat_acc_col(int tile_n) { return tile_n * 16 + (rat_lane() & 15); }
 
 // sum the persistent-gradient slabs of all work-groups: out[p] = sum_wg slab[wg][p], fixed order
-__global__ void rat_reduce_slabs_kernel(const float* slabs, int nslabs, int64_t stride, float* out, int64_t n);
 int rat_launch_reduce_slabs(const float* slabs, int nslabs, int64_t stride, float* const* outs_host,
                             const int64_t* offsets, const int64_t* sizes, int nouts, void* stream);

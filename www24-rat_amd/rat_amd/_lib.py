@@ -53,6 +53,7 @@ _SIGNATURES = {
                               c_int, _P]),
     "rat_l2_reg": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
     "rat_sumsq": (c_int, [_P, c_int64, _P, _P]),
+    "rat_dropout": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P]),
     "rat_clip_adam": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -66,6 +67,8 @@ class RatLib:
         if not os.path.exists(self.path):
             raise RatError("librat_hip.so not found at %s — build it with `python www24-rat_amd/build.py` "
                            "(hipcc --offload-arch=gfx950).  There is no fallback path." % self.path)
+        import torch  # noqa: F401 — FIRST: torch loads its bundled libamdhip64 (soname libamdhip64.so.7); loading
+        #                 librat_hip.so afterwards binds it to that same HIP runtime instead of a second copy.
         self.cdll = ctypes.CDLL(self.path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(self.cdll, name)          # AttributeError if the library does not export the symbol

@@ -1,0 +1,93 @@
+"""Batch source for the plugin: the 4-tuple the reference's DataLoader hands to ``forward``
+(fuxictr/pytorch/data_generator.py:66-78,239-241), assembled a whole batch at a time.
+
+The reference builds every sample in a Python ``__getitem__`` (``pool[retr_indices[i]]`` + concat) inside 3 worker
+processes and collates float64 tensors; this class does the same gather with one vectorised fancy-index per batch and
+hands over int32 ids / float32 labels (the model converts once anyway).  On-disk formats: the reference's ``*.h5``
+(``data`` = float [N, L+1] with the label last; ``retrieval_{K}_{split}.h5`` with ``indices``/``values``/``lens``) are
+read when ``h5py`` is importable; ``.npz`` files with the same keys are always accepted.  BM25 retrieval itself is an
+offline pre-computation and out of scope."""
+import os
+
+import numpy as np
+import torch
+
+
+def load_array_file(path, keys):
+    if path.endswith(".npz"):
+        blob = np.load(path)
+        return {k: blob[k] for k in keys}
+    try:
+        import h5py
+    except ImportError as exc:
+        raise RuntimeError("%s is an HDF5 file and h5py is not installed; export it to .npz with keys %s" % (path, keys)) from exc
+    with h5py.File(path, "r") as hf:
+        return {k: hf[k][:] for k in keys}
+
+
+class RetrievalBatches:
+    """Iterable over batches of (X [B,1+K,L], y [B,1+K], retrieved_values [B,K], retrieved_lens [B])."""
+
+    def __init__(self, data, pool, retr_indices, retr_values, retr_lens, batch_size, shuffle=False, seed=0,
+                 drop_last=False):
+        data, pool = np.asarray(data), np.asarray(pool)
+        self.ids = np.ascontiguousarray(data[:, :-1].astype(np.int32))
+        self.labels = np.ascontiguousarray(data[:, -1].astype(np.float32))
+        same = pool is data
+        self.pool_ids = self.ids if same else np.ascontiguousarray(pool[:, :-1].astype(np.int32))
+        self.pool_labels = self.labels if same else np.ascontiguousarray(pool[:, -1].astype(np.float32))
+        self.retr_indices = np.asarray(retr_indices).astype(np.int64)     # -1 selects the last pool row, like numpy does
+        self.retr_values = np.asarray(retr_values, dtype=np.float32)
+        self.retr_lens = np.asarray(retr_lens, dtype=np.int64)
+        assert len(self.ids) == len(self.retr_indices) == len(self.retr_values) == len(self.retr_lens)
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self._rng = np.random.RandomState(seed)
+
+    def __len__(self):
+        n = len(self.ids)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.ids)
+        order = self._rng.permutation(n) if self.shuffle else np.arange(n)
+        for b in range(len(self)):
+            rows = order[b * self.batch_size:(b + 1) * self.batch_size]
+            ridx = self.retr_indices[rows]                                              # [B, K]
+            X = np.concatenate([self.ids[rows][:, None, :], self.pool_ids[ridx]], axis=1)
+            y = np.concatenate([self.labels[rows][:, None], self.pool_labels[ridx]], axis=1)
+            yield (torch.from_numpy(X), torch.from_numpy(y), torch.from_numpy(self.retr_values[rows]),
+                   torch.from_numpy(self.retr_lens[rows]))
+
+
+def batches_from_files(data_path, retrieval_path, batch_size, pool_path=None, **kw):
+    data = load_array_file(data_path, ["data"])["data"]
+    pool = data if pool_path is None else load_array_file(pool_path, ["data"])["data"]
+    r = load_array_file(retrieval_path, ["indices", "values", "lens"])
+    return RetrievalBatches(data, pool, r["indices"], r["values"], r["lens"], batch_size, **kw)
+
+
+def synthetic_split(feature_map, n_rows, topk, seed, label_rule=True):
+    """A self-contained synthetic dataset with learnable structure (labels depend on the ids), for end-to-end runs
+    when no real data is present: returns (data [N, L+1] float64, retr_indices, retr_values, retr_lens)."""
+    rs = np.random.RandomState(seed)
+    cols, score = [], np.zeros(n_rows)
+    for j, spec in enumerate(feature_map.feature_specs.values()):
+        ncols = len(spec["index"]) if isinstance(spec["index"], (list, tuple)) else 1
+        v = spec["vocab_size"]
+        ids = rs.randint(0, v - 1 if ncols > 1 else v, size=(n_rows, ncols))
+        wts = np.random.RandomState(1000 + j).standard_normal(v)
+        score += wts[ids].sum(axis=1)
+        cols.append(ids)
+    X = np.concatenate(cols, axis=1).astype(np.float64)
+    prob = 1.0 / (1.0 + np.exp(-score / np.sqrt(len(cols)))) if label_rule else np.full(n_rows, 0.5)
+    y = (rs.rand(n_rows) < prob).astype(np.float64)
+    data = np.concatenate([X, y[:, None]], axis=1)
+    # stand-in for BM25: neighbours that share the first column's id when possible, else random rows
+    order = np.argsort(X[:, 0], kind="mergesort")
+    pos = np.empty(n_rows, dtype=np.int64)
+    pos[order] = np.arange(n_rows)
+    offs = np.arange(1, topk + 1)[None, :]
+    indices = order[(pos[:, None] + offs) % n_rows]
+    values = rs.rand(n_rows, topk)
+    lens = np.full(n_rows, topk, dtype=np.int64)
+    return data, indices, values, lens

@@ -333,16 +333,18 @@ class RAT_m2(BaseModel):
         d, F, H, heads, dh = c["d"], c["nf"], c["hidden"], c["heads"], c["dh"]
         S = F + 1
         training = self.training
-        if training and (c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers)):
-            raise NotImplementedError("emb_dropout / net_dropout > 0 in training mode is not implemented yet")
         x0 = ops.gather_fwd(idx, labels, self._ftab, F, self._p("label_embedding_layer.weight"), B, T, L, d, lib=lib)
         saved = {"batch": batch, "dims": (B, T, L, S), "blocks": [], "dnn": []}
+        # dropout seeds come from torch's CPU generator, so seed_everything() governs them (masks are re-derived in backward)
+        drop = training and (c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers))
+        seeds = torch.randint(0, 2 ** 62, (1 + len(self._dnn_layers),)).tolist() if drop else None
+        saved["seeds"] = seeds
         # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
         dnn_out = None
         if self.dnn is not None:
             mods = self.dnn.dnn
             a_prev, lda, K = x0[:, 0, 1:, :], T * S * d, F * d
-            for lin, bn, _ in self._dnn_layers:
+            for li, (lin, bn, pdrop) in enumerate(self._dnn_layers):
                 W, bvec = mods[lin].weight.data, mods[lin].bias.data
                 N = W.shape[0]
                 z = torch.empty((B, N), dtype=torch.float32, device=x0.device)
@@ -355,8 +357,11 @@ class RAT_m2(BaseModel):
                         m.num_batches_tracked += 1
                 else:
                     a, sm, sr = ops.bn_relu_fwd(z, None, None, None, None, training, False, lib=lib)
+                a_act = a
+                if drop and pdrop > 0:                                      # net_dropout (deep.py:133-134)
+                    a = ops.dropout(a_act, pdrop, seeds[1 + li], lib=lib)
                 if save:
-                    saved["dnn"].append((a_prev, lda, K, z, a, sm, sr))
+                    saved["dnn"].append((a_prev, lda, K, z, a_act, sm, sr))
                 a_prev, lda, K = a, N, N
             W, bvec = mods[self._dnn_out].weight.data, mods[self._dnn_out].bias.data
             dnn_out = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
@@ -366,8 +371,10 @@ class RAT_m2(BaseModel):
         # ---- encoder: depth x (intra attention, cross attention, FFN), each with its residual
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
         x = x0
+        if drop and c["emb_dropout"] > 0:                                  # self.dropout(x) (RAT_m2.py:135); X_emb for the DNN stays un-dropped
+            x = ops.dropout(x0, c["emb_dropout"], seeds[0], lib=lib)
         for bi, blk in enumerate(self._blocks):
-            inplace = (not save) and bi > 0                    # eval: x0 must survive (DNN input), later grids are reused
+            inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
             xa, o1, l1 = ops.attn_fwd(x, blk["intra"][1], imap, d, heads, dh, save=save, out=x if inplace else None, lib=lib)
             xb, o2, l2 = ops.attn_fwd(xa, blk["cross"][1], cmap, d, heads, dh, save=save, out=xa if not save else None, lib=lib)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
@@ -418,8 +425,11 @@ class RAT_m2(BaseModel):
             ops.colsum(dlogit, 1, G(pre + "bias"), B, 1, lib=lib)
             da = torch.empty((B, K), dtype=torch.float32, device=dev)
             ops.sgemm(0, 0, B, K, 1, dlogit, 1, W, K, da, K, lib=lib)                             # da = dlogit W
-            for (lin, bn, _), (a_in, lda_in, K_in, z, a, sm, sr) in zip(reversed(self._dnn_layers), reversed(saved["dnn"])):
+            seeds = saved["seeds"]
+            for li, ((lin, bn, pdrop), (a_in, lda_in, K_in, z, a, sm, sr)) in reversed(list(enumerate(zip(self._dnn_layers, saved["dnn"])))):
                 N = z.shape[1]
+                if seeds is not None and pdrop > 0:
+                    da = ops.dropout(da, pdrop, seeds[1 + li], out=da, lib=lib)
                 if bn is not None:
                     m = mods[bn]
                     dz = ops.bn_relu_bwd(z, a, da, m.weight.data, sm, sr, G("dnn.dnn.%d.weight" % bn), G("dnn.dnn.%d.bias" % bn),
@@ -444,6 +454,8 @@ class RAT_m2(BaseModel):
                 names, params = blk[which]
                 grads = ops.attn_params(*[G(n) if n else None for n in names])
                 dx, _ = ops.attn_bwd(xin, dx, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+        if saved["seeds"] is not None and c["emb_dropout"] > 0:
+            dx = ops.dropout(dx, c["emb_dropout"], saved["seeds"][0], out=dx, lib=lib)
         # ---- embedding tables
         emb_prefix = "embedding_layer.embedding_layer.embedding_layer."
         gftab = ops.field_table(self._fields, [G(emb_prefix + f.name + ".weight") for f in self._fields], dev)

@@ -188,3 +188,11 @@ def clip_adam(w, g, m, v, norm_sq, max_norm, lr, beta1, beta2, eps, step, lib=No
     lib = lib or get_lib()
     lib.call("rat_clip_adam", _p(w), _p(g), _p(m), _p(v), w.numel(), _p(norm_sq), float(max_norm), float(lr), float(beta1),
              float(beta2), float(eps), int(step), _stream(w))
+
+
+def dropout(x, p, seed, out=None, lib=None):
+    lib = lib or get_lib()
+    _chk(x, name="x")
+    y = out if out is not None else torch.empty_like(x)
+    lib.call("rat_dropout", _p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(x))
+    return y
