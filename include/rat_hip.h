@@ -105,14 +105,16 @@ int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int
               float* C, int ldc, const float* bias, float beta, void* stream);
 
 /* BatchNorm1d (train: batch stats, biased var; running stats momentum update with unbiased var; eval:
- * running stats) followed by ReLU — deep.py:128-132.  use_bn=0 -> ReLU only.  z,a [M][N]. */
+ * running stats) followed by ReLU — deep.py:128-132.  use_bn=0 -> ReLU only.  z,a [M][N].
+ * workspace: rat_bn_workspace(N) bytes (per-row-split partial sums; needed when use_bn && training, and by bwd). */
+size_t rat_bn_workspace(int N);
 int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
-                    float* running_var, float* save_mean, float* save_rstd, int M, int N, int training,
-                    int use_bn, float eps, float momentum, void* stream);
+                    float* running_var, float* save_mean, float* save_rstd, float* workspace, int M, int N,
+                    int training, int use_bn, float eps, float momentum, void* stream);
 /* a = the forward output (its sign is the ReLU mask); dgamma/dbeta overwritten */
 int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
-                    const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, int M, int N,
-                    int use_bn, void* stream);
+                    const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* workspace,
+                    int M, int N, int use_bn, void* stream);
 /* column sums of a [M][N] matrix (bias gradients) */
 int rat_colsum(const float* a, int lda, float* out, int M, int N, void* stream);
 

@@ -34,18 +34,22 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, prof=False):
+    """prof=True builds the DIAGNOSTIC variant librat_hip_prof.so (-DRAT_PROF: in-kernel phase stamps; used only by
+    tools/phase_profile.py, never by the product or the tests)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "librat_hip.digest")
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
-    objdir = os.path.join(LIBDIR, "obj")
+    lib = os.path.join(LIBDIR, "librat_hip_prof.so") if prof else LIB
+    flags = FLAGS + (["-DRAT_PROF"] if prof else [])
+    stamp = lib.replace(".so", ".digest")
+    dig = _digest() + ("-prof" if prof else "")
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
+    objdir = os.path.join(LIBDIR, "obj_prof" if prof else "obj")
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), flush=True)
@@ -58,14 +62,14 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, _sources()))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp, "w") as f:
         f.write(dig)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, prof="--prof" in sys.argv))

@@ -56,6 +56,7 @@ struct AttnArgs {
     int d, heads, dh;
     float eps, scale;
     int vec_x, vec_wqkv, vec_wout;
+    unsigned long long* prof;
 };
 
 struct AttnGeom {
@@ -219,6 +220,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     zero_cols(xs, ldx, D);
     zero_cols(qkv, ldq, g.Q3);
     __syncthreads();
+    RAT_PROF_DECL
 
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         int nsq, rows;
@@ -229,6 +231,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         layer_norm_rows<COLS>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
+        RAT_PROF_MARK(0);
 
         // Q|K|V = LN(x) W_qkv^T  -> qkv[rows][0:3I]
         {
@@ -242,6 +245,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             });
         }
         __syncthreads();
+        RAT_PROF_MARK(1);
 
         // softmax(Q K^T * scale) V, one lane per (sequence, head, query); result replaces Q in place
         const int ntasks = nsq * a.heads * L;
@@ -275,6 +279,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             if (a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + logf(l);
         }
         __syncthreads();
+        RAT_PROF_MARK(2);
 
         // y = O W_out^T + b_out + x   (or y = O + x when Attention has no output projection)
         if (a.w_out != nullptr) {
@@ -302,7 +307,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(3);
     }
+    RAT_PROF_FLUSH(a.prof, 0);
 }
 
 // ----------------------------------------------------------------------------------------------- backward
@@ -345,6 +352,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     zero_cols(ob, ldt, 0);
     zero_cols(dob, ldt, 0);
     __syncthreads();
+    RAT_PROF_DECL
 
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         int nsq, rows;
@@ -361,6 +369,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         layer_norm_rows<COLS>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
+        RAT_PROF_MARK(0);
 
         // (1) recompute Q|K|V
         {
@@ -403,6 +412,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(1);
 
         // (4) attention backward, pass 1: one lane per query row -> delta, dQ (written over O)
         const int ntasks = nsq * H * L;
@@ -432,6 +442,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             dq.store(op, dh, a.scale);
         }
         __syncthreads();
+        RAT_PROF_MARK(2);
         // pass 2: one lane per key row -> dK, dV (written over K, V)
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int j = task % L;
@@ -458,6 +469,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             dv.store(kp + I, dh, 1.0f);
         }
         __syncthreads();
+        RAT_PROF_MARK(3);
         // dQ (in ob) -> Q columns of qkv: qkv now holds d[Q|K|V]
         if (FAST) {
             const int w4 = I >> 2;
@@ -472,6 +484,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(4);
 
         // (5) d(LN out) = dQKV W_qkv -> dob[rows][0:D] ; (6) dW_qkv += dQKV^T LN(x)
         {
@@ -492,6 +505,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(5);
 
         // (7) LayerNorm backward + residual: dx = dy + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma
         {
@@ -528,7 +542,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(6);
     }
+    RAT_PROF_FLUSH(a.prof, 12);
 
     // ---- write this work-group's parameter-gradient slab: [dW_qkv | dW_out | db_out | dgamma | dbeta]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
@@ -638,6 +654,7 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
     const int I = heads * dim_head;
     a.vec_wqkv = (d % 4 == 0) && aligned16(w->w_qkv);
     a.vec_wout = (I % 4 == 0) && aligned16(w->w_out);
+    a.prof = rat_prof_buffer();
 }
 
 // which compiled fast shape (if any) serves these dimensions

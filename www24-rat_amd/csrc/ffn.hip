@@ -32,6 +32,7 @@ struct FfnArgs {
     int64_t ntok, nchunks;
     int d, hidden;
     int vec_x, vec_w1, vec_w2;
+    unsigned long long* prof;
 };
 
 struct FfnGeom {
@@ -106,14 +107,17 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
     ffn_zero_cols(xs, g.ldx, g.D);
     ffn_zero_cols(hs, g.ldh, g.H);
     __syncthreads();
+    RAT_PROF_DECL
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         const int64_t tok0 = chunk * FFN_ROWS;
         const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
         const int mt_valid = (rows + 15) / 16;
         ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, FAST || a.vec_x != 0);
         __syncthreads();
+        RAT_PROF_MARK(0);
         ffn_hidden<FAST, 0>(a, g, xs, hs, nullptr, mt_valid, rows);
         __syncthreads();
+        RAT_PROF_MARK(1);
         // y = gelu(h) W2^T + b2 + x
         {
             const RatLdsRows A{hs, g.ldh};
@@ -131,7 +135,9 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
             });
         }
         __syncthreads();
+        RAT_PROF_MARK(2);
     }
+    RAT_PROF_FLUSH(a.prof, 24);
 }
 
 template <int TD>
@@ -157,6 +163,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
     ffn_zero_cols(hs, g.ldh, H);
     ffn_zero_cols(gs, g.ldh, H);
     __syncthreads();
+    RAT_PROF_DECL
 
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
         const int64_t tok0 = chunk * FFN_ROWS;
@@ -165,8 +172,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         ffn_load(xs, g.ldx, a.x, tok0, rows, D, FAST || a.vec_x != 0);
         ffn_load(dys, g.ldx, a.dy, tok0, rows, D, FAST || a.vec_x != 0);
         __syncthreads();
+        RAT_PROF_MARK(0);
         ffn_hidden<FAST, 1>(a, g, xs, hs, gs, mt_valid, rows);
         __syncthreads();
+        RAT_PROF_MARK(1);
         // dW2 += dy^T gelu(h) ; db2 += colsum(dy)
         {
             const RatLdsCols At{dys, g.ldx};
@@ -183,6 +192,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(2);
         // dh = (dy W2) * gelu'(h)  -> gs
         {
             const RatLdsRows A{dys, g.ldx};
@@ -199,6 +209,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             });
         }
         __syncthreads();
+        RAT_PROF_MARK(3);
         // dx = dh W1 + dy ; dW1 += dh^T x ; db1 += colsum(dh)
         {
             const RatLdsRows A{gs, g.ldh};
@@ -226,7 +237,9 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(4);
     }
+    RAT_PROF_FLUSH(a.prof, 36);
 
     // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
@@ -298,6 +311,7 @@ extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const floa
     a.vec_x = (d % 4 == 0) && aligned16(x);
     a.vec_w1 = (d % 4 == 0) && aligned16(w1);
     a.vec_w2 = (hidden % 4 == 0) && aligned16(w2);
+    a.prof = rat_prof_buffer();
     const FfnGeom g(d, hidden);
     const size_t smem = g.fwd_smem();
     int per_cu = (int)((160 * 1024) / smem);
@@ -338,6 +352,7 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
     a.vec_x = (d % 4 == 0) && aligned16(x) && aligned16(dy);
     a.vec_w1 = (d % 4 == 0) && aligned16(w1);
     a.vec_w2 = (hidden % 4 == 0) && aligned16(w2);
+    a.prof = rat_prof_buffer();
     const FfnGeom g(d, hidden);
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();

@@ -1,7 +1,8 @@
 // gemm.hip — plain fp32 GEMM on v_mfma_f32_16x16x4_f32 for the prediction head's nn.Linear layers
 // (MLP_Layer, fuxictr/pytorch/layers/deep.py:126-141): forward (x W^T + b), dgrad (dy W) and wgrad (dy^T x).
-// The head is 1.4 % of the model's FLOPs; this kernel is a straightforward 64x64x16 LDS-tiled
-// design: 4 waves, each owning a 32x32 quadrant as 2x2 MFMA tiles.
+// The head is 1.4 % of the model's FLOPs.  64x64x32 LDS tiles, 4 waves each owning a 32x32 quadrant
+// (2x2 MFMA tiles); the next k-tile is fetched into registers with 16-byte loads while the current one feeds the
+// MFMAs (register-staged software pipeline: one barrier pair per 32-deep step).
 #include "rat_device.h"
 #include "../../include/rat_hip.h"
 
@@ -9,8 +10,9 @@ namespace {
 
 constexpr int GM_THREADS = 256;
 constexpr int GM_TILE = 64;
-constexpr int GM_K = 16;
+constexpr int GM_K = 32;
 constexpr int GM_LD = GM_K + 4;
+constexpr int GM_VEC = GM_TILE * GM_K / 4 / GM_THREADS;      // float4 loads per thread per operand tile (= 2)
 
 struct GemmArgs {
     const float* A;
@@ -19,7 +21,65 @@ struct GemmArgs {
     const float* bias;
     int M, N, K, lda, ldb, ldc;
     int ta, tb;
+    int veca, vecb;       // 16-byte loads are legal for that operand (ld % 4 == 0, base 16-byte aligned)
     float beta;
+};
+
+// One operand tile: T[r][k] (r = m or n index inside the tile, k inside the k-tile).  `kmajor` = the operand is stored
+// with k as the slow index ([K][R], contiguous along r); otherwise [R][K], contiguous along k.
+struct TileLoader {
+    const float* base;
+    int R, K, ld, r0;
+    bool kmajor, vec;
+    __device__ __forceinline__ void fetch(int k0, float4 (&v)[GM_VEC]) const {
+#pragma unroll
+        for (int u = 0; u < GM_VEC; ++u) {
+            const int e = threadIdx.x + GM_THREADS * u;
+            int r, k;
+            if (kmajor) { k = e / (GM_TILE / 4); r = (e % (GM_TILE / 4)) * 4; }
+            else        { r = e / (GM_K / 4);    k = (e % (GM_K / 4)) * 4; }
+            const int gr = r0 + r, gk = k0 + k;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kmajor) {
+                if (gk < K) {
+                    const float* p = base + (size_t)gk * ld + gr;
+                    if (vec && gr + 3 < R) t = *reinterpret_cast<const float4*>(p);
+                    else {
+                        if (gr + 0 < R) t.x = p[0];
+                        if (gr + 1 < R) t.y = p[1];
+                        if (gr + 2 < R) t.z = p[2];
+                        if (gr + 3 < R) t.w = p[3];
+                    }
+                }
+            } else if (gr < R) {
+                const float* p = base + (size_t)gr * ld + gk;
+                if (vec && gk + 3 < K) t = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (gk + 0 < K) t.x = p[0];
+                    if (gk + 1 < K) t.y = p[1];
+                    if (gk + 2 < K) t.z = p[2];
+                    if (gk + 3 < K) t.w = p[3];
+                }
+            }
+            v[u] = t;
+        }
+    }
+    __device__ __forceinline__ void stash(float* tile, const float4 (&v)[GM_VEC]) const {
+#pragma unroll
+        for (int u = 0; u < GM_VEC; ++u) {
+            const int e = threadIdx.x + GM_THREADS * u;
+            if (kmajor) {
+                const int k = e / (GM_TILE / 4), r = (e % (GM_TILE / 4)) * 4;
+                tile[(r + 0) * GM_LD + k] = v[u].x;
+                tile[(r + 1) * GM_LD + k] = v[u].y;
+                tile[(r + 2) * GM_LD + k] = v[u].z;
+                tile[(r + 3) * GM_LD + k] = v[u].w;
+            } else {
+                const int r = e / (GM_K / 4), k = (e % (GM_K / 4)) * 4;
+                *reinterpret_cast<float4*>(tile + r * GM_LD + k) = v[u];
+            }
+        }
+    }
 };
 
 __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
@@ -31,27 +91,25 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
     const int n0 = (blockIdx.x % tiles_n) * GM_TILE;
     const int wave = rat_wave();
     const int wm = (wave >> 1) * 2, wn = (wave & 1) * 2;  // first 16-row / 16-col tile of this wave's quadrant
+    // op(A)[m][k]: ta=0 -> A[m*lda+k] (k contiguous); ta=1 -> A[k*lda+m] (k-major).  op(B)[k][n]: tb=1 -> B[n*ldb+k]; tb=0 -> B[k*ldb+n]
+    const TileLoader la{g.A, g.M, g.K, g.lda, m0, g.ta != 0, g.veca != 0};
+    const TileLoader lb{g.B, g.N, g.K, g.ldb, n0, g.tb == 0, g.vecb != 0};
     f32x4 acc[2][2];
     acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = rat_zero4();
     const RatLdsRows Af{As, GM_LD};
     const RatLdsRows Bf{Bs, GM_LD};
+    float4 ra[GM_VEC], rb[GM_VEC];
+    la.fetch(0, ra);
+    lb.fetch(0, rb);
     for (int k0 = 0; k0 < g.K; k0 += GM_K) {
-        for (int e = threadIdx.x; e < GM_TILE * GM_K; e += GM_THREADS) {
-            int m, k;
-            if (g.ta) { m = e % GM_TILE; k = e / GM_TILE; } else { m = e / GM_K; k = e % GM_K; }
-            const int gm = m0 + m, gk = k0 + k;
-            float v = 0.f;
-            if (gm < g.M && gk < g.K) v = g.ta ? g.A[(size_t)gk * g.lda + gm] : g.A[(size_t)gm * g.lda + gk];
-            As[m * GM_LD + k] = v;
-            int n, kk;
-            if (g.tb) { n = e / GM_K; kk = e % GM_K; } else { n = e % GM_TILE; kk = e / GM_TILE; }
-            const int gn = n0 + n, gk2 = k0 + kk;
-            float w = 0.f;
-            if (gn < g.N && gk2 < g.K) w = g.tb ? g.B[(size_t)gn * g.ldb + gk2] : g.B[(size_t)gk2 * g.ldb + gn];
-            Bs[n * GM_LD + kk] = w;
-        }
+        la.stash(As, ra);
+        lb.stash(Bs, rb);
         __syncthreads();
-        rat_wave_gemm<2, 2>(acc, Af, Bf, wm, wn, 2, 2, 1);
+        if (k0 + GM_K < g.K) {                             // next tile's loads fly while this one is multiplied
+            la.fetch(k0 + GM_K, ra);
+            lb.fetch(k0 + GM_K, rb);
+        }
+        rat_wave_gemm<2, 2>(acc, Af, Bf, wm, wn, 2, 2, GM_K / 16);
         __syncthreads();
     }
 #pragma unroll
@@ -75,13 +133,17 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
         }
 }
 
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 }  // namespace
 
 extern "C" int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, const float* bias, float beta, void* stream) {
     RAT_REQUIRE(M > 0 && N > 0 && K > 0, "bad dims");
     RAT_REQUIRE(A && B && C, "null pointer");
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, beta};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, 0, 0, beta};
+    g.veca = (lda % 4 == 0) && aligned16(A);
+    g.vecb = (ldb % 4 == 0) && aligned16(B);
     const int tiles = ((M + GM_TILE - 1) / GM_TILE) * ((N + GM_TILE - 1) / GM_TILE);
     RAT_LAUNCH(sgemm_kernel, tiles, GM_THREADS, (size_t)2 * GM_TILE * GM_LD * sizeof(float), stream, g);
     return rat_check_launch("rat_sgemm");

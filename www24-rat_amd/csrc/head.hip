@@ -22,76 +22,136 @@ __device__ __forceinline__ float col_reduce(float v, float* scratch) {
     return s;
 }
 
+constexpr int BN_SPLITS = 32;               // row splits: grid = (N/32 column blocks) x BN_SPLITS
+
+// phase 1 of BatchNorm statistics: per (row split, column) partial sums about a pivot (the column's first row),
+// which keeps the one-pass variance free of cancellation: var = (S2 - S1^2/M)/M with S = sums of (z - pivot).
 __global__ void __launch_bounds__(HD_THREADS)
-bn_relu_fwd_kernel(const float* __restrict__ z, float* __restrict__ a, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* save_mean, float* save_rstd, int M, int N,
-                   int training, int use_bn, float eps, float momentum) {
+bn_stats_kernel(const float* __restrict__ z, float* __restrict__ ws, int M, int N) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
-    const int col = blockIdx.x * HD_COLS + cg;
-    const bool ok = col < N;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    const int per = (M + BN_SPLITS - 1) / BN_SPLITS;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
+    float s1 = 0.f, s2 = 0.f;
+    if (col < N) {
+        const float pivot = z[col];
+        for (int m = r0 + rg; m < r1; m += HD_RG) {
+            const float t = z[(size_t)m * N + col] - pivot;
+            s1 += t;
+            s2 = fmaf(t, t, s2);
+        }
+    }
+    s1 = col_reduce(s1, scratch);
+    s2 = col_reduce(s2, scratch);
+    if (col < N && rg == 0) {
+        ws[(size_t)split * N + col] = s1;
+        ws[(size_t)(BN_SPLITS + split) * N + col] = s2;
+    }
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_relu_apply_kernel(const float* __restrict__ z, float* __restrict__ a, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* ws, int M,
+                     int N, int training, int use_bn, float eps, float momentum) {
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    if (col >= N) return;
     float mean = 0.f, rstd = 1.f, gam = 1.f, bet = 0.f;
     if (use_bn) {
         if (training) {
-            float s = 0.f;
-            if (ok) for (int m = rg; m < M; m += HD_RG) s += z[(size_t)m * N + col];
-            mean = col_reduce(s, scratch) / (float)M;
-            float v = 0.f;
-            if (ok) for (int m = rg; m < M; m += HD_RG) { const float t = z[(size_t)m * N + col] - mean; v += t * t; }
-            const float var = col_reduce(v, scratch) / (float)M;
+            float s1 = 0.f, s2 = 0.f;
+            for (int w = 0; w < BN_SPLITS; ++w) {                      // fixed order -> every block gets the same bits
+                s1 += ws[(size_t)w * N + col];
+                s2 += ws[(size_t)(BN_SPLITS + w) * N + col];
+            }
+            const float d1 = s1 / (float)M;
+            mean = z[col] + d1;
+            float var = s2 / (float)M - d1 * d1;
+            var = var > 0.f ? var : 0.f;
             rstd = 1.0f / sqrtf(var + eps);
-            if (ok && rg == 0) {
+            if (split == 0 && rg == 0) {
                 save_mean[col] = mean;
                 save_rstd[col] = rstd;
                 const float unbiased = M > 1 ? var * (float)M / (float)(M - 1) : var;
                 running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
                 running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
             }
-        } else if (ok) {
+        } else {
             mean = running_mean[col];
             rstd = 1.0f / sqrtf(running_var[col] + eps);
         }
-        if (ok) { gam = gamma[col]; bet = beta[col]; }
+        gam = gamma[col];
+        bet = beta[col];
     }
-    if (ok)
-        for (int m = rg; m < M; m += HD_RG) {
-            const float y = (z[(size_t)m * N + col] - mean) * rstd * gam + bet;
-            a[(size_t)m * N + col] = y > 0.f ? y : 0.f;
-        }
+    const int per = (M + BN_SPLITS - 1) / BN_SPLITS;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
+    for (int m = r0 + rg; m < r1; m += HD_RG) {
+        const float y = (z[(size_t)m * N + col] - mean) * rstd * gam + bet;
+        a[(size_t)m * N + col] = y > 0.f ? y : 0.f;
+    }
 }
 
 __global__ void __launch_bounds__(HD_THREADS)
-bn_relu_bwd_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
-                   float* __restrict__ dz, const float* gamma, const float* save_mean, const float* save_rstd,
-                   float* dgamma, float* dbeta, int M, int N, int use_bn) {
+bn_bwd_stats_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
+                    const float* save_mean, const float* save_rstd, float* __restrict__ ws, int M, int N) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
-    const int col = blockIdx.x * HD_COLS + cg;
-    const bool ok = col < N;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    const int per = (M + BN_SPLITS - 1) / BN_SPLITS;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
+    float s1 = 0.f, s2 = 0.f;
+    if (col < N) {
+        const float mean = save_mean[col], rstd = save_rstd[col];
+        for (int m = r0 + rg; m < r1; m += HD_RG) {
+            const size_t o = (size_t)m * N + col;
+            const float g = a[o] > 0.f ? da[o] : 0.f;
+            s1 += g;
+            s2 = fmaf(g, (z[o] - mean) * rstd, s2);
+        }
+    }
+    s1 = col_reduce(s1, scratch);
+    s2 = col_reduce(s2, scratch);
+    if (col < N && rg == 0) {
+        ws[(size_t)split * N + col] = s1;
+        ws[(size_t)(BN_SPLITS + split) * N + col] = s2;
+    }
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_relu_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
+                         float* __restrict__ dz, const float* gamma, const float* save_mean, const float* save_rstd,
+                         float* dgamma, float* dbeta, const float* ws, int M, int N, int use_bn) {
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    if (col >= N) return;
+    const int per = (M + BN_SPLITS - 1) / BN_SPLITS;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
     if (!use_bn) {
-        if (ok) for (int m = rg; m < M; m += HD_RG) {
+        for (int m = r0 + rg; m < r1; m += HD_RG) {
             const size_t o = (size_t)m * N + col;
             dz[o] = a[o] > 0.f ? da[o] : 0.f;
         }
         return;
     }
-    const float mean = ok ? save_mean[col] : 0.f, rstd = ok ? save_rstd[col] : 1.f;
-    const float gam = ok ? gamma[col] : 1.f;
     float s1 = 0.f, s2 = 0.f;
-    if (ok) for (int m = rg; m < M; m += HD_RG) {
-        const size_t o = (size_t)m * N + col;
-        const float xh = (z[o] - mean) * rstd;
-        const float g = a[o] > 0.f ? da[o] : 0.f;
-        s1 += g;
-        s2 += g * xh;
+    for (int w = 0; w < BN_SPLITS; ++w) {
+        s1 += ws[(size_t)w * N + col];
+        s2 += ws[(size_t)(BN_SPLITS + w) * N + col];
     }
-    s1 = col_reduce(s1, scratch);
-    s2 = col_reduce(s2, scratch);
-    if (ok && rg == 0) { dgamma[col] = s2; dbeta[col] = s1; }
+    if (split == 0 && rg == 0) {
+        dgamma[col] = s2;
+        dbeta[col] = s1;
+    }
+    const float mean = save_mean[col], rstd = save_rstd[col], gam = gamma[col];
     const float m1 = s1 / (float)M, m2 = s2 / (float)M;
-    if (ok) for (int m = rg; m < M; m += HD_RG) {
+    for (int m = r0 + rg; m < r1; m += HD_RG) {
         const size_t o = (size_t)m * N + col;
         const float xh = (z[o] - mean) * rstd;
         const float g = a[o] > 0.f ? da[o] : 0.f;
@@ -197,13 +257,22 @@ logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_t
 
 }  // namespace
 
+extern "C" size_t rat_bn_workspace(int N) { return (size_t)2 * BN_SPLITS * (size_t)N * sizeof(float); }
+
 extern "C" int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
-                               float* running_var, float* save_mean, float* save_rstd, int M, int N, int training,
-                               int use_bn, float eps, float momentum, void* stream) {
+                               float* running_var, float* save_mean, float* save_rstd, float* workspace, int M, int N,
+                               int training, int use_bn, float eps, float momentum, void* stream) {
     RAT_REQUIRE(M > 0 && N > 0 && z && a, "bad args");
-    if (use_bn) RAT_REQUIRE(gamma && beta && running_mean && running_var && (!training || (save_mean && save_rstd)), "null BN pointer");
-    RAT_LAUNCH(bn_relu_fwd_kernel, (N + HD_COLS - 1) / HD_COLS, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, gamma,
-               beta, running_mean, running_var, save_mean, save_rstd, M, N, training, use_bn, eps, momentum);
+    const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
+    if (use_bn) {
+        RAT_REQUIRE(gamma && beta && running_mean && running_var, "null BN pointer");
+        if (training) {
+            RAT_REQUIRE(save_mean && save_rstd && workspace, "training BN needs save_mean/save_rstd/workspace");
+            RAT_LAUNCH(bn_stats_kernel, blocks, HD_THREADS, HD_THREADS * sizeof(float), stream, z, workspace, M, N);
+        }
+    }
+    RAT_LAUNCH(bn_relu_apply_kernel, blocks, HD_THREADS, 0, stream, z, a, gamma, beta, running_mean, running_var, save_mean,
+               save_rstd, workspace, M, N, training, use_bn, eps, momentum);
     return rat_check_launch("rat_bn_relu_fwd");
 }
 
@@ -236,11 +305,16 @@ extern "C" int rat_logit_bwd(const float* y_pred, const float* y_true, const flo
 }
 
 extern "C" int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
-                               const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, int M, int N,
-                               int use_bn, void* stream) {
+                               const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                               float* workspace, int M, int N, int use_bn, void* stream) {
     RAT_REQUIRE(M > 0 && N > 0 && z && a && da && dz, "bad args");
-    if (use_bn) RAT_REQUIRE(gamma && save_mean && save_rstd && dgamma && dbeta, "null BN pointer");
-    RAT_LAUNCH(bn_relu_bwd_kernel, (N + HD_COLS - 1) / HD_COLS, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, da, dz,
-               gamma, save_mean, save_rstd, dgamma, dbeta, M, N, use_bn);
+    const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
+    if (use_bn) {
+        RAT_REQUIRE(gamma && save_mean && save_rstd && dgamma && dbeta && workspace, "null BN pointer");
+        RAT_LAUNCH(bn_bwd_stats_kernel, blocks, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, da, save_mean, save_rstd,
+                   workspace, M, N);
+    }
+    RAT_LAUNCH(bn_relu_bwd_apply_kernel, blocks, HD_THREADS, 0, stream, z, a, da, dz, gamma, save_mean, save_rstd, dgamma,
+               dbeta, workspace, M, N, use_bn);
     return rat_check_launch("rat_bn_relu_bwd");
 }

@@ -18,6 +18,12 @@ int rat_check_launch(const char* what) {
     return 0;
 }
 
+static unsigned long long* g_prof = nullptr;
+unsigned long long* rat_prof_buffer() { return g_prof; }
+// diagnostic hook: 64 x u64 device buffer receiving per-phase cycle sums from a -DRAT_PROF build (slots: 0 attn_fwd,
+// 12 attn_bwd, 24 ffn_fwd, 36 ffn_bwd); a no-op for the product build, whose kernels contain no stamps.
+extern "C" void rat_debug_set_prof(void* device_u64x64) { g_prof = static_cast<unsigned long long*>(device_u64x64); }
+
 extern "C" int rat_version(void) { return RAT_ABI_VERSION; }
 extern "C" const char* rat_last_error(void) { return g_last_error.c_str(); }
 

@@ -27,6 +27,20 @@ typedef float f32x4 __attribute__((vector_size(16)));
 
 #include <string>
 
+// ---- optional in-kernel phase stamps (diagnostic build only: -DRAT_PROF -> librat_hip_prof.so, never the product).
+// Thread 0 of every work-group accumulates s_memtime deltas per phase and adds them to a debug buffer that no other
+// code reads (cdna_hip_programming.md §7 "In-kernel stamps").
+#if defined(RAT_PROF) && !defined(RAT_EMU)
+#define RAT_PROF_DECL unsigned long long prof_t0 = clock64(); unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RAT_PROF_MARK(i) do { const unsigned long long prof_t = clock64(); prof_acc[i] += prof_t - prof_t0; prof_t0 = prof_t; } while (0)
+#define RAT_PROF_FLUSH(ptr, base) do { if (threadIdx.x == 0 && (ptr) != nullptr) for (int pi = 0; pi < 12; ++pi) atomicAdd((ptr) + (base) + pi, prof_acc[pi]); } while (0)
+#else
+#define RAT_PROF_DECL
+#define RAT_PROF_MARK(i) do { } while (0)
+#define RAT_PROF_FLUSH(ptr, base) do { } while (0)
+#endif
+unsigned long long* rat_prof_buffer();                // device pointer set by rat_debug_set_prof (nullptr by default)
+
 // ------------------------------------------------------------------------------------------- host side
 const char* rat_set_error(const std::string& msg);   // stores thread-local, returns c_str
 int rat_fail(const std::string& msg);                 // sets error, returns -1

@@ -128,17 +128,22 @@ def sgemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, beta=0.0, lib=Non
     lib.call("rat_sgemm", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta), _stream(C))
 
 
+def _bn_ws(N, device, lib):
+    return torch.empty((lib.size("rat_bn_workspace", N) + 3) // 4, dtype=torch.float32, device=device)
+
+
 def bn_relu_fwd(z, gamma, beta, running_mean, running_var, training, use_bn, eps=1e-5, momentum=0.1, lib=None):
     lib = lib or get_lib()
     _chk(z, name="z")
     M, N = z.shape
     a = torch.empty_like(z)
-    save_mean = save_rstd = None
+    save_mean = save_rstd = ws = None
     if use_bn and training:
         save_mean = torch.empty(N, dtype=torch.float32, device=z.device)
         save_rstd = torch.empty(N, dtype=torch.float32, device=z.device)
+        ws = _bn_ws(N, z.device, lib)
     lib.call("rat_bn_relu_fwd", _p(z), _p(a), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(save_mean),
-             _p(save_rstd), M, N, int(training), int(use_bn), eps, momentum, _stream(z))
+             _p(save_rstd), _p(ws), M, N, int(training), int(use_bn), eps, momentum, _stream(z))
     return a, save_mean, save_rstd
 
 
@@ -146,8 +151,9 @@ def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, li
     lib = lib or get_lib()
     M, N = z.shape
     dz = torch.empty_like(z)
+    ws = _bn_ws(N, z.device, lib) if use_bn else None
     lib.call("rat_bn_relu_bwd", _p(z), _p(a), _p(da), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd), _p(dgamma), _p(dbeta),
-             M, N, int(use_bn), _stream(z))
+             _p(ws), M, N, int(use_bn), _stream(z))
     return dz
 
 
