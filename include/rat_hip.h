@@ -78,8 +78,8 @@ typedef struct RatAttnParams {      /* HOST struct of device pointers; state_dic
     float* b_out; /* [d]          ...fn.to_out.0.bias                                                    */
 } RatAttnParams;
 
-/* o_save [ntok][h*dh] and lse_save [ntok][h] (token-indexed like x) are written when non-NULL (training)
- * and consumed by rat_attn_bwd. */
+/* o_save [ntok][h*dh] (attention output before to_out) and lse_save [ntok][h] (log2-domain log-sum-exp of the
+ * scaled scores), token-indexed like x, are written when non-NULL (training) and consumed by rat_attn_bwd. */
 int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                  const RatSeqMap* map_host, int d, int heads, int dim_head, float ln_eps, void* stream);
 

@@ -121,38 +121,66 @@ __device__ __forceinline__ void zero_cols(float* tile, int ld, int c0) {   // ti
     for (int e = threadIdx.x; e < ATT_ROWS * w; e += ATT_THREADS) tile[(size_t)(e / w) * ld + c0 + e % w] = 0.f;
 }
 
-// in-place LayerNorm of the valid rows of xs (8 lanes per row, COLS columns each); optionally keeps mean / rstd
-template <int COLS>
+// in-place LayerNorm of the valid rows of xs: 8 lanes per row, lane `sub` owns the COLS contiguous columns
+// [sub*COLS, sub*COLS + COLS) (COLS = ceil(D/8); 16-byte LDS accesses when COLS % 4 == 0); optionally keeps mean / rstd
+template <int COLS, bool VEC>
 __device__ __forceinline__ void layer_norm_rows(float* xs, int ld, int D, int rows, const float* g, const float* b,
                                                 float eps, float* mu_out, float* rs_out) {
     const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    float* xr = xs + (size_t)r * ld;
+    float* xr = xs + (size_t)r * ld + sub * COLS;
+    const int c0 = sub * COLS;
     float xv[COLS];
     float s = 0.f;
+    if (VEC && COLS % 4 == 0) {                                  // 8 * COLS == D: every lane's columns are real
 #pragma unroll
-    for (int k = 0; k < COLS; ++k) {
-        const int c = sub + 8 * k;
-        xv[k] = c < D ? xr[c] : 0.f;
-        s += xv[k];
+        for (int k = 0; k < COLS; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + k);
+            xv[k] = t.x; xv[k + 1] = t.y; xv[k + 2] = t.z; xv[k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) xv[k] = c0 + k < D ? xr[k] : 0.f;
     }
+#pragma unroll
+    for (int k = 0; k < COLS; ++k) s += (c0 + k < D) ? xv[k] : 0.f;
     const float mean = rat_group_sum<8>(s) / (float)D;
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < COLS; ++k) {
-        const float t = (sub + 8 * k < D) ? xv[k] - mean : 0.f;
+        const float t = (c0 + k < D) ? xv[k] - mean : 0.f;
         v += t * t;
     }
     const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / (float)D + eps);
     if (r < rows) {
 #pragma unroll
-        for (int k = 0; k < COLS; ++k) {
-            const int c = sub + 8 * k;
-            if (c < D) xr[c] = (xv[k] - mean) * rstd * g[c] + b[c];
-        }
+        for (int k = 0; k < COLS; ++k)
+            if (c0 + k < D) xr[k] = (xv[k] - mean) * rstd * g[c0 + k] + b[c0 + k];
     }
     if (mu_out != nullptr && sub == 0) {
         mu_out[r] = mean;
         rs_out[r] = rstd;
+    }
+}
+
+// tile[rows][0:width] (+ residual rows of `res`, token-indexed) -> dst rows, 16-byte coalesced when vec
+__device__ __forceinline__ void store_rows_residual(float* dst, const float* tile, int ld, const float* res,
+                                                    const int64_t* rowtok, int rows, int width, bool vec) {
+    if (vec) {
+        const int w4 = width >> 2;
+        for (int e = threadIdx.x; e < rows * w4; e += ATT_THREADS) {
+            const int r = e / w4, c4 = e - r * w4;
+            const int64_t tok = rowtok[r];
+            float4 v = *reinterpret_cast<const float4*>(tile + (size_t)r * ld + 4 * c4);
+            const float4 x = *reinterpret_cast<const float4*>(res + tok * width + 4 * c4);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            *reinterpret_cast<float4*>(dst + tok * width + 4 * c4) = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < rows * width; e += ATT_THREADS) {
+            const int r = e / width, c = e - r * width;
+            const int64_t tok = rowtok[r];
+            dst[tok * width + c] = tile[(size_t)r * ld + c] + res[tok * width + c];
+        }
     }
 }
 
@@ -228,7 +256,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
         load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
         __syncthreads();
-        layer_norm_rows<COLS>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
+        layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
         RAT_PROF_MARK(0);
@@ -237,7 +265,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         {
             const RatLdsRows A{xs, ldx};
             const RatGlobalWnkT<!FAST> Bw{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0};
-            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < g.Q3)
 #pragma unroll
@@ -249,6 +277,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
 
         // softmax(Q K^T * scale) V, one lane per (sequence, head, query); result replaces Q in place
         const int ntasks = nsq * a.heads * L;
+        const float sl2 = a.scale * RAT_LOG2E;
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % a.heads;
@@ -263,10 +292,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             for (int j = 0; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * ldq;
                 kv.load(kp, dh);
-                const float s = q.dot(kv) * a.scale;
+                const float s = q.dot(kv) * sl2;                     // score in log2 units
                 const float mn = fmaxf(m, s);
-                const float corr = expf(m - mn);
-                const float p = expf(s - mn);
+                const float corr = rat_exp2(m - mn);
+                const float p = rat_exp2(s - mn);
                 l = l * corr + p;
                 kv.load(kp + I, dh);
                 o.scale_axpy(corr, p, kv);
@@ -276,35 +305,28 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             o.store(qp, dh, inv);
             const int64_t tok = rowtok[row_i];
             if (a.o_save != nullptr) o.store(a.o_save + tok * I + h * dh, dh, inv);
-            if (a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + logf(l);
+            if (a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + rat_log2(l);   // log2-domain log-sum-exp
         }
         __syncthreads();
         RAT_PROF_MARK(2);
 
-        // y = O W_out^T + b_out + x   (or y = O + x when Attention has no output projection)
+        // y = O W_out^T + b_out + x   (or y = O + x when Attention has no output projection).  The projection tile is
+        // staged in xs (free since the QKV projection) so that the residual add and the store are whole-row, 16-byte accesses.
         if (a.w_out != nullptr) {
             const RatLdsRows A{qkv, ldq};
             const RatGlobalWnkT<!FAST> Bw{a.w_out, D, I, I, a.vec_wout != 0};
-            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.D16 / 16, g.I16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.I16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < D) {
                     const float bias = a.b_out[col];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rat_acc_row(mt, r);
-                        if (row < rows) {
-                            const int64_t tok = rowtok[row];
-                            a.y[tok * D + col] = acc[r] + bias + a.x[tok * D + col];
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r) xs[(size_t)rat_acc_row(mt, r) * ldx + col] = acc[r] + bias;
                 }
             });
+            __syncthreads();
+            store_rows_residual(a.y, xs, ldx, a.x, rowtok, rows, D, FAST || a.vec_x != 0);
         } else {
-            for (int e = threadIdx.x; e < rows * D; e += ATT_THREADS) {
-                const int r = e / D, c = e - r * D;
-                const int64_t tok = rowtok[r];
-                a.y[tok * D + c] = qkv[(size_t)r * ldq + c] + a.x[tok * D + c];
-            }
+            store_rows_residual(a.y, qkv, ldq, a.x, rowtok, rows, D, FAST || a.vec_x != 0);
         }
         __syncthreads();
         RAT_PROF_MARK(3);
@@ -366,7 +388,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             lses[e] = tok >= 0 ? a.lse_save[tok * H + e % H] : 0.f;
         }
         __syncthreads();
-        layer_norm_rows<COLS>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
+        layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
         RAT_PROF_MARK(0);
@@ -375,7 +397,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         {
             const RatLdsRows A{xs, ldx};
             const RatGlobalWnkT<!FAST> Bw{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0};
-            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < g.Q3)
 #pragma unroll
@@ -386,7 +408,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             // (2) dO = dy W_out  (dob[rows][0:I])
             const RatLdsRows A{dys, ldx};
             const RatGlobalWknT<!FAST> Bw{a.w_out, D, I, I};
-            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.I16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.I16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < I)
 #pragma unroll
@@ -395,11 +417,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             // (3) dW_out += dy^T O ; db_out += colsum(dy)
             const RatLdsCols At{dys, ldx};
             const RatLdsCols Bt{ob, ldt};
-#pragma unroll
-            for (int s = 0; s < OSLOTS; ++s) {
-                const int id = rat_wave() + ATT_WAVES * s;
-                if (id < o_tiles) acco[s] = rat_wave_gemm1(acco[s], At, Bt, id / o_tn, id % o_tn, mt_valid);
-            }
+            rat_wave_gemm_slots<OSLOTS, ATT_WAVES>(acco, At, Bt, o_tiles, o_tn, mt_valid);
             if (threadIdx.x < D) {
                 float sacc = 0.f;
                 for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * ldx + threadIdx.x];
@@ -416,6 +434,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
 
         // (4) attention backward, pass 1: one lane per query row -> delta, dQ (written over O)
         const int ntasks = nsq * H * L;
+        const float sl2 = a.scale * RAT_LOG2E;
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % H;
@@ -436,7 +455,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 kv.load(kp + I, dh);
                 const float dp = go.dot(kv);
                 kv.load(kp, dh);
-                const float p = expf(q.dot(kv) * a.scale - lse);
+                const float p = rat_exp2(q.dot(kv) * sl2 - lse);
                 dq.axpy(p * (dp - delta), kv);
             }
             dq.store(op, dh, a.scale);
@@ -461,7 +480,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 const float lse = lses[row_i * H + h], delta = dlt[row_i * H + h];
                 HeadVec<TDH> qv;
                 qv.load(qkv + (size_t)row_i * ldq + h * dh, dh);
-                const float p = expf(qv.dot(kk) * a.scale - lse);
+                const float p = rat_exp2(qv.dot(kk) * sl2 - lse);
                 dv.axpy(p, t);
                 dk.axpy(p * (dp - delta), qv);
             }
@@ -490,7 +509,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         {
             const RatLdsRows A{qkv, ldq};
             const RatGlobalWknT<!FAST> Bw{a.w_qkv, g.Q3, D, D};
-            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < D)
 #pragma unroll
@@ -498,46 +517,68 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             });
             const RatLdsCols At{qkv, ldq};
             const RatLdsCols Bt{xs, ldx};
-#pragma unroll
-            for (int s = 0; s < QSLOTS; ++s) {
-                const int id = rat_wave() + ATT_WAVES * s;
-                if (id < q_tiles) accq[s] = rat_wave_gemm1(accq[s], At, Bt, id / q_tn, id % q_tn, mt_valid);
-            }
+            rat_wave_gemm_slots<QSLOTS, ATT_WAVES>(accq, At, Bt, q_tiles, q_tn, mt_valid);
         }
         __syncthreads();
         RAT_PROF_MARK(5);
 
         // (7) LayerNorm backward + residual: dx = dy + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma
+        //     8 lanes per row, lane `sub` owns COLS contiguous columns -> 16-byte global / LDS accesses
         {
             const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
+            const int c0 = sub * COLS;
             const bool valid = r < rows;
-            const int64_t tok = rowtok[r];
+            const int64_t tok = valid ? rowtok[r] : 0;
             const float mean = mu[r], rstd = rs[r];
-            float xh[COLS], gg[COLS];
+            float xh[COLS], gg[COLS], out[COLS];
             float s1 = 0.f, s2 = 0.f;
+            if (FAST && COLS % 4 == 0) {
+#pragma unroll
+                for (int k = 0; k < COLS; k += 4) {
+                    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid) xv = *reinterpret_cast<const float4*>(a.x + tok * D + c0 + k);
+                    const float4 gv = *reinterpret_cast<const float4*>(dob + (size_t)r * ldt + c0 + k);
+                    xh[k] = xv.x; xh[k + 1] = xv.y; xh[k + 2] = xv.z; xh[k + 3] = xv.w;
+                    gg[k] = gv.x; gg[k + 1] = gv.y; gg[k + 2] = gv.z; gg[k + 3] = gv.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < COLS; ++k) {
+                    const int c = c0 + k;
+                    xh[k] = (c < D && valid) ? a.x[tok * D + c] : 0.f;
+                    gg[k] = (c < D && valid) ? dob[(size_t)r * ldt + c] : 0.f;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < COLS; ++k) {
-                const int c = sub + 8 * k;
-                xh[k] = 0.f;
-                gg[k] = 0.f;
-                if (c < D && valid) {
-                    xh[k] = (a.x[tok * D + c] - mean) * rstd;
-                    gg[k] = dob[(size_t)r * ldt + c];
-                    const float gw = gg[k] * a.ln_g[c];
-                    s1 += gw;
-                    s2 += gw * xh[k];
-                }
+                const int c = c0 + k;
+                const bool on = (FAST || c < D) && valid;
+                xh[k] = on ? (xh[k] - mean) * rstd : 0.f;
+                gg[k] = on ? gg[k] : 0.f;
+                const float gw = on ? gg[k] * a.ln_g[c] : 0.f;
+                s1 += gw;
+                s2 += gw * xh[k];
             }
             s1 = rat_group_sum<8>(s1) / (float)D;
             s2 = rat_group_sum<8>(s2) / (float)D;
 #pragma unroll
             for (int k = 0; k < COLS; ++k) {
-                const int c = sub + 8 * k;
-                if (c < D && valid) {
-                    const float gw = gg[k] * a.ln_g[c];
-                    a.y[tok * D + c] = dys[(size_t)r * ldx + c] + rstd * (gw - s1 - xh[k] * s2);
-                    dgam[k] += gg[k] * xh[k];
-                    dbet[k] += gg[k];
+                const int c = c0 + k;
+                const bool on = (FAST || c < D) && valid;
+                const float gw = on ? gg[k] * a.ln_g[c] : 0.f;
+                out[k] = on ? dys[(size_t)r * ldx + c] + rstd * (gw - s1 - xh[k] * s2) : 0.f;
+                dgam[k] += gg[k] * xh[k];
+                dbet[k] += gg[k];
+            }
+            if (valid) {
+                if (FAST && COLS % 4 == 0) {
+#pragma unroll
+                    for (int k = 0; k < COLS; k += 4)
+                        *reinterpret_cast<float4*>(a.y + tok * D + c0 + k) = make_float4(out[k], out[k + 1], out[k + 2], out[k + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < COLS; ++k)
+                        if (c0 + k < D) a.y[tok * D + c0 + k] = out[k];
                 }
             }
         }
@@ -586,7 +627,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
 #pragma unroll
         for (int k = 0; k < COLS; ++k) {
-            const int c = sub + 8 * k;
+            const int c = sub * COLS + k;
             if (c < D) red[(size_t)r * ldx + c] = dgam[k];
         }
         __syncthreads();
@@ -598,7 +639,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < COLS; ++k) {
-            const int c = sub + 8 * k;
+            const int c = sub * COLS + k;
             if (c < D) red[(size_t)r * ldx + c] = dbet[k];
         }
         __syncthreads();

@@ -45,7 +45,7 @@ struct FfnGeom {
         ldx = D16 + 4;
         ldh = H16 + 4;
     }
-    size_t fwd_smem() const { return (size_t)FFN_ROWS * (ldx + ldh) * 4; }
+    size_t fwd_smem() const { return (size_t)FFN_ROWS * (2 * ldx + ldh) * 4; }
     size_t bwd_smem() const { return (size_t)FFN_ROWS * (2 * ldx + 2 * ldh) * 4; }
     int64_t slab_floats() const { return 2 * (int64_t)H * D + H + D; }
 };
@@ -67,18 +67,34 @@ __device__ __forceinline__ void ffn_load(float* tile, int ld, const float* src, 
     }
 }
 
+__device__ __forceinline__ void ffn_store(float* dst, const float* tile, int ld, int64_t tok0, int rows, int width, bool vec) {
+    if (vec) {
+        const int w4 = width >> 2;
+        for (int e = threadIdx.x; e < rows * w4; e += FFN_THREADS) {
+            const int r = e / w4, c4 = e - r * w4;
+            *reinterpret_cast<float4*>(dst + (tok0 + r) * width + 4 * c4) = *reinterpret_cast<const float4*>(tile + (size_t)r * ld + 4 * c4);
+        }
+    } else {
+        for (int e = threadIdx.x; e < rows * width; e += FFN_THREADS) {
+            const int r = e / width, c = e - r * width;
+            dst[(tok0 + r) * width + c] = tile[(size_t)r * ld + c];
+        }
+    }
+}
+
 __device__ __forceinline__ void ffn_zero_cols(float* tile, int ld, int c0) {
     const int w = ld - c0;
     for (int e = threadIdx.x; e < FFN_ROWS * w; e += FFN_THREADS) tile[(size_t)(e / w) * ld + c0 + e % w] = 0.f;
 }
 
 // hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- h, gs <- gelu(h))
-template <bool FAST, int MODE>
+template <int TD, int MODE>
 __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
                                            int mt_valid, int rows) {
+    constexpr bool FAST = TD > 0;
     const RatLdsRows A{xs, g.ldx};
     const RatGlobalWnkT<!FAST> Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
-    rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+    rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
         const int col = rat_acc_col(nt);
         if (FAST || col < g.H) {
             const float bias = a.b1[col];
@@ -104,6 +120,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
     const FfnGeom g(FAST ? TD : a.d, a.hidden);
     float* xs = reinterpret_cast<float*>(smem);
     float* hs = xs + (size_t)FFN_ROWS * g.ldx;
+    float* ys = hs + (size_t)FFN_ROWS * g.ldh;                  // [64][ldx] output staging (whole-row coalesced stores)
     ffn_zero_cols(xs, g.ldx, g.D);
     ffn_zero_cols(hs, g.ldh, g.H);
     __syncthreads();
@@ -115,26 +132,27 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, FAST || a.vec_x != 0);
         __syncthreads();
         RAT_PROF_MARK(0);
-        ffn_hidden<FAST, 0>(a, g, xs, hs, nullptr, mt_valid, rows);
+        ffn_hidden<TD, 0>(a, g, xs, hs, nullptr, mt_valid, rows);
         __syncthreads();
         RAT_PROF_MARK(1);
         // y = gelu(h) W2^T + b2 + x
         {
             const RatLdsRows A{hs, g.ldh};
             const RatGlobalWnkT<!FAST> Bw{a.w2, g.D, g.H, g.H, a.vec_w2 != 0};
-            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < g.D) {
                     const float bias = a.b2[col];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = rat_acc_row(mt, r);
-                        if (row < rows) a.y[(tok0 + row) * g.D + col] = acc[r] + bias + xs[(size_t)row * g.ldx + col];
+                        const size_t o = (size_t)rat_acc_row(mt, r) * g.ldx + col;
+                        ys[o] = acc[r] + bias + xs[o];
                     }
                 }
             });
         }
         __syncthreads();
+        ffn_store(a.y, ys, g.ldx, tok0, rows, g.D, FAST || a.vec_x != 0);
         RAT_PROF_MARK(2);
     }
     RAT_PROF_FLUSH(a.prof, 24);
@@ -173,18 +191,14 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         ffn_load(dys, g.ldx, a.dy, tok0, rows, D, FAST || a.vec_x != 0);
         __syncthreads();
         RAT_PROF_MARK(0);
-        ffn_hidden<FAST, 1>(a, g, xs, hs, gs, mt_valid, rows);
+        ffn_hidden<TD, 1>(a, g, xs, hs, gs, mt_valid, rows);
         __syncthreads();
         RAT_PROF_MARK(1);
         // dW2 += dy^T gelu(h) ; db2 += colsum(dy)
         {
             const RatLdsCols At{dys, g.ldx};
             const RatLdsCols Bt{gs, g.ldh};
-#pragma unroll
-            for (int s = 0; s < WSLOTS; ++s) {
-                const int id = rat_wave() + FFN_WAVES * s;
-                if (id < t2) acc2[s] = rat_wave_gemm1(acc2[s], At, Bt, id / t2n, id % t2n, mt_valid);
-            }
+            rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc2, At, Bt, t2, t2n, mt_valid);
             if (threadIdx.x < D) {
                 float sacc = 0.f;
                 for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * g.ldx + threadIdx.x];
@@ -197,7 +211,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         {
             const RatLdsRows A{dys, g.ldx};
             const RatGlobalWknT<!FAST> Bw{a.w2, D, H, H};
-            rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < H)
 #pragma unroll
@@ -214,28 +228,23 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         {
             const RatLdsRows A{gs, g.ldh};
             const RatGlobalWknT<!FAST> Bw{a.w1, H, D, D};
-            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < D)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rat_acc_row(mt, r);
-                        if (row < rows) a.y[(tok0 + row) * D + col] = acc[r] + dys[(size_t)row * g.ldx + col];
-                    }
+                    for (int r = 0; r < 4; ++r) dys[(size_t)rat_acc_row(mt, r) * g.ldx + col] += acc[r];   // dx tile, in place
             });
             const RatLdsCols At{gs, g.ldh};
             const RatLdsCols Bt{xs, g.ldx};
-#pragma unroll
-            for (int s = 0; s < WSLOTS; ++s) {
-                const int id = rat_wave() + FFN_WAVES * s;
-                if (id < t1) acc1[s] = rat_wave_gemm1(acc1[s], At, Bt, id / t1n, id % t1n, mt_valid);
-            }
+            rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc1, At, Bt, t1, t1n, mt_valid);
             if (threadIdx.x < H) {
                 float sacc = 0.f;
                 for (int r = 0; r < rows; ++r) sacc += gs[(size_t)r * g.ldh + threadIdx.x];
                 db1 += sacc;
             }
         }
+        __syncthreads();
+        ffn_store(a.y, dys, g.ldx, tok0, rows, D, FAST || a.vec_x != 0);
         __syncthreads();
         RAT_PROF_MARK(4);
     }

@@ -72,6 +72,16 @@ __device__ __forceinline__ float rat_group_sum(float v) {
     return v;
 }
 
+// softmax runs in the log2 domain: one v_exp_f32 / v_log_f32 per call (about 1 ulp), no range-reduction sequence
+#ifdef RAT_EMU
+__device__ __forceinline__ float rat_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float rat_log2(float x) { return log2f(x); }
+#else
+__device__ __forceinline__ float rat_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float rat_log2(float x) { return __builtin_amdgcn_logf(x); }
+#endif
+#define RAT_LOG2E 1.44269504088896340736f
+
 __device__ __forceinline__ float rat_gelu(float x) {          // nn.GELU() exact erf form
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
@@ -152,26 +162,55 @@ struct RatGlobalWknT {
 };
 typedef RatGlobalWknT<true> RatGlobalWkn;
 
-// acc[i] += A(tile mt0+i) * B(tile nt) for i < MT, every tile valid, B fetched one k-block ahead (the B operand
-// comes from global memory / L2; the next fragment is in flight while the current one feeds the MFMAs).
-template <int MT, class AF, class BF>
+// acc[i] += A(tile mt0+i) * B(tile nt) for i < MT, every tile valid.  The B operand comes from global memory / L2
+// (latency of several hundred cycles), so its fragments are requested well ahead of the MFMAs that consume them:
+//   KBS > 0 (k extent known at compile time): all KBS fragments are in flight before the first MFMA;
+//   KBS == 0: a two-deep rotating prefetch.  A fragments (LDS) are fetched one k-block ahead.
+template <int MT>
+__device__ __forceinline__ void rat_mfma_block(f32x4 (&acc)[MT], const float4 (&a)[MT], const float4& b) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].x, b.x, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].y, b.y, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].z, b.z, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].w, b.w, acc[i]);
+}
+
+template <int MT, int KBS, class AF, class BF>
 __device__ __forceinline__ void rat_wave_gemm_col(f32x4 (&acc)[MT], const AF& af, const BF& bf, int mt0, int nt,
                                                   int kblocks) {
-    float4 bn = bf(nt, 0);
-    for (int kb = 0; kb < kblocks; ++kb) {
-        const float4 b = bn;
-        bn = bf(nt, kb + 1 < kblocks ? kb + 1 : kb);
-        float4 a[MT];
+    if (KBS > 0) {
+        float4 b[KBS > 0 ? KBS : 1];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = af(mt0 + i, kb);
+        for (int kb = 0; kb < KBS; ++kb) b[kb] = bf(nt, kb);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].x, b.x, acc[i]);
+        for (int kb = 0; kb < KBS; ++kb) {
+            float4 a[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].y, b.y, acc[i]);
+            for (int i = 0; i < MT; ++i) a[i] = af(mt0 + i, kb);
+            rat_mfma_block<MT>(acc, a, b[kb]);
+        }
+    } else {
+        const int last = kblocks - 1;
+        float4 b0 = bf(nt, 0);
+        float4 b1 = bf(nt, last < 1 ? last : 1);
+        float4 an[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].z, b.z, acc[i]);
+        for (int i = 0; i < MT; ++i) an[i] = af(mt0 + i, 0);
+        for (int kb = 0; kb < kblocks; ++kb) {
+            const float4 b2 = bf(nt, kb + 2 < last ? kb + 2 : last);
+            float4 a[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA16(a[i].w, b.w, acc[i]);
+            for (int i = 0; i < MT; ++i) a[i] = an[i];
+            const int kn = kb + 1 < last ? kb + 1 : last;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) an[i] = af(mt0 + i, kn);
+            rat_mfma_block<MT>(acc, a, b0);
+            b0 = b1;
+            b1 = b2;
+        }
     }
 }
 
@@ -212,7 +251,7 @@ __device__ __forceinline__ void rat_wave_gemm(f32x4 (&acc)[MT][NB], const AF& af
 // C[MTILES*16 rows][n_tiles*16] = A (LDS rows) x B (weights in L2) as 16x16 tiles; tasks = (M block of MT tiles) x (N tile),
 // dealt round-robin to the NWAVES waves; epi(mt, nt, acc) consumes each finished tile.
 // FAST: all M tiles are always computed (padding rows are zero), no validity predicates, B one k-block ahead.
-template <bool FAST, int MT, int NWAVES, int MTILES, class AF, class BF, class Epi>
+template <bool FAST, int MT, int NWAVES, int MTILES, int KBS, class AF, class BF, class Epi>
 __device__ __forceinline__ void rat_gemm_phase(const AF& A, const BF& Bw, int mt_valid, int n_tiles, int kblocks, const Epi& epi) {
     constexpr int MBLOCKS = MTILES / MT;
     const int ntasks = MBLOCKS * n_tiles;
@@ -223,7 +262,7 @@ __device__ __forceinline__ void rat_gemm_phase(const AF& A, const BF& Bw, int mt
             f32x4 acc[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) acc[i] = rat_zero4();
-            rat_wave_gemm_col<MT>(acc, A, Bw, mt0, nt, kblocks);
+            rat_wave_gemm_col<MT, KBS>(acc, A, Bw, mt0, nt, kblocks);
 #pragma unroll
             for (int i = 0; i < MT; ++i) epi(mt0 + i, nt, acc[i]);
         } else {
@@ -251,6 +290,50 @@ __device__ __forceinline__ f32x4 rat_wave_gemm1(f32x4 acc, const AF& af, const B
         acc = RAT_MFMA16(a.w, b.w, acc);
     }
     return acc;
+}
+
+// Persistent weight-gradient tiles of one wave: tile ids wave + NWAVES*s (s < SLOTS) of an (m_tiles x ntn) grid,
+// acc[s] += A^T-tile(mt_s) * B-tile(nt_s) over `kblocks` token blocks.  When ntn divides NWAVES every slot of a wave
+// shares the same nt, so the B fragment is fetched once per k-block and the (independent) slots' MFMAs issue back to back.
+template <int SLOTS, int NWAVES, class AF, class BF>
+__device__ __forceinline__ void rat_wave_gemm_slots(f32x4 (&acc)[SLOTS], const AF& af, const BF& bf, int ntiles, int ntn,
+                                                    int kblocks) {
+    const int w = rat_wave();
+    if (NWAVES % ntn == 0) {
+        const int nt = w % ntn;
+        constexpr int HALF = SLOTS > 4 ? 4 : SLOTS;
+#pragma unroll
+        for (int s0 = 0; s0 < SLOTS; s0 += HALF) {
+            if (w + NWAVES * s0 >= ntiles) break;
+            for (int kb = 0; kb < kblocks; ++kb) {
+                const float4 b = bf(nt, kb);
+                float4 a[HALF];
+#pragma unroll
+                for (int s = 0; s < HALF; ++s) {
+                    const int id = w + NWAVES * (s0 + s);
+                    a[s] = af((id < ntiles ? id : w) / ntn, kb);
+                }
+#pragma unroll
+                for (int s = 0; s < HALF; ++s)
+                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].x, b.x, acc[s0 + s]);
+#pragma unroll
+                for (int s = 0; s < HALF; ++s)
+                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].y, b.y, acc[s0 + s]);
+#pragma unroll
+                for (int s = 0; s < HALF; ++s)
+                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].z, b.z, acc[s0 + s]);
+#pragma unroll
+                for (int s = 0; s < HALF; ++s)
+                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].w, b.w, acc[s0 + s]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int id = w + NWAVES * s;
+            if (id < ntiles) acc[s] = rat_wave_gemm1(acc[s], af, bf, id / ntn, id % ntn, kblocks);
+        }
+    }
 }
 
 // row/col of accumulator register r of a 16x16 tile
