@@ -20,7 +20,8 @@ from rat_amd.model import RAT_m2  # noqa: E402
 
 PHASES = {
     0: ("attn_fwd", ["load+LN", "QKV gemm", "softmax(QK)V valu", "out-proj+store"]),
-    12: ("attn_bwd", ["load+LN", "QKV+dO gemm, dWout", "pass1 (dQ)", "pass2 (dK,dV)", "copy dQ", "dXn gemm + dWqkv", "LN bwd + store"]),
+    12: ("attn_bwd", ["map rows", "load x,dy,O,lse", "LN", "QKV gemm (wave 0)", "dO gemm (wave 0)", "dWout+colsum+barrier", "pass1 (dQ)",
+                      "pass2 (dK,dV) + copy", "dXn gemm (wave 0)", "dWqkv + barrier", "LN bwd + store"]),
     24: ("ffn_fwd", ["load", "W1 gemm + gelu", "W2 gemm + store"]),
     36: ("ffn_bwd", ["load", "W1 gemm + gelu", "dW2", "dh gemm", "dx gemm + dW1"]),
 }

@@ -380,6 +380,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         int nsq, rows;
         map_rows(a, chunk, rowtok, nsq, rows);
         __syncthreads();
+        RAT_PROF_MARK(0);
         load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
         load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0);
         load_rows(ob, ldt, a.o_save, rowtok, I, FAST || ((I % 4) == 0 && a.vec_x != 0));
@@ -388,10 +389,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             lses[e] = tok >= 0 ? a.lse_save[tok * H + e % H] : 0.f;
         }
         __syncthreads();
+        RAT_PROF_MARK(1);
         layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
-        RAT_PROF_MARK(0);
+        RAT_PROF_MARK(2);
 
         // (1) recompute Q|K|V
         {
@@ -404,6 +406,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                     for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * ldq + col] = acc[r];
             });
         }
+        RAT_PROF_MARK(3);
         if (has_out) {
             // (2) dO = dy W_out  (dob[rows][0:I])
             const RatLdsRows A{dys, ldx};
@@ -414,14 +417,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
             });
+            RAT_PROF_MARK(4);
             // (3) dW_out += dy^T O ; db_out += colsum(dy)
             const RatLdsCols At{dys, ldx};
             const RatLdsCols Bt{ob, ldt};
             rat_wave_gemm_slots<OSLOTS, ATT_WAVES>(acco, At, Bt, o_tiles, o_tn, mt_valid);
-            if (threadIdx.x < D) {
-                float sacc = 0.f;
-                for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * ldx + threadIdx.x];
-                dbo += sacc;
+            {   // db_out partials: thread = (column, row group); the row groups are combined once, after the chunk loop
+                const int nrg = ATT_THREADS / D, col = threadIdx.x % D, rg = threadIdx.x / D;
+                if (rg < nrg)
+                    for (int r = rg; r < rows; r += nrg) dbo += dys[(size_t)r * ldx + col];
             }
         } else {
             for (int e = threadIdx.x; e < ATT_ROWS * D; e += ATT_THREADS) {
@@ -430,7 +434,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
-        RAT_PROF_MARK(1);
+        RAT_PROF_MARK(5);
 
         // (4) attention backward, pass 1: one lane per query row -> delta, dQ (written over O)
         const int ntasks = nsq * H * L;
@@ -461,7 +465,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             dq.store(op, dh, a.scale);
         }
         __syncthreads();
-        RAT_PROF_MARK(2);
+        RAT_PROF_MARK(6);
         // pass 2: one lane per key row -> dK, dV (written over K, V)
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int j = task % L;
@@ -488,7 +492,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             dv.store(kp + I, dh, 1.0f);
         }
         __syncthreads();
-        RAT_PROF_MARK(3);
         // dQ (in ob) -> Q columns of qkv: qkv now holds d[Q|K|V]
         if (FAST) {
             const int w4 = I >> 2;
@@ -503,7 +506,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
-        RAT_PROF_MARK(4);
+        RAT_PROF_MARK(7);
 
         // (5) d(LN out) = dQKV W_qkv -> dob[rows][0:D] ; (6) dW_qkv += dQKV^T LN(x)
         {
@@ -515,12 +518,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
             });
+            RAT_PROF_MARK(8);
             const RatLdsCols At{qkv, ldq};
             const RatLdsCols Bt{xs, ldx};
             rat_wave_gemm_slots<QSLOTS, ATT_WAVES>(accq, At, Bt, q_tiles, q_tn, mt_valid);
         }
         __syncthreads();
-        RAT_PROF_MARK(5);
+        RAT_PROF_MARK(9);
 
         // (7) LayerNorm backward + residual: dx = dy + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma
         //     8 lanes per row, lane `sub` owns COLS contiguous columns -> 16-byte global / LDS accesses
@@ -583,7 +587,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
-        RAT_PROF_MARK(6);
+        RAT_PROF_MARK(10);
     }
     RAT_PROF_FLUSH(a.prof, 12);
 
@@ -619,7 +623,18 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 }
             }
         }
-        if (threadIdx.x < D) s_bout[threadIdx.x] = dbo;
+        {
+            __syncthreads();
+            float* red0 = dys;                                   // free now: [nrg][D] partials
+            const int nrg = ATT_THREADS / D, col = threadIdx.x % D, rg = threadIdx.x / D;
+            if (rg < nrg) red0[rg * D + col] = dbo;
+            __syncthreads();
+            if (threadIdx.x < D) {
+                float sacc = 0.f;
+                for (int k = 0; k < nrg; ++k) sacc += red0[k * D + threadIdx.x];
+                s_bout[threadIdx.x] = sacc;
+            }
+        }
     }
     // dgamma / dbeta: 64 row-slots x D partials -> LDS -> column sums
     float* red = xs;                                             // [64][ldx] is free now

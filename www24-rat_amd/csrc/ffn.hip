@@ -199,10 +199,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             const RatLdsCols At{dys, g.ldx};
             const RatLdsCols Bt{gs, g.ldh};
             rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc2, At, Bt, t2, t2n, mt_valid);
-            if (threadIdx.x < D) {
-                float sacc = 0.f;
-                for (int r = 0; r < rows; ++r) sacc += dys[(size_t)r * g.ldx + threadIdx.x];
-                db2 += sacc;
+            {   // db2 partials: thread = (column, row group), combined after the chunk loop
+                const int nrg = FFN_THREADS / D, col = threadIdx.x % D, rg = threadIdx.x / D;
+                if (rg < nrg)
+                    for (int r = rg; r < rows; r += nrg) db2 += dys[(size_t)r * g.ldx + col];
             }
         }
         __syncthreads();
@@ -237,10 +237,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             const RatLdsCols At{gs, g.ldh};
             const RatLdsCols Bt{xs, g.ldx};
             rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc1, At, Bt, t1, t1n, mt_valid);
-            if (threadIdx.x < H) {
-                float sacc = 0.f;
-                for (int r = 0; r < rows; ++r) sacc += gs[(size_t)r * g.ldh + threadIdx.x];
-                db1 += sacc;
+            {
+                const int nrg = FFN_THREADS / H, col = threadIdx.x % H, rg = threadIdx.x / H;
+                if (rg < nrg)
+                    for (int r = rg; r < rows; r += nrg) db1 += gs[(size_t)r * g.ldh + col];
             }
         }
         __syncthreads();
@@ -276,8 +276,25 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             }
         }
     }
-    if (threadIdx.x < H) s_b1[threadIdx.x] = db1;
-    if (threadIdx.x < D) s_b2[threadIdx.x] = db2;
+    {   // combine the row-group partials of the bias gradients through LDS
+        __syncthreads();
+        float* red1 = hs;                                        // [nrg][H]
+        float* red2 = gs;                                        // [nrg][D]
+        const int nrg1 = FFN_THREADS / H, nrg2 = FFN_THREADS / D;
+        if ((int)threadIdx.x / H < nrg1) red1[threadIdx.x] = db1;     // index = rg * H + col = threadIdx.x
+        if ((int)threadIdx.x / D < nrg2) red2[threadIdx.x] = db2;
+        __syncthreads();
+        if (threadIdx.x < H) {
+            float sacc = 0.f;
+            for (int k = 0; k < nrg1; ++k) sacc += red1[k * H + threadIdx.x];
+            s_b1[threadIdx.x] = sacc;
+        }
+        if (threadIdx.x < D) {
+            float sacc = 0.f;
+            for (int k = 0; k < nrg2; ++k) sacc += red2[k * D + threadIdx.x];
+            s_b2[threadIdx.x] = sacc;
+        }
+    }
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

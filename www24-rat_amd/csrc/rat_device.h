@@ -57,7 +57,14 @@ static inline int rat_round_up(int v, int m) { return (v + m - 1) / m * m; }
 #define RAT_WAVE 64
 
 __device__ __forceinline__ int rat_lane() { return threadIdx.x & 63; }
+// wave index, PROVABLY wave-uniform for the compiler: anything derived from threadIdx is divergent to hipcc (even
+// threadIdx.x >> 6), which turns every per-wave task loop / tile predicate into EXEC-masked branches around each MFMA;
+// readfirstlane makes it an SGPR value and those branches scalar (cdna_hip_programming.md T5/T20 notes).
+#ifdef RAT_EMU
 __device__ __forceinline__ int rat_wave() { return threadIdx.x >> 6; }
+#else
+__device__ __forceinline__ int rat_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+#endif
 
 __device__ __forceinline__ f32x4 rat_zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
