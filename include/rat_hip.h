@@ -115,8 +115,8 @@ int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* b
 int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* workspace,
                     int M, int N, int use_bn, void* stream);
-/* column sums of a [M][N] matrix (bias gradients) */
-int rat_colsum(const float* a, int lda, float* out, int M, int N, void* stream);
+/* column sums of a [M][N] matrix (bias gradients); workspace: rat_bn_workspace(N) bytes */
+int rat_colsum(const float* a, int lda, float* out, float* workspace, int M, int N, void* stream);
 
 /* logit = fc(cls) + dnn_out + sum_f lr_table_f[idx] ; y_pred = sigmoid(logit)  (RAT_m2.py:138-150,
  * shallow.py:36-45); loss_sum += sum_b BCE(y_pred, y_true)/B with torch's log clamp at -100

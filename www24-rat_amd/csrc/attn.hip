@@ -116,6 +116,24 @@ __device__ __forceinline__ void load_rows(float* tile, int ld, const float* src,
     }
 }
 
+// Warm L2 with the NEXT chunk's rows: every thread touches one dword of one 128-byte line (64 rows x `bytes` per
+// source).  Issued at the start of a phase that performs no other global loads, so the HBM round trip hides behind it
+// and the next iteration's tile loads hit L2.  Returns the touched value; the caller keeps it alive until loop end.
+__device__ __forceinline__ float prefetch_lines(const AttnArgs& a, int64_t chunk, int slot, int nlines_row, const float* src,
+                                                int width) {
+    // slot in [0, 64 * nlines_row): row = slot / nlines_row, line = slot % nlines_row
+    if (chunk >= a.nchunks) return 0.f;
+    const int r = slot / nlines_row, ln = slot - r * nlines_row;
+    const int64_t q0 = chunk * a.nsq_chunk;
+    const int64_t left = a.nseq - q0;
+    const int nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+    if (r >= nsq * a.L) return 0.f;
+    const int64_t tok = seq_token(a, q0 + r / a.L, r % a.L);
+    int c = ln * 32;
+    if (c >= width) c = width - 1;
+    return src[tok * width + c];
+}
+
 __device__ __forceinline__ void zero_cols(float* tile, int ld, int c0) {   // tile[:, c0:ld] = 0
     const int w = ld - c0;
     for (int e = threadIdx.x; e < ATT_ROWS * w; e += ATT_THREADS) tile[(size_t)(e / w) * ld + c0 + e % w] = 0.f;
@@ -217,10 +235,26 @@ struct HeadVec {
         for (int c = 0; c < N; ++c) v[c] = 0.f;
     }
     __device__ __forceinline__ float dot(const HeadVec& o) const {       // padded lanes are 0 on both sides
-        float s = 0.f;
+#if !defined(RAT_EMU)
+        if (N % 2 == 0) {                                                // two partial sums -> v_pk_fma_f32 (half the VALU issue slots)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 acc = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < N; ++c) s = fmaf(v[c], o.v[c], s);
-        return s;
+            for (int c = 0; c < N; c += 2) {
+                const f32x2 x = {v[c], v[c + 1]}, y = {o.v[c], o.v[c + 1]};
+                acc = __builtin_elementwise_fma(x, y, acc);
+            }
+            return acc.x + acc.y;
+        }
+#endif
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c + 1 < N; c += 2) {
+            s0 = fmaf(v[c], o.v[c], s0);
+            s1 = fmaf(v[c + 1], o.v[c + 1], s1);
+        }
+        if (N % 2) s0 = fmaf(v[N - 1], o.v[N - 1], s0);
+        return s0 + s1;
     }
     __device__ __forceinline__ void axpy(float a, const HeadVec& x) {    // v += a * x
 #pragma unroll
@@ -276,6 +310,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         RAT_PROF_MARK(1);
 
         // softmax(Q K^T * scale) V, one lane per (sequence, head, query); result replaces Q in place
+        float pf = 0.f;
+        {
+            const int nl = (D * 4 + 127) / 128;
+            if ((int)threadIdx.x < ATT_ROWS * nl) pf = prefetch_lines(a, chunk + gridDim.x, threadIdx.x, nl, a.x, D);
+        }
         const int ntasks = nsq * a.heads * L;
         const float sl2 = a.scale * RAT_LOG2E;
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
@@ -329,6 +368,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             store_rows_residual(a.y, qkv, ldq, a.x, rowtok, rows, D, FAST || a.vec_x != 0);
         }
         __syncthreads();
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));                              // keep the prefetch load alive (its value is irrelevant)
+#endif
         RAT_PROF_MARK(3);
     }
     RAT_PROF_FLUSH(a.prof, 0);
@@ -439,6 +481,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         // (4) attention backward, pass 1: one lane per query row -> delta, dQ (written over O)
         const int ntasks = nsq * H * L;
         const float sl2 = a.scale * RAT_LOG2E;
+        float pf = 0.f;
+        {   // passes 1 and 2 touch LDS only: the next chunk's x / dy / O / lse lines travel HBM -> L2 meanwhile
+            const int nlx = (D * 4 + 127) / 128, nlo = (I * 4 + 127) / 128;
+            int t = threadIdx.x;
+            if (t < ATT_ROWS * nlx) pf = prefetch_lines(a, chunk + gridDim.x, t, nlx, a.x, D);
+            else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlx) pf = prefetch_lines(a, chunk + gridDim.x, t, nlx, a.dy, D);
+            else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlo) pf = prefetch_lines(a, chunk + gridDim.x, t, nlo, a.o_save, I);
+            else if ((t -= ATT_ROWS * nlo) < ATT_ROWS) pf = prefetch_lines(a, chunk + gridDim.x, t, 1, a.lse_save, H);
+        }
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % H;
@@ -512,12 +563,38 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         {
             const RatLdsRows A{qkv, ldq};
             const RatGlobalWknT<!FAST> Bw{a.w_qkv, g.Q3, D, D};
-            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
-                const int col = rat_acc_col(nt);
-                if (FAST || col < D)
+            if (FAST && TD == 64) {
+                // N = 64 gives only 4 column tiles for 8 waves: pair the waves on the K extent (3I = 15 k-blocks -> 8 + 7),
+                // each with all 4 row tiles (16 MFMAs per k-block keep the 2-deep L2 prefetch of B ahead of the math),
+                // and combine the two partial tiles through LDS.
+                const int w = rat_wave(), nt = w & 3, half = w >> 2;
+                const int kbt = g.Q16 / 16, mid = (kbt + 1) / 2;
+                f32x4 acc[ATT_MT];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
-            });
+                for (int i = 0; i < ATT_MT; ++i) acc[i] = rat_zero4();
+                rat_wave_gemm_col<ATT_MT, 0>(acc, A, Bw, 0, nt, half ? kbt : mid, half ? mid : 0);
+                const int col = rat_acc_col(nt);
+                if (half == 0) {
+#pragma unroll
+                    for (int i = 0; i < ATT_MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(i, r) * ldt + col] = acc[i][r];
+                }
+                __syncthreads();
+                if (half == 1) {
+#pragma unroll
+                    for (int i = 0; i < ATT_MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(i, r) * ldt + col] += acc[i][r];
+                }
+            } else {
+                rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
+                    const int col = rat_acc_col(nt);
+                    if (FAST || col < D)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
+                });
+            }
             RAT_PROF_MARK(8);
             const RatLdsCols At{qkv, ldq};
             const RatLdsCols Bt{xs, ldx};
@@ -587,6 +664,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             }
         }
         __syncthreads();
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));
+#endif
         RAT_PROF_MARK(10);
     }
     RAT_PROF_FLUSH(a.prof, 12);

@@ -134,6 +134,12 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         RAT_PROF_MARK(0);
         ffn_hidden<TD, 0>(a, g, xs, hs, nullptr, mt_valid, rows);
         __syncthreads();
+        float pf = 0.f;
+        {   // touch one dword per 128-byte line of the NEXT chunk's x rows: they travel HBM -> L2 behind the second GEMM
+            const int64_t nt0 = (chunk + gridDim.x) * FFN_ROWS;
+            const int64_t e = nt0 * g.D + (int64_t)threadIdx.x * 32;
+            if (e < a.ntok * g.D && threadIdx.x * 32 < FFN_ROWS * g.D) pf = a.x[e];
+        }
         RAT_PROF_MARK(1);
         // y = gelu(h) W2^T + b2 + x
         {
@@ -153,6 +159,9 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         }
         __syncthreads();
         ffn_store(a.y, ys, g.ldx, tok0, rows, g.D, FAST || a.vec_x != 0);
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));
+#endif
         RAT_PROF_MARK(2);
     }
     RAT_PROF_FLUSH(a.prof, 24);
@@ -206,6 +215,15 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             }
         }
         __syncthreads();
+        float pf = 0.f;
+        {   // next chunk's x and dy lines -> L2
+            const int64_t nt0 = (chunk + gridDim.x) * FFN_ROWS;
+            const int per = FFN_ROWS * D / 32;                   // 128-byte lines per operand tile
+            const int t = threadIdx.x;
+            const float* src = t < per ? a.x : a.dy;
+            const int64_t e = nt0 * D + (int64_t)(t < per ? t : t - per) * 32;
+            if (t < 2 * per && e < a.ntok * D) pf = src[e];
+        }
         RAT_PROF_MARK(2);
         // dh = (dy W2) * gelu'(h)  -> gs
         {
@@ -246,6 +264,9 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         __syncthreads();
         ffn_store(a.y, dys, g.ldx, tok0, rows, D, FAST || a.vec_x != 0);
         __syncthreads();
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));
+#endif
         RAT_PROF_MARK(4);
     }
     RAT_PROF_FLUSH(a.prof, 36);

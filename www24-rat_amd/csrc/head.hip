@@ -159,16 +159,30 @@ bn_relu_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ 
     }
 }
 
+// column sums, two stages when the matrix is tall: (column block x row split) partials into `ws`, then a fixed-order
+// combine — deterministic, and 32x more blocks in flight than one block per 32 columns.
 __global__ void __launch_bounds__(HD_THREADS)
-colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N) {
+colsum_partial_kernel(const float* __restrict__ a, int lda, float* __restrict__ ws, int M, int N, int splits) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
-    const int col = blockIdx.x * HD_COLS + cg;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    const int per = (M + splits - 1) / splits;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
     float s = 0.f;
-    if (col < N) for (int m = rg; m < M; m += HD_RG) s += a[(size_t)m * lda + col];
+    if (col < N) for (int m = r0 + rg; m < r1; m += HD_RG) s += a[(size_t)m * lda + col];
     s = col_reduce(s, scratch);
-    if (col < N && rg == 0) out[col] = s;
+    if (col < N && rg == 0) ws[(size_t)split * N + col] = s;
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int N, int splits) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+    for (int w = 0; w < splits; ++w) s += ws[(size_t)w * N + col];
+    out[col] = s;
 }
 
 __device__ __forceinline__ float block_sum(float v, float* scratch) {   // 256 threads
@@ -276,9 +290,12 @@ extern "C" int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, con
     return rat_check_launch("rat_bn_relu_fwd");
 }
 
-extern "C" int rat_colsum(const float* a, int lda, float* out, int M, int N, void* stream) {
-    RAT_REQUIRE(M > 0 && N > 0 && a && out, "bad args");
-    RAT_LAUNCH(colsum_kernel, (N + HD_COLS - 1) / HD_COLS, HD_THREADS, HD_THREADS * sizeof(float), stream, a, lda, out, M, N);
+extern "C" int rat_colsum(const float* a, int lda, float* out, float* workspace, int M, int N, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && a && out && workspace, "bad args");     // workspace: rat_bn_workspace(N) bytes
+    const int splits = M >= 1024 ? BN_SPLITS : (M >= 64 ? 4 : 1);
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    RAT_LAUNCH(colsum_partial_kernel, nblk * splits, HD_THREADS, HD_THREADS * sizeof(float), stream, a, lda, workspace, M, N, splits);
+    RAT_LAUNCH(colsum_final_kernel, (N + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 0, stream, workspace, out, N, splits);
     return rat_check_launch("rat_colsum");
 }
 

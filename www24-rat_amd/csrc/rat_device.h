@@ -187,7 +187,7 @@ __device__ __forceinline__ void rat_mfma_block(f32x4 (&acc)[MT], const float4 (&
 
 template <int MT, int KBS, class AF, class BF>
 __device__ __forceinline__ void rat_wave_gemm_col(f32x4 (&acc)[MT], const AF& af, const BF& bf, int mt0, int nt,
-                                                  int kblocks) {
+                                                  int kblocks, int kb_begin = 0) {
     if (KBS > 0) {
         float4 b[KBS > 0 ? KBS : 1];
 #pragma unroll
@@ -200,13 +200,13 @@ __device__ __forceinline__ void rat_wave_gemm_col(f32x4 (&acc)[MT], const AF& af
             rat_mfma_block<MT>(acc, a, b[kb]);
         }
     } else {
-        const int last = kblocks - 1;
-        float4 b0 = bf(nt, 0);
-        float4 b1 = bf(nt, last < 1 ? last : 1);
+        const int last = kblocks - 1;                              // k-blocks [kb_begin, kblocks)
+        float4 b0 = bf(nt, kb_begin);
+        float4 b1 = bf(nt, last < kb_begin + 1 ? last : kb_begin + 1);
         float4 an[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) an[i] = af(mt0 + i, 0);
-        for (int kb = 0; kb < kblocks; ++kb) {
+        for (int i = 0; i < MT; ++i) an[i] = af(mt0 + i, kb_begin);
+        for (int kb = kb_begin; kb < kblocks; ++kb) {
             const float4 b2 = bf(nt, kb + 2 < last ? kb + 2 : last);
             float4 a[MT];
 #pragma unroll
@@ -320,18 +320,15 @@ __device__ __forceinline__ void rat_wave_gemm_slots(f32x4 (&acc)[SLOTS], const A
                     const int id = w + NWAVES * (s0 + s);
                     a[s] = af((id < ntiles ? id : w) / ntn, kb);
                 }
+                // slots past the last tile recompute a valid tile into an accumulator nobody reads: no per-MFMA predicate
 #pragma unroll
-                for (int s = 0; s < HALF; ++s)
-                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].x, b.x, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].x, b.x, acc[s0 + s]);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s)
-                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].y, b.y, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].y, b.y, acc[s0 + s]);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s)
-                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].z, b.z, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].z, b.z, acc[s0 + s]);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s)
-                    if (w + NWAVES * (s0 + s) < ntiles) acc[s0 + s] = RAT_MFMA16(a[s].w, b.w, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].w, b.w, acc[s0 + s]);
             }
         }
     } else {

@@ -48,7 +48,7 @@ _SIGNATURES = {
     "rat_bn_workspace": (c_size_t, [c_int]),
     "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "rat_colsum": (c_int, [_P, c_int, _P, c_int, c_int, _P]),
+    "rat_colsum": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P]),
     "rat_logit_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, _P, _P, _P, c_int, c_int, _P]),
     "rat_logit_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, c_int, _P, c_int64, c_float, c_int,
                               c_int, _P]),

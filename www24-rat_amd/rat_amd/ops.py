@@ -159,7 +159,8 @@ def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, li
 
 def colsum(a, lda, out, M, N, lib=None):
     lib = lib or get_lib()
-    lib.call("rat_colsum", _p(a), lda, _p(out), M, N, _stream(out))
+    ws = _bn_ws(N, out.device, lib)
+    lib.call("rat_colsum", _p(a), lda, _p(out), _p(ws), M, N, _stream(out))
 
 
 def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_stride, y_true, loss_sum, B, d, lib=None):
