@@ -35,6 +35,7 @@ ATTN_CASES = [  # B, T, S, d, heads, dh, project_out
     (2, 2, 3, 8, 1, 8, False),
     (1, 3, 4, 16, 8, 10, True),      # served by the compiled fast shape <TD=16, TDH=10>
     (1, 2, 3, 64, 8, 10, True),      # fast shape <TD=64, TDH=10> (split-K dXn path)
+    (1, 2, 19, 16, 8, 10, True),     # intra length 19 -> two key/query tiles in the MFMA attention core
 ]
 
 

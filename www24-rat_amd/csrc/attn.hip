@@ -266,6 +266,113 @@ struct HeadVec {
     }
 };
 
+// ---- attention core on the matrix pipe (sequence length <= 16*NT, NT <= 2) ----------------------------------------
+// One WAVE per (sequence, head).  With the k-permutation of rat_device.h (MFMA step j of lane group g consumes
+// k = 4g + j) the accumulator layout of a 16x16 tile IS the B-operand layout of the next product, so
+//     S^T = K Q^T      (rows: keys, cols: queries)   ->  softmax over the rows of each column: 4 registers x 4 lane groups
+//     O^T = V^T P^T    (rows: head channels, cols: queries), P^T taken straight from the S^T accumulators
+// needs no transposes and no LDS round trip; every lane owns one query column, so max / sum / 1/l are lane-local up to
+// two xor-shuffles across the lane groups.  dim_head is zero-padded to the 16-wide k-block in registers (the 11x11x10 or
+// 21x21x10 problems fill 27-39 % of the tiles they issue — the matrix pipe is otherwise idle in this phase and the VALU
+// instruction count drops ~3x versus one lane per query).
+__device__ __forceinline__ float4 head_frag(const float* row, int dh, int g) {   // row[4g .. 4g+3] of a dim_head slice, zero padded
+    const float2 lo = *reinterpret_cast<const float2*>(row + 4 * g);
+    const float2 hi = *reinterpret_cast<const float2*>(row + 4 * g + 2);
+    float4 r;
+    r.x = 4 * g + 0 < dh ? lo.x : 0.f;
+    r.y = 4 * g + 1 < dh ? lo.y : 0.f;
+    r.z = 4 * g + 2 < dh ? hi.x : 0.f;
+    r.w = 4 * g + 3 < dh ? hi.y : 0.f;
+    return r;
+}
+
+template <int NT>
+__device__ __forceinline__ void attn_core_fwd_mfma(const AttnArgs& a, float* qkv, int ldq, const int64_t* rowtok, int nsq, int L,
+                                                   int I, int dh, float sl2) {
+    const int l = rat_lane(), n = l & 15, g = l >> 4;
+    const int npairs = nsq * a.heads;
+    for (int pair = rat_wave(); pair < npairs; pair += ATT_WAVES) {
+        const int sq = pair / a.heads, h = pair - sq * a.heads;
+        const int r0 = sq * L;
+        float4 qb[NT], ka[NT], va[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int pos = 16 * t + n < L ? 16 * t + n : L - 1;                   // clamp: padded rows reuse a real one
+            const float* row = qkv + (size_t)(r0 + pos) * ldq + h * dh;
+            qb[t] = head_frag(row, dh, g);
+            ka[t] = head_frag(row + I, dh, g);
+            const float* vcol = qkv + 2 * I + h * dh + (n < dh ? n : 0);
+            float vv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = 16 * t + 4 * g + j;
+                const float x = vcol[(size_t)(r0 + (key < L ? key : L - 1)) * ldq];
+                vv[j] = (n < dh && key < L) ? x : 0.f;
+            }
+            va[t] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            if (16 * it >= L) break;
+            f32x4 st[NT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                f32x4 acc = rat_zero4();
+                acc = RAT_MFMA16(ka[jt].x, qb[it].x, acc);
+                acc = RAT_MFMA16(ka[jt].y, qb[it].y, acc);
+                acc = RAT_MFMA16(ka[jt].z, qb[it].z, acc);
+                acc = RAT_MFMA16(ka[jt].w, qb[it].w, acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = 16 * jt + 4 * g + r < L ? acc[r] * sl2 : -INFINITY;
+                    acc[r] = sv;
+                    m = fmaxf(m, sv);
+                }
+                st[jt] = acc;
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float lsum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = rat_exp2(st[jt][r] - m);                       // exp2(-inf) = 0 on masked keys
+                    st[jt][r] = p;
+                    lsum += p;
+                }
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
+            f32x4 ot = rat_zero4();
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                ot = RAT_MFMA16(va[jt].x, st[jt][0], ot);
+                ot = RAT_MFMA16(va[jt].y, st[jt][1], ot);
+                ot = RAT_MFMA16(va[jt].z, st[jt][2], ot);
+                ot = RAT_MFMA16(va[jt].w, st[jt][3], ot);
+            }
+            const int qi = 16 * it + n;
+            if (qi < L) {
+                const float inv = 1.0f / lsum;
+                const int row_i = r0 + qi;
+                const int64_t tok = rowtok[row_i];
+                float* op = qkv + (size_t)row_i * ldq + h * dh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * g + r;
+                    if (c < dh) {
+                        const float ov = ot[r] * inv;
+                        op[c] = ov;
+                        if (a.o_save != nullptr) a.o_save[tok * I + h * dh + c] = ov;
+                    }
+                }
+                if (g == 0 && a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + rat_log2(lsum);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int TD, int TDH>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
@@ -317,6 +424,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         }
         const int ntasks = nsq * a.heads * L;
         const float sl2 = a.scale * RAT_LOG2E;
+        if (FAST && L <= 16) {
+            attn_core_fwd_mfma<1>(a, qkv, ldq, rowtok, nsq, L, I, dh, sl2);
+        } else if (FAST && L <= 32) {
+            attn_core_fwd_mfma<2>(a, qkv, ldq, rowtok, nsq, L, I, dh, sl2);
+        } else
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % a.heads;
@@ -408,7 +520,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     for (int k = 0; k < COLS; ++k) dgam[k] = dbet[k] = 0.f;
     float dbo = 0.f;
     const int q_tn = g.D16 / 16, q_tiles = (g.Q16 / 16) * q_tn;       // dW_qkv tiles: (3I16/16) x (D16/16)
-    const int o_tn = g.I16 / 16, o_tiles = (g.D16 / 16) * o_tn;       // dW_out tiles: (D16/16) x (I16/16)
+    const int o_tn = g.D16 / 16, o_tiles = (g.I16 / 16) * o_tn;       // dW_out^T tiles: (I16/16) x (D16/16)
 
     zero_cols(xs, ldx, D);
     zero_cols(dys, ldx, D);
@@ -461,8 +573,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             });
             RAT_PROF_MARK(4);
             // (3) dW_out += dy^T O ; db_out += colsum(dy)
-            const RatLdsCols At{dys, ldx};
-            const RatLdsCols Bt{ob, ldt};
+            const RatLdsCols At{ob, ldt};                          // transposed tile grid (I16/16 x D16/16): dW_out^T = O^T dy,
+            const RatLdsCols Bt{dys, ldx};                         // so that the column-tile count (D/16) divides the wave count
             rat_wave_gemm_slots<OSLOTS, ATT_WAVES>(acco, At, Bt, o_tiles, o_tn, mt_valid);
             {   // db_out partials: thread = (column, row group); the row groups are combined once, after the chunk loop
                 const int nrg = ATT_THREADS / D, col = threadIdx.x % D, rg = threadIdx.x / D;
@@ -574,19 +686,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 for (int i = 0; i < ATT_MT; ++i) acc[i] = rat_zero4();
                 rat_wave_gemm_col<ATT_MT, 0>(acc, A, Bw, 0, nt, half ? kbt : mid, half ? mid : 0);
                 const int col = rat_acc_col(nt);
-                if (half == 0) {
+                float* part = half ? ob : dob;                  // ob is free since dQ moved into qkv; LN-bwd adds the two partials
 #pragma unroll
-                    for (int i = 0; i < ATT_MT; ++i)
+                for (int i = 0; i < ATT_MT; ++i)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(i, r) * ldt + col] = acc[i][r];
-                }
-                __syncthreads();
-                if (half == 1) {
-#pragma unroll
-                    for (int i = 0; i < ATT_MT; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(i, r) * ldt + col] += acc[i][r];
-                }
+                    for (int r = 0; r < 4; ++r) part[(size_t)rat_acc_row(i, r) * ldt + col] = acc[i][r];
             } else {
                 rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
                     const int col = rat_acc_col(nt);
@@ -618,7 +722,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 for (int k = 0; k < COLS; k += 4) {
                     float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (valid) xv = *reinterpret_cast<const float4*>(a.x + tok * D + c0 + k);
-                    const float4 gv = *reinterpret_cast<const float4*>(dob + (size_t)r * ldt + c0 + k);
+                    float4 gv = *reinterpret_cast<const float4*>(dob + (size_t)r * ldt + c0 + k);
+                    if (TD == 64) {                                 // second K-half of the split dXn GEMM
+                        const float4 g2 = *reinterpret_cast<const float4*>(ob + (size_t)r * ldt + c0 + k);
+                        gv.x += g2.x; gv.y += g2.y; gv.z += g2.z; gv.w += g2.w;
+                    }
                     xh[k] = xv.x; xh[k + 1] = xv.y; xh[k + 2] = xv.z; xh[k + 3] = xv.w;
                     gg[k] = gv.x; gg[k + 1] = gv.y; gg[k + 2] = gv.z; gg[k + 3] = gv.w;
                 }
@@ -695,11 +803,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         for (int s = 0; s < OSLOTS; ++s) {
             const int id = rat_wave() + ATT_WAVES * s;
             if (id < o_tiles) {
-                const int col = rat_acc_col(id % o_tn);
+                const int col = rat_acc_col(id % o_tn);           // output-feature index (row of W_out)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rat_acc_row(id / o_tn, r);
-                    if (row < D && col < I) s_wout[(int64_t)row * I + col] = acco[s][r];
+                    const int row = rat_acc_row(id / o_tn, r);     // inner index (column of W_out)
+                    if (row < I && col < D) s_wout[(int64_t)col * I + row] = acco[s][r];
                 }
             }
         }
