@@ -45,7 +45,7 @@ def test_attn_fwd_bwd(emu, case, mode):
     kc.check_attn(emu, "cpu", case, mode)
 
 
-@pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128)])
+@pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (77, 64, 128), (45, 16, 32)])
 def test_ffn_fwd_bwd(emu, ntok, d, hidden):
     kc.check_ffn(emu, "cpu", ntok, d, hidden)
 

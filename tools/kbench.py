@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Diagnostic: time single C-ABI kernels at the north-star shapes (B=4096, T=11, S=21, d=64, h=8, dh=10, H=128).
+
+    python tools/kbench.py [ffn_fwd ffn_bwd attn_fwd attn_bwd] [--reps 10] [--check]
+
+Never used by the product or the tests; bench.py is the contract benchmark."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "www24-rat_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+from rat_amd import ops  # noqa: E402
+
+PEAK = 157.3
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["ffn_fwd", "ffn_bwd", "attn_fwd", "attn_bwd"])
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--B", type=int, default=4096)
+    args = ap.parse_args()
+    dev = "cuda"
+    B, T, S, d, heads, dh, H = args.B, 11, 21, 64, 8, 10, 128
+    I = heads * dh
+    tok = B * T * S
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, T, S, d, generator=g).to(dev)
+    dy = torch.randn(B, T, S, d, generator=g).to(dev)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    if any(w.startswith("ffn") for w in args.which):
+        w1, b1, w2, b2 = rn(H, d, sc=d ** -0.5), rn(H, sc=0.1), rn(d, H, sc=H ** -0.5), rn(d, sc=0.1)
+        y = torch.empty_like(x)
+        if "ffn_fwd" in args.which:
+            ms = timeit(lambda: ops.ffn_fwd(x, w1, b1, w2, b2, d, H, out=y), args.reps)
+            fl = tok * 4 * d * H
+            print("ffn_fwd   %.4f ms  %.1f TFLOP/s  (%.1f %% of %.1f)" % (ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK, PEAK))
+        if "ffn_bwd" in args.which:
+            gs = [torch.zeros_like(t) for t in (w1, b1, w2, b2)]
+            ws = [None]
+
+            def run():
+                _, ws[0] = ops.ffn_bwd(x, dy, w1, b1, w2, b2, gs[0], gs[1], gs[2], gs[3], d, H, workspace=ws[0])
+            ms = timeit(run, args.reps)
+            fl = 2 * tok * 4 * d * H
+            print("ffn_bwd   %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
+    if any(w.startswith("attn") for w in args.which):
+        ln_g, ln_b = 1 + rn(d, sc=0.1), rn(d, sc=0.1)
+        w_qkv, w_out, b_out = rn(3 * I, d, sc=d ** -0.5), rn(d, I, sc=I ** -0.5), rn(d, sc=0.1)
+        params = ops.attn_params(ln_g, ln_b, w_qkv, w_out, b_out)
+        gsl = [torch.zeros_like(t) for t in (ln_g, ln_b, w_qkv, w_out, b_out)]
+        grads = ops.attn_params(*gsl)
+        for mode, smap, L in (("intra", ops.intra_map(B, T, S), S), ("cross", ops.cross_map(B, T, S), T)):
+            y = torch.empty_like(x)
+            fl = tok * (8 * d * I + 4 * I * L)
+            y, o_save, lse = ops.attn_fwd(x, params, smap, d, heads, dh, save=True, out=y)
+            if "attn_fwd" in args.which:
+                ms = timeit(lambda: ops.attn_fwd(x, params, smap, d, heads, dh, save=True, out=y), args.reps)
+                print("attn_fwd L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (L, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
+            if "attn_bwd" in args.which:
+                ws = [None]
+
+                def run():
+                    _, ws[0] = ops.attn_bwd(x, dy, o_save, lse, params, grads, smap, d, heads, dh, workspace=ws[0])
+                ms = timeit(run, args.reps)
+                print("attn_bwd L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (L, ms, 2 * fl / ms / 1e9, 100 * 2 * fl / ms / 1e9 / PEAK))
+
+
+if __name__ == "__main__":
+    main()

@@ -424,9 +424,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         }
         const int ntasks = nsq * a.heads * L;
         const float sl2 = a.scale * RAT_LOG2E;
-        if (FAST && L <= 16) {
+        constexpr bool CORE16 = false;   // 16x16x4 tiles fill 27-39 % of what they issue: measured slower than the VALU core (0.95 vs 0.64 ms)
+        if (CORE16 && FAST && L <= 16) {
             attn_core_fwd_mfma<1>(a, qkv, ldq, rowtok, nsq, L, I, dh, sl2);
-        } else if (FAST && L <= 32) {
+        } else if (CORE16 && FAST && L <= 32) {
             attn_core_fwd_mfma<2>(a, qkv, ldq, rowtok, nsq, L, I, dh, sl2);
         } else
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {

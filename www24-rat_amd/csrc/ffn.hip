@@ -10,6 +10,7 @@
 #include "../../include/rat_hip.h"
 
 #include <initializer_list>
+#include <stdlib.h>
 
 namespace {
 
@@ -318,6 +319,164 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
     }
 }
 
+
+// ======================================================================================================================
+// Fast path (D, H multiples of 16; D <= 64): "token-on-lanes" formulation.  Every product is computed TRANSPOSED,
+//     h^T = W1 x^T,   y^T = W2 g^T,   dh^T = W2^T dy^T,   dx^T = W1^T dhp^T,
+// with the weights as the MFMA A operand and a 16-token tile as the B operand: lane (g, n) = (lane >> 4, lane & 15)
+// holds x[token n][16 kb + 4 g + j] — one 16-byte global load per k-block.  The accumulator of such a product (rows =
+// output features 4 g + r, column = token n) IS the B operand of the next product (rat_device.h k-permutation), and its four
+// registers are four CONTIGUOUS features of one token: activations never pass through LDS between the GEMMs, results
+// are stored straight from the accumulators with 16-byte stores, and a wave needs no barrier to run the whole chain.
+// ======================================================================================================================
+__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c) {
+    c = RAT_MFMA16(a.x, b.x, c);
+    c = RAT_MFMA16(a.y, b.y, c);
+    c = RAT_MFMA16(a.z, b.z, c);
+    c = RAT_MFMA16(a.w, b.w, c);
+    return c;
+}
+__device__ __forceinline__ float4 as_f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ f32x4 as_v4(const float4& v) {
+    f32x4 r = {v.x, v.y, v.z, v.w};
+    return r;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
+constexpr int FT_THREADS = 1024;     // 16 waves = 4 per SIMD, ONE work-group per CU (uniform residency by construction)
+constexpr int FT_WAVES = FT_THREADS / 64;
+
+template <int D, int H>
+struct FfnTGeom {
+    static constexpr int LDW1 = D + 4, LDW2 = H + 4;
+    static constexpr size_t fwd_smem = (size_t)(H * LDW1 + D * LDW2 + H + D) * 4;
+};
+
+// two independent accumulator chains (M tiles `a0`, `a1` against the same B fragment), MFMAs issued alternately so that a
+// wave alone sustains the 32-cycle issue rate (dependent-accumulator latency is 40 cycles)
+__device__ __forceinline__ void mfma4x2(const float4& a0, const float4& a1, const float4& b, f32x4& c0, f32x4& c1) {
+    c0 = RAT_MFMA16(a0.x, b.x, c0);
+    c1 = RAT_MFMA16(a1.x, b.x, c1);
+    c0 = RAT_MFMA16(a0.y, b.y, c0);
+    c1 = RAT_MFMA16(a1.y, b.y, c1);
+    c0 = RAT_MFMA16(a0.z, b.z, c0);
+    c1 = RAT_MFMA16(a1.z, b.z, c1);
+    c0 = RAT_MFMA16(a0.w, b.w, c0);
+    c1 = RAT_MFMA16(a1.w, b.w, c1);
+}
+__device__ __forceinline__ float4 gelu4(const f32x4& h) {
+    return make_float4(rat_gelu(h[0]), rat_gelu(h[1]), rat_gelu(h[2]), rat_gelu(h[3]));
+}
+
+// forward: weights resident in LDS (A operands, 16-byte row reads); one 16-token tile per wave iteration, the next tile's
+// x fragments prefetched into registers; hidden tiles are produced in pairs and the GELU of pair p-1 is scheduled into the
+// MFMA shadow of pair p.
+template <int D, int H>
+__global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
+    typedef FfnTGeom<D, H> G;
+    constexpr int KD = D / 16, KH = H / 16;
+    static_assert(KH % 2 == 0, "hidden tiles are processed in pairs");
+    RAT_DYN_SMEM(smem);
+    float* w1s = reinterpret_cast<float*>(smem);         // [H][LDW1]
+    float* w2s = w1s + H * G::LDW1;                       // [D][LDW2]
+    float* b1s = w2s + D * G::LDW2;                       // [H]
+    float* b2s = b1s + H;                                 // [D]
+    for (int e = threadIdx.x; e < H * D / 4; e += FT_THREADS) {
+        const int r = e / (D / 4), c4 = e - r * (D / 4);
+        st4(w1s + r * G::LDW1 + 4 * c4, ld4(a.w1 + (size_t)r * D + 4 * c4));
+    }
+    for (int e = threadIdx.x; e < D * H / 4; e += FT_THREADS) {
+        const int r = e / (H / 4), c4 = e - r * (H / 4);
+        st4(w2s + r * G::LDW2 + 4 * c4, ld4(a.w2 + (size_t)r * H + 4 * c4));
+    }
+    for (int e = threadIdx.x; e < H; e += FT_THREADS) b1s[e] = a.b1[e];
+    for (int e = threadIdx.x; e < D; e += FT_THREADS) b2s[e] = a.b2[e];
+    __syncthreads();
+
+    const int l = rat_lane(), n = l & 15, g = l >> 4;
+    const int64_t ntiles = (a.ntok + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * FT_WAVES;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t t = (int64_t)blockIdx.x * FT_WAVES + rat_wave();
+    float4 xN[KD];
+    {
+        const int64_t tk = t * 16 + n;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) xN[kb] = (t < ntiles && tk < a.ntok) ? ld4(a.x + tk * D + 16 * kb + 4 * g) : zero4;
+    }
+    for (; t < ntiles; t += stride) {
+        float4 xT[KD];
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) xT[kb] = xN[kb];
+        const int64_t tok = t * 16 + n;
+        {   // next tile's fragments: in flight behind this tile's 256 MFMAs
+            const int64_t tk = (t + stride) * 16 + n;
+            const bool ok = t + stride < ntiles && tk < a.ntok;
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) xN[kb] = ok ? ld4(a.x + tk * D + 16 * kb + 4 * g) : zero4;
+        }
+        float4 gT[KH];
+        f32x4 hp0 = rat_zero4(), hp1 = rat_zero4();
+#pragma unroll
+        for (int p = 0; p < KH / 2; ++p) {
+            f32x4 c0 = as_v4(ld4(b1s + 32 * p + 4 * g)), c1 = as_v4(ld4(b1s + 32 * p + 16 + 4 * g));
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) {
+                const float4 a0 = ld4(w1s + (32 * p + n) * G::LDW1 + 16 * kb + 4 * g);
+                const float4 a1 = ld4(w1s + (32 * p + 16 + n) * G::LDW1 + 16 * kb + 4 * g);
+                mfma4x2(a0, a1, xT[kb], c0, c1);
+            }
+            if (p > 0) {
+                gT[2 * p - 2] = gelu4(hp0);
+                gT[2 * p - 1] = gelu4(hp1);
+                RAT_SCHED_MFMA_VALU(8 * KD, (KD >= 4 ? 7 : 28));
+            }
+            hp0 = c0;
+            hp1 = c1;
+            RAT_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int q = 0; q < (KD + 1) / 2; ++q) {
+            const bool two = 2 * q + 1 < KD;
+            const int m0 = 2 * q, m1 = two ? 2 * q + 1 : 2 * q;
+            const float4 bs0 = ld4(b2s + 16 * m0 + 4 * g), bs1 = ld4(b2s + 16 * m1 + 4 * g);
+            f32x4 c0 = {bs0.x + xT[m0].x, bs0.y + xT[m0].y, bs0.z + xT[m0].z, bs0.w + xT[m0].w};
+            f32x4 c1 = {bs1.x + xT[m1].x, bs1.y + xT[m1].y, bs1.z + xT[m1].z, bs1.w + xT[m1].w};
+            if (q == 0) {   // the last hidden pair's GELU rides in the shadow of the first K-blocks of this product
+#pragma unroll
+                for (int kb = 0; kb < KH - 2; ++kb) {
+                    const float4 a0 = ld4(w2s + (16 * m0 + n) * G::LDW2 + 16 * kb + 4 * g);
+                    const float4 a1 = ld4(w2s + (16 * m1 + n) * G::LDW2 + 16 * kb + 4 * g);
+                    mfma4x2(a0, a1, gT[kb], c0, c1);
+                }
+                gT[KH - 2] = gelu4(hp0);
+                gT[KH - 1] = gelu4(hp1);
+                if (KH > 2) RAT_SCHED_MFMA_VALU(8 * (KH - 2), (KH >= 8 ? 5 : 28));
+                RAT_SCHED_FENCE();
+#pragma unroll
+                for (int kb = KH - 2; kb < KH; ++kb) {
+                    const float4 a0 = ld4(w2s + (16 * m0 + n) * G::LDW2 + 16 * kb + 4 * g);
+                    const float4 a1 = ld4(w2s + (16 * m1 + n) * G::LDW2 + 16 * kb + 4 * g);
+                    mfma4x2(a0, a1, gT[kb], c0, c1);
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < KH; ++kb) {
+                    const float4 a0 = ld4(w2s + (16 * m0 + n) * G::LDW2 + 16 * kb + 4 * g);
+                    const float4 a1 = ld4(w2s + (16 * m1 + n) * G::LDW2 + 16 * kb + 4 * g);
+                    mfma4x2(a0, a1, gT[kb], c0, c1);
+                }
+            }
+            if (tok < a.ntok) {
+                st4(a.y + tok * D + 16 * m0 + 4 * g, as_f4(c0));
+                if (two) st4(a.y + tok * D + 16 * m1 + 4 * g, as_f4(c1));
+            }
+            RAT_SCHED_FENCE();
+        }
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ffn_fast_dim(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
@@ -365,10 +524,14 @@ extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const floa
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     const int64_t blocks = a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu;
-    switch (ffn_fast_dim(a, {x, y})) {
-        case 64: RAT_LAUNCH((ffn_fwd_kernel<64>), (unsigned)blocks, FFN_THREADS, smem, stream, a); break;
-        case 16: RAT_LAUNCH((ffn_fwd_kernel<16>), (unsigned)blocks, FFN_THREADS, smem, stream, a); break;
-        default: RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, smem, stream, a); break;
+    const int fast = ffn_fast_dim(a, {x, y, b1, b2});
+    const int64_t wtiles = ((ntok + 15) / 16 + FT_WAVES - 1) / FT_WAVES;
+    if (fast == 64 && hidden == 128) {
+        RAT_LAUNCH((ffn_fwd_t_kernel<64, 128>), (unsigned)(wtiles < 256 ? wtiles : 256), FT_THREADS, (FfnTGeom<64, 128>::fwd_smem), stream, a);
+    } else if (fast == 16 && hidden == 32) {
+        RAT_LAUNCH((ffn_fwd_t_kernel<16, 32>), (unsigned)(wtiles < 256 ? wtiles : 256), FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
+    } else {
+        RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     }
     return rat_check_launch("rat_ffn_fwd");
 }
