@@ -113,6 +113,18 @@ static inline f32x4 emu_mfma_f32_16x16x4f32(float a, float b, f32x4 c) {
     return c;
 }
 
+// v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 blocks (block = lane / 4), K = 1:
+//   D[reg r][lane l] = C[r][l] + A(lane 4*(l/4) + r) * B(lane l)      (lane map measured on gfx950: tools/probes/mfma4x4_probe.hip)
+static inline f32x4 emu_mfma_f32_4x4x1f32(float a, float b, f32x4 c) {
+    float* wa = &emu::g_block->xa[emu::wave() * 64];
+    const int l = emu::lane();
+    wa[l] = a;
+    emu::wave_sync();
+    for (int r = 0; r < 4; ++r) c[r] = std::fmaf(wa[(l & ~3) + r], b, c[r]);
+    emu::wave_sync();
+    return c;
+}
+
 #define RAT_LAUNCH(kernel, grid, block, smem, stream, ...) \
     emu::launch(dim3(grid), dim3(block), (smem), [&]() { kernel(__VA_ARGS__); })
 #define RAT_DYN_SMEM(name) char* name = emu::g_block->smem.data()

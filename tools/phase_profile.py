@@ -24,6 +24,8 @@ PHASES = {
                       "pass2 (dK,dV) + copy", "dXn gemm (wave 0)", "dWqkv + barrier", "LN bwd + store"]),
     24: ("ffn_fwd", ["load", "W1 gemm + gelu", "W2 gemm + store"]),
     36: ("ffn_bwd", ["load", "W1 gemm + gelu", "dW2", "dh gemm", "dx gemm + dW1"]),
+    48: ("attn2_fwd", ["load+LN (+prev out-proj tail)", "QKV gemm", "core 4x4", "out-proj+store (wave 0)"]),
+    60: ("attn2_core_fwd(wave0)", ["loads issue", "S mfma", "softmax", "PV", "stores", "-", "-", "-", "-", "-", "-", "loop"]),
 }
 
 
@@ -36,7 +38,7 @@ def main():
     batch = synthetic.make_batch(spec, fm, seed=1, device=model.device)
     model.train()
     model.train_step(batch)
-    buf = torch.zeros(64, dtype=torch.int64, device=model.device)
+    buf = torch.zeros(96, dtype=torch.int64, device=model.device)
     model._lib.cdll.rat_debug_set_prof(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
         model.train_step(batch)

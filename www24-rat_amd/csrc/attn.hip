@@ -266,113 +266,6 @@ struct HeadVec {
     }
 };
 
-// ---- attention core on the matrix pipe (sequence length <= 16*NT, NT <= 2) ----------------------------------------
-// One WAVE per (sequence, head).  With the k-permutation of rat_device.h (MFMA step j of lane group g consumes
-// k = 4g + j) the accumulator layout of a 16x16 tile IS the B-operand layout of the next product, so
-//     S^T = K Q^T      (rows: keys, cols: queries)   ->  softmax over the rows of each column: 4 registers x 4 lane groups
-//     O^T = V^T P^T    (rows: head channels, cols: queries), P^T taken straight from the S^T accumulators
-// needs no transposes and no LDS round trip; every lane owns one query column, so max / sum / 1/l are lane-local up to
-// two xor-shuffles across the lane groups.  dim_head is zero-padded to the 16-wide k-block in registers (the 11x11x10 or
-// 21x21x10 problems fill 27-39 % of the tiles they issue — the matrix pipe is otherwise idle in this phase and the VALU
-// instruction count drops ~3x versus one lane per query).
-__device__ __forceinline__ float4 head_frag(const float* row, int dh, int g) {   // row[4g .. 4g+3] of a dim_head slice, zero padded
-    const float2 lo = *reinterpret_cast<const float2*>(row + 4 * g);
-    const float2 hi = *reinterpret_cast<const float2*>(row + 4 * g + 2);
-    float4 r;
-    r.x = 4 * g + 0 < dh ? lo.x : 0.f;
-    r.y = 4 * g + 1 < dh ? lo.y : 0.f;
-    r.z = 4 * g + 2 < dh ? hi.x : 0.f;
-    r.w = 4 * g + 3 < dh ? hi.y : 0.f;
-    return r;
-}
-
-template <int NT>
-__device__ __forceinline__ void attn_core_fwd_mfma(const AttnArgs& a, float* qkv, int ldq, const int64_t* rowtok, int nsq, int L,
-                                                   int I, int dh, float sl2) {
-    const int l = rat_lane(), n = l & 15, g = l >> 4;
-    const int npairs = nsq * a.heads;
-    for (int pair = rat_wave(); pair < npairs; pair += ATT_WAVES) {
-        const int sq = pair / a.heads, h = pair - sq * a.heads;
-        const int r0 = sq * L;
-        float4 qb[NT], ka[NT], va[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int pos = 16 * t + n < L ? 16 * t + n : L - 1;                   // clamp: padded rows reuse a real one
-            const float* row = qkv + (size_t)(r0 + pos) * ldq + h * dh;
-            qb[t] = head_frag(row, dh, g);
-            ka[t] = head_frag(row + I, dh, g);
-            const float* vcol = qkv + 2 * I + h * dh + (n < dh ? n : 0);
-            float vv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = 16 * t + 4 * g + j;
-                const float x = vcol[(size_t)(r0 + (key < L ? key : L - 1)) * ldq];
-                vv[j] = (n < dh && key < L) ? x : 0.f;
-            }
-            va[t] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        }
-#pragma unroll
-        for (int it = 0; it < NT; ++it) {
-            if (16 * it >= L) break;
-            f32x4 st[NT];
-            float m = -INFINITY;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                f32x4 acc = rat_zero4();
-                acc = RAT_MFMA16(ka[jt].x, qb[it].x, acc);
-                acc = RAT_MFMA16(ka[jt].y, qb[it].y, acc);
-                acc = RAT_MFMA16(ka[jt].z, qb[it].z, acc);
-                acc = RAT_MFMA16(ka[jt].w, qb[it].w, acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sv = 16 * jt + 4 * g + r < L ? acc[r] * sl2 : -INFINITY;
-                    acc[r] = sv;
-                    m = fmaxf(m, sv);
-                }
-                st[jt] = acc;
-            }
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float lsum = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = rat_exp2(st[jt][r] - m);                       // exp2(-inf) = 0 on masked keys
-                    st[jt][r] = p;
-                    lsum += p;
-                }
-            lsum += __shfl_xor(lsum, 16, 64);
-            lsum += __shfl_xor(lsum, 32, 64);
-            f32x4 ot = rat_zero4();
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                ot = RAT_MFMA16(va[jt].x, st[jt][0], ot);
-                ot = RAT_MFMA16(va[jt].y, st[jt][1], ot);
-                ot = RAT_MFMA16(va[jt].z, st[jt][2], ot);
-                ot = RAT_MFMA16(va[jt].w, st[jt][3], ot);
-            }
-            const int qi = 16 * it + n;
-            if (qi < L) {
-                const float inv = 1.0f / lsum;
-                const int row_i = r0 + qi;
-                const int64_t tok = rowtok[row_i];
-                float* op = qkv + (size_t)row_i * ldq + h * dh;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 4 * g + r;
-                    if (c < dh) {
-                        const float ov = ot[r] * inv;
-                        op[c] = ov;
-                        if (a.o_save != nullptr) a.o_save[tok * I + h * dh + c] = ov;
-                    }
-                }
-                if (g == 0 && a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + rat_log2(lsum);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ forward
 template <int TD, int TDH>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
@@ -424,12 +317,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         }
         const int ntasks = nsq * a.heads * L;
         const float sl2 = a.scale * RAT_LOG2E;
-        constexpr bool CORE16 = false;   // 16x16x4 tiles fill 27-39 % of what they issue: measured slower than the VALU core (0.95 vs 0.64 ms)
-        if (CORE16 && FAST && L <= 16) {
-            attn_core_fwd_mfma<1>(a, qkv, ldq, rowtok, nsq, L, I, dh, sl2);
-        } else if (CORE16 && FAST && L <= 32) {
-            attn_core_fwd_mfma<2>(a, qkv, ldq, rowtok, nsq, L, I, dh, sl2);
-        } else
+        // (A 4x4x1-MFMA formulation of this core — one block per (sequence, head, 4 queries) — and a 16x16x4 one were built
+        //  and measured slower than this VALU loop at L = 11 / 21: tools/experiments/README.md.)
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % a.heads;
@@ -461,7 +350,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         }
         __syncthreads();
         RAT_PROF_MARK(2);
-
         // y = O W_out^T + b_out + x   (or y = O + x when Attention has no output projection).  The projection tile is
         // staged in xs (free since the QKV projection) so that the residual add and the store are whole-row, 16-byte accesses.
         if (a.w_out != nullptr) {
@@ -929,7 +817,7 @@ extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_
     const size_t smem = g.fwd_smem();
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
     const unsigned blocks = (unsigned)(a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu);
-    switch (fast_dim(a, {x, y, o_save})) {
+    switch (fast_dim(a, {x, y, o_save, lse_save})) {
         case 64: RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a); break;
         case 16: RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a); break;
         default: RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a); break;

@@ -399,18 +399,17 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
     const int64_t stride = (int64_t)gridDim.x * FT_WAVES;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int64_t t = (int64_t)blockIdx.x * FT_WAVES + rat_wave();
-    float4 xN[KD];
+    float4 xN[KD], xT[KD];
     {
         const int64_t tk = t * 16 + n;
 #pragma unroll
         for (int kb = 0; kb < KD; ++kb) xN[kb] = (t < ntiles && tk < a.ntok) ? ld4(a.x + tk * D + 16 * kb + 4 * g) : zero4;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) xT[kb] = rat_consume4(xN[kb]);
     }
     for (; t < ntiles; t += stride) {
-        float4 xT[KD];
-#pragma unroll
-        for (int kb = 0; kb < KD; ++kb) xT[kb] = xN[kb];
         const int64_t tok = t * 16 + n;
-        {   // next tile's fragments: in flight behind this tile's 256 MFMAs
+        {   // next tile's fragments: in flight behind this tile's 256 MFMAs; consumed (rat_consume4) before this tile's stores
             const int64_t tk = (t + stride) * 16 + n;
             const bool ok = t + stride < ntiles && tk < a.ntok;
 #pragma unroll
@@ -436,6 +435,7 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
             hp1 = c1;
             RAT_SCHED_FENCE();
         }
+        f32x4 yo[KD];
 #pragma unroll
         for (int q = 0; q < (KD + 1) / 2; ++q) {
             const bool two = 2 * q + 1 < KD;
@@ -468,11 +468,17 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
                     mfma4x2(a0, a1, gT[kb], c0, c1);
                 }
             }
-            if (tok < a.ntok) {
-                st4(a.y + tok * D + 16 * m0 + 4 * g, as_f4(c0));
-                if (two) st4(a.y + tok * D + 16 * m1 + 4 * g, as_f4(c1));
-            }
+            yo[m0] = c0;
+            if (two) yo[m1] = c1;
             RAT_SCHED_FENCE();
+        }
+        // hand-over point: every outstanding global operation (the prefetch issued at the top of this iteration, the stores
+        // of the previous tile) is a whole tile old, so this wait is free; the stores below then start a fresh queue
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) xT[kb] = rat_consume4(xN[kb]);
+        if (tok < a.ntok) {
+#pragma unroll
+            for (int m = 0; m < KD; ++m) st4(a.y + tok * D + 16 * m + 4 * g, as_f4(yo[m]));
         }
     }
 }

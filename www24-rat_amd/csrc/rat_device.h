@@ -16,10 +16,14 @@
 #ifdef RAT_EMU
 #include "hip_emu.h"
 #define RAT_MFMA16(a, b, c) emu_mfma_f32_16x16x4f32((a), (b), (c))
+#define RAT_MFMA4(a, b, c) emu_mfma_f32_4x4x1f32((a), (b), (c))
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((vector_size(16)));
 #define RAT_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4x1 outer products per wave (block = lane / 4):
+//   D[reg r][lane l] += A(lane 4*(l/4) + r) * B(lane l) — the shape of one (sequence, head) attention block
+#define RAT_MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 #define RAT_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (hipStream_t)(stream), __VA_ARGS__)
 #define RAT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -81,6 +85,23 @@ __device__ __forceinline__ int rat_wave() { return threadIdx.x >> 6; }
 #else
 __device__ __forceinline__ int rat_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 #endif
+
+// Hand a prefetched (global-load) register set over to its consumer with REAL moves.  hipcc's s_waitcnt insertion is
+// conservative across a loop back-edge: a value loaded in iteration i and first used in iteration i+1 is waited for with
+// vmcnt(0) at that use, i.e. AFTER the next prefetch has been issued — which serialises the prefetch it was meant to hide.
+// Copying at a point where every outstanding vector-memory operation is old makes the (free) wait happen there, and the
+// copy's destination carries no pending-load state.
+__device__ __forceinline__ float4 rat_consume4(const float4& src) {
+#ifdef RAT_EMU
+    return src;
+#else
+    float4 d;
+    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                 : "=&v"(d.x), "=&v"(d.y), "=&v"(d.z), "=&v"(d.w)
+                 : "v"(src.x), "v"(src.y), "v"(src.z), "v"(src.w));
+    return d;
+#endif
+}
 
 __device__ __forceinline__ f32x4 rat_zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
