@@ -103,6 +103,12 @@ int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, con
  * C[M][N] = op(A) op(B) (+ bias[N]) (+ beta*C), row-major with leading dimensions, op = transpose flag. */
 int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
               float* C, int ldc, const float* bias, float beta, void* stream);
+/* Same product with a caller-owned workspace of rat_sgemm_workspace(M, N, K) bytes (0 = none needed): when the output
+ * has few tiles and K is long (the weight gradients: K = batch), the k range is split across work-groups and the raw
+ * partial tiles are summed in slice order by a second launch — deterministic, no atomics. */
+size_t rat_sgemm_workspace(int M, int N, int K);
+int rat_sgemm_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                 float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm1d (train: batch stats, biased var; running stats momentum update with unbiased var; eval:
  * running stats) followed by ReLU — deep.py:128-132.  use_bn=0 -> ReLU only.  z,a [M][N].

@@ -29,6 +29,13 @@ def test_sgemm(emu, ta, tb):
     kc.check_sgemm(emu, "cpu", ta, tb)
 
 
+def test_sgemm_split_k(emu):
+    """few output tiles, long K: the k range is split across work-groups and reduced in slice order"""
+    assert emu.size("rat_sgemm_workspace", 40, 33, 700) > 0
+    kc.check_sgemm(emu, "cpu", 1, 0, 40, 33, 700)
+    kc.check_sgemm(emu, "cpu", 0, 1, 3, 70, 515)
+
+
 ATTN_CASES = [  # B, T, S, d, heads, dh, project_out
     (2, 3, 4, 8, 2, 4, True),
     (1, 4, 5, 10, 2, 10, True),

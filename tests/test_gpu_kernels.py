@@ -21,7 +21,7 @@ def test_gather_fwd_bwd(lib, d):
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
-@pytest.mark.parametrize("shape", [(70, 37, 29), (512, 400, 1280), (4096, 1, 400), (400, 1280, 512)])
+@pytest.mark.parametrize("shape", [(70, 37, 29), (512, 400, 1280), (4096, 1, 400), (400, 1280, 512), (400, 400, 4096), (1, 400, 4096)])
 def test_sgemm(lib, ta, tb, shape):
     kc.check_sgemm(lib, "cuda", ta, tb, *shape)
 

@@ -82,5 +82,34 @@ def main():
                 print("attn_bwd L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (L, ms, 2 * fl / ms / 1e9, 100 * 2 * fl / ms / 1e9 / PEAK))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "sgemm" not in sys.argv:
     main()
+
+
+def sgemm_bench(reps=10):
+    """DNN-head GEMM shapes of the north-star config (B=4096, 1280 -> 400 -> 400 -> 400 -> 1)."""
+    dev = "cuda"
+    B = 4096
+    shapes = []
+    dims = [1280, 400, 400, 400]
+    for li in range(3):
+        K, N = dims[li], dims[li + 1]
+        shapes.append(("fwd L%d" % li, 0, 1, B, N, K, (B, K), (N, K)))
+        shapes.append(("wgrad L%d" % li, 1, 0, N, K, B, (B, N), (B, K)))
+        shapes.append(("dgrad L%d" % li, 0, 0, B, K, N, (B, N), (N, K)))
+    shapes.append(("fwd out", 0, 1, B, 1, 400, (B, 400), (1, 400)))
+    shapes.append(("wgrad out", 1, 0, 1, 400, B, (B, 1), (B, 400)))
+    shapes.append(("dgrad out", 0, 0, B, 400, 1, (B, 1), (1, 400)))
+    tot = 0.0
+    for name, ta, tb, M, N, K, sa, sb in shapes:
+        A = torch.randn(*sa, device=dev)
+        Bm = torch.randn(*sb, device=dev)
+        C = torch.empty(M, N, device=dev)
+        ms = timeit(lambda: ops.sgemm(ta, tb, M, N, K, A, sa[1], Bm, sb[1], C, N), reps)
+        tot += ms
+        print("sgemm %-10s M=%5d N=%5d K=%5d  %.4f ms  %.1f TFLOP/s" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+    print("sgemm total %.3f ms" % tot)
+
+
+if __name__ == "__main__" and "sgemm" in sys.argv:
+    sgemm_bench()

@@ -23,6 +23,8 @@ struct GemmArgs {
     int ta, tb;
     int veca, vecb;       // 16-byte loads are legal for that operand (ld % 4 == 0, base 16-byte aligned)
     float beta;
+    int slices, kper;     // split-K: the k range is cut into `slices` pieces of `kper` (multiple of GM_K); slice s of tile t is
+    float* partial;       //          block t * slices + s and writes its raw tile to partial[s][M][N] (summed in fixed order later)
 };
 
 // One operand tile: T[r][k] (r = m or n index inside the tile, k inside the k-tile).  `kmajor` = the operand is stored
@@ -87,8 +89,10 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
     float* As = reinterpret_cast<float*>(smem);           // [64][GM_LD]  As[m][k] = op(A)[m0+m][k0+k]
     float* Bs = As + GM_TILE * GM_LD;                     // [64][GM_LD]  Bs[n][k] = op(B)[k0+k][n0+n]
     const int tiles_n = (g.N + GM_TILE - 1) / GM_TILE;
-    const int m0 = (blockIdx.x / tiles_n) * GM_TILE;
-    const int n0 = (blockIdx.x % tiles_n) * GM_TILE;
+    const int tile = blockIdx.x / g.slices, slice = blockIdx.x - tile * g.slices;
+    const int m0 = (tile / tiles_n) * GM_TILE;
+    const int n0 = (tile % tiles_n) * GM_TILE;
+    const int kbeg = slice * g.kper, kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
     const int wave = rat_wave();
     const int wm = (wave >> 1) * 2, wn = (wave & 1) * 2;  // first 16-row / 16-col tile of this wave's quadrant
     // op(A)[m][k]: ta=0 -> A[m*lda+k] (k contiguous); ta=1 -> A[k*lda+m] (k-major).  op(B)[k][n]: tb=1 -> B[n*ldb+k]; tb=0 -> B[k*ldb+n]
@@ -99,13 +103,13 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
     const RatLdsRows Af{As, GM_LD};
     const RatLdsRows Bf{Bs, GM_LD};
     float4 ra[GM_VEC], rb[GM_VEC];
-    la.fetch(0, ra);
-    lb.fetch(0, rb);
-    for (int k0 = 0; k0 < g.K; k0 += GM_K) {
+    la.fetch(kbeg, ra);
+    lb.fetch(kbeg, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GM_K) {
         la.stash(As, ra);
         lb.stash(Bs, rb);
         __syncthreads();
-        if (k0 + GM_K < g.K) {                             // next tile's loads fly while this one is multiplied
+        if (k0 + GM_K < kend) {                            // next tile's loads fly while this one is multiplied
             la.fetch(k0 + GM_K, ra);
             lb.fetch(k0 + GM_K, rb);
         }
@@ -117,6 +121,15 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + rat_acc_col(wn + j);
+            if (g.slices > 1) {                            // raw partial tile; bias / beta are applied by the reduction
+                if (col < g.N)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + rat_acc_row(wm + i, r);
+                        if (row < g.M) g.partial[((size_t)slice * g.M + row) * g.N + col] = acc[i][j][r];
+                    }
+                continue;
+            }
             if (col < g.N) {
                 const float b = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
@@ -133,18 +146,77 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
         }
 }
 
+// C[m][n] = sum_s partial[s][m][n] (+ bias[n]) (+ beta * C[m][n]), slices summed in index order (deterministic)
+__global__ void __launch_bounds__(256) sgemm_reduce_kernel(GemmArgs g) {
+    const size_t total = (size_t)g.M * g.N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int row = (int)(e / g.N), col = (int)(e - (size_t)row * g.N);
+        float v = 0.f;
+        for (int s = 0; s < g.slices; ++s) v += g.partial[(size_t)s * total + e];
+        if (g.bias) v += g.bias[col];
+        float* c = g.C + (size_t)row * g.ldc + col;
+        if (g.beta != 0.f) v += g.beta * (*c);
+        *c = v;
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// split-K plan: enough work-groups to cover the HBM latency of the k-loop by occupancy (the weight-gradient GEMMs of the
+// head have 7..140 output tiles and k = batch = 4096)
+void plan_split(int M, int N, int K, int& slices, int& kper) {
+    const int tiles = ((M + GM_TILE - 1) / GM_TILE) * ((N + GM_TILE - 1) / GM_TILE);
+    slices = 1;
+    kper = (K + GM_K - 1) / GM_K * GM_K;
+    if (tiles >= 512 || K < 8 * GM_K) return;
+    int want = (1024 + tiles - 1) / tiles;
+    const int max_slices = K / (2 * GM_K);
+    if (want > max_slices) want = max_slices;
+    if (want <= 1) return;
+    kper = ((K + want - 1) / want + GM_K - 1) / GM_K * GM_K;
+    slices = (K + kper - 1) / kper;
+}
 
 }  // namespace
 
-extern "C" int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                         float* C, int ldc, const float* bias, float beta, void* stream) {
+extern "C" size_t rat_sgemm_workspace(int M, int N, int K) {
+    int slices, kper;
+    plan_split(M, N, K, slices, kper);
+    return slices > 1 ? (size_t)slices * M * N * sizeof(float) : 0;
+}
+
+static int sgemm_launch(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                        float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes, void* stream) {
     RAT_REQUIRE(M > 0 && N > 0 && K > 0, "bad dims");
     RAT_REQUIRE(A && B && C, "null pointer");
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, 0, 0, beta};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, 0, 0, beta, 1, 0, nullptr};
     g.veca = (lda % 4 == 0) && aligned16(A);
     g.vecb = (ldb % 4 == 0) && aligned16(B);
+    plan_split(M, N, K, g.slices, g.kper);
+    if (g.slices > 1 && (workspace == nullptr || workspace_bytes < (size_t)g.slices * M * N * sizeof(float))) {
+        g.slices = 1;                                       // no (or too small a) workspace: single pass over k
+        g.kper = (K + GM_K - 1) / GM_K * GM_K;
+    }
+    g.partial = workspace;
     const int tiles = ((M + GM_TILE - 1) / GM_TILE) * ((N + GM_TILE - 1) / GM_TILE);
-    RAT_LAUNCH(sgemm_kernel, tiles, GM_THREADS, (size_t)2 * GM_TILE * GM_LD * sizeof(float), stream, g);
-    return rat_check_launch("rat_sgemm");
+    RAT_LAUNCH(sgemm_kernel, tiles * g.slices, GM_THREADS, (size_t)2 * GM_TILE * GM_LD * sizeof(float), stream, g);
+    if (rat_check_launch("rat_sgemm")) return -1;
+    if (g.slices > 1) {
+        const size_t total = (size_t)M * N;
+        const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        RAT_LAUNCH(sgemm_reduce_kernel, blocks, 256, 0, stream, g);
+        return rat_check_launch("rat_sgemm (split-K reduction)");
+    }
+    return 0;
+}
+
+extern "C" int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, const float* bias, float beta, void* stream) {
+    return sgemm_launch(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, nullptr, 0, stream);
+}
+
+extern "C" int rat_sgemm_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                            float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes,
+                            void* stream) {
+    return sgemm_launch(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, workspace, workspace_bytes, stream);
 }

@@ -125,7 +125,13 @@ def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None
 # ----------------------------------------------------------------------------- K3
 def sgemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, beta=0.0, lib=None):
     lib = lib or get_lib()
-    lib.call("rat_sgemm", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta), _stream(C))
+    need = lib.size("rat_sgemm_workspace", M, N, K)
+    if need:                                       # long-K / few-tile products (weight gradients): split-K partial tiles
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=C.device)
+        lib.call("rat_sgemm_ws", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta),
+                 _p(ws), ws.numel() * 4, _stream(C))
+    else:
+        lib.call("rat_sgemm", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta), _stream(C))
 
 
 def _bn_ws(N, device, lib):
