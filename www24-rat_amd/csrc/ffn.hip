@@ -28,6 +28,8 @@ struct FfnArgs {
     const float* b1;
     const float* w2;     // [D][H]
     const float* b2;
+    const float* w1t;    // backward fast path: [D][H] = w1^T, [H][D] = w2^T (16-byte B-fragment loads for the two dgrad GEMMs)
+    const float* w2t;
     float* slabs;
     int64_t slab_stride;
     int64_t ntok, nchunks;
@@ -229,8 +231,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         // dh = (dy W2) * gelu'(h)  -> gs
         {
             const RatLdsRows A{dys, g.ldx};
-            const RatGlobalWknT<!FAST> Bw{a.w2, D, H, H};
-            rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto dh_epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < H)
 #pragma unroll
@@ -239,20 +240,33 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
                         const size_t o = (size_t)row * g.ldh + col;
                         gs[o] = row < rows ? acc[r] * rat_gelu_grad(hs[o]) : 0.f;
                     }
-            });
+            };
+            if (FAST) {
+                const RatGlobalWnkT<false> Bw{a.w2t, H, D, D, true};
+                rat_gemm_phase<true, FFN_MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, dh_epi);
+            } else {
+                const RatGlobalWknT<true> Bw{a.w2, D, H, H};
+                rat_gemm_phase<false, FFN_MT, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, dh_epi);
+            }
         }
         __syncthreads();
         RAT_PROF_MARK(3);
         // dx = dh W1 + dy ; dW1 += dh^T x ; db1 += colsum(dh)
         {
             const RatLdsRows A{gs, g.ldh};
-            const RatGlobalWknT<!FAST> Bw{a.w1, H, D, D};
-            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto dx_epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < D)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dys[(size_t)rat_acc_row(mt, r) * g.ldx + col] += acc[r];   // dx tile, in place
-            });
+            };
+            if (FAST) {
+                const RatGlobalWnkT<false> Bw{a.w1t, D, H, H, true};
+                rat_gemm_phase<true, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, dx_epi);
+            } else {
+                const RatGlobalWknT<true> Bw{a.w1, H, D, D};
+                rat_gemm_phase<false, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, dx_epi);
+            }
             const RatLdsCols At{gs, g.ldh};
             const RatLdsCols Bt{xs, g.ldx};
             rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc1, At, Bt, t1, t1n, mt_valid);
@@ -544,7 +558,7 @@ extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const floa
 
 extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
     const FfnGeom g(d, hidden);
-    return (size_t)256 * (size_t)g.slab_floats() * sizeof(float);
+    return ((size_t)256 * (size_t)g.slab_floats() + 2 * (size_t)d * hidden) * sizeof(float);   // slabs + w1^T + w2^T
 }
 
 extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
@@ -573,7 +587,15 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
-    switch (ffn_fast_dim(a, {x, dy, dx})) {
+    const int fast = ffn_fast_dim(a, {x, dy, dx});
+    if (fast) {
+        float* w1t = workspace + (size_t)256 * a.slab_stride;
+        float* w2t = w1t + (size_t)d * hidden;
+        if (rat_launch_transpose(w1, w1t, hidden, d, stream) || rat_launch_transpose(w2, w2t, d, hidden, stream)) return -1;
+        a.w1t = w1t;
+        a.w2t = w2t;
+    }
+    switch (fast) {
         case 64: RAT_LAUNCH((ffn_bwd_kernel<64>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
         case 16: RAT_LAUNCH((ffn_bwd_kernel<16>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
         default: RAT_LAUNCH((ffn_bwd_kernel<0>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;

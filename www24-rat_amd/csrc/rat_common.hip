@@ -81,3 +81,17 @@ int rat_launch_reduce_slabs(const float* slabs, int nslabs, int64_t stride, floa
     RAT_LAUNCH(rat_reduce_slabs_kernel, (unsigned)blocks, 256, 0, stream, r);
     return rat_check_launch("rat_reduce_slabs");
 }
+
+// dst[c][r] = src[r][c]: transposed copies of the (small) weight matrices so that the backward kernels fetch every MFMA B
+// fragment with one 16-byte load instead of four strided dwords
+__global__ void __launch_bounds__(256) rat_transpose_kernel(const float* src, float* dst, int R, int C) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < R * C; e += gridDim.x * 256) {
+        const int c = e / R, r = e - c * R;          // consecutive threads write consecutive dst elements
+        dst[e] = src[(size_t)r * C + c];
+    }
+}
+int rat_launch_transpose(const float* src, float* dst, int R, int C, void* stream) {
+    const int blocks = (R * C + 255) / 256;
+    RAT_LAUNCH(rat_transpose_kernel, (unsigned)(blocks < 256 ? blocks : 256), 256, 0, stream, src, dst, R, C);
+    return rat_check_launch("rat_transpose");
+}

@@ -38,10 +38,13 @@ typedef float f32x4 __attribute__((vector_size(16)));
 #define RAT_PROF_DECL unsigned long long prof_t0 = clock64(); unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RAT_PROF_MARK(i) do { const unsigned long long prof_t = clock64(); prof_acc[i] += prof_t - prof_t0; prof_t0 = prof_t; } while (0)
 #define RAT_PROF_FLUSH(ptr, base) do { if (threadIdx.x == 0 && (ptr) != nullptr) for (int pi = 0; pi < 12; ++pi) atomicAdd((ptr) + (base) + pi, prof_acc[pi]); } while (0)
+// per-wave timeline of ONE chunk iteration of work-group 0 (trace slots live behind the 256 phase sums)
+#define RAT_TRACE(ptr, on, slot) do { if ((ptr) != nullptr && (on) && blockIdx.x == 0 && (threadIdx.x & 63) == 0) (ptr)[256 + (threadIdx.x >> 6) * 32 + (slot)] = clock64(); } while (0)
 #else
 #define RAT_PROF_DECL
 #define RAT_PROF_MARK(i) do { } while (0)
 #define RAT_PROF_FLUSH(ptr, base) do { } while (0)
+#define RAT_TRACE(ptr, on, slot) do { } while (0)
 #endif
 unsigned long long* rat_prof_buffer();                // device pointer set by rat_debug_set_prof (nullptr by default)
 
@@ -280,6 +283,35 @@ __device__ __forceinline__ void rat_wave_gemm_col(f32x4 (&acc)[MT], const AF& af
     }
 }
 
+// B fragments of one 16-column tile held in registers for the life of the kernel ("persistent weight fragments"): a wave
+// that always owns the same column tile of a weight matrix loads its fragments ONCE, so the chunk loop issues no global
+// load for that product at all (no L2 round trip after every barrier, nothing for s_waitcnt vmcnt to queue behind).
+template <int KB>
+struct RatBFrags {
+    float4 f[KB];
+    // W[n][k] row-major (ld floats per row): tile nt, k-blocks kb0 .. kb0 + KB - 1
+    __device__ __forceinline__ void load(const float* w, int ld, int nt, int kb0 = 0) {
+        const int l = rat_lane();
+        const float* p = w + (size_t)(nt * 16 + (l & 15)) * ld + kb0 * 16 + 4 * (l >> 4);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) f[kb] = *reinterpret_cast<const float4*>(p + 16 * kb);
+    }
+};
+// acc[i] += A(tile mt0 + i, k-block kb0 + kb) * frag[kb], kb < nkb <= KB (nkb wave-uniform)
+template <int MT, int KB, class AF>
+__device__ __forceinline__ void rat_wave_gemm_regb(f32x4 (&acc)[MT], const AF& af, const RatBFrags<KB>& b, int mt0, int kb0 = 0,
+                                                   int nkb = KB) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (kb < nkb) {
+            float4 a[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = af(mt0 + i, kb0 + kb);
+            rat_mfma_block<MT>(acc, a, b.f[kb]);
+        }
+    }
+}
+
 // acc[i][j] += A(tile mt0+i) * B(tile nt0+j) over kblocks 16-wide k-blocks; tiles beyond mt_valid/nb_valid
 // are skipped (wave-uniform).  All 64 lanes of the wave must call this together.
 template <int MT, int NB, class AF, class BF>
@@ -371,23 +403,27 @@ __device__ __forceinline__ void rat_wave_gemm_slots(f32x4 (&acc)[SLOTS], const A
 #pragma unroll
         for (int s0 = 0; s0 < SLOTS; s0 += HALF) {
             if (w + NWAVES * s0 >= ntiles) break;
+            // live slots of this group (wave-uniform): slots past the last tile issue nothing
+            int live = (ntiles - w - NWAVES * s0 + NWAVES - 1) / NWAVES;
+            if (live > HALF) live = HALF;
             for (int kb = 0; kb < kblocks; ++kb) {
                 const float4 b = bf(nt, kb);
                 float4 a[HALF];
 #pragma unroll
-                for (int s = 0; s < HALF; ++s) {
-                    const int id = w + NWAVES * (s0 + s);
-                    a[s] = af((id < ntiles ? id : w) / ntn, kb);
-                }
-                // slots past the last tile recompute a valid tile into an accumulator nobody reads: no per-MFMA predicate
+                for (int s = 0; s < HALF; ++s)
+                    if (s < live) a[s] = af((w + NWAVES * (s0 + s)) / ntn, kb);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].x, b.x, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s)
+                    if (s < live) acc[s0 + s] = RAT_MFMA16(a[s].x, b.x, acc[s0 + s]);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].y, b.y, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s)
+                    if (s < live) acc[s0 + s] = RAT_MFMA16(a[s].y, b.y, acc[s0 + s]);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].z, b.z, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s)
+                    if (s < live) acc[s0 + s] = RAT_MFMA16(a[s].z, b.z, acc[s0 + s]);
 #pragma unroll
-                for (int s = 0; s < HALF; ++s) acc[s0 + s] = RAT_MFMA16(a[s].w, b.w, acc[s0 + s]);
+                for (int s = 0; s < HALF; ++s)
+                    if (s < live) acc[s0 + s] = RAT_MFMA16(a[s].w, b.w, acc[s0 + s]);
             }
         }
     } else {
@@ -404,5 +440,6 @@ __device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 
 __device__ __forceinline__ int rat_acc_col(int tile_n) { return tile_n * 16 + (rat_lane() & 15); }
 
 // sum the persistent-gradient slabs of all work-groups: out[p] = sum_wg slab[wg][p], fixed order
+int rat_launch_transpose(const float* src, float* dst, int R, int C, void* stream);     // dst[C][R] = src[R][C]^T
 int rat_launch_reduce_slabs(const float* slabs, int nslabs, int64_t stride, float* const* outs_host,
                             const int64_t* offsets, const int64_t* sizes, int nouts, void* stream);
