@@ -25,6 +25,19 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, exact fp32
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+# HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected with rocprofv3 in
+# separate runs (bench.py cannot host the profiler) and committed next to the kernel stats; valid for the north-star shapes only
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round1", "r1_traffic_pmc.json")
+
+
+def pmc_traffic(kernel, workload):
+    if workload != "synthetic_F20_V1M_K10_d64_B4096" or not os.path.exists(TRAFFIC_FILE):
+        return None
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -211,8 +224,10 @@ def main():
         else:
             achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
         roofline = dict(kernel=dom_name, bound=dom["bound"], achieved=round(achieved, 3), peak=peak, unit=unit,
-                        frac=round(achieved / peak, 4), traffic=None, avg_launch_ms=round(avg_s * 1e3, 4),
-                        launches_per_step=round(dom["n"], 2))
+                        frac=round(achieved / peak, 4), traffic=pmc_traffic(dom_name, args.workload),
+                        traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1/r1_traffic_pmc.json)",
+                        algorithmic=round(per_launch, 1), algorithmic_unit="FLOP/launch" if dom["bound"] == "mfma" else "bytes/launch",
+                        avg_launch_ms=round(avg_s * 1e3, 4), launches_per_step=round(dom["n"], 2))
         result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64", value=round(B * world * args.steps / elapsed, 1),
                       unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
