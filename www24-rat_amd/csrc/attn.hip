@@ -36,6 +36,7 @@ constexpr int ATT_MT = ATT_ROWS / 16;
 constexpr int DH_MAX = 16;        // dim_head <= 16 (every shipped config uses 10)
 constexpr int QSLOTS = 8;         // persistent dW_qkv tiles per wave  (3I16/16 * D16/16 <= 64)
 constexpr int OSLOTS = 4;         // persistent dW_out tiles per wave  (D16/16 * I16/16 <= 32)
+constexpr int CORE_UNROLL = 3;    // keys (queries) per trip of the VALU attention-core loops
 
 struct AttnArgs {
     const float* x;
@@ -330,10 +331,35 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             o.zero();
             float m = -INFINITY, l = 0.f;
             const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh;
-            for (int j = 0; j < L; ++j) {
+            // keys three at a time: all six K / V rows are requested before anything waits (one exposed LDS latency per three
+            // keys instead of two per key) and the three score dot products are independent chains; the online-softmax
+            // recurrence itself runs in the original key order, so the result is bit-identical to the one-key loop
+            int j = 0;
+            for (; j + CORE_UNROLL <= L; j += CORE_UNROLL) {
+                HeadVec<TDH> kk[CORE_UNROLL], vv[CORE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CORE_UNROLL; ++u) {
+                    const float* kp = kbase + (size_t)(j + u) * ldq;
+                    kk[u].load(kp, dh);
+                    vv[u].load(kp + I, dh);
+                }
+                float sc[CORE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CORE_UNROLL; ++u) sc[u] = q.dot(kk[u]) * sl2;   // scores in log2 units
+#pragma unroll
+                for (int u = 0; u < CORE_UNROLL; ++u) {
+                    const float mn = fmaxf(m, sc[u]);
+                    const float corr = rat_exp2(m - mn);
+                    const float p = rat_exp2(sc[u] - mn);
+                    l = l * corr + p;
+                    o.scale_axpy(corr, p, vv[u]);
+                    m = mn;
+                }
+            }
+            for (; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * ldq;
                 kv.load(kp, dh);
-                const float s = q.dot(kv) * sl2;                     // score in log2 units
+                const float s = q.dot(kv) * sl2;
                 const float mn = fmaxf(m, s);
                 const float corr = rat_exp2(m - mn);
                 const float p = rat_exp2(s - mn);
@@ -506,7 +532,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             dlt[row_i * H + h] = delta;
             const float lse = lses[row_i * H + h];
             const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh;
-            for (int j = 0; j < L; ++j) {
+            int j = 0;
+            for (; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * ldq;
                 kv.load(kp + I, dh);
                 const float dp = go.dot(kv);
@@ -529,7 +556,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             vv.load(kp + I, dh);
             dk.zero();
             dv.zero();
-            for (int i = 0; i < L; ++i) {
+            int i = 0;
+            for (; i < L; ++i) {
                 const int row_i = sq * L + i;
                 t.load(dob + (size_t)row_i * ldt + h * dh, dh);
                 const float dp = t.dot(vv);
