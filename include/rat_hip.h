@@ -57,6 +57,17 @@ int rat_gather_bwd(const float* dgrid, const float* dflat, const int32_t* idx, c
                    const RatField* grad_fields_dev, int nfields, float* dlabel_table,
                    int B, int T, int L, int d, void* stream);
 
+/* ---- K0: device-side batch assembly ---------------------------------------------------------------------
+ * replaces Dataset.__getitem__ + default_collate + inputs_to_device for retrieval-augmented batches
+ * (fuxictr/pytorch/data_generator.py:66-78, 239-241; base_model.py:125-133): the encoded query table
+ * data_ids [Q][L] / data_labels [Q], the retrieval pool pool_ids [N][L] / pool_labels [N] and the pre-computed
+ * neighbour lists retr_indices [Q][K] (negative = counted from the end of the pool, numpy semantics) are resident
+ * in HBM; rows [B] selects the batch.  Outputs are exactly rat_gather_fwd's inputs: idx [B][1+K][L],
+ * label_ids [B][1+K] (2 for the target row, the neighbour's label otherwise), plus y_true [B]. */
+int rat_batch_assemble(const int32_t* data_ids, const float* data_labels, const int32_t* pool_ids,
+                       const float* pool_labels, const int64_t* retr_indices, const int64_t* rows, int32_t* idx,
+                       int32_t* label_ids, float* y_true, int64_t Q, int64_t N, int B, int K, int L, void* stream);
+
 /* ---- K2: attention phase of CrossIntraEncoderBlock --------------------------------------------------
  * y = Attention(LayerNorm(x)) + x over groups of L tokens (RAT_m2.py:155-161, 176-202, 222-230).
  * Sequence q in [0, nseq) owns tokens  tok(q, p) = (q / q_div) * hi_stride + (q % q_div) * lo_stride

@@ -68,6 +68,9 @@ def main(argv=None):
     parser.add_argument("--gpu", type=int, default=-1, help="The gpu index, -1 for cpu")
     parser.add_argument("--synthetic", type=int, default=0, help="generate N synthetic training rows instead of reading data")
     parser.add_argument("--epochs", type=int, default=None, help="override the config's epochs")
+    parser.add_argument("--host_batches", action="store_true",
+                        help="assemble batches on the host like the reference's DataLoader (default on a GPU: the data stays "
+                             "resident in HBM and every batch is one rat_batch_assemble launch)")
     args = vars(parser.parse_args(argv))
     params = load_config(args["config"], args["expid"])
     params["gpu"], params["version"] = args["gpu"], args["version"]
@@ -92,6 +95,9 @@ def main(argv=None):
     model_class = getattr(models, params["model"])
     model = model_class(feature_map, **params)
     model.count_parameters()
+    if model.device.type == "cuda" and not args["host_batches"]:
+        train_gen, valid_gen = train_gen.to_device(model.device), valid_gen.to_device(model.device)
+        test_gen = test_gen.to_device(model.device) if test_gen else test_gen
     model.fit_generator(train_gen, validation_data=valid_gen, **params)
 
     logging.info("Load best model: {}".format(model.checkpoint))

@@ -1,0 +1,126 @@
+"""Device-side batch assembly (rat_batch_assemble): oracle pinned to batches collated by the real
+reference Dataset (tests/golden/batch_assembly.npz, made by tests/golden/make_golden_batch.py), then the HIP kernel —
+host-emulated on CPU, the real build with -m gpu — checked bit for bit against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(HERE, "emu"))
+
+from make_golden_batch import batch_cases  # noqa: E402  (case inputs only; nothing of the reference is imported here)
+from oracle import batch_oracle as bo  # noqa: E402
+from rat_amd import ops  # noqa: E402
+from rat_amd.data import DeviceBatch, DeviceRetrievalBatches, RetrievalBatches  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "batch_assembly.npz"))
+CASES = batch_cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_collate(name):
+    c = CASES[name]
+    pool = c["data"] if c["pool"] is None else c["pool"]
+    X, y = bo.assemble_batch(c["data"], pool, c["retr_indices"], c["rows"])
+    assert X.dtype == np.float64 and np.array_equal(X, GOLD[name + "/X"])
+    assert np.array_equal(y, GOLD[name + "/y"])
+    assert np.array_equal(c["retr_values"][c["rows"]], GOLD[name + "/values"])
+    assert np.array_equal(c["retr_lens"][c["rows"]], GOLD[name + "/lens"])
+
+
+def _kernel_vs_oracle(lib, dev, data, pool, ri, rows):
+    d = torch.from_numpy
+    same = pool is data
+    data_ids, data_labels = d(data[:, :-1].astype(np.int32)).to(dev), d(data[:, -1].astype(np.float32)).to(dev)
+    pool_ids = data_ids if same else d(pool[:, :-1].astype(np.int32)).to(dev)
+    pool_labels = data_labels if same else d(pool[:, -1].astype(np.float32)).to(dev)
+    idx, lab, yt = ops.batch_assemble(data_ids, data_labels, pool_ids, pool_labels, d(ri.astype(np.int64)).to(dev),
+                                      d(rows.astype(np.int64)).to(dev), lib=lib)
+    X, y = bo.assemble_batch(data, pool, ri, rows)
+    ridx, rlab, ryt = bo.model_inputs(X, y)
+    assert np.array_equal(idx.cpu().numpy(), ridx), "ids must be bit-exact"
+    assert np.array_equal(lab.cpu().numpy(), rlab)
+    assert np.array_equal(yt.cpu().numpy(), ryt)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build_emu
+    from rat_amd._lib import RatLib
+    return RatLib(build_emu.build())
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_emulated_kernel_matches_oracle(emu, name):
+    c = CASES[name]
+    pool = c["data"] if c["pool"] is None else c["pool"]
+    _kernel_vs_oracle(emu, "cpu", c["data"], pool, c["retr_indices"], c["rows"])
+
+
+def test_emulated_kernel_edge_cases(emu):
+    rs = np.random.RandomState(3)
+    data = np.concatenate([rs.randint(0, 99, (5, 1)), rs.randint(0, 2, (5, 1))], 1).astype(np.float64)   # L = 1
+    _kernel_vs_oracle(emu, "cpu", data, data, np.full((5, 1), -1), np.array([4, 4, 0]))                  # all padding, repeated rows
+    ri = rs.randint(-5, 5, (5, 7))                                                                        # every legal negative index
+    _kernel_vs_oracle(emu, "cpu", data, data, ri, np.array([2]))                                          # B = 1
+
+
+def test_device_batches_equal_host_batches(emu):
+    """same seed -> the HBM-resident source yields exactly the batches of the host source (and of the reference loader)"""
+    rs = np.random.RandomState(5)
+    Q, L, K = 23, 4, 3
+    data = np.concatenate([rs.randint(0, 50, (Q, L)), rs.randint(0, 2, (Q, 1))], 1).astype(np.float64)
+    ri = rs.randint(-1, Q, (Q, K))
+    host = RetrievalBatches(data, data, ri, rs.rand(Q, K), np.full(Q, K), batch_size=8, shuffle=True, seed=9)
+    devb = DeviceRetrievalBatches(data, data, ri, batch_size=8, device="cpu", shuffle=True, seed=9, lib=emu)
+    assert len(host) == len(devb) == 3
+    for (X, y, _, _), b in zip(host, devb):
+        assert isinstance(b, DeviceBatch) and len(b) == X.shape[0]
+        assert torch.equal(b.idx, X.to(torch.int32))
+        lab = y.to(torch.int32).clone()
+        lab[:, 0] = 2
+        assert torch.equal(b.label_ids, lab) and torch.equal(b.y_true, y[:, 0].float())
+
+
+@pytest.mark.gpu
+def test_gpu_kernel_matches_oracle_north_star_shape():
+    from rat_amd._lib import get_lib
+    rs = np.random.RandomState(7)
+    Q, N, L, K, B = 20000, 50000, 20, 10, 4096
+    data = np.concatenate([rs.randint(0, 50000, (Q, L)), rs.randint(0, 2, (Q, 1))], 1).astype(np.float64)
+    pool = np.concatenate([rs.randint(0, 50000, (N, L)), rs.randint(0, 2, (N, 1))], 1).astype(np.float64)
+    ri = rs.randint(-1, N, (Q, K))
+    _kernel_vs_oracle(get_lib(), "cuda", data, pool, ri, rs.permutation(Q)[:B])
+    for name, c in CASES.items():
+        _kernel_vs_oracle(get_lib(), "cuda", c["data"], c["data"] if c["pool"] is None else c["pool"], c["retr_indices"], c["rows"])
+
+
+@pytest.mark.gpu
+def test_gpu_training_step_from_device_batch_equals_host_batch():
+    """one training step fed by rat_batch_assemble == the same step fed by the reference-style host 4-tuple"""
+    import golden_cases as gc
+    import model_cases as mc
+    case = gc.case_by_name("mltag_shape")
+    X, y, rv, rl = mc.batch_of(case)
+    B, T, L = X.shape
+    # a pool that reproduces this batch: row b*T + t of the pool is sample (b, t); the target rows double as the query table
+    pool = np.concatenate([X.numpy().reshape(B * T, L), y.numpy().reshape(B * T, 1)], 1)
+    data = pool[::T].copy()
+    ri = (np.arange(B)[:, None] * T + np.arange(1, T)[None, :]).astype(np.int64)
+    losses = []
+    for use_device in (False, True):
+        model = mc.build_model(case, gpu=0, seed=1)
+        mc.load_weights(model, case)
+        model.train()
+        if use_device:
+            src = DeviceRetrievalBatches(data, pool, ri, batch_size=B, device=model.device)
+            batch = next(iter(src))
+            assert torch.equal(batch.idx.cpu(), X.to(torch.int32))
+        else:
+            batch = (X, y, rv, rl)
+        losses.append(float(model.train_step(batch)))
+    assert losses[0] == losses[1], losses

@@ -254,7 +254,8 @@ class BaseModel(nn.Module):
         preds = []
         with torch.no_grad():
             for batch_data in data_generator:
-                assert batch_data[0].ndim == 3, "retrieval augmented mode requires input_shape like [Bx(1+K)xF]"
+                ids = batch_data.idx if hasattr(batch_data, "idx") else batch_data[0]      # DeviceBatch or the 4-tuple
+                assert ids.ndim == 3, "retrieval augmented mode requires input_shape like [Bx(1+K)xF]"
                 preds.append(self.forward(batch_data)["y_pred"])
         return torch.cat(preds).double().cpu().numpy().reshape(-1)
 

@@ -47,6 +47,15 @@ class RetrievalBatches:
         n = len(self.ids)
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
+    def to_device(self, device, lib=None):
+        """The same dataset, HBM-resident: batches are then assembled by ``rat_batch_assemble`` (same order for the same seed)."""
+        src = DeviceRetrievalBatches.__new__(DeviceRetrievalBatches)
+        src._init_from_arrays(self.ids, self.labels, self.pool_ids, self.pool_labels, self.retr_indices, self.batch_size, device,
+                              self.shuffle, self.drop_last, lib)
+        src._rng = np.random.RandomState()
+        src._rng.set_state(self._rng.get_state())
+        return src
+
     def __iter__(self):
         n = len(self.ids)
         order = self._rng.permutation(n) if self.shuffle else np.arange(n)
@@ -57,6 +66,64 @@ class RetrievalBatches:
             y = np.concatenate([self.labels[rows][:, None], self.pool_labels[ridx]], axis=1)
             yield (torch.from_numpy(X), torch.from_numpy(y), torch.from_numpy(self.retr_values[rows]),
                    torch.from_numpy(self.retr_lens[rows]))
+
+
+class DeviceBatch:
+    """A batch already assembled on the device (ids int32 [B,1+K,L], label-token ids int32 [B,1+K], y_true fp32 [B]):
+    ``RAT_m2`` consumes it as is — no host tensors, no float64 -> int32 conversion, no H2D copy."""
+
+    __slots__ = ("idx", "label_ids", "y_true")
+
+    def __init__(self, idx, label_ids, y_true):
+        self.idx, self.label_ids, self.y_true = idx, label_ids, y_true
+
+    def __len__(self):
+        return int(self.idx.shape[0])
+
+
+class DeviceRetrievalBatches:
+    """HBM-resident replacement of the reference's Dataset + DataLoader for retrieval-augmented training
+    (fuxictr/pytorch/data_generator.py:66-78, 239-241): the encoded query table, the retrieval pool and the neighbour
+    lists are uploaded ONCE (int32 ids, fp32 labels, int64 neighbour indices); every batch is one ``rat_batch_assemble``
+    launch over the batch's row ids.  Yields ``DeviceBatch`` objects.  Same ordering rule as ``RetrievalBatches`` (a numpy
+    permutation per epoch when ``shuffle``), so both sources produce identical batches for the same seed."""
+
+    def __init__(self, data, pool, retr_indices, batch_size, device, shuffle=False, seed=0, drop_last=False, lib=None):
+        data, pool_arr = np.asarray(data), np.asarray(pool)
+        same = pool is data
+        ids, labels = data[:, :-1].astype(np.int32), data[:, -1].astype(np.float32)
+        self._init_from_arrays(ids, labels, ids if same else pool_arr[:, :-1].astype(np.int32),
+                               labels if same else pool_arr[:, -1].astype(np.float32), np.asarray(retr_indices).astype(np.int64),
+                               batch_size, device, shuffle, drop_last, lib)
+        self._rng = np.random.RandomState(seed)
+
+    def _init_from_arrays(self, ids, labels, pool_ids, pool_labels, retr_indices, batch_size, device, shuffle, drop_last, lib):
+        from . import ops
+        self._ops, self._lib = ops, lib
+        dev = torch.device(device)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.data_ids, self.data_labels = up(ids), up(labels)
+        self.pool_ids = self.data_ids if pool_ids is ids else up(pool_ids)
+        self.pool_labels = self.data_labels if pool_labels is labels else up(pool_labels)
+        self.retr_indices = up(retr_indices)
+        assert self.retr_indices.shape[0] == self.data_ids.shape[0]
+        self.n = int(self.data_ids.shape[0])
+        self.batch_size, self.shuffle, self.drop_last, self.device = int(batch_size), shuffle, drop_last, dev
+
+    def __len__(self):
+        return self.n // self.batch_size if self.drop_last else (self.n + self.batch_size - 1) // self.batch_size
+
+    def assemble(self, rows):
+        """rows: int64 tensor (device) of query-row ids -> DeviceBatch"""
+        idx, label_ids, y_true = self._ops.batch_assemble(self.data_ids, self.data_labels, self.pool_ids, self.pool_labels,
+                                                          self.retr_indices, rows.contiguous(), lib=self._lib)
+        return DeviceBatch(idx, label_ids, y_true)
+
+    def __iter__(self):
+        order = self._rng.permutation(self.n) if self.shuffle else np.arange(self.n)
+        order_dev = torch.from_numpy(order.astype(np.int64)).to(self.device)      # one small upload per epoch
+        for b in range(len(self)):
+            yield self.assemble(order_dev[b * self.batch_size:(b + 1) * self.batch_size])
 
 
 def batches_from_files(data_path, retrieval_path, batch_size, pool_path=None, **kw):

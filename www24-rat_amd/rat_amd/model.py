@@ -20,6 +20,7 @@ from torch import nn
 from . import ops
 from ._lib import get_lib
 from .base_model import BaseModel, parse_regularizer
+from .data import DeviceBatch
 from .features import field_infos
 
 
@@ -281,6 +282,8 @@ class RAT_m2(BaseModel):
     def _prepare_batch(self, inputs):
         """inputs_to_device (base_model.py:125-133) + the slicing of RAT_m2.forward lines 110-116: ids become int32
         once, on the host side of the boundary; the target row's label token is id 2."""
+        if isinstance(inputs, DeviceBatch):            # assembled on the device by rat_batch_assemble (data.py)
+            return inputs.idx, inputs.label_ids, inputs.y_true
         X, y = inputs[0], inputs[1]
         if len(inputs) >= 4:
             assert inputs[3].ndim == 1, "RIM does not support label-wise retrieval-enhanced training"

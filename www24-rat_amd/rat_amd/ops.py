@@ -59,6 +59,24 @@ def attn_params(ln_g, ln_b, w_qkv, w_out, b_out):
                          b_out.data_ptr() if b_out is not None else None)
 
 
+# ----------------------------------------------------------------------------- K0
+def batch_assemble(data_ids, data_labels, pool_ids, pool_labels, retr_indices, rows, lib=None):
+    """Device-side Dataset.__getitem__ + collate: -> (idx [B,1+K,L] int32, label_ids [B,1+K] int32, y_true [B] fp32)."""
+    lib = lib or get_lib()
+    _chk(data_ids, torch.int32, "data_ids"), _chk(pool_ids, torch.int32, "pool_ids")
+    _chk(data_labels, name="data_labels"), _chk(pool_labels, name="pool_labels")
+    _chk(retr_indices, torch.int64, "retr_indices"), _chk(rows, torch.int64, "rows")
+    Q, L = data_ids.shape
+    N, K, B = pool_ids.shape[0], retr_indices.shape[1], rows.numel()
+    dev = data_ids.device
+    idx = torch.empty((B, K + 1, L), dtype=torch.int32, device=dev)
+    label_ids = torch.empty((B, K + 1), dtype=torch.int32, device=dev)
+    y_true = torch.empty((B,), dtype=torch.float32, device=dev)
+    lib.call("rat_batch_assemble", _p(data_ids), _p(data_labels), _p(pool_ids), _p(pool_labels), _p(retr_indices), _p(rows),
+             _p(idx), _p(label_ids), _p(y_true), Q, N, B, K, L, _stream(data_ids))
+    return idx, label_ids, y_true
+
+
 # ----------------------------------------------------------------------------- K1
 def gather_fwd(idx, label_ids, ftab, nfields, label_table, B, T, L, d, lib=None):
     lib = lib or get_lib()
