@@ -71,6 +71,29 @@ template <int A>
 __device__ __forceinline__ float qb(float x) {      // value of lane A of this lane's quad (DPP quad_perm broadcast)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), A | (A << 2) | (A << 4) | (A << 6), 0xf, 0xf, true));
 }
+// acc += (lane A of the quad's x) * y, one v_fmac_f32 with a DPP quad_perm source (hipcc does not fold update_dpp into the FMA)
+template <int A>
+__device__ __forceinline__ void qfma(float& acc, float x, float y) {
+    if (A == 0) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
+    if (A == 1) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
+    if (A == 2) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
+    if (A == 3) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y));
+}
+template <int A>
+__device__ __forceinline__ void key_step_asm(const V10& q, const V10& go, const V10& kq, const V10& vq, V10& dq, float lse, float delta, bool on) {
+    float dp0 = 0.f, dp1 = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; c += 2) {
+        qfma<A>(dp0, vq.v[c], go.v[c]);
+        qfma<A>(dp1, vq.v[c + 1], go.v[c + 1]);
+        qfma<A>(s0, kq.v[c], q.v[c]);
+        qfma<A>(s1, kq.v[c + 1], q.v[c + 1]);
+    }
+    const float p = __builtin_amdgcn_exp2f((s0 + s1) * 0.4f - lse);
+    const float w = on ? p * ((dp0 + dp1) - delta) : 0.f;
+#pragma unroll
+    for (int c = 0; c < DH; ++c) qfma<A>(dq.v[c], kq.v[c], w);
+}
 template <int A>
 __device__ __forceinline__ void key_step(const V10& q, const V10& go, const V10& kq, const V10& vq, V10& dq, float lse, float delta, bool on) {
     float dp0 = 0.f, dp1 = 0.f, s0 = 0.f, s1 = 0.f;
@@ -136,6 +159,56 @@ __global__ void __launch_bounds__(NT) pass1_quad(float* out, long long* cyc, int
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = (t1 - t0) / iters;
     out[(blockIdx.x * NT + threadIdx.x) % 4096] = acc;
 }
+// quads = 4 queries of one (sequence, head); lane a of the quad loads the K / V rows of keys 4 kb + a and the quad shares them by DPP
+template <int NT>
+__global__ void __launch_bounds__(NT) pass1_quad_asm(float* out, long long* cyc, int L, int iters) {
+    extern __shared__ float sm[];
+    float* qkv = sm;
+    float* dob = qkv + ROWS * LDQ;
+    float* ob = dob + ROWS * LDT;
+    float* lses = ob + ROWS * LDT;
+    for (int e = threadIdx.x; e < ROWS * (LDQ + 2 * LDT + H); e += NT) sm[e] = 0.01f * (float)((e * 2654435761u) >> 20) - 20.f;
+    __syncthreads();
+    const int nsq = ROWS / L, nqb = (L + 3) / 4, ntasks = nsq * H * nqb * 4;
+    long long t0 = clock64();
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        for (int task = threadIdx.x; task < ntasks; task += NT) {
+            const int a = task & 3, u = task >> 2;
+            const int blk = u % nqb, h = (u / nqb) % H, sq = u / (nqb * H);
+            const int i = 4 * blk + a, row_i = sq * L + (i < L ? i : L - 1);
+            V10 q, go, kv, dq, kq, vq;
+            ld(q, qkv + row_i * LDQ + h * DH);
+            ld(go, dob + row_i * LDT + h * DH);
+            ld(kv, ob + row_i * LDT + h * DH);
+            const float delta = dot(go, kv);
+#pragma unroll
+            for (int c = 0; c < DH; ++c) dq.v[c] = 0.f;
+            const float lse = lses[row_i * H + h];
+            const float* kbase = qkv + (sq * L) * LDQ + I + h * DH;
+            for (int kb = 0; kb < nqb; ++kb) {
+                const int jj = 4 * kb + a;
+                const float* kp = kbase + (jj < L ? jj : L - 1) * LDQ;
+                ld(kq, kp);
+                ld(vq, kp + I);
+                key_step_asm<0>(q, go, kq, vq, dq, lse, delta, 4 * kb + 0 < L);
+                key_step_asm<1>(q, go, kq, vq, dq, lse, delta, 4 * kb + 1 < L);
+                key_step_asm<2>(q, go, kq, vq, dq, lse, delta, 4 * kb + 2 < L);
+                key_step_asm<3>(q, go, kq, vq, dq, lse, delta, 4 * kb + 3 < L);
+            }
+            if (i < L) {
+                float* op = ob + row_i * LDT + h * DH;
+#pragma unroll
+                for (int c = 0; c < DH; c += 2) *reinterpret_cast<float2*>(op + c) = make_float2(dq.v[c] * 1e-3f, dq.v[c + 1] * 1e-3f);
+            }
+            acc += dq.v[0];
+        }
+        __syncthreads();
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = (t1 - t0) / iters;
+    out[(blockIdx.x * NT + threadIdx.x) % 4096] = acc;
+}
 int main() {
     float* out; long long* cyc;
     (void)hipMalloc(&out, 4096 * 4); (void)hipMalloc(&cyc, 8);
@@ -150,6 +223,10 @@ int main() {
         printf("L=%d 1024 threads, keys split over 2 lanes: %lld\n", L, h);
         pass1_quad<512><<<256, 512, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         printf("L=%d  512 threads, DPP quad sharing: %lld\n", L, h);
+        pass1_quad_asm<512><<<256, 512, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("L=%d  512 threads, DPP quad sharing, asm fmac_dpp: %lld\n", L, h);
+        pass1_quad_asm<1024><<<256, 1024, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("L=%d 1024 threads, DPP quad sharing, asm fmac_dpp: %lld\n", L, h);
         pass1_quad<1024><<<256, 1024, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         printf("L=%d 1024 threads, DPP quad sharing: %lld\n", L, h);
         pass1<512, 2><<<256, 512, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);

@@ -90,7 +90,7 @@ __device__ __forceinline__ void ffn_zero_cols(float* tile, int ld, int c0) {
     for (int e = threadIdx.x; e < FFN_ROWS * w; e += FFN_THREADS) tile[(size_t)(e / w) * ld + c0 + e % w] = 0.f;
 }
 
-// hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- h, gs <- gelu(h))
+// hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- gelu'(h), gs <- gelu(h))
 template <int TD, int MODE>
 __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
                                            int mt_valid, int rows) {
@@ -107,9 +107,11 @@ __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, c
                 const float h = row < rows ? acc[r] + bias : 0.f;    // padding rows stay exactly 0
                 if (MODE == 0) {
                     hs[(size_t)row * g.ldh + col] = rat_gelu(h);
-                } else {
-                    hs[(size_t)row * g.ldh + col] = h;
-                    gs[(size_t)row * g.ldh + col] = rat_gelu(h);
+                } else {                                             // backward: hs <- gelu'(h) (h itself is not needed again)
+                    float gv, dgv;
+                    rat_gelu_both(h, gv, dgv);
+                    hs[(size_t)row * g.ldh + col] = dgv;
+                    gs[(size_t)row * g.ldh + col] = gv;
                 }
             }
         }
@@ -238,7 +240,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int row = rat_acc_row(mt, r);
                         const size_t o = (size_t)row * g.ldh + col;
-                        gs[o] = row < rows ? acc[r] * rat_gelu_grad(hs[o]) : 0.f;
+                        gs[o] = row < rows ? acc[r] * hs[o] : 0.f;          // hs holds gelu'(h) since the recomputation
                     }
             };
             if (FAST) {

@@ -154,6 +154,13 @@ __device__ __forceinline__ float rat_erf(float a) {
 __device__ __forceinline__ float rat_gelu(float x) {          // nn.GELU() exact erf form
     return 0.5f * x * (1.0f + rat_erf(x * 0.70710678118654752440f));
 }
+// gelu(x) and d/dx gelu(x) from ONE erf evaluation (the backward FFN needs both for every hidden activation)
+__device__ __forceinline__ void rat_gelu_both(float x, float& g, float& dg) {
+    const float cdf = 0.5f * (1.0f + rat_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * rat_exp2(x * x * (-0.5f * RAT_LOG2E));
+    g = x * cdf;
+    dg = cdf + x * pdf;
+}
 __device__ __forceinline__ float rat_gelu_grad(float x) {     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
     const float cdf = 0.5f * (1.0f + rat_erf(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * rat_exp2(x * x * (-0.5f * RAT_LOG2E));
