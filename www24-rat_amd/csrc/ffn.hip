@@ -101,17 +101,24 @@ __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, c
         const int col = rat_acc_col(nt);
         if (FAST || col < g.H) {
             const float bias = a.b1[col];
+            float h[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rat_acc_row(mt, r);
-                const float h = row < rows ? acc[r] + bias : 0.f;    // padding rows stay exactly 0
+            for (int r = 0; r < 4; ++r) h[r] = rat_acc_row(mt, r) < rows ? acc[r] + bias : 0.f;    // padding rows stay exactly 0
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {                      // two activations per packed-math evaluation
+                const size_t o0 = (size_t)rat_acc_row(mt, r) * g.ldh + col, o1 = (size_t)rat_acc_row(mt, r + 1) * g.ldh + col;
                 if (MODE == 0) {
-                    hs[(size_t)row * g.ldh + col] = rat_gelu(h);
-                } else {                                             // backward: hs <- gelu'(h) (h itself is not needed again)
-                    float gv, dgv;
-                    rat_gelu_both(h, gv, dgv);
-                    hs[(size_t)row * g.ldh + col] = dgv;
-                    gs[(size_t)row * g.ldh + col] = gv;
+                    const rat_f2 gv = rat_gelu2(rat_f2_make(h[r], h[r + 1]));
+                    hs[o0] = gv.x;
+                    hs[o1] = gv.y;
+                } else {                                         // backward: hs <- gelu'(h) (h itself is not needed again);
+                    float g0, d0, g1, d1;                        // scalar form: the packed one measured 3 % slower here
+                    rat_gelu_both(h[r], g0, d0);
+                    rat_gelu_both(h[r + 1], g1, d1);
+                    hs[o0] = d0;
+                    hs[o1] = d1;
+                    gs[o0] = g0;
+                    gs[o1] = g1;
                 }
             }
         }
@@ -382,7 +389,8 @@ __device__ __forceinline__ void mfma4x2(const float4& a0, const float4& a1, cons
     c1 = RAT_MFMA16(a1.w, b.w, c1);
 }
 __device__ __forceinline__ float4 gelu4(const f32x4& h) {
-    return make_float4(rat_gelu(h[0]), rat_gelu(h[1]), rat_gelu(h[2]), rat_gelu(h[3]));
+    const rat_f2 g01 = rat_gelu2(rat_f2_make(h[0], h[1])), g23 = rat_gelu2(rat_f2_make(h[2], h[3]));
+    return make_float4(g01.x, g01.y, g23.x, g23.y);
 }
 
 // forward: weights resident in LDS (A operands, 16-byte row reads); one 16-token tile per wave iteration, the next tile's

@@ -151,6 +151,56 @@ __device__ __forceinline__ float rat_erf(float a) {
     const float small = fmaf(q, a, a);
     return t > 0.927734375f ? big : small;
 }
+// Two-at-a-time variants: the polynomial parts run on v_pk_fma_f32 / v_pk_mul_f32 (plain fp32 VALU instructions cost 4
+// cycles per wave on gfx950 — the packed forms do twice the work in the same slot); per-component arithmetic is identical
+// to rat_erf (IEEE fma per lane), so scalar and packed paths agree bit for bit.
+#ifdef RAT_EMU
+struct rat_f2 { float x, y; };
+__device__ __forceinline__ rat_f2 rat_f2_make(float a, float b) { return rat_f2{a, b}; }
+__device__ __forceinline__ rat_f2 rat_pk_fma(rat_f2 a, rat_f2 b, rat_f2 c) { return rat_f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ rat_f2 rat_pk_mul(rat_f2 a, rat_f2 b) { return rat_f2{a.x * b.x, a.y * b.y}; }
+#else
+typedef float rat_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rat_f2 rat_f2_make(float a, float b) { rat_f2 r = {a, b}; return r; }
+__device__ __forceinline__ rat_f2 rat_pk_fma(rat_f2 a, rat_f2 b, rat_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ rat_f2 rat_pk_mul(rat_f2 a, rat_f2 b) { return a * b; }
+#endif
+__device__ __forceinline__ rat_f2 rat_f2_splat(float a) { return rat_f2_make(a, a); }
+__device__ __forceinline__ rat_f2 rat_erf2(rat_f2 a) {
+    const rat_f2 t = rat_f2_make(fabsf(a.x), fabsf(a.y)), s = rat_pk_mul(a, a);
+    rat_f2 r = rat_pk_fma(rat_f2_splat(-1.72853470e-5f), t, rat_f2_splat(3.83197126e-4f));
+    const rat_f2 u = rat_pk_fma(rat_f2_splat(-3.88396438e-3f), t, rat_f2_splat(2.42546219e-2f));
+    r = rat_pk_fma(r, s, u);
+    r = rat_pk_fma(r, t, rat_f2_splat(-1.06777877e-1f));
+    r = rat_pk_fma(r, t, rat_f2_splat(-6.34846687e-1f));
+    r = rat_pk_fma(r, t, rat_f2_splat(-1.28717512e-1f));
+    r = rat_pk_fma(r, t, rat_f2_make(-t.x, -t.y));
+    r = rat_pk_mul(r, rat_f2_splat(RAT_LOG2E));
+    const float bx = copysignf(1.0f - rat_exp2(r.x), a.x), by = copysignf(1.0f - rat_exp2(r.y), a.y);
+    rat_f2 q = rat_f2_splat(-5.96761703e-4f);
+    q = rat_pk_fma(q, s, rat_f2_splat(4.99119423e-3f));
+    q = rat_pk_fma(q, s, rat_f2_splat(-2.67681349e-2f));
+    q = rat_pk_fma(q, s, rat_f2_splat(1.12819925e-1f));
+    q = rat_pk_fma(q, s, rat_f2_splat(-3.76125336e-1f));
+    q = rat_pk_fma(q, s, rat_f2_splat(1.28379166e-1f));
+    const rat_f2 sm = rat_pk_fma(q, a, a);
+    return rat_f2_make(t.x > 0.927734375f ? bx : sm.x, t.y > 0.927734375f ? by : sm.y);
+}
+// gelu of two values
+__device__ __forceinline__ rat_f2 rat_gelu2(rat_f2 x) {
+    const rat_f2 e = rat_erf2(rat_pk_mul(x, rat_f2_splat(0.70710678118654752440f)));
+    return rat_pk_mul(rat_pk_mul(rat_f2_splat(0.5f), x), rat_f2_make(1.0f + e.x, 1.0f + e.y));
+}
+// gelu and gelu' of two values from one erf evaluation each
+__device__ __forceinline__ void rat_gelu_both2(rat_f2 x, rat_f2& g, rat_f2& dg) {
+    const rat_f2 e = rat_erf2(rat_pk_mul(x, rat_f2_splat(0.70710678118654752440f)));
+    const rat_f2 cdf = rat_pk_mul(rat_f2_splat(0.5f), rat_f2_make(1.0f + e.x, 1.0f + e.y));
+    const rat_f2 ex = rat_pk_mul(rat_pk_mul(x, x), rat_f2_splat(-0.5f * RAT_LOG2E));
+    const rat_f2 pdf = rat_pk_mul(rat_f2_splat(0.39894228040143267794f), rat_f2_make(rat_exp2(ex.x), rat_exp2(ex.y)));
+    g = rat_pk_mul(x, cdf);
+    dg = rat_pk_fma(x, pdf, cdf);
+}
+
 __device__ __forceinline__ float rat_gelu(float x) {          // nn.GELU() exact erf form
     return 0.5f * x * (1.0f + rat_erf(x * 0.70710678118654752440f));
 }
@@ -159,12 +209,12 @@ __device__ __forceinline__ void rat_gelu_both(float x, float& g, float& dg) {
     const float cdf = 0.5f * (1.0f + rat_erf(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * rat_exp2(x * x * (-0.5f * RAT_LOG2E));
     g = x * cdf;
-    dg = cdf + x * pdf;
+    dg = fmaf(x, pdf, cdf);
 }
 __device__ __forceinline__ float rat_gelu_grad(float x) {     // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
     const float cdf = 0.5f * (1.0f + rat_erf(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * rat_exp2(x * x * (-0.5f * RAT_LOG2E));
-    return cdf + x * pdf;
+    return fmaf(x, pdf, cdf);
 }
 
 // ---- MFMA operand fetchers.  Each returns the lane's 4 values of k-block `kb` for 16-row/col tile `tile`.
