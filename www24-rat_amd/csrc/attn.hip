@@ -36,6 +36,7 @@ constexpr int ATT_MT = ATT_ROWS / 16;
 constexpr int DH_MAX = 16;        // dim_head <= 16 (every shipped config uses 10)
 constexpr int QSLOTS = 8;         // persistent dW_qkv tiles per wave  (3I16/16 * D16/16 <= 64)
 constexpr int OSLOTS = 4;         // persistent dW_out tiles per wave  (D16/16 * I16/16 <= 32)
+constexpr int FAST_HEADS = 8;     // the compiled fast shapes fix heads = 8 (x dim_head = 10): the whole LDS geometry is then compile-time
 constexpr int CORE_UNROLL = 3;    // keys (queries) per trip of the VALU attention-core loops
 
 struct AttnArgs {
@@ -273,7 +274,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
     constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
     RAT_DYN_SMEM(smem);
-    const AttnGeom g(FAST ? TD : a.d, a.heads, FAST && TDH > 0 ? TDH : a.dh);
+    const int heads_c = FAST ? FAST_HEADS : a.heads;
+    const AttnGeom g(FAST ? TD : a.d, heads_c, FAST && TDH > 0 ? TDH : a.dh);
     float* xs = reinterpret_cast<float*>(smem);
     float* qkv = xs + (size_t)ATT_ROWS * g.ldx;
     int64_t* rowtok = reinterpret_cast<int64_t*>(qkv + (size_t)ATT_ROWS * g.ldq);
@@ -316,14 +318,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             const int nl = (D * 4 + 127) / 128;
             if ((int)threadIdx.x < ATT_ROWS * nl) pf = prefetch_lines(a, chunk + gridDim.x, threadIdx.x, nl, a.x, D);
         }
-        const int ntasks = nsq * a.heads * L;
+        const int ntasks = nsq * heads_c * L;
         const float sl2 = a.scale * RAT_LOG2E;
         // (A 4x4x1-MFMA formulation of this core — one block per (sequence, head, 4 queries) — and a 16x16x4 one were built
         //  and measured slower than this VALU loop at L = 11 / 21: tools/experiments/README.md.)
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
-            const int h = (task / L) % a.heads;
-            const int sq = task / (L * a.heads);
+            const int h = (task / L) % heads_c;
+            const int sq = task / (L * heads_c);
             const int row_i = sq * L + i;
             float* qp = qkv + (size_t)row_i * ldq + h * dh;
             HeadVec<TDH> q, o, kv;
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             o.store(qp, dh, inv);
             const int64_t tok = rowtok[row_i];
             if (a.o_save != nullptr) o.store(a.o_save + tok * I + h * dh, dh, inv);
-            if (a.lse_save != nullptr) a.lse_save[tok * a.heads + h] = m + rat_log2(l);   // log2-domain log-sum-exp
+            if (a.lse_save != nullptr) a.lse_save[tok * heads_c + h] = m + rat_log2(l);   // log2-domain log-sum-exp
         }
         __syncthreads();
         RAT_PROF_MARK(2);
@@ -409,8 +411,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
     constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
     RAT_DYN_SMEM(smem);
-    const AttnGeom g(FAST ? TD : a.d, a.heads, FAST && TDH > 0 ? TDH : a.dh);
-    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = a.heads;
+    const AttnGeom g(FAST ? TD : a.d, FAST ? FAST_HEADS : a.heads, FAST && TDH > 0 ? TDH : a.dh);
+    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = FAST ? FAST_HEADS : a.heads;
     const int ldx = g.ldx, ldq = g.ldq, ldt = g.ldt;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx]  LayerNorm(x)
     float* dys = xs + (size_t)ATT_ROWS * ldx;                   // [64][ldx]  dL/dy
@@ -820,7 +822,7 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
 
 // which compiled fast shape (if any) serves these dimensions
 int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
-    if (a.dh != 10 || (a.heads * a.dh) % 16 != 0 || a.w_out == nullptr) return 0;
+    if (a.dh != 10 || a.heads != FAST_HEADS || a.w_out == nullptr) return 0;
     for (const void* p : ptrs)
         if (p != nullptr && !aligned16(p)) return 0;
     if (!aligned16(a.w_qkv) || !aligned16(a.w_out)) return 0;
