@@ -183,7 +183,7 @@ template <int TD>
 __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
     constexpr bool FAST = TD > 0;
     RAT_DYN_SMEM(smem);
-    const FfnGeom g(FAST ? TD : a.d, a.hidden);
+    const FfnGeom g(FAST ? TD : a.d, FAST ? 2 * TD : a.hidden);      // fast shapes: hidden = 2 d (scale_dim 2), geometry is compile-time
     const int D = g.D, H = g.H;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx] x
     float* dys = xs + (size_t)FFN_ROWS * g.ldx;                 // [64][ldx] dL/dy
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         {
             const RatLdsCols At{dys, g.ldx};
             const RatLdsCols Bt{gs, g.ldh};
-            rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc2, At, Bt, t2, t2n, mt_valid);
+            rat_wave_gemm_slots<WSLOTS, FFN_WAVES, 0>(acc2, At, Bt, t2, t2n, mt_valid);
             {   // db2 partials: thread = (column, row group), combined after the chunk loop
                 const int nrg = FFN_THREADS / D, col = threadIdx.x % D, rg = threadIdx.x / D;
                 if (rg < nrg)
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             }
             const RatLdsCols At{gs, g.ldh};
             const RatLdsCols Bt{xs, g.ldx};
-            rat_wave_gemm_slots<WSLOTS, FFN_WAVES>(acc1, At, Bt, t1, t1n, mt_valid);
+            rat_wave_gemm_slots<WSLOTS, FFN_WAVES, 0>(acc1, At, Bt, t1, t1n, mt_valid);
             {
                 const int nrg = FFN_THREADS / H, col = threadIdx.x % H, rg = threadIdx.x / H;
                 if (rg < nrg)
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ffn_fast_dim(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
-    if (a.hidden % 16 != 0) return 0;
+    if (a.hidden != 2 * a.d) return 0;              // the compiled fast shapes are (d, 2 d) = (64, 128), (16, 32)
     for (const void* p : ptrs)
         if (!aligned16(p)) return 0;
     if (!aligned16(a.w1) || !aligned16(a.w2)) return 0;

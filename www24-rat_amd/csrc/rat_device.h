@@ -450,9 +450,12 @@ __device__ __forceinline__ f32x4 rat_wave_gemm1(f32x4 acc, const AF& af, const B
 // Persistent weight-gradient tiles of one wave: tile ids wave + NWAVES*s (s < SLOTS) of an (m_tiles x ntn) grid,
 // acc[s] += A^T-tile(mt_s) * B-tile(nt_s) over `kblocks` token blocks.  When ntn divides NWAVES every slot of a wave
 // shares the same nt, so the B fragment is fetched once per k-block and the (independent) slots' MFMAs issue back to back.
-template <int SLOTS, int NWAVES, class AF, class BF>
+// KBC > 0: the k extent is a compile-time constant (fast paths: all 64 rows, padding rows are exact zeros) — the k loop
+// unrolls and the operand fetches of later k-blocks are scheduled over the MFMAs of earlier ones.
+template <int SLOTS, int NWAVES, int KBC = 0, class AF, class BF>
 __device__ __forceinline__ void rat_wave_gemm_slots(f32x4 (&acc)[SLOTS], const AF& af, const BF& bf, int ntiles, int ntn,
-                                                    int kblocks) {
+                                                    int kblocks_rt) {
+    const int kblocks = KBC > 0 ? KBC : kblocks_rt;
     const int w = rat_wave();
     if (NWAVES % ntn == 0) {
         const int nt = w % ntn;
@@ -463,6 +466,7 @@ __device__ __forceinline__ void rat_wave_gemm_slots(f32x4 (&acc)[SLOTS], const A
             // live slots of this group (wave-uniform): slots past the last tile issue nothing
             int live = (ntiles - w - NWAVES * s0 + NWAVES - 1) / NWAVES;
             if (live > HALF) live = HALF;
+#pragma unroll
             for (int kb = 0; kb < kblocks; ++kb) {
                 const float4 b = bf(nt, kb);
                 float4 a[HALF];
