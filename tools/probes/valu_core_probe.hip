@@ -4,9 +4,13 @@
 #include <cstdio>
 constexpr int ROWS = 64, LDQ = 244, LDT = 84, H = 8, DH = 10, I = 80;
 struct V10 { float v[DH]; };
+#ifndef LDVOL
+#define LDVOL
+#endif
+typedef float vf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void ld(V10& x, const float* p) {
 #pragma unroll
-    for (int c = 0; c < DH; c += 2) { const float2 t = *reinterpret_cast<const float2*>(p + c); x.v[c] = t.x; x.v[c + 1] = t.y; }
+    for (int c = 0; c < DH; c += 2) { const vf2 t = *reinterpret_cast<const LDVOL vf2*>(p + c); x.v[c] = t.x; x.v[c + 1] = t.y; }
 }
 __device__ __forceinline__ float dot(const V10& a, const V10& b) {
     float s0 = 0.f, s1 = 0.f;
@@ -60,6 +64,95 @@ __global__ void __launch_bounds__(NT) pass1(float* out, long long* cyc, int L, i
                 for (int c = 0; c < DH; c += 2) *reinterpret_cast<float2*>(op + c) = make_float2(dq.v[c] * 1e-3f, dq.v[c + 1] * 1e-3f);
             }
             acc += dq.v[0];
+        }
+        __syncthreads();
+    }
+    long long t1 = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = (t1 - t0) / iters;
+    out[(blockIdx.x * NT + threadIdx.x) % 4096] = acc;
+}
+// K and V rows through hand-issued ds_read_b64 (hipcc merges adjacent b64 loads into ds_read2_b64, which the LDS serves at half
+// the bytes per clock): loads of the NEXT key are issued before the wait for the current one (lgkmcnt(10) = ten newer loads in flight)
+__device__ __forceinline__ void issue10(vf2 (&k)[5], vf2 (&v)[5], const float* kp) {
+    const unsigned addr = (unsigned)(unsigned long long)kp;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(k[0]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:8" : "=v"(k[1]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(k[2]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:24" : "=v"(k[3]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(k[4]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:320" : "=v"(v[0]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:328" : "=v"(v[1]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:336" : "=v"(v[2]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:344" : "=v"(v[3]) : "v"(addr));
+    asm volatile("ds_read_b64 %0, %1 offset:352" : "=v"(v[4]) : "v"(addr));
+}
+template <int N>
+__device__ __forceinline__ void wait10(vf2 (&k)[5], vf2 (&v)[5]) {
+    if (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+}
+__device__ __forceinline__ float dot5(const V10& a, const vf2 (&b)[5]) {
+    vf2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { const vf2 x = {a.v[2 * c], a.v[2 * c + 1]}; acc = __builtin_elementwise_fma(x, b[c], acc); }
+    return acc.x + acc.y;
+}
+template <int NT>
+__global__ void __launch_bounds__(NT) pass1_asm(float* out, long long* cyc, int L, int iters) {
+    extern __shared__ float sm[];
+    float* qkv = sm;
+    float* dob = qkv + ROWS * LDQ;
+    float* ob = dob + ROWS * LDT;
+    float* lses = ob + ROWS * LDT;
+    for (int e = threadIdx.x; e < ROWS * (LDQ + 2 * LDT + H); e += NT) sm[e] = 0.01f * (float)((e * 2654435761u) >> 20) - 20.f;
+    __syncthreads();
+    const int nsq = ROWS / L, ntasks = nsq * H * L;
+    long long t0 = clock64();
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        for (int task = threadIdx.x; task < ntasks; task += NT) {
+            const int i = task % L, h = (task / L) % H, sq = task / (L * H);
+            const int row_i = sq * L + i;
+            V10 q, go, kv;
+            ld(q, qkv + row_i * LDQ + h * DH);
+            ld(go, dob + row_i * LDT + h * DH);
+            ld(kv, ob + row_i * LDT + h * DH);
+            const float delta = dot(go, kv);
+            vf2 dq[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            const float lse = lses[row_i * H + h];
+            const float* kbase = qkv + (sq * L) * LDQ + I + h * DH;
+            vf2 k0[5], v0[5], k1[5], v1[5];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue10(k0, v0, kbase);
+            for (int j = 0; j < L; j += 2) {
+                issue10(k1, v1, kbase + (j + 1 < L ? j + 1 : j) * LDQ);
+                wait10<10>(k0, v0);
+                {
+                    const float dp = dot5(go, v0);
+                    const float p = __builtin_amdgcn_exp2f(dot5(q, k0) * 0.4f - lse);
+                    const float w = p * (dp - delta);
+                    const vf2 w2 = {w, w};
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) dq[c] = __builtin_elementwise_fma(w2, k0[c], dq[c]);
+                }
+                if (j + 1 < L) {
+                    issue10(k0, v0, kbase + (j + 2 < L ? j + 2 : j + 1) * LDQ);
+                    wait10<10>(k1, v1);
+                    const float dp = dot5(go, v1);
+                    const float p = __builtin_amdgcn_exp2f(dot5(q, k1) * 0.4f - lse);
+                    const float w = p * (dp - delta);
+                    const vf2 w2 = {w, w};
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) dq[c] = __builtin_elementwise_fma(w2, k1[c], dq[c]);
+                } else {
+                    wait10<0>(k1, v1);
+                }
+            }
+            wait10<0>(k0, v0);
+            float* op = ob + row_i * LDT + h * DH;
+#pragma unroll
+            for (int c = 0; c < 5; ++c) *reinterpret_cast<float2*>(op + 2 * c) = make_float2(dq[c].x * 1e-3f, dq[c].y * 1e-3f);
+            acc += dq[0].x;
         }
         __syncthreads();
     }
@@ -221,6 +314,8 @@ int main() {
         printf("L=%d 1024 threads, full loop (half idle): %lld\n", L, h);
         pass1<1024, 2><<<256, 1024, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         printf("L=%d 1024 threads, keys split over 2 lanes: %lld\n", L, h);
+        pass1_asm<512><<<256, 512, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("L=%d  512 threads, hand-issued ds_read_b64, double-buffered: %lld\n", L, h);
         pass1_quad<512><<<256, 512, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         printf("L=%d  512 threads, DPP quad sharing: %lld\n", L, h);
         pass1_quad_asm<512><<<256, 512, smem>>>(out, cyc, L, 200); (void)hipDeviceSynchronize(); (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);

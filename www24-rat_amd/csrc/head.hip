@@ -22,6 +22,7 @@ __device__ __forceinline__ float col_reduce(float v, float* scratch) {
     return s;
 }
 
+constexpr int LB_SAMPLES = 64;              // samples per block of logit_bwd (one wave computes their dlogit)
 constexpr int BN_SPLITS = 32;               // row splits: grid = (N/32 column blocks) x BN_SPLITS
 
 // phase 1 of BatchNorm statistics: per (row split, column) partial sums about a pivot (the column's first row),
@@ -238,35 +239,55 @@ logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_t
                  int64_t cls_stride, const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
                  float* dfc_b, const RatField* lr_grad_fields, int nfields, const int32_t* idx, int64_t idx_stride,
                  float gscale, int B, int d) {
+    // One block = LB_SAMPLES samples.  Phase 1: one thread per sample (dlogit, LR-table atomics, dfc_b partial).  Phase 2:
+    // thread = (column k, sample group): dcls rows and the dfc_w partial sums are produced column-parallel — no LDS atomics
+    // (the first version issued d LDS atomics per sample onto the same d addresses and ran on B/256 CUs only).
     RAT_DYN_SMEM(smem);
-    float* part = reinterpret_cast<float*>(smem);             // [d + 1] block partials of dfc_w, dfc_b
-    for (int i = threadIdx.x; i <= d; i += blockDim.x) part[i] = 0.f;
-    __syncthreads();
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) {
-        const float dl = gscale * (y_pred[b] - y_true[b]) / (float)B;
-        dlogit[b] = dl;
-        const float* c = cls + (int64_t)b * cls_stride;
-        float* dc = dcls + (int64_t)b * dcls_stride;
-        for (int k = 0; k < d; ++k) {
-            dc[k] = dl * fc_w[k];
-            atomicAdd(&part[k], dl * c[k]);
-        }
-        atomicAdd(&part[d], dl);
-        if (lr_grad_fields != nullptr)
-            for (int f = 0; f < nfields; ++f) {
-                const RatField fd = lr_grad_fields[f];
-                const int32_t* ids = idx + (int64_t)b * idx_stride + fd.col;
-                for (int j = 0; j < fd.ncols; ++j) {
-                    int id = ids[j];
-                    id = id < 0 ? 0 : (id >= fd.vocab ? fd.vocab - 1 : id);
-                    if (id != fd.padding_idx) atomicAdd(fd.table + id, dl);
+    float* dls = reinterpret_cast<float*>(smem);              // [LB_SAMPLES] dlogit of this block's samples
+    float* part = dls + LB_SAMPLES;                           // [groups][d] partial dfc_w
+    const int b0 = blockIdx.x * LB_SAMPLES;
+    const int nb = B - b0 < LB_SAMPLES ? B - b0 : LB_SAMPLES;
+    float dbias = 0.f;
+    if ((int)threadIdx.x < LB_SAMPLES) {
+        float dl = 0.f;
+        if ((int)threadIdx.x < nb) {
+            const int b = b0 + threadIdx.x;
+            dl = gscale * (y_pred[b] - y_true[b]) / (float)B;
+            dlogit[b] = dl;
+            if (lr_grad_fields != nullptr)
+                for (int f = 0; f < nfields; ++f) {
+                    const RatField fd = lr_grad_fields[f];
+                    const int32_t* ids = idx + (int64_t)b * idx_stride + fd.col;
+                    for (int j = 0; j < fd.ncols; ++j) {
+                        int id = ids[j];
+                        id = id < 0 ? 0 : (id >= fd.vocab ? fd.vocab - 1 : id);
+                        if (id != fd.padding_idx) atomicAdd(fd.table + id, dl);
+                    }
                 }
-            }
+        }
+        dls[threadIdx.x] = dl;
+        dbias = rat_group_sum<64>(dl);                        // LB_SAMPLES == 64: one wave
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < d; i += blockDim.x) atomicAdd(&dfc_w[i], part[i]);
-    if (threadIdx.x == 0) atomicAdd(dfc_b, part[d]);
+    const int groups = blockDim.x / d;                        // d <= blockDim.x (checked on the host)
+    const int k = threadIdx.x % d, grp = threadIdx.x / d;
+    if (grp < groups) {
+        const float w = fc_w[k];
+        float acc = 0.f;
+        for (int s = grp; s < nb; s += groups) {
+            const float dl = dls[s];
+            dcls[(int64_t)(b0 + s) * dcls_stride + k] = dl * w;
+            acc = fmaf(dl, cls[(int64_t)(b0 + s) * cls_stride + k], acc);
+        }
+        part[grp * d + k] = acc;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < d) {
+        float acc = 0.f;
+        for (int gI = 0; gI < groups; ++gI) acc += part[gI * d + threadIdx.x];
+        atomicAdd(&dfc_w[threadIdx.x], acc);
+    }
+    if (threadIdx.x == 0) atomicAdd(dfc_b, dbias);
 }
 
 }  // namespace
@@ -315,7 +336,8 @@ extern "C" int rat_logit_bwd(const float* y_pred, const float* y_true, const flo
                              float gscale, int B, int d, void* stream) {
     RAT_REQUIRE(B > 0 && d > 0 && y_pred && y_true && cls && fc_w && dlogit && dcls && dfc_w && dfc_b, "bad args");
     RAT_REQUIRE(lr_grad_fields_dev == nullptr || idx != nullptr, "LR term needs idx");
-    RAT_LAUNCH(logit_bwd_kernel, (B + HD_THREADS - 1) / HD_THREADS, HD_THREADS, (size_t)(d + 1) * sizeof(float), stream,
+    RAT_REQUIRE(d <= HD_THREADS, "embedding_dim above the block size");
+    RAT_LAUNCH(logit_bwd_kernel, (B + LB_SAMPLES - 1) / LB_SAMPLES, HD_THREADS, (size_t)(LB_SAMPLES + HD_THREADS) * sizeof(float), stream,
                y_pred, y_true, cls, cls_stride, fc_w, dlogit, dcls, dcls_stride, dfc_w, dfc_b, lr_grad_fields_dev, nfields,
                idx, idx_stride, gscale, B, d);
     return rat_check_launch("rat_logit_bwd");
