@@ -76,7 +76,7 @@ struct AttnGeom {
     }
     size_t fwd_smem() const { return (size_t)ATT_ROWS * (ldx + ldq) * 4 + ATT_ROWS * 8; }
     size_t bwd_smem(int heads) const {
-        return (size_t)ATT_ROWS * (2 * ldx + ldq + 2 * ldt) * 4 + (size_t)ATT_ROWS * (2 + 2 * heads) * 4 + ATT_ROWS * 8;
+        return (size_t)ATT_ROWS * (2 * ldx + ldq + 2 * ldt) * 4 + (size_t)ATT_ROWS * (2 + 2 * heads) * 4 + 2 * ATT_ROWS * 8;
     }
     int64_t slab_floats() const { return (int64_t)Q3 * D + (int64_t)D * I + 3 * (int64_t)D; }
 };
@@ -447,10 +447,22 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
     RAT_PROF_DECL
 
-    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+    int64_t* rowtok_buf[2] = {rowtok, rowtok + ATT_ROWS};     // row maps are double-buffered: chunk c+1's map is written during chunk c
+    {
+        int nsq0, rows0;
+        map_rows(a, blockIdx.x, rowtok_buf[0], nsq0, rows0);
+    }
+    __syncthreads();
+    int parity = 0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
+        rowtok = rowtok_buf[parity];
         int nsq, rows;
-        map_rows(a, chunk, rowtok, nsq, rows);
-        __syncthreads();
+        {
+            const int64_t q0 = chunk * a.nsq_chunk;
+            const int64_t left = a.nseq - q0;
+            nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+            rows = nsq * a.L;
+        }
         RAT_PROF_MARK(0);
         load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
         load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0);
@@ -462,6 +474,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         __syncthreads();
         RAT_PROF_MARK(1);
         layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
+        if (chunk + gridDim.x < a.nchunks) {
+            int nsq1, rows1;
+            map_rows(a, chunk + gridDim.x, rowtok_buf[parity ^ 1], nsq1, rows1);
+        }
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
         RAT_PROF_MARK(2);
