@@ -74,7 +74,7 @@ struct AttnGeom {
         ldq = Q16 + 4;
         ldt = (D16 > I16 ? D16 : I16) + 4;
     }
-    size_t fwd_smem() const { return (size_t)ATT_ROWS * (ldx + ldq) * 4 + ATT_ROWS * 8; }
+    size_t fwd_smem() const { return (size_t)ATT_ROWS * (ldx + ldq) * 4 + 2 * ATT_ROWS * 8; }
     size_t bwd_smem(int heads) const {
         return (size_t)ATT_ROWS * (2 * ldx + ldq + 2 * ldt) * 4 + (size_t)ATT_ROWS * (2 + 2 * heads) * 4 + 2 * ATT_ROWS * 8;
     }
@@ -131,6 +131,16 @@ __device__ __forceinline__ float prefetch_lines(const AttnArgs& a, int64_t chunk
     const int nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
     if (r >= nsq * a.L) return 0.f;
     const int64_t tok = seq_token(a, q0 + r / a.L, r % a.L);
+    int c = ln * 32;
+    if (c >= width) c = width - 1;
+    return src[tok * width + c];
+}
+
+// the same touch with the token taken from the NEXT chunk's row map (double-buffered maps: no 64-bit divisions here)
+__device__ __forceinline__ float prefetch_lines_map(const int64_t* next_rowtok, int slot, int nlines_row, const float* src, int width) {
+    const int r = slot / nlines_row, ln = slot - r * nlines_row;
+    const int64_t tok = next_rowtok[r];
+    if (tok < 0) return 0.f;
     int c = ln * 32;
     if (c >= width) c = width - 1;
     return src[tok * width + c];
@@ -287,13 +297,29 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     RAT_PROF_DECL
 
-    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x) {
+    int64_t* rowtok_buf[2] = {rowtok, rowtok + ATT_ROWS};     // double-buffered row maps: chunk c+1's map is written during chunk c
+    {
+        int nsq0, rows0;
+        map_rows(a, blockIdx.x, rowtok_buf[0], nsq0, rows0);
+    }
+    __syncthreads();
+    int parity = 0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
+        rowtok = rowtok_buf[parity];
         int nsq, rows;
-        map_rows(a, chunk, rowtok, nsq, rows);
-        __syncthreads();
+        {
+            const int64_t q0 = chunk * a.nsq_chunk;
+            const int64_t left = a.nseq - q0;
+            nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+            rows = nsq * a.L;
+        }
         load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
         __syncthreads();
         layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
+        if (chunk + gridDim.x < a.nchunks) {
+            int nsq1, rows1;
+            map_rows(a, chunk + gridDim.x, rowtok_buf[parity ^ 1], nsq1, rows1);
+        }
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
         RAT_PROF_MARK(0);
@@ -316,7 +342,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         float pf = 0.f;
         {
             const int nl = (D * 4 + 127) / 128;
-            if ((int)threadIdx.x < ATT_ROWS * nl) pf = prefetch_lines(a, chunk + gridDim.x, threadIdx.x, nl, a.x, D);
+            if ((int)threadIdx.x < ATT_ROWS * nl && chunk + gridDim.x < a.nchunks)
+                pf = prefetch_lines_map(rowtok_buf[parity ^ 1], threadIdx.x, nl, a.x, D);
         }
         const int ntasks = nsq * heads_c * L;
         const float sl2 = a.scale * RAT_LOG2E;
@@ -530,10 +557,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         {   // passes 1 and 2 touch LDS only: the next chunk's x / dy / O / lse lines travel HBM -> L2 meanwhile
             const int nlx = (D * 4 + 127) / 128, nlo = (I * 4 + 127) / 128;
             int t = threadIdx.x;
-            if (t < ATT_ROWS * nlx) pf = prefetch_lines(a, chunk + gridDim.x, t, nlx, a.x, D);
-            else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlx) pf = prefetch_lines(a, chunk + gridDim.x, t, nlx, a.dy, D);
-            else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlo) pf = prefetch_lines(a, chunk + gridDim.x, t, nlo, a.o_save, I);
-            else if ((t -= ATT_ROWS * nlo) < ATT_ROWS) pf = prefetch_lines(a, chunk + gridDim.x, t, 1, a.lse_save, H);
+            if (chunk + gridDim.x < a.nchunks) {
+                const int64_t* nrt = rowtok_buf[parity ^ 1];          // written before the barrier that opened this phase
+                if (t < ATT_ROWS * nlx) pf = prefetch_lines_map(nrt, t, nlx, a.x, D);
+                else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlx) pf = prefetch_lines_map(nrt, t, nlx, a.dy, D);
+                else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlo) pf = prefetch_lines_map(nrt, t, nlo, a.o_save, I);
+                else if ((t -= ATT_ROWS * nlo) < ATT_ROWS) pf = prefetch_lines_map(nrt, t, 1, a.lse_save, H);
+            }
         }
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
