@@ -48,18 +48,23 @@ def parse():
     ap.add_argument("--workload", default="synthetic_F20_V1M_K10_d64_B4096")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256)
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="HIP-event timing around EVERY C-ABI launch (adds ~2 events x 60 launches of host work per step); "
+                         "default: only the encoder kernels (attention / FFN forward and backward), which hold >90 %% of the step")
     return ap.parse_args()
 
 
 class KernelTimer:
     """HIP-event timing of every C-ABI launch on torch's current stream (the stream the kernels are launched on)."""
 
-    def __init__(self, lib):
-        self.lib, self.inner, self.records, self.enabled = lib, lib.call, [], False
+    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_ffn_fwd", "rat_ffn_bwd")
+
+    def __init__(self, lib, everything=False):
+        self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
         lib.call = self._call
 
     def _call(self, name, *args):
-        if not self.enabled:
+        if not self.enabled or not (self.everything or name in self.HEAVY):
             return self.inner(name, *args)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -170,7 +175,7 @@ def main():
     model = RAT_m2(fm, **synthetic.model_kwargs(spec, gpu=local_rank))
     batch = synthetic.make_batch(spec, fm, seed=1000 + rank, device=model.device)
     model.train()
-    timer = KernelTimer(model._lib)
+    timer = KernelTimer(model._lib, everything=args.time_all_kernels)
 
     def sync():
         if world > 1:
