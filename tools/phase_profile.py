@@ -25,6 +25,7 @@ PHASES = {
     24: ("ffn_fwd", ["load", "W1 gemm + gelu", "W2 gemm + store"]),
     36: ("ffn_bwd", ["load", "W1 gemm + gelu", "dW2", "dh gemm", "dx gemm + dW1"]),
     48: ("attn2_fwd", ["load+LN (+prev out-proj tail)", "QKV gemm", "core 4x4", "out-proj+store (wave 0)"]),
+    72: ("ffn_bwd_t (wave 0)", ["consume + stage", "h / dh chain + gelu", "dx partial", "barrier 1", "dx store + prefetch issue", "dW1, dW2", "barrier 2"]),
     60: ("attn2_core_fwd(wave0)", ["loads issue", "S mfma", "softmax", "PV", "stores", "-", "-", "-", "-", "-", "-", "loop"]),
 }
 

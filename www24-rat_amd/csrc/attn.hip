@@ -535,7 +535,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             // (3) dW_out += dy^T O ; db_out += colsum(dy)
             const RatLdsCols At{ob, ldt};                          // transposed tile grid (I16/16 x D16/16): dW_out^T = O^T dy,
             const RatLdsCols Bt{dys, ldx};                         // so that the column-tile count (D/16) divides the wave count
-            rat_wave_gemm_slots<OSLOTS, ATT_WAVES, 0>(acco, At, Bt, o_tiles, o_tn, mt_valid);
+            if (FAST && mt_valid == ATT_MT) rat_wave_gemm_ct<OSLOTS, ATT_WAVES, (FAST ? 5 * (TD / 16) : 8), (FAST ? TD / 16 : 1), ATT_MT>(acco, At, Bt);
+            else if (FAST) rat_wave_gemm_ct<OSLOTS, ATT_WAVES, (FAST ? 5 * (TD / 16) : 8), (FAST ? TD / 16 : 1), 0>(acco, At, Bt, mt_valid);
+            else rat_wave_gemm_slots<OSLOTS, ATT_WAVES, 0>(acco, At, Bt, o_tiles, o_tn, mt_valid);
             {   // db_out partials: thread = (column, row group); the row groups are combined once, after the chunk loop
                 const int nrg = ATT_THREADS / D, col = threadIdx.x % D, rg = threadIdx.x / D;
                 if (rg < nrg)
@@ -667,7 +669,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             RAT_PROF_MARK(8);
             const RatLdsCols At{qkv, ldq};
             const RatLdsCols Bt{xs, ldx};
-            rat_wave_gemm_slots<QSLOTS, ATT_WAVES, 0>(accq, At, Bt, q_tiles, q_tn, mt_valid);
+            if (FAST && mt_valid == ATT_MT) rat_wave_gemm_ct<QSLOTS, ATT_WAVES, (FAST ? 15 * (TD / 16) : 8), (FAST ? TD / 16 : 1), ATT_MT>(accq, At, Bt);
+            else if (FAST) rat_wave_gemm_ct<QSLOTS, ATT_WAVES, (FAST ? 15 * (TD / 16) : 8), (FAST ? TD / 16 : 1), 0>(accq, At, Bt, mt_valid);
+            else rat_wave_gemm_slots<QSLOTS, ATT_WAVES, 0>(accq, At, Bt, q_tiles, q_tn, mt_valid);
         }
         __syncthreads();
         RAT_PROF_MARK(9);

@@ -507,6 +507,260 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
     }
 }
 
+// backward, same formulation.  512 threads (8 waves, one work-group per CU), 64 tokens per iteration: wave (tt, half) =
+// (wave & 3, wave >> 2) owns token tile tt and one half of the hidden tiles.  Chain phase (no barrier): h^T and dh^T
+// (shared token B fragments x^T / dy^T, weights W1 / W2^T rows as A operands straight from L2), gelu / gelu' on the
+// accumulators, partial dx^T over the half's hidden tiles from the accumulator-resident dh'.  gelu(h) and dh' are written
+// TOKEN-major into LDS only as operands of the weight-gradient GEMMs (dW1 += dh'^T x, dW2 += dy^T gelu(h)), whose
+// accumulators persist across the work-group's chunk loop.  Two barriers per 64 tokens (the slab-era kernel had six).
+constexpr int FB_THREADS = 512;
+constexpr int FB_WAVES = FB_THREADS / 64;
+constexpr int FB_TOK = 64;
+
+template <int D, int H>
+struct FfnBTGeom {
+    static constexpr int LDX = D + 4, LDH = H + 4;
+    static constexpr size_t smem = (size_t)FB_TOK * (3 * LDX + 2 * LDH) * 4;
+};
+
+__device__ __forceinline__ void mfma4x2b(const float4& a0, const float4& a1, const float4& b0, const float4& b1, f32x4& c0, f32x4& c1) {
+    c0 = RAT_MFMA16(a0.x, b0.x, c0);
+    c1 = RAT_MFMA16(a1.x, b1.x, c1);
+    c0 = RAT_MFMA16(a0.y, b0.y, c0);
+    c1 = RAT_MFMA16(a1.y, b1.y, c1);
+    c0 = RAT_MFMA16(a0.z, b0.z, c0);
+    c1 = RAT_MFMA16(a1.z, b1.z, c1);
+    c0 = RAT_MFMA16(a0.w, b0.w, c0);
+    c1 = RAT_MFMA16(a1.w, b1.w, c1);
+}
+
+template <int D, int H>
+__global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t_kernel(FfnArgs a) {
+    typedef FfnBTGeom<D, H> G;
+    constexpr int KD = D / 16, KH = H / 16, HT = KH / 2;          // HT hidden tiles per wave half
+    constexpr int NT = KH * KD;                                    // 16x16 tiles of dW1 (and of dW2)
+    constexpr int SL = (NT + FB_WAVES - 1) / FB_WAVES;             // persistent tiles per wave, each of dW1 / dW2
+    static_assert(KH % 2 == 0 && SL <= 4, "geometry");
+    RAT_DYN_SMEM(smem);
+    float* xs = reinterpret_cast<float*>(smem);                    // [64][LDX] x         (B operand of dW1)
+    float* dys = xs + FB_TOK * G::LDX;                             // [64][LDX] dy        (A^T operand of dW2)
+    float* px = dys + FB_TOK * G::LDX;                             // [64][LDX] dx partial of the upper hidden half
+    float* gs = px + FB_TOK * G::LDX;                              // [64][LDH] gelu(h)   (B operand of dW2)
+    float* dhs = gs + FB_TOK * G::LDH;                             // [64][LDH] dh'       (A^T operand of dW1)
+
+    const int l = rat_lane(), n = l & 15, g = l >> 4;
+    const int w = rat_wave(), tt = w & 3, half = w >> 2;
+    const int row = 16 * tt + n;                                   // this lane's token row inside the 64-token chunk
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    f32x4 acc1[SL], acc2[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) acc1[s] = acc2[s] = rat_zero4();
+    f32x4 db1a[HT], db2a[KD];                                      // bias-gradient partials of this lane's token column
+#pragma unroll
+    for (int i = 0; i < HT; ++i) db1a[i] = rat_zero4();
+#pragma unroll
+    for (int kb = 0; kb < KD; ++kb) db2a[kb] = rat_zero4();
+
+    float4 xN[KD], dyN[KD], xT[KD], dyT[KD];
+    int64_t chunk = blockIdx.x;
+    {
+        const int64_t tk = chunk * FB_TOK + row;
+        const bool ok = chunk < a.nchunks && tk < a.ntok;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) {
+            xN[kb] = ok ? ld4(a.x + tk * D + 16 * kb + 4 * g) : zero4;
+            dyN[kb] = ok ? ld4(a.dy + tk * D + 16 * kb + 4 * g) : zero4;
+        }
+    }
+    RAT_PROF_DECL
+    for (; chunk < a.nchunks; chunk += gridDim.x) {
+        const int64_t tok = chunk * FB_TOK + row;
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb) {
+            xT[kb] = rat_consume4(xN[kb]);
+            dyT[kb] = rat_consume4(dyN[kb]);
+        }
+        if (half == 0) {
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) st4(xs + row * G::LDX + 16 * kb + 4 * g, xT[kb]);
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) st4(dys + row * G::LDX + 16 * kb + 4 * g, dyT[kb]);
+        }
+        RAT_PROF_MARK(0);
+        // ---- chain: h^T, dh^T per hidden tile; gelu / gelu' of tile i-1 in the MFMA shadow of tile i
+        float4 dhpT[HT];
+        f32x4 hp0 = rat_zero4(), hp1 = rat_zero4();
+        auto epilogue = [&](int i, const f32x4& hacc, const f32x4& dacc) {
+            float4 gv, dp;
+#ifdef RAT_FFN_PK
+            rat_f2 g01, d01, g23, d23;
+            rat_gelu_both2(rat_f2_make(hacc[0], hacc[1]), g01, d01);
+            rat_gelu_both2(rat_f2_make(hacc[2], hacc[3]), g23, d23);
+            gv = make_float4(g01.x, g01.y, g23.x, g23.y);
+            dp = make_float4(dacc[0] * d01.x, dacc[1] * d01.y, dacc[2] * d23.x, dacc[3] * d23.y);
+#else
+            float dg;
+            rat_gelu_both(hacc[0], gv.x, dg);
+            dp.x = dacc[0] * dg;
+            rat_gelu_both(hacc[1], gv.y, dg);
+            dp.y = dacc[1] * dg;
+            rat_gelu_both(hacc[2], gv.z, dg);
+            dp.z = dacc[2] * dg;
+            rat_gelu_both(hacc[3], gv.w, dg);
+            dp.w = dacc[3] * dg;
+#endif
+            const int col = 16 * (HT * half + i) + 4 * g;
+            st4(gs + row * G::LDH + col, gv);
+            st4(dhs + row * G::LDH + col, dp);
+            dhpT[i] = dp;
+            db1a[i][0] += dp.x;
+            db1a[i][1] += dp.y;
+            db1a[i][2] += dp.z;
+            db1a[i][3] += dp.w;
+        };
+#pragma unroll
+        for (int i = 0; i < HT; ++i) {
+            const int m = HT * half + i;
+            f32x4 c0 = as_v4(ld4(a.b1 + 16 * m + 4 * g)), c1 = rat_zero4();
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) {
+                const float4 a0 = ld4(a.w1 + (size_t)(16 * m + n) * D + 16 * kb + 4 * g);
+                const float4 a1 = ld4(a.w2t + (size_t)(16 * m + n) * D + 16 * kb + 4 * g);
+                mfma4x2b(a0, a1, xT[kb], dyT[kb], c0, c1);
+            }
+            if (i > 0) {
+                epilogue(i - 1, hp0, hp1);
+                RAT_SCHED_MFMA_VALU(8 * KD, (KD >= 4 ? 5 : 20));
+            }
+            hp0 = c0;
+            hp1 = c1;
+            RAT_SCHED_FENCE();
+        }
+        RAT_PROF_MARK(1);
+        // ---- partial dx^T over this half's hidden tiles (k-blocks = the accumulator-resident dh' tiles)
+        f32x4 dxa[KD];
+#pragma unroll
+        for (int q = 0; q < (KD + 1) / 2; ++q) {
+            const bool two = 2 * q + 1 < KD;
+            const int m0 = 2 * q, m1 = two ? 2 * q + 1 : 2 * q;
+            f32x4 c0 = rat_zero4(), c1 = rat_zero4();
+            if (q == 0) {
+#pragma unroll
+                for (int i = 0; i < HT - 1; ++i) {
+                    const float4 a0 = ld4(a.w1t + (size_t)(16 * m0 + n) * H + 16 * (HT * half + i) + 4 * g);
+                    const float4 a1 = ld4(a.w1t + (size_t)(16 * m1 + n) * H + 16 * (HT * half + i) + 4 * g);
+                    mfma4x2(a0, a1, dhpT[i], c0, c1);
+                }
+                epilogue(HT - 1, hp0, hp1);
+                if (HT > 1) RAT_SCHED_MFMA_VALU(8 * (HT - 1), (HT >= 4 ? 7 : 28));
+                RAT_SCHED_FENCE();
+                {
+                    const float4 a0 = ld4(a.w1t + (size_t)(16 * m0 + n) * H + 16 * (HT * half + HT - 1) + 4 * g);
+                    const float4 a1 = ld4(a.w1t + (size_t)(16 * m1 + n) * H + 16 * (HT * half + HT - 1) + 4 * g);
+                    mfma4x2(a0, a1, dhpT[HT - 1], c0, c1);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < HT; ++i) {
+                    const float4 a0 = ld4(a.w1t + (size_t)(16 * m0 + n) * H + 16 * (HT * half + i) + 4 * g);
+                    const float4 a1 = ld4(a.w1t + (size_t)(16 * m1 + n) * H + 16 * (HT * half + i) + 4 * g);
+                    mfma4x2(a0, a1, dhpT[i], c0, c1);
+                }
+            }
+            dxa[m0] = c0;
+            if (two) dxa[m1] = c1;
+            RAT_SCHED_FENCE();
+        }
+        RAT_PROF_MARK(2);
+        // the d tiles of dx are split between the halves: each parks its partial of the OTHER half's tiles in LDS
+        constexpr int KD0 = (KD + 1) / 2;                          // half 0 finishes tiles [0, KD0), half 1 tiles [KD0, KD)
+        if (half == 0) {
+#pragma unroll
+            for (int m = KD0; m < KD; ++m) st4(px + row * G::LDX + 16 * m + 4 * g, as_f4(dxa[m]));
+        } else {
+#pragma unroll
+            for (int m = 0; m < KD0; ++m) st4(px + row * G::LDX + 16 * m + 4 * g, as_f4(dxa[m]));
+        }
+        __syncthreads();
+        RAT_PROF_MARK(3);
+        auto finish = [&](int m) {                                 // dx = dy + dh' W1 (both halves), straight from registers
+            const float4 p = ld4(px + row * G::LDX + 16 * m + 4 * g);
+            const float4 o = make_float4(dxa[m][0] + p.x + dyT[m].x, dxa[m][1] + p.y + dyT[m].y, dxa[m][2] + p.z + dyT[m].z,
+                                         dxa[m][3] + p.w + dyT[m].w);
+            if (tok < a.ntok) st4(a.y + tok * D + 16 * m + 4 * g, o);
+            db2a[m][0] += dyT[m].x;
+            db2a[m][1] += dyT[m].y;
+            db2a[m][2] += dyT[m].z;
+            db2a[m][3] += dyT[m].w;
+        };
+        if (half == 0) {
+#pragma unroll
+            for (int m = 0; m < KD0; ++m) finish(m);
+        } else {
+#pragma unroll
+            for (int m = KD0; m < KD; ++m) finish(m);
+        }
+        {   // next chunk's token fragments: in flight behind the weight-gradient GEMMs
+            const int64_t tk = (chunk + gridDim.x) * FB_TOK + row;
+            const bool ok = chunk + gridDim.x < a.nchunks && tk < a.ntok;
+#pragma unroll
+            for (int kb = 0; kb < KD; ++kb) {
+                xN[kb] = ok ? ld4(a.x + tk * D + 16 * kb + 4 * g) : zero4;
+                dyN[kb] = ok ? ld4(a.dy + tk * D + 16 * kb + 4 * g) : zero4;
+            }
+        }
+        RAT_PROF_MARK(4);
+        // ---- dW1 += dh'^T x ; dW2 += dy^T gelu(h)    (contraction over the chunk's 64 tokens)
+        rat_wave_gemm_ct<SL, FB_WAVES, NT, KD, FB_TOK / 16>(acc1, RatLdsCols{dhs, G::LDH}, RatLdsCols{xs, G::LDX});
+        rat_wave_gemm_ct<SL, FB_WAVES, NT, KH, FB_TOK / 16>(acc2, RatLdsCols{dys, G::LDX}, RatLdsCols{gs, G::LDH});
+        RAT_PROF_MARK(5);
+        __syncthreads();
+        RAT_PROF_MARK(6);
+    }
+    RAT_PROF_FLUSH(a.prof, 72);
+
+    // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+    float* s_w1 = slab;
+    float* s_w2 = s_w1 + (int64_t)H * D;
+    float* s_b1 = s_w2 + (int64_t)D * H;
+    float* s_b2 = s_b1 + H;
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int id = w + FB_WAVES * s;
+        if (id < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s_w1[(int64_t)rat_acc_row(id / KD, r) * D + rat_acc_col(id % KD)] = acc1[s][r];
+                s_w2[(int64_t)rat_acc_row(id / KH, r) * H + rat_acc_col(id % KH)] = acc2[s][r];
+            }
+        }
+    }
+    {   // bias gradients: per-token-column partials -> LDS [feature][64 token columns] -> fixed-order sums
+        constexpr int LR = FB_TOK + 1;
+        float* red1 = reinterpret_cast<float*>(smem);              // [H][LR]
+        float* red2 = red1 + H * LR;                               // [D][LR]
+#pragma unroll
+        for (int i = 0; i < HT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red1[(16 * (HT * half + i) + 4 * g + r) * LR + row] = db1a[i][r];
+#pragma unroll
+        for (int kb = 0; kb < KD; ++kb)
+            if ((kb < (KD + 1) / 2) == (half == 0))
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red2[(16 * kb + 4 * g + r) * LR + row] = db2a[kb][r];
+        __syncthreads();
+        for (int c = threadIdx.x; c < H + D; c += FB_THREADS) {
+            const float* src = c < H ? red1 + c * LR : red2 + (c - H) * LR;
+            float sacc = 0.f;
+            for (int k = 0; k < FB_TOK; ++k) sacc += src[k];
+            if (c < H) s_b1[c] = sacc; else s_b2[c - H] = sacc;
+        }
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ffn_fast_dim(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
@@ -597,7 +851,7 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
-    const int fast = ffn_fast_dim(a, {x, dy, dx});
+    const int fast = ffn_fast_dim(a, {x, dy, dx, b1});
     if (fast) {
         float* w1t = workspace + (size_t)256 * a.slab_stride;
         float* w2t = w1t + (size_t)d * hidden;
@@ -605,10 +859,12 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
         a.w1t = w1t;
         a.w2t = w2t;
     }
-    switch (fast) {
-        case 64: RAT_LAUNCH((ffn_bwd_kernel<64>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
-        case 16: RAT_LAUNCH((ffn_bwd_kernel<16>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
-        default: RAT_LAUNCH((ffn_bwd_kernel<0>), blocks, FFN_THREADS, g.bwd_smem(), stream, a); break;
+    if (fast == 64 && hidden == 128) {
+        RAT_LAUNCH((ffn_bwd_t_kernel<64, 128>), blocks, FB_THREADS, (FfnBTGeom<64, 128>::smem), stream, a);
+    } else if (fast == 16 && hidden == 32) {
+        RAT_LAUNCH((ffn_bwd_t_kernel<16, 32>), blocks, FB_THREADS, (FfnBTGeom<16, 32>::smem), stream, a);
+    } else {
+        RAT_LAUNCH((ffn_bwd_kernel<0>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     }
     if (rat_check_launch("rat_ffn_bwd")) return -1;
     float* outs[4] = {dw1, dw2, db1, db2};

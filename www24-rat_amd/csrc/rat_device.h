@@ -496,6 +496,48 @@ __device__ __forceinline__ void rat_wave_gemm_slots(f32x4 (&acc)[SLOTS], const A
     }
 }
 
+// Compile-time geometry variant: NT tiles (NTN per tile row) spread over NWAVES waves, KB k-blocks.  Slots that every wave
+// owns (NT / NWAVES of them) run branch-free with their MFMAs interleaved; a ragged last slot takes ONE wave-uniform branch.
+// KB > 0: k extent known, loop unrolled; KB == 0: `kblocks` at run time, loop kept rolled.
+template <int SL, int NWAVES, int NT, int NTN, int KB, class AF, class BF>
+__device__ __forceinline__ void rat_wave_gemm_ct(f32x4 (&acc)[SL], const AF& af, const BF& bf, int kblocks = KB) {
+    static_assert(NWAVES % NTN == 0, "every wave keeps one B tile column");
+    constexpr int FULL = NT / NWAVES;
+    static_assert(FULL <= SL && (NT + NWAVES - 1) / NWAVES <= SL, "slots");
+    const int w = rat_wave();
+    const int nt = w % NTN;
+    if (FULL > 0) {
+#pragma unroll(KB > 0 ? KB : 1)
+        for (int kb = 0; kb < (KB > 0 ? KB : kblocks); ++kb) {
+            const float4 b = bf(nt, kb);
+            float4 a[FULL > 0 ? FULL : 1];
+#pragma unroll
+            for (int s = 0; s < FULL; ++s) a[s] = af((w + NWAVES * s) / NTN, kb);
+#pragma unroll
+            for (int s = 0; s < FULL; ++s) acc[s] = RAT_MFMA16(a[s].x, b.x, acc[s]);
+#pragma unroll
+            for (int s = 0; s < FULL; ++s) acc[s] = RAT_MFMA16(a[s].y, b.y, acc[s]);
+#pragma unroll
+            for (int s = 0; s < FULL; ++s) acc[s] = RAT_MFMA16(a[s].z, b.z, acc[s]);
+#pragma unroll
+            for (int s = 0; s < FULL; ++s) acc[s] = RAT_MFMA16(a[s].w, b.w, acc[s]);
+        }
+    }
+    if (FULL * NWAVES < NT) {
+        if (w + NWAVES * FULL < NT) {
+#pragma unroll(KB > 0 ? KB : 1)
+            for (int kb = 0; kb < (KB > 0 ? KB : kblocks); ++kb) {
+                const float4 b = bf(nt, kb);
+                const float4 a = af((w + NWAVES * FULL) / NTN, kb);
+                acc[FULL] = RAT_MFMA16(a.x, b.x, acc[FULL]);
+                acc[FULL] = RAT_MFMA16(a.y, b.y, acc[FULL]);
+                acc[FULL] = RAT_MFMA16(a.z, b.z, acc[FULL]);
+                acc[FULL] = RAT_MFMA16(a.w, b.w, acc[FULL]);
+            }
+        }
+    }
+}
+
 // row/col of accumulator register r of a 16x16 tile
 __device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 16 + (rat_lane() >> 4) * 4 + r; }
 __device__ __forceinline__ int rat_acc_col(int tile_n) { return tile_n * 16 + (rat_lane() & 15); }
