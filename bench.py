@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="synthetic_F20_V1M_K10_d64_B4096")
+    ap.add_argument("--model", default="RAT_m2", choices=["RAT_m2", "RAT_m1"],
+                    help="RAT_m2 (default) is the BASELINE.json metric; RAT_m1 times the cascaded variant (SURVEY §8f rank 2) on the same workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -57,7 +59,7 @@ def parse():
 class KernelTimer:
     """HIP-event timing of every C-ABI launch on torch's current stream (the stream the kernels are launched on)."""
 
-    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_ffn_fwd", "rat_ffn_bwd")
+    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res", "rat_ffn_bwd_res")
 
     def __init__(self, lib, everything=False):
         self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
@@ -77,6 +79,8 @@ class KernelTimer:
         if name in ("rat_attn_fwd", "rat_attn_bwd"):
             smap = args[5 if name == "rat_attn_fwd" else 9]._obj
             return "L%d" % smap.L
+        if name in ("rat_ffn_fwd_res", "rat_ffn_bwd_res"):               # RAT_m1 runs the block MLP at two token counts
+            return "n%d" % int(args[7 if name == "rat_ffn_fwd_res" else 13])
         return ""
 
     def summary(self, steps):
@@ -88,7 +92,7 @@ class KernelTimer:
         return {k: dict(launches_per_step=v[0] / steps, avg_ms=v[1] / v[0], ms_per_step=v[1] / steps) for k, v in out.items()}
 
 
-def algorithmic_work(spec):
+def algorithmic_work(spec, model="RAT_m2"):
     """FLOPs / bytes per LAUNCH of each hot kernel (SURVEY.md §8d; padded MFMA lanes and recompute do not count;
     backward = 2x forward)."""
     B, F, K, d = spec["batch"], spec["F"], spec["K"], spec["d"]
@@ -96,10 +100,13 @@ def algorithmic_work(spec):
     I, H = spec["num_heads"] * spec["dim_head"], d * spec["scale_dim"]
     tok = B * T * S
     work = {}
-    for L in (S, T):
-        f = tok * (8 * d * I + 4 * I * L)
+    # RAT_m2: both attentions and the MLP see the whole grid; RAT_m1: the cross transformer sees one token per sample
+    for L, n in ((S, tok), (T, tok if model == "RAT_m2" else B * T)):
+        f = n * (8 * d * I + 4 * I * L)
         work[("rat_attn_fwd", "L%d" % L)] = ("mfma", f)
         work[("rat_attn_bwd", "L%d" % L)] = ("mfma", 2 * f)
+        work[("rat_ffn_fwd_res", "n%d" % n)] = ("mfma", n * 4 * d * H)
+        work[("rat_ffn_bwd_res", "n%d" % n)] = ("mfma", 2 * n * 4 * d * H)
     work[("rat_ffn_fwd", "")] = ("mfma", tok * 4 * d * H)
     work[("rat_ffn_bwd", "")] = ("mfma", 2 * tok * 4 * d * H)
     work[("rat_gather_fwd", "")] = ("hbm", B * (T * F * d * 4 + T * S * d * 4 + T * F * 4))
@@ -107,7 +114,7 @@ def algorithmic_work(spec):
     return work
 
 
-def cpu_baseline(spec, fm, batch_size, seed):
+def cpu_baseline(spec, fm, batch_size, seed, model="RAT_m2"):
     """The oracle (a port: oracle/rat_m2_oracle.py, pinned to the reference's golden vectors) timed on this box's host
     cores on a bounded sample of the same workload: full training steps at a reduced batch."""
     from oracle import rat_m2_oracle as orc
@@ -117,7 +124,8 @@ def cpu_baseline(spec, fm, batch_size, seed):
     cfg = orc.Config(fields=orc.fields_from_specs(fm.feature_specs), embedding_dim=spec["d"], num_heads=spec["num_heads"],
                      dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
                      dnn_hidden_units=tuple(spec["dnn_hidden_units"]), batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],
-                     embedding_regularizer=0.0005, learning_rate=spec["learning_rate"])
+                     embedding_regularizer=0.0005, learning_rate=spec["learning_rate"],
+                     variant={"RAT_m2": "m2", "RAT_m1": "m1"}[model])
     g = torch.Generator().manual_seed(seed)
     w = {}
     for name, shp in orc.parameter_shapes(cfg).items():         # reference-like init scales
@@ -155,7 +163,7 @@ def main():
     import torch.distributed as dist
     from rat_amd import synthetic
     from rat_amd.base_model import seed_everything
-    from rat_amd.model import RAT_m2
+    from rat_amd import models
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +180,7 @@ def main():
     spec = synthetic.WORKLOADS[args.workload]
     fm = synthetic.feature_map_for(args.workload, spec)
     seed_everything(2021)
-    model = RAT_m2(fm, **synthetic.model_kwargs(spec, gpu=local_rank))
+    model = getattr(models, args.model)(fm, **synthetic.model_kwargs(spec, gpu=local_rank))
     batch = synthetic.make_batch(spec, fm, seed=1000 + rank, device=model.device)
     model.train()
     timer = KernelTimer(model._lib, everything=args.time_all_kernels)
@@ -200,7 +208,7 @@ def main():
     if rank == 0:
         B = spec["batch"]
         ksum = timer.summary(args.steps)
-        work = algorithmic_work(spec)
+        work = algorithmic_work(spec, args.model)
         kernels = []
         for key, st in sorted(ksum.items(), key=lambda kv: -kv[1]["ms_per_step"]):
             row = dict(kernel=key[0] + (":" + key[1] if key[1] else ""), launches_per_step=round(st["launches_per_step"], 2),
@@ -229,7 +237,7 @@ def main():
         else:
             achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
         roofline = dict(kernel=dom_name, bound=dom["bound"], achieved=round(achieved, 3), peak=peak, unit=unit,
-                        frac=round(achieved / peak, 4), traffic=pmc_traffic(dom_name, args.workload),
+                        frac=round(achieved / peak, 4), traffic=pmc_traffic(dom_name, args.workload) if args.model == "RAT_m2" else None,
                         traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1/r1_traffic_pmc.json)",
                         algorithmic=round(per_launch, 1), algorithmic_unit="FLOP/launch" if dom["bound"] == "mfma" else "bytes/launch",
                         avg_launch_ms=round(avg_s * 1e3, 4), launches_per_step=round(dom["n"], 2))
@@ -243,8 +251,10 @@ def main():
                                   dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam",
                                   parallelism="dp%d" % world),
                       roofline=roofline, kernels=kernels)
+        if args.model != "RAT_m2":
+            result["config"]["variant"] = args.model
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(spec, fm, args.cpu_batch, seed=1000)
+            result["cpu_baseline"] = cpu_baseline(spec, fm, args.cpu_batch, seed=1000, model=args.model)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

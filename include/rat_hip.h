@@ -109,6 +109,29 @@ int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, con
                 const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                 size_t workspace_bytes, int64_t ntok, int d, int hidden, void* stream);
 
+/* The same block MLP with the residual taken from a SEPARATE tensor: y = W2 gelu_erf(W1 x + b1) + b2 + res (res == x gives
+ * rat_ffn_fwd; res == NULL: no residual).  RAT_m1's PreNorm(FeedForward) (RAT_m1.py:143-161,201,207: ff(norm(x)) + x) is
+ * rat_layernorm_fwd followed by this with x = norm(x), res = x.  Backward: add_dy = 1 adds dy to dx (residual from x
+ * itself), add_dy = 0 returns only the gradient through the two Linear layers. */
+int rat_ffn_fwd_res(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2,
+                    const float* b2, int64_t ntok, int d, int hidden, void* stream);
+int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                    const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                    size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, void* stream);
+
+/* ---- K2c: stand-alone nn.LayerNorm(d) (biased variance, affine) over selected token rows — RAT_m1's PreNorm in front of
+ * FeedForward and the final `self.norm` of each Transformer (RAT_m1.py:137-141,198,209), of which only token 0 of every
+ * sequence is read (RAT_m1.py:125,128).  Row r is read at x + r * x_stride; y is a compact [nrows][d]. */
+int rat_layernorm_fwd(const float* x, int64_t x_stride, float* y, const float* gamma, const float* beta, int64_t nrows,
+                      int d, float eps, void* stream);
+size_t rat_layernorm_bwd_workspace(int64_t nrows, int d);
+/* dx row r (at dx + r * dx_stride; rows not addressed are left untouched) = [add row r +] LayerNorm backward of the compact
+ * dy [nrows][d]; dgamma / dbeta are OVERWRITTEN with the row sums (fixed-order reduction, no atomics).  `add` (optional)
+ * is laid out like dx and may alias it. */
+int rat_layernorm_bwd(const float* x, int64_t x_stride, const float* dy, const float* gamma, const float* add, float* dx,
+                      int64_t dx_stride, float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                      int64_t nrows, int d, float eps, void* stream);
+
 /* ---- K3: prediction head -----------------------------------------------------------------------------
  * Plain fp32 GEMM on MFMA for MLP_Layer's nn.Linear (deep.py:126-141) forward / dgrad / wgrad:
  * C[M][N] = op(A) op(B) (+ bias[N]) (+ beta*C), row-major with leading dimensions, op = transpose flag. */

@@ -68,6 +68,7 @@ class Config:
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
     ln_eps: float = 1e-5
+    variant: str = "m2"       # "m2": cross/intra encoder blocks (RAT_m2.py); "m1": cascaded transformers (RAT_m1.py)
 
     @property
     def num_fields(self) -> int:
@@ -117,20 +118,36 @@ def parameter_shapes(cfg: Config) -> "OrderedDict[str, Tuple[int, ...]]":
     shapes["label_embedding_layer.weight"] = (3, d)
     shapes["query_proj.weight"] = (d * nf, d * nf)
     shapes["query_proj.bias"] = (d * nf,)
-    for i in range(cfg.depth):
-        for which in ("cross_attention", "intra_attention"):
-            p = "encoder.encoder.%d.%s." % (i, which)
-            shapes[p + "norm.weight"] = (d,)
-            shapes[p + "norm.bias"] = (d,)
-            shapes[p + "fn.to_qkv.weight"] = (3 * inner, d)
-            if not (cfg.num_heads == 1 and cfg.dim_head == d):   # project_out, RAT_m2.py:180
-                shapes[p + "fn.to_out.0.weight"] = (d, inner)
-                shapes[p + "fn.to_out.0.bias"] = (d,)
-        p = "encoder.encoder.%d.mlp.net." % i
+    def attn_shapes(p):
+        shapes[p + "norm.weight"] = (d,)
+        shapes[p + "norm.bias"] = (d,)
+        shapes[p + "fn.to_qkv.weight"] = (3 * inner, d)
+        if not (cfg.num_heads == 1 and cfg.dim_head == d):       # project_out, RAT_m2.py:180 / RAT_m1.py:166
+            shapes[p + "fn.to_out.0.weight"] = (d, inner)
+            shapes[p + "fn.to_out.0.bias"] = (d,)
+
+    def mlp_shapes(p):
         shapes[p + "0.weight"] = (hid, d)
         shapes[p + "0.bias"] = (hid,)
         shapes[p + "3.weight"] = (d, hid)
         shapes[p + "3.bias"] = (d,)
+
+    if cfg.variant == "m1":
+        # RAT_m1.__init__ (RAT_m1.py:71-72): intra_transformer, cross_transformer; Transformer registers `layers`
+        # before `norm` (RAT_m1.py:194-203): layers.i.0 = PreNorm(Attention), layers.i.1 = PreNorm(FeedForward)
+        for t in ("intra_transformer.", "cross_transformer."):
+            for i in range(cfg.depth):
+                attn_shapes(t + "layers.%d.0." % i)
+                shapes[t + "layers.%d.1.norm.weight" % i] = (d,)
+                shapes[t + "layers.%d.1.norm.bias" % i] = (d,)
+                mlp_shapes(t + "layers.%d.1.fn.net." % i)
+            shapes[t + "norm.weight"] = (d,)
+            shapes[t + "norm.bias"] = (d,)
+    else:
+        for i in range(cfg.depth):
+            for which in ("cross_attention", "intra_attention"):
+                attn_shapes("encoder.encoder.%d.%s." % (i, which))
+            mlp_shapes("encoder.encoder.%d.mlp.net." % i)
     if cfg.use_wide:
         for f in cfg.fields:
             shapes[LR + f.name + ".weight"] = (f.vocab_size, 1)
@@ -252,6 +269,17 @@ def encoder_block(x: Tensor, w: Dict[str, Tensor], i: int, cfg: Config) -> Tenso
     return xc.reshape(b, s, t, d).transpose(1, 2)
 
 
+def transformer(x: Tensor, w: Dict[str, Tensor], prefix: str, cfg: Config) -> Tensor:
+    """RAT_m1's Transformer.forward (RAT_m1.py:205-209) on x: [N, L, d]: depth x (PreNorm attention + residual,
+    PreNorm feed-forward + residual), then the final LayerNorm."""
+    for i in range(cfg.depth):
+        p = prefix + "layers.%d." % i
+        x = attention(x, w, p + "0.", cfg) + x
+        xn = layer_norm(x, w[p + "1.norm.weight"], w[p + "1.norm.bias"], cfg.ln_eps)
+        x = feed_forward(xn, w, p + "1.fn.net.") + x
+    return layer_norm(x, w[prefix + "norm.weight"], w[prefix + "norm.bias"], cfg.ln_eps)
+
+
 def dnn_head(flat: Tensor, w: Dict[str, Tensor], cfg: Config, training: bool,
              bn_state: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """MLP_Layer.forward (deep.py:108-141) with ReLU hidden activations.
@@ -307,10 +335,18 @@ def forward(w: Dict[str, Tensor], X: Tensor, y: Tensor, cfg: Config, training: b
             bn_state: Optional[Dict[str, Tensor]] = None, return_logit: bool = False):
     """RAT_m2.forward (RAT_m2.py:104-152) with dropout p=0.  Returns y_pred [B, 1]."""
     grid, target_fields = build_grid(X, y, w, cfg)
-    x = grid
-    for i in range(cfg.depth):
-        x = encoder_block(x, w, i, cfg)
-    cls = x[:, 0, 0]                                                    # target sample, label token
+    if cfg.variant == "m1":
+        # RAT_m1.forward (RAT_m1.py:121-130): every sample's S tokens through the intra transformer, its label token
+        # [:, 0] becomes that sample's vector; the T sample vectors go through the cross transformer; target = [:, 0]
+        b, t, s, d = grid.shape
+        xi = transformer(grid.reshape(b * t, s, d), w, "intra_transformer.", cfg)
+        xc = transformer(xi[:, 0].reshape(b, t, d), w, "cross_transformer.", cfg)
+        cls = xc[:, 0]
+    else:
+        x = grid
+        for i in range(cfg.depth):
+            x = encoder_block(x, w, i, cfg)
+        cls = x[:, 0, 0]                                                # target sample, label token
     logit = cls @ w["fc.weight"].t() + w["fc.bias"]
     if cfg.dnn_hidden_units:
         logit = logit + dnn_head(target_fields.flatten(1), w, cfg, training, bn_state)

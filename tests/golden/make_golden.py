@@ -31,13 +31,13 @@ def import_reference():
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules["dgl.nn.functional"].edge_softmax = None
     sys.path.insert(0, "/root/reference")
-    from fuxictr.pytorch.models import RAT_m2          # noqa: E402
+    from fuxictr.pytorch import models                 # noqa: E402
     from fuxictr.features import FeatureMap            # noqa: E402
     from fuxictr.pytorch.torch_utils import seed_everything  # noqa: E402
-    return RAT_m2, FeatureMap, seed_everything
+    return models, FeatureMap, seed_everything
 
 
-def build_reference_model(case, RAT_m2, FeatureMap, seed_everything, seed=None):
+def build_reference_model(case, models, FeatureMap, seed_everything, seed=None):
     fm = FeatureMap(case["name"], "/tmp/rat_golden")
     fm.feature_specs = gc.feature_specs(case)
     fm.num_fields = len(fm.feature_specs)
@@ -45,13 +45,13 @@ def build_reference_model(case, RAT_m2, FeatureMap, seed_everything, seed=None):
         seed_everything(seed)
     kw = gc.model_kwargs(case)
     kw["model_root"] = "/tmp/rat_golden/models"
-    return RAT_m2(fm, **kw)
+    return getattr(models, case.get("model", "RAT_m2"))(fm, **kw)       # like run_expid.py:75
 
 
-def run_case(case, RAT_m2, FeatureMap, seed_everything):
+def run_case(case, models, FeatureMap, seed_everything):
     out = {}
     # ---- (1) initial weights under the reference's own init rules
-    model = build_reference_model(case, RAT_m2, FeatureMap, seed_everything, seed=case["init_seed"])
+    model = build_reference_model(case, models, FeatureMap, seed_everything, seed=case["init_seed"])
     sd = model.state_dict()
     for k, v in sd.items():
         if k.startswith("query_proj"):
@@ -113,11 +113,14 @@ def run_case(case, RAT_m2, FeatureMap, seed_everything):
 
 
 def main():
-    RAT_m2, FeatureMap, seed_everything = import_reference()
+    models, FeatureMap, seed_everything = import_reference()
     os.makedirs("/tmp/rat_golden/models", exist_ok=True)
     torch.set_num_threads(1)          # one thread -> reproducible reduction order
     for case in gc.CASES:
-        out = run_case(case, RAT_m2, FeatureMap, seed_everything)
+        only = sys.argv[1:]
+        if only and case["name"] not in only:
+            continue
+        out = run_case(case, models, FeatureMap, seed_everything)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **out)
         print("%-16s %4d arrays  %7.1f KB  params=%d" % (case["name"], len(out), os.path.getsize(path) / 1024,
@@ -125,7 +128,7 @@ def main():
     # known-answer parameter counts of the three shipped configs (exps/RAT_m2/*/*.log)
     counts = {}
     for kc in gc.KNOWN_COUNT_CASES:
-        m = build_reference_model(kc, RAT_m2, FeatureMap, seed_everything, seed=1)
+        m = build_reference_model(kc, models, FeatureMap, seed_everything, seed=1)
         counts[kc["name"]] = np.int64(sum(p.numel() for p in m.parameters() if p.requires_grad))
         print("count", kc["name"], int(counts[kc["name"]]), "expected", kc["expected_params"])
         assert int(counts[kc["name"]]) == kc["expected_params"]

@@ -56,6 +56,22 @@ CASES = [
          batch_norm=False, use_wide=False, embedding_regularizer=0, net_regularizer=0),
 ]
 
+# RAT_m1 (cascaded intra / cross transformers, RAT_m1.py) — same fields / seeds machinery.
+CASES += [
+    dict(name="m1_tiny_seq", model="RAT_m1", batch=6, topk=3, init_seed=2021, data_seed=71, weight_seed=72, full_limit=1 << 20,
+         fields=[_cat("a", 7), _cat("b", 5), _seq("c", 6), _cat("e", 9, padding_idx=8)],
+         embedding_dim=8, num_heads=2, dim_head=4, depth=2, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="m1_northstar_shape", model="RAT_m1", batch=3, topk=10, init_seed=2021, data_seed=81, weight_seed=82, full_limit=1024,
+         fields=[_cat("c%02d" % i, 37) for i in range(20)],
+         embedding_dim=64, num_heads=8, dim_head=10, depth=1, scale_dim=2, dnn_hidden_units=[16, 16],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.0005, net_regularizer=0),
+    dict(name="m1_bare", model="RAT_m1", batch=4, topk=2, init_seed=7, data_seed=91, weight_seed=92, full_limit=1 << 20,
+         fields=[_cat("p", 6), _cat("q", 5)],
+         embedding_dim=16, num_heads=1, dim_head=16, depth=1, scale_dim=2, dnn_hidden_units=[],
+         batch_norm=False, use_wide=False, embedding_regularizer=0, net_regularizer=0),
+]
+
 # The three shipped experiments (exps/RAT_m2/*/*.log "Total number of parameters").
 KNOWN_COUNT_CASES = [
     dict(name="count_mltag", expected_params=1337241, topk=5,
@@ -110,7 +126,7 @@ def input_length(case):
 
 def model_kwargs(case):
     """The flattened params dict run_expid.py would splat into the constructor."""
-    return dict(model_id="RAT_m2_" + case["name"], gpu=-1, task="binary_classification", learning_rate=1e-3,
+    return dict(model_id=case.get("model", "RAT_m2") + "_" + case["name"], gpu=-1, task="binary_classification", learning_rate=1e-3,
                 embedding_dim=case["embedding_dim"], dnn_hidden_units=list(case["dnn_hidden_units"]),
                 dnn_activations="relu", num_heads=case["num_heads"], dim_head=case["dim_head"],
                 depth=case["depth"], scale_dim=case["scale_dim"], dropout=0.0, emb_dropout=0.0, net_dropout=0,

@@ -139,6 +139,59 @@ def check_ffn(lib, dev, ntok, d, hidden):
         close(g, w.grad, 1e-4, 1e-4 * scale)
 
 
+def check_ffn_res(lib, dev, ntok, d, hidden, with_res):
+    """y = FFN(x) + res with the residual from a separate tensor (or none): rat_ffn_fwd_res / rat_ffn_bwd_res(add_dy=0)."""
+    rs = np.random.RandomState(13)
+    x, res = rnd(rs, ntok, d), rnd(rs, ntok, d)
+    ws = (rnd(rs, hidden, d, scale=d ** -0.5), 0.1 * rnd(rs, hidden), rnd(rs, d, hidden, scale=hidden ** -0.5), 0.1 * rnd(rs, d))
+    dy = rnd(rs, ntok, d)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    hdn = xr @ wr[0].t() + wr[1]
+    ref = (0.5 * hdn * (1.0 + torch.erf(hdn / 2.0 ** 0.5))) @ wr[2].t() + wr[3]
+    if with_res:
+        ref = ref + res.double()
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    wd = [w.to(dev) for w in ws]
+    y = ops.ffn_fwd_res(xd, res.to(dev) if with_res else None, *wd, d, hidden, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    gs = [torch.zeros_like(w) for w in wd]
+    dx, _ = ops.ffn_bwd_res(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, add_dy=False, lib=lib)
+    scale = max(1.0, ntok ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    for g, w in zip(gs, wr):
+        close(g, w.grad, 1e-4, 1e-4 * scale)
+
+
+def check_layernorm(lib, dev, nrows, d, stride_mul, with_add):
+    """rat_layernorm_fwd / bwd on strided rows against torch's float64 layer_norm."""
+    rs = np.random.RandomState(14)
+    stride = d * stride_mul
+    xfull = rnd(rs, nrows, stride)
+    gamma, beta = 1 + 0.1 * rnd(rs, d), 0.1 * rnd(rs, d)
+    dy = rnd(rs, nrows, d)
+    add = rnd(rs, nrows, stride) if with_add else None
+    xr = xfull[:, :d].double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    ref.backward(dy.double())
+    xd = xfull.to(dev)
+    y = ops.layernorm_fwd(xd, stride, nrows, gamma.to(dev), beta.to(dev), d, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "ln y")
+    sentinel = 7.5
+    dx = torch.full((nrows, stride), sentinel, dtype=torch.float32, device=dev)
+    dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+    ops.layernorm_bwd(xd, stride, dy.to(dev), gamma.to(dev), dx, stride, dg, db, d, add=add.to(dev) if with_add else None, lib=lib)
+    want = xr.grad + (add[:, :d].double() if with_add else 0.0)
+    close(dx[:, :d], want, 1e-4, 1e-4, "ln dx")
+    if stride_mul > 1:
+        assert bool((dx[:, d:] == sentinel).all()), "rows outside the addressed tokens were touched"
+    scale = max(1.0, nrows ** 0.5 / 4)
+    close(dg, gr.grad, 1e-4, 1e-4 * scale, "dgamma")
+    close(db, br.grad, 1e-4, 1e-4 * scale, "dbeta")
+
+
 def check_bn_relu(lib, dev, M, N, use_bn):
     rs = np.random.RandomState(4)
     z = rnd(rs, M, N)

@@ -12,7 +12,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def build_model(case, gpu=-1, seed=None, **overrides):
     from rat_amd.base_model import seed_everything
     from rat_amd.features import FeatureMap
-    from rat_amd.model import RAT_m2
+    from rat_amd import models
     fm = FeatureMap.from_specs(case["name"], gc.feature_specs(case))
     kw = gc.model_kwargs(case)
     kw["gpu"] = gpu
@@ -20,7 +20,7 @@ def build_model(case, gpu=-1, seed=None, **overrides):
     kw.update(overrides)
     if seed is not None:
         seed_everything(seed)
-    return RAT_m2(fm, **kw)
+    return getattr(models, case.get("model", "RAT_m2"))(fm, **kw)      # resolved by name like run_expid.py:75
 
 
 def load_weights(model, case):
@@ -82,12 +82,16 @@ def check_training(name, gpu):
             if k.startswith("query_proj"):
                 assert p.grad is None
                 continue
-            gc.check_summary(gold, "train%d/grad/%s" % (step, k), p.grad.detach().cpu().numpy(), rtol=3e-4, atol=3e-6)
+            # a bias feeding BatchNorm has the exact gradient 0: both sides hold cancellation noise of sum(dz) there, whose size
+            # scales with |dz| (1/sqrt(var) of a 3-row batch can be large) — only bound it
+            gc.check_summary(gold, "train%d/grad/%s" % (step, k), p.grad.detach().cpu().numpy(), rtol=3e-4,
+                             atol=3e-5 if k in noise else 3e-6)
             n += 1
         assert n == sum(1 for k in gold.files if k.startswith("train%d/grad/" % step))
         norm_sq = model.optimizer.clip_and_step(10.0)
         gn = float(torch.sqrt(norm_sq)[0])
-        assert abs(gn - float(gold["train%d/gnorm" % step])) < 1e-5 * max(1.0, gn)
+        # fp32 on both sides: on m1_northstar_shape the reference's own norm is 7e-6 (relative) away from the float64 oracle's
+        assert abs(gn - float(gold["train%d/gnorm" % step])) < 3e-5 * max(1.0, gn)
         for k, v in model.state_dict().items():
             if k.startswith("query_proj"):
                 assert torch.equal(v, before[k])

@@ -57,6 +57,16 @@ def test_ffn_fwd_bwd(emu, ntok, d, hidden):
     kc.check_ffn(emu, "cpu", ntok, d, hidden)
 
 
+@pytest.mark.parametrize("ntok,d,hidden,with_res", [(70, 8, 16, True), (64, 64, 128, True), (77, 64, 128, False), (45, 16, 32, True)])
+def test_ffn_separate_residual(emu, ntok, d, hidden, with_res):
+    kc.check_ffn_res(emu, "cpu", ntok, d, hidden, with_res)
+
+
+@pytest.mark.parametrize("nrows,d,stride_mul,with_add", [(37, 8, 1, False), (50, 64, 1, True), (21, 64, 21, False), (19, 10, 3, True), (5, 100, 2, False)])
+def test_layernorm_fwd_bwd(emu, nrows, d, stride_mul, with_add):
+    kc.check_layernorm(emu, "cpu", nrows, d, stride_mul, with_add)
+
+
 @pytest.mark.parametrize("use_bn", [True, False])
 def test_bn_relu_colsum(emu, use_bn):
     kc.check_bn_relu(emu, "cpu", 37, 40, use_bn)

@@ -11,23 +11,25 @@ pytestmark = pytest.mark.gpu
 NAME = "synthetic_F20_V1M_K10_d64_B4096"
 
 
-@pytest.fixture(scope="module")
-def setup():
-    from rat_amd import synthetic
+VARIANT = {"RAT_m2": "m2", "RAT_m1": "m1"}
+
+
+@pytest.fixture(scope="module", params=["RAT_m2", "RAT_m1"])
+def setup(request):
+    from rat_amd import models, synthetic
     from rat_amd.base_model import seed_everything
-    from rat_amd.model import RAT_m2
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     spec = synthetic.WORKLOADS[NAME]
     fm = synthetic.feature_map_for(NAME, spec)
     seed_everything(2021)
-    model = RAT_m2(fm, **synthetic.model_kwargs(spec, gpu=0))
+    model = getattr(models, request.param)(fm, **synthetic.model_kwargs(spec, gpu=0))
     # the reference initialises tables with std 1e-4: scale them up so that attention is far from uniform and every path matters
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.startswith("embedding_layer.") and p.shape[-1] == spec["d"]:      # feature tables only (the label table is N(0,1) already)
                 p.mul_(3000.0)
     batch = synthetic.make_batch(spec, fm, seed=7)             # host float64 4-tuple, like the reference loader
-    return spec, fm, model, batch
+    return spec, fm, model, batch, request.param
 
 
 def _predict(model, batch):
@@ -38,14 +40,15 @@ def _predict(model, batch):
 
 def test_slice_of_full_batch_matches_oracle(setup):
     from oracle import rat_m2_oracle as orc
-    spec, fm, model, batch = setup
+    spec, fm, model, batch, which = setup
     full = _predict(model, batch)
     assert full.shape[0] == spec["batch"] and bool(torch.isfinite(full).all())
     assert float(full.std()) > 1e-3, "degenerate predictions would make the comparison vacuous"
     rows = torch.arange(0, spec["batch"], spec["batch"] // 48)[:48]
     cfg = orc.Config(fields=orc.fields_from_specs(fm.feature_specs), embedding_dim=spec["d"], num_heads=spec["num_heads"],
                      dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
-                     dnn_hidden_units=tuple(spec["dnn_hidden_units"]), batch_norm=spec["batch_norm"], use_wide=spec["use_wide"])
+                     dnn_hidden_units=tuple(spec["dnn_hidden_units"]), batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],
+                     variant=VARIANT[which])
     w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     ref = orc.forward(w, batch[0][rows], batch[1][rows], cfg, training=False)
     ref = (ref[0] if isinstance(ref, (tuple, list)) else ref).reshape(-1).double()
@@ -54,7 +57,7 @@ def test_slice_of_full_batch_matches_oracle(setup):
 
 def test_prediction_is_per_sample_and_chunking_independent(setup):
     """eval-mode predictions of a sub-batch equal the same rows of the full batch (different chunking / tile occupancy)"""
-    spec, fm, model, batch = setup
+    spec, fm, model, batch, which = setup
     full = _predict(model, batch)
     for lo, n in ((0, 1), (5, 37), (1000, 1027)):
         sub = tuple(t[lo:lo + n] for t in batch)
@@ -63,7 +66,7 @@ def test_prediction_is_per_sample_and_chunking_independent(setup):
 
 def test_prediction_invariant_to_retrieved_order(setup):
     """the K retrieved samples form a set: permuting them (with their labels) must not change the target's prediction"""
-    spec, fm, model, batch = setup
+    spec, fm, model, batch, which = setup
     X, y, rv, rl = batch
     perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(spec["K"], generator=torch.Generator().manual_seed(3))])
     a = _predict(model, batch)
@@ -72,20 +75,19 @@ def test_prediction_invariant_to_retrieved_order(setup):
 
 
 def test_forward_is_deterministic(setup):
-    spec, fm, model, batch = setup
+    spec, fm, model, batch, which = setup
     assert torch.equal(_predict(model, batch), _predict(model, batch))
 
 
 def test_full_batch_gradient_is_mean_of_half_batch_gradients(setup):
     """loss = mean BCE (+ batch-independent L2): with BatchNorm in eval mode the gradient of the full batch is the average of
     the two half-batch gradients — checks the whole backward path (atomics, slabs, split-K) at the full size."""
-    from rat_amd import synthetic
+    from rat_amd import models, synthetic
     from rat_amd.base_model import seed_everything
-    from rat_amd.model import RAT_m2
-    spec, fm, _, batch = setup
+    spec, fm, _, batch, which = setup
     spec2 = dict(spec, batch_norm=False)
     seed_everything(2021)
-    model = RAT_m2(fm, **synthetic.model_kwargs(spec2, gpu=0, embedding_regularizer=0.0))
+    model = getattr(models, which)(fm, **synthetic.model_kwargs(spec2, gpu=0, embedding_regularizer=0.0))
     with torch.no_grad():
         for n, p in model.named_parameters():
             if n.startswith("embedding_layer.") and p.shape[-1] == spec["d"]:

@@ -48,6 +48,16 @@ def test_ffn_fwd_bwd(lib, ntok, d, hidden):
     kc.check_ffn(lib, "cuda", ntok, d, hidden)
 
 
+@pytest.mark.parametrize("ntok,d,hidden,with_res", [(70, 8, 16, True), (64, 64, 128, True), (100000, 64, 128, True), (100000, 64, 128, False), (5000, 40, 80, True), (999, 16, 32, True)])
+def test_ffn_separate_residual(lib, ntok, d, hidden, with_res):
+    kc.check_ffn_res(lib, "cuda", ntok, d, hidden, with_res)
+
+
+@pytest.mark.parametrize("nrows,d,stride_mul,with_add", [(37, 8, 1, False), (100000, 64, 1, True), (8192, 64, 21, False), (4096, 64, 11, True), (1000, 10, 3, True), (300, 400, 2, False)])
+def test_layernorm_fwd_bwd(lib, nrows, d, stride_mul, with_add):
+    kc.check_layernorm(lib, "cuda", nrows, d, stride_mul, with_add)
+
+
 @pytest.mark.parametrize("use_bn", [True, False])
 def test_bn_relu_colsum(lib, use_bn):
     kc.check_bn_relu(lib, "cuda", 4096, 400, use_bn)

@@ -17,7 +17,8 @@ def oracle_config(case):
                       dim_head=case["dim_head"], depth=case["depth"], scale_dim=case["scale_dim"],
                       dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=case["batch_norm"],
                       use_wide=case["use_wide"], embedding_regularizer=float(case["embedding_regularizer"] or 0.0),
-                      net_regularizer=float(case["net_regularizer"] or 0.0))
+                      net_regularizer=float(case["net_regularizer"] or 0.0),
+                      variant={"RAT_m2": "m2", "RAT_m1": "m1"}[case.get("model", "RAT_m2")])
 
 
 def state_shapes(cfg):

@@ -24,6 +24,8 @@ struct FfnArgs {
     const float* x;
     const float* dy;
     float* y;            // forward output / backward dx
+    const float* res;    // forward: residual source (== x for the RAT_m2 block MLP; nullptr: none)
+    int add_dy;          // backward: dx = dy W-chain (+ dy when the residual came from x itself)
     const float* w1;     // [H][D]
     const float* b1;
     const float* w2;     // [D][H]
@@ -163,8 +165,12 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
                     const float bias = a.b2[col];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const size_t o = (size_t)rat_acc_row(mt, r) * g.ldx + col;
-                        ys[o] = acc[r] + bias + xs[o];
+                        const int row = rat_acc_row(mt, r);
+                        const size_t o = (size_t)row * g.ldx + col;
+                        float rv = 0.f;
+                        if (a.res == a.x) rv = xs[o];
+                        else if (a.res != nullptr && row < rows) rv = a.res[(tok0 + row) * g.D + col];
+                        ys[o] = acc[r] + bias + rv;
                     }
                 }
             });
@@ -267,7 +273,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < D)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dys[(size_t)rat_acc_row(mt, r) * g.ldx + col] += acc[r];   // dx tile, in place
+                    for (int r = 0; r < 4; ++r) {                                                   // dx tile, in place
+                        const size_t o = (size_t)rat_acc_row(mt, r) * g.ldx + col;
+                        dys[o] = a.add_dy ? dys[o] + acc[r] : acc[r];
+                    }
             };
             if (FAST) {
                 const RatGlobalWnkT<false> Bw{a.w1t, D, H, H, true};
@@ -396,7 +405,7 @@ __device__ __forceinline__ float4 gelu4(const f32x4& h) {
 // forward: weights resident in LDS (A operands, 16-byte row reads); one 16-token tile per wave iteration, the next tile's
 // x fragments prefetched into registers; hidden tiles are produced in pairs and the GELU of pair p-1 is scheduled into the
 // MFMA shadow of pair p.
-template <int D, int H>
+template <int D, int H, bool XRES>
 __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
     typedef FfnTGeom<D, H> G;
     constexpr int KD = D / 16, KH = H / 16;
@@ -465,8 +474,14 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
             const bool two = 2 * q + 1 < KD;
             const int m0 = 2 * q, m1 = two ? 2 * q + 1 : 2 * q;
             const float4 bs0 = ld4(b2s + 16 * m0 + 4 * g), bs1 = ld4(b2s + 16 * m1 + 4 * g);
-            f32x4 c0 = {bs0.x + xT[m0].x, bs0.y + xT[m0].y, bs0.z + xT[m0].z, bs0.w + xT[m0].w};
-            f32x4 c1 = {bs1.x + xT[m1].x, bs1.y + xT[m1].y, bs1.z + xT[m1].z, bs1.w + xT[m1].w};
+            float4 r0 = xT[m0], r1 = xT[m1];                   // XRES: the residual is the tile already in registers
+            if (!XRES) {
+                const bool ok = a.res != nullptr && tok < a.ntok;
+                r0 = ok ? ld4(a.res + tok * D + 16 * m0 + 4 * g) : zero4;
+                r1 = ok ? ld4(a.res + tok * D + 16 * m1 + 4 * g) : zero4;
+            }
+            f32x4 c0 = {bs0.x + r0.x, bs0.y + r0.y, bs0.z + r0.z, bs0.w + r0.w};
+            f32x4 c1 = {bs1.x + r1.x, bs1.y + r1.y, bs1.z + r1.z, bs1.w + r1.w};
             if (q == 0) {   // the last hidden pair's GELU rides in the shadow of the first K-blocks of this product
 #pragma unroll
                 for (int kb = 0; kb < KH - 2; ++kb) {
@@ -687,8 +702,8 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t_kernel(FfnArgs a) {
         RAT_PROF_MARK(3);
         auto finish = [&](int m) {                                 // dx = dy + dh' W1 (both halves), straight from registers
             const float4 p = ld4(px + row * G::LDX + 16 * m + 4 * g);
-            const float4 o = make_float4(dxa[m][0] + p.x + dyT[m].x, dxa[m][1] + p.y + dyT[m].y, dxa[m][2] + p.z + dyT[m].z,
-                                         dxa[m][3] + p.w + dyT[m].w);
+            const float4 dr = a.add_dy ? dyT[m] : zero4;
+            const float4 o = make_float4(dxa[m][0] + p.x + dr.x, dxa[m][1] + p.y + dr.y, dxa[m][2] + p.z + dr.z, dxa[m][3] + p.w + dr.w);
             if (tok < a.ntok) st4(a.y + tok * D + 16 * m + 4 * g, o);
             db2a[m][0] += dyT[m].x;
             db2a[m][1] += dyT[m].y;
@@ -785,10 +800,16 @@ int ffn_check(int64_t ntok, int d, int hidden, bool backward) {
 
 extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                            int64_t ntok, int d, int hidden, void* stream) {
+    return rat_ffn_fwd_res(x, x, y, w1, b1, w2, b2, ntok, d, hidden, stream);
+}
+
+extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2,
+                               const float* b2, int64_t ntok, int d, int hidden, void* stream) {
     if (ffn_check(ntok, d, hidden, false)) return -1;
     RAT_REQUIRE(x && y && w1 && b1 && w2 && b2, "null pointer");
     FfnArgs a{};
     a.x = x;
+    a.res = res;
     a.y = y;
     a.w1 = w1;
     a.b1 = b1;
@@ -808,12 +829,16 @@ extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const floa
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     const int64_t blocks = a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu;
-    const int fast = ffn_fast_dim(a, {x, y, b1, b2});
+    const int fast = ffn_fast_dim(a, {x, y, b1, b2, res});
     const int64_t wtiles = ((ntok + 15) / 16 + FT_WAVES - 1) / FT_WAVES;
+    const unsigned tgrid = (unsigned)(wtiles < 256 ? wtiles : 256);
+    const bool xres = res == x;
     if (fast == 64 && hidden == 128) {
-        RAT_LAUNCH((ffn_fwd_t_kernel<64, 128>), (unsigned)(wtiles < 256 ? wtiles : 256), FT_THREADS, (FfnTGeom<64, 128>::fwd_smem), stream, a);
+        if (xres) RAT_LAUNCH((ffn_fwd_t_kernel<64, 128, true>), tgrid, FT_THREADS, (FfnTGeom<64, 128>::fwd_smem), stream, a);
+        else RAT_LAUNCH((ffn_fwd_t_kernel<64, 128, false>), tgrid, FT_THREADS, (FfnTGeom<64, 128>::fwd_smem), stream, a);
     } else if (fast == 16 && hidden == 32) {
-        RAT_LAUNCH((ffn_fwd_t_kernel<16, 32>), (unsigned)(wtiles < 256 ? wtiles : 256), FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
+        if (xres) RAT_LAUNCH((ffn_fwd_t_kernel<16, 32, true>), tgrid, FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
+        else RAT_LAUNCH((ffn_fwd_t_kernel<16, 32, false>), tgrid, FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
     } else {
         RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     }
@@ -828,6 +853,12 @@ extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
 extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                            const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                            size_t workspace_bytes, int64_t ntok, int d, int hidden, void* stream) {
+    return rat_ffn_bwd_res(x, dy, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, ntok, d, hidden, 1, stream);
+}
+
+extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                               size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, void* stream) {
     if (ffn_check(ntok, d, hidden, true)) return -1;
     RAT_REQUIRE(x && dy && dx && w1 && b1 && w2 && b2 && dw1 && db1 && dw2 && db2 && workspace, "null pointer");
     RAT_REQUIRE(workspace_bytes >= rat_ffn_bwd_workspace(d, hidden), "workspace too small");
@@ -835,6 +866,7 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
     a.x = x;
     a.dy = dy;
     a.y = dx;
+    a.add_dy = add_dy;
     a.w1 = w1;
     a.b1 = b1;
     a.w2 = w2;

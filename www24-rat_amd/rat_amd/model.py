@@ -95,6 +95,19 @@ class _Encoder(nn.Module):
         self.encoder = nn.ModuleList([_Block(dim, heads, dim_head, dropout, hidden) for _ in range(depth)])
 
 
+class _Transformer(nn.Module):
+    """RAT_m1's Transformer (RAT_m1.py:194-203): `layers` is registered before `norm`; layers[i] = [PreNorm(Attention),
+    PreNorm(FeedForward)]."""
+
+    def __init__(self, dim, depth, heads, dim_head, hidden, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        self.norm = nn.LayerNorm(dim)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([_PreNorm(dim, _Attention(dim, heads, dim_head, dropout)),
+                                              _PreNorm(dim, _FeedForward(dim, hidden))]))
+
+
 class _MLP(nn.Module):
     """MLP_Layer's module list (deep.py:108-139): [Linear, (BatchNorm1d), act, (Dropout)]* + Linear(.,1)."""
 
@@ -157,8 +170,7 @@ class RAT_m2(BaseModel):
         self.query_proj = nn.Linear(d * nf, d * nf)           # dead in the reference too (RAT_m2.py:66-67), kept for state_dict
         self.query_dropout = nn.Dropout(net_dropout) if (not isinstance(net_dropout, list) and net_dropout > 0) else None
         kwargs["retrieval_configs"]["topK"]                    # the reference requires the key (RAT_m2.py:73)
-        torch.randn(1, 1, d)                                   # `space_token` (RAT_m2.py:74): unregistered, but it advances the RNG
-        self.encoder = _Encoder(d, num_heads, dim_head, dropout, depth, d * scale_dim)
+        self._make_encoder(d, num_heads, dim_head, dropout, depth, d * scale_dim)
         self.dropout = nn.Dropout(emb_dropout)
         self.lr_layer = _LRLayer(feature_map) if use_wide else None
         self.dnn = _MLP(d * nf, dnn_hidden_units, dnn_activations, net_dropout, batch_norm) if dnn_hidden_units else None
@@ -171,6 +183,64 @@ class RAT_m2(BaseModel):
         self.compile(kwargs["optimizer"], loss=kwargs["loss"], lr=learning_rate)
         self.reset_parameters()
         self.model_to_device()
+
+    # ------------------------------------------------------------------------------ encoder (overridden by the variants)
+    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
+        torch.randn(1, 1, d)                                   # `space_token` (RAT_m2.py:74): unregistered, but it advances the RNG
+        self.encoder = _Encoder(d, num_heads, dim_head, dropout, depth, hidden)
+
+    def _attn_descriptor(self, p):
+        """(names, RatAttnParams) of the PreNorm(Attention) whose parameters live under prefix p."""
+        has_out = (p + "fn.to_out.0.weight") in self._params
+        names = [p + "norm.weight", p + "norm.bias", p + "fn.to_qkv.weight",
+                 p + "fn.to_out.0.weight" if has_out else None, p + "fn.to_out.0.bias" if has_out else None]
+        return names, ops.attn_params(*[self._p(n) if n else None for n in names])
+
+    def _build_encoder_descriptors(self):
+        self._blocks = []
+        for i in range(self._cfg["depth"]):
+            blk = {}
+            for which in ("intra", "cross"):
+                blk[which] = self._attn_descriptor("encoder.encoder.%d.%s_attention." % (i, which))
+            p = "encoder.encoder.%d.mlp.net." % i
+            blk["ffn"] = [p + "0.weight", p + "0.bias", p + "3.weight", p + "3.bias"]
+            self._blocks.append(blk)
+
+    def _encoder_forward(self, x, x0, dims, save, saved):
+        """depth x (intra attention, cross attention, FFN), each with its residual (RAT_m2.py:219-236).
+        Returns (tensor holding the class token rows, row stride in floats)."""
+        c, lib = self._cfg, self._lib
+        B, T, L, S = dims
+        d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
+        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        for bi, blk in enumerate(self._blocks):
+            inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
+            xa, o1, l1 = ops.attn_fwd(x, blk["intra"][1], imap, d, heads, dh, save=save, out=x if inplace else None, lib=lib)
+            xb, o2, l2 = ops.attn_fwd(xa, blk["cross"][1], cmap, d, heads, dh, save=save, out=xa if not save else None, lib=lib)
+            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+            xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, lib=lib)
+            if save:
+                saved["blocks"].append((x, o1, l1, xa, o2, l2, xb))
+            x = xc
+        return x, T * S * d
+
+    def _encoder_backward(self, saved, dx, G):
+        """dx: gradient of the tensor _encoder_forward returned -> gradient of the [B,T,S,d] grid."""
+        c, lib = self._cfg, self._lib
+        B, T, L, S = saved["dims"]
+        d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
+        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
+        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
+        for blk, (x_in, o1, l1, xa, o2, l2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
+            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+            gw = [G(n) for n in blk["ffn"]]
+            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, lib=lib)
+            for which, xin, o, l, smap in (("cross", xa, o2, l2, cmap), ("intra", x_in, o1, l1, imap)):
+                names, params = blk[which]
+                grads = ops.attn_params(*[G(n) if n else None for n in names])
+                dx, _ = ops.attn_bwd(xin, dx, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+        return dx
 
     # ------------------------------------------------------------------------------ flat parameter buffer
     def _trainable(self):
@@ -216,18 +286,7 @@ class RAT_m2(BaseModel):
             self._lr_ftab = ops.field_table(self._fields, self._lr_tables, dev)
         else:
             self._lr_tables, self._lr_ftab = None, None
-        self._blocks = []
-        for i in range(c["depth"]):
-            blk = {}
-            for which in ("intra", "cross"):
-                p = "encoder.encoder.%d.%s_attention." % (i, which)
-                has_out = (p + "fn.to_out.0.weight") in self._params
-                names = [p + "norm.weight", p + "norm.bias", p + "fn.to_qkv.weight",
-                         p + "fn.to_out.0.weight" if has_out else None, p + "fn.to_out.0.bias" if has_out else None]
-                blk[which] = (names, ops.attn_params(*[self._p(n) if n else None for n in names]))
-            p = "encoder.encoder.%d.mlp.net." % i
-            blk["ffn"] = [p + "0.weight", p + "0.bias", p + "3.weight", p + "3.bias"]
-            self._blocks.append(blk)
+        self._build_encoder_descriptors()
         # DNN head layout: [(linear_idx, bn_idx or None, dropout_p)], out linear idx
         self._dnn_layers, self._dnn_out = [], None
         if self.dnn is not None:
@@ -371,27 +430,18 @@ class RAT_m2(BaseModel):
             ops.sgemm(0, 1, B, 1, K, a_prev, lda, W, K, dnn_out, 1, bias=bvec, lib=lib)
             if save:
                 saved["dnn_last"] = (a_prev, lda, K)
-        # ---- encoder: depth x (intra attention, cross attention, FFN), each with its residual
-        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        # ---- encoder on the token grid
         x = x0
         if drop and c["emb_dropout"] > 0:                                  # self.dropout(x) (RAT_m2.py:135); X_emb for the DNN stays un-dropped
             x = ops.dropout(x0, c["emb_dropout"], seeds[0], lib=lib)
-        for bi, blk in enumerate(self._blocks):
-            inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
-            xa, o1, l1 = ops.attn_fwd(x, blk["intra"][1], imap, d, heads, dh, save=save, out=x if inplace else None, lib=lib)
-            xb, o2, l2 = ops.attn_fwd(xa, blk["cross"][1], cmap, d, heads, dh, save=save, out=xa if not save else None, lib=lib)
-            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, lib=lib)
-            if save:
-                saved["blocks"].append((x, o1, l1, xa, o2, l2, xb))
-            x = xc
+        x, cls_stride = self._encoder_forward(x, x0, (B, T, L, S), save, saved)
         # ---- logit = fc(cls) + dnn + wide ; sigmoid ; BCE
         loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
-        y_pred = ops.logit_fwd(x, T * S * d, self.fc.weight.data, self.fc.bias.data, dnn_out, self._lr_ftab, F, idx, T * L,
+        y_pred = ops.logit_fwd(x, cls_stride, self.fc.weight.data, self.fc.bias.data, dnn_out, self._lr_ftab, F, idx, T * L,
                                y_true, loss, B, d, lib=lib)
         reg = self._regularization_value() if with_reg else torch.zeros((), dtype=torch.float32, device=x0.device)
         if save:
-            saved["x_final"], saved["y_pred"] = x, y_pred
+            saved["x_final"], saved["cls_stride"], saved["y_pred"] = x, cls_stride, y_pred
         return y_pred, loss[0], reg, saved
 
     def _workspace(self, key, nbytes):
@@ -416,7 +466,8 @@ class RAT_m2(BaseModel):
         if c["use_wide"]:
             lr_prefix = "lr_layer.embedding_layer.embedding_layer.embedding_layer."
             lr_gftab = ops.field_table(self._fields, [G(lr_prefix + f.name + ".weight") for f in self._fields], dev)
-        dlogit = ops.logit_bwd(y_pred, y_true, x_final, T * S * d, self.fc.weight.data, dx, T * S * d, G("fc.weight"),
+        cs = saved["cls_stride"]
+        dlogit = ops.logit_bwd(y_pred, y_true, x_final, cs, self.fc.weight.data, dx, cs, G("fc.weight"),
                                G("fc.bias"), lr_gftab, F, idx, T * L, g_loss, B, d, lib=lib)
         dflat = None
         if self.dnn is not None:
@@ -446,17 +497,7 @@ class RAT_m2(BaseModel):
                 ops.sgemm(0, 0, B, K_in, N, dz, N, mods[lin].weight.data, K_in, da, K_in, lib=lib)   # da_in = dz W
             dflat = da                                                                             # [B, F*d]
         # ---- encoder, reversed
-        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
-        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
-        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
-        for blk, (x_in, o1, l1, xa, o2, l2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
-            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            gw = [G(n) for n in blk["ffn"]]
-            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, lib=lib)
-            for which, xin, o, l, smap in (("cross", xa, o2, l2, cmap), ("intra", x_in, o1, l1, imap)):
-                names, params = blk[which]
-                grads = ops.attn_params(*[G(n) if n else None for n in names])
-                dx, _ = ops.attn_bwd(xin, dx, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+        dx = self._encoder_backward(saved, dx, G)
         if saved["seeds"] is not None and c["emb_dropout"] > 0:
             dx = ops.dropout(dx, c["emb_dropout"], saved["seeds"][0], out=dx, lib=lib)
         # ---- embedding tables
@@ -471,3 +512,80 @@ class RAT_m2(BaseModel):
                 ops.l2_reg(self._flat[self._n_emb:], gflat[self._n_emb:], c["lam_net"] * g_reg, None, lib=lib)
         self._last_gflat = gflat
         return [self._gflat_view(gflat, n) for n in self._order]
+
+
+class RAT_m1(RAT_m2):
+    """RAT_m1 (fuxictr/pytorch/models/RAT_m1.py:24-130): the cascaded variant.  Every sample's S = F+1 tokens go through
+    an intra `Transformer` (depth x [PreNorm attention + residual, PreNorm feed-forward + residual], final LayerNorm);
+    the label token of each of the T samples is kept, the [B, T, d] result goes through a second, cross `Transformer`,
+    and the target's row feeds `fc`.  Same constructor, batch layout, head, loss, optimizer and C-ABI as RAT_m2; the
+    encoder is K2a (attention) + K2c (LayerNorm) + K2b with a separate residual (rat_ffn_fwd_res)."""
+
+    def __init__(self, feature_map, model_id="RAT_m1", **kwargs):
+        super().__init__(feature_map, model_id=model_id, **kwargs)
+
+    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
+        self.intra_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:71
+        self.cross_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:72
+
+    def _build_encoder_descriptors(self):
+        self._stacks = {}
+        for t in ("intra_transformer", "cross_transformer"):
+            layers = []
+            for i in range(self._cfg["depth"]):
+                p = "%s.layers.%d." % (t, i)
+                layers.append(dict(attn=self._attn_descriptor(p + "0."), ln=[p + "1.norm.weight", p + "1.norm.bias"],
+                                   ffn=[p + "1.fn.net.0.weight", p + "1.fn.net.0.bias", p + "1.fn.net.3.weight", p + "1.fn.net.3.bias"]))
+            self._stacks[t] = (layers, [t + ".norm.weight", t + ".norm.bias"])
+
+    def _stack_forward(self, which, x, smap, ntok, cls_stride, ncls, save, saved):
+        """One Transformer (RAT_m1.py:205-209) on `ntok` tokens; the final LayerNorm is applied to token 0 of every
+        sequence only (the sole rows read afterwards, RAT_m1.py:125,128) -> [ncls, d]."""
+        c, lib = self._cfg, self._lib
+        d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
+        layers, norm = self._stacks[which]
+        rec = []
+        for lay in layers:
+            xa, o, l = ops.attn_fwd(x, lay["attn"][1], smap, d, heads, dh, save=save, lib=lib)        # attn(norm(x)) + x
+            xn = ops.layernorm_fwd(xa, d, ntok, self._p(lay["ln"][0]), self._p(lay["ln"][1]), d, lib=lib)
+            w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
+            xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, lib=lib)                               # ff(norm(x)) + x
+            if save:
+                rec.append((x, o, l, xa, xn))
+            x = xb
+        out = ops.layernorm_fwd(x, cls_stride, ncls, self._p(norm[0]), self._p(norm[1]), d, lib=lib)
+        if save:
+            saved[which] = (rec, x)
+        return out
+
+    def _stack_backward(self, which, saved, dcls, smap, cls_stride, shape, G):
+        c, lib = self._cfg, self._lib
+        d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
+        layers, norm = self._stacks[which]
+        rec, x_last = saved[which]
+        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
+        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
+        dx = torch.zeros(shape, dtype=torch.float32, device=dcls.device)          # only the class-token rows get a gradient
+        ops.layernorm_bwd(x_last, cls_stride, dcls, self._p(norm[0]), dx, cls_stride, G(norm[0]), G(norm[1]), d, lib=lib)
+        for lay, (x_in, o, l, xa, xn) in zip(reversed(layers), reversed(rec)):
+            w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
+            gw = [G(n) for n in lay["ffn"]]
+            dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn, lib=lib)
+            dxa = ops.layernorm_bwd(xa, d, dxn, self._p(lay["ln"][0]), dxn, d, G(lay["ln"][0]), G(lay["ln"][1]), d, add=dx, lib=lib)
+            names, params = lay["attn"]
+            grads = ops.attn_params(*[G(n) if n else None for n in names])
+            dx, _ = ops.attn_bwd(x_in, dxa, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+        return dx
+
+    def _encoder_forward(self, x, x0, dims, save, saved):
+        B, T, L, S = dims
+        d = self._cfg["d"]
+        xi = self._stack_forward("intra_transformer", x, ops.intra_map(B, T, S), B * T * S, S * d, B * T, save, saved)
+        xc = self._stack_forward("cross_transformer", xi, ops.intra_map(B, 1, T), B * T, T * d, B, save, saved)
+        return xc, d
+
+    def _encoder_backward(self, saved, dx, G):
+        B, T, L, S = saved["dims"]
+        d = self._cfg["d"]
+        dxi = self._stack_backward("cross_transformer", saved, dx, ops.intra_map(B, 1, T), T * d, (B, T, d), G)
+        return self._stack_backward("intra_transformer", saved, dxi, ops.intra_map(B, T, S), S * d, (B, T, S, d), G)

@@ -140,6 +140,51 @@ def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None
     return dx, workspace
 
 
+def ffn_fwd_res(x, res, w1, b1, w2, b2, d, hidden, out=None, lib=None):
+    """y = FFN(x) + res (res None: no residual) — rat_ffn_fwd_res."""
+    lib = lib or get_lib()
+    _chk(x, name="x")
+    if res is not None:
+        _chk(res, name="res")
+    y = out if out is not None else torch.empty_like(x)
+    lib.call("rat_ffn_fwd_res", _p(x), _p(res), _p(y), _p(w1), _p(b1), _p(w2), _p(b2), x.numel() // d, d, hidden, _stream(x))
+    return y
+
+
+def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, lib=None):
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy, name="dy")
+    need = lib.size("rat_ffn_bwd_workspace", d, hidden)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    lib.call("rat_ffn_bwd_res", _p(x), _p(dy), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2), _p(db2),
+             _p(workspace), workspace.numel() * 4, x.numel() // d, d, hidden, int(bool(add_dy)), _stream(x))
+    return dx, workspace
+
+
+# ----------------------------------------------------------------------------- K2c
+def layernorm_fwd(x, x_stride, nrows, gamma, beta, d, eps=1e-5, lib=None):
+    """LayerNorm of rows x[r * x_stride : r * x_stride + d] -> compact [nrows, d]."""
+    lib = lib or get_lib()
+    _chk(x, name="x")
+    y = torch.empty((nrows, d), dtype=torch.float32, device=x.device)
+    lib.call("rat_layernorm_fwd", _p(x), int(x_stride), _p(y), _p(gamma), _p(beta), int(nrows), d, float(eps), _stream(x))
+    return y
+
+
+def layernorm_bwd(x, x_stride, dy, gamma, dx, dx_stride, dgamma, dbeta, d, add=None, eps=1e-5, lib=None):
+    """dx rows (stride dx_stride) = [add +] LN-backward(dy); dgamma / dbeta overwritten."""
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy, name="dy"), _chk(dx, name="dx")
+    nrows = dy.numel() // d
+    need = lib.size("rat_layernorm_bwd_workspace", nrows, d)
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    lib.call("rat_layernorm_bwd", _p(x), int(x_stride), _p(dy), _p(gamma), _p(add), _p(dx), int(dx_stride), _p(dgamma),
+             _p(dbeta), _p(ws), ws.numel() * 4, int(nrows), d, float(eps), _stream(x))
+    return dx
+
+
 # ----------------------------------------------------------------------------- K3
 def sgemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, beta=0.0, lib=None):
     lib = lib or get_lib()
