@@ -1,7 +1,7 @@
 """Drop-in wiring for code written against the reference's package names.
 
-``install()`` makes ``fuxictr.pytorch.models.RAT_m2`` resolve to the HIP-backed plugin:
-  * if the real FuxiCTR fork is importable it only swaps that one attribute (every other model stays the reference's);
+``install()`` makes ``fuxictr.pytorch.models.RAT_m2`` (and ``RAT_m1``) resolve to the HIP-backed plugins:
+  * if the real FuxiCTR fork is importable it only swaps those attributes (every other model stays the reference's);
   * otherwise it registers a minimal ``fuxictr`` namespace (version 1.2.3, ``fuxictr.pytorch.models``,
     ``fuxictr.pytorch.torch_utils.seed_everything``, ``fuxictr.features.FeatureMap``, ``fuxictr.utils``) backed by
     this package, which is all the reference's ``run_expid.py`` touches on the RAT_m2 path."""
@@ -14,6 +14,7 @@ def install():
     try:
         import fuxictr.pytorch.models as ref_models          # the real fork, if present
         ref_models.RAT_m2 = models.RAT_m2
+        ref_models.RAT_m1 = models.RAT_m1
         return "patched"
     except Exception:
         pass
