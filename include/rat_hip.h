@@ -101,6 +101,20 @@ int rat_attn_bwd(const float* x, const float* dy, const float* o_save, const flo
                  size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
                  float ln_eps, void* stream);
 
+/* The same kernels with the three constants of `PreNorm(Attention)(x) + x` exposed — RAT_m3's block (RAT_m3.py:164-243) runs two
+ * attentions on the same input and averages them, with heads/2 heads of width 2*dim_head but the softmax scale of dim_head:
+ *   y = out_scale * to_out(softmax(Q K^T * softmax_scale) V) + res
+ * res: residual source — x (rat_attn_fwd), y itself (accumulate onto the first attention's result), or NULL;
+ * softmax_scale <= 0 selects dim_head^-0.5.  Backward: the gradient through the projection is out_scale * dy and
+ * dx = add + LayerNorm-backward(...), add = dy (rat_attn_bwd), another tensor laid out like dx (may alias dx), or NULL. */
+int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
+                    const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
+                    float ln_eps, void* stream);
+int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save, float* dx,
+                    const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace, size_t workspace_bytes,
+                    const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
+                    float ln_eps, void* stream);
+
 /* ---- K2 (cont.): FeedForward + residual, y = W2 gelu_erf(W1 x + b1) + b2 + x (RAT_m2.py:163-174, 232) */
 int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                 int64_t ntok, int d, int hidden, void* stream);

@@ -68,7 +68,8 @@ class Config:
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
     ln_eps: float = 1e-5
-    variant: str = "m2"       # "m2": cross/intra encoder blocks (RAT_m2.py); "m1": cascaded transformers (RAT_m1.py)
+    variant: str = "m2"       # "m2": cross/intra encoder blocks (RAT_m2.py); "m1": cascaded transformers (RAT_m1.py);
+                              # "m3": parallel intra/cross attention with a shared query projection, mean fusion (RAT_m3.py)
 
     @property
     def num_fields(self) -> int:
@@ -143,6 +144,20 @@ def parameter_shapes(cfg: Config) -> "OrderedDict[str, Tuple[int, ...]]":
                 mlp_shapes(t + "layers.%d.1.fn.net." % i)
             shapes[t + "norm.weight"] = (d,)
             shapes[t + "norm.bias"] = (d,)
+    elif cfg.variant == "m3":
+        # CrossIntraEncoderBlock of RAT_m3 (RAT_m3.py:196-213): five bias-free projections owned by the block (W_q is shared
+        # by both attentions), then intra_attention BEFORE cross_attention (each: norm + to_out), then the MLP
+        for i in range(cfg.depth):
+            p = "encoder.encoder.%d." % i
+            for name in ("W_q", "W_k_s", "W_v_s", "W_k_t", "W_v_t"):
+                shapes[p + name + ".weight"] = (inner, d)
+            for which in ("intra_attention.", "cross_attention."):
+                shapes[p + which + "norm.weight"] = (d,)
+                shapes[p + which + "norm.bias"] = (d,)
+                if not (cfg.num_heads == 1 and cfg.dim_head == d):
+                    shapes[p + which + "fn.to_out.0.weight"] = (d, inner)
+                    shapes[p + which + "fn.to_out.0.bias"] = (d,)
+            mlp_shapes(p + "mlp.net.")
     else:
         for i in range(cfg.depth):
             for which in ("cross_attention", "intra_attention"):
@@ -231,17 +246,21 @@ def gelu_erf(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
-def attention(x: Tensor, w: Dict[str, Tensor], prefix: str, cfg: Config) -> Tensor:
-    """PreNorm(Attention) (RAT_m2.py:155-161,176-202) on x: [N, L, d] -> [N, L, d] (no residual)."""
-    h, dh = cfg.num_heads, cfg.dim_head
+def attention(x: Tensor, w: Dict[str, Tensor], prefix: str, cfg: Config, w_qkv: Optional[Tensor] = None,
+              heads: Optional[int] = None, dim_head: Optional[int] = None, scale: Optional[float] = None) -> Tensor:
+    """PreNorm(Attention) (RAT_m2.py:155-161,176-202) on x: [N, L, d] -> [N, L, d] (no residual).
+    The optional arguments serve RAT_m3 (RAT_m3.py:164-189): separate W_q / W_k / W_v Linear layers (passed stacked as
+    ``w_qkv``), heads/2 heads of twice the width, and the softmax scale of the CONFIGURED dim_head."""
+    h, dh = heads or cfg.num_heads, dim_head or cfg.dim_head
+    scale = dh ** -0.5 if scale is None else scale
     n, l, _ = x.shape
     xn = layer_norm(x, w[prefix + "norm.weight"], w[prefix + "norm.bias"], cfg.ln_eps)
-    qkv = xn @ w[prefix + "fn.to_qkv.weight"].t()                      # [N, L, 3*h*dh]
+    qkv = xn @ (w[prefix + "fn.to_qkv.weight"] if w_qkv is None else w_qkv).t()   # [N, L, 3*h*dh]
     q, k, v = qkv.split(h * dh, dim=-1)
     q = q.reshape(n, l, h, dh).permute(0, 2, 1, 3)                     # [N, h, L, dh]
     k = k.reshape(n, l, h, dh).permute(0, 2, 1, 3)
     v = v.reshape(n, l, h, dh).permute(0, 2, 1, 3)
-    scores = (q @ k.transpose(-1, -2)) * (dh ** -0.5)
+    scores = (q @ k.transpose(-1, -2)) * scale
     scores = scores - scores.max(dim=-1, keepdim=True).values
     p = torch.exp(scores)
     p = p / p.sum(dim=-1, keepdim=True)
@@ -267,6 +286,41 @@ def encoder_block(x: Tensor, w: Dict[str, Tensor], i: int, cfg: Config) -> Tenso
     xc = attention(xc, w, p + "cross_attention.", cfg) + xc            # over the T samples
     xc = feed_forward(xc, w, p + "mlp.net.") + xc                      # no norm before the MLP
     return xc.reshape(b, s, t, d).transpose(1, 2)
+
+
+def m3_state_aliases(cfg: Config) -> "OrderedDict[str, str]":
+    """state_dict-only names of RAT_m3: the shared projection modules are also registered inside both Attention modules
+    (RAT_m3.py:168-170,204-209), so ``state_dict()`` lists them again under those paths.  alias -> owning parameter, in
+    state_dict order (``load_state_dict`` copies in that order, so the LAST alias of a tensor decides its loaded value)."""
+    out: "OrderedDict[str, str]" = OrderedDict()
+    for i in range(cfg.depth):
+        p = "encoder.encoder.%d." % i
+        for which, (k, v) in (("intra_attention.", ("W_k_s", "W_v_s")), ("cross_attention.", ("W_k_t", "W_v_t"))):
+            out[p + which + "fn.W_q.weight"] = p + "W_q.weight"
+            out[p + which + "fn.W_k.weight"] = p + k + ".weight"
+            out[p + which + "fn.W_v.weight"] = p + v + ".weight"
+    return out
+
+
+def encoder_block_m3(x: Tensor, w: Dict[str, Tensor], i: int, cfg: Config) -> Tensor:
+    """CrossIntraEncoderBlock.forward of RAT_m3 (RAT_m3.py:215-243): intra and cross attention both read the block INPUT
+    (no residual of their own), share W_q, use heads/2 heads of width 2*dim_head with the softmax scale dim_head^-0.5
+    (RAT_m3.py:172-189); their mean goes through the MLP, whose residual is the block input."""
+    b, t, s, d = x.shape
+    p = "encoder.encoder.%d." % i
+    h = int(cfg.num_heads / 2)
+    dh = cfg.inner_dim // h
+    scale = cfg.dim_head ** -0.5
+    wq = w[p + "W_q.weight"]
+    w_s = torch.cat([wq, w[p + "W_k_s.weight"], w[p + "W_v_s.weight"]], dim=0)
+    w_t = torch.cat([wq, w[p + "W_k_t.weight"], w[p + "W_v_t.weight"]], dim=0)
+    out_s = attention(x.reshape(b * t, s, d), w, p + "intra_attention.", cfg, w_qkv=w_s, heads=h, dim_head=dh, scale=scale)
+    out_s = out_s.reshape(b, t, s, d)
+    xc = x.transpose(1, 2).reshape(b * s, t, d)
+    out_t = attention(xc, w, p + "cross_attention.", cfg, w_qkv=w_t, heads=h, dim_head=dh, scale=scale)
+    out_t = out_t.reshape(b, s, t, d).transpose(1, 2)
+    out = torch.cat((out_s.unsqueeze(1), out_t.unsqueeze(1)), dim=1).mean(dim=1)
+    return feed_forward(out, w, p + "mlp.net.") + x
 
 
 def transformer(x: Tensor, w: Dict[str, Tensor], prefix: str, cfg: Config) -> Tensor:
@@ -345,7 +399,7 @@ def forward(w: Dict[str, Tensor], X: Tensor, y: Tensor, cfg: Config, training: b
     else:
         x = grid
         for i in range(cfg.depth):
-            x = encoder_block(x, w, i, cfg)
+            x = encoder_block_m3(x, w, i, cfg) if cfg.variant == "m3" else encoder_block(x, w, i, cfg)
         cls = x[:, 0, 0]                                                # target sample, label token
     logit = cls @ w["fc.weight"].t() + w["fc.bias"]
     if cfg.dnn_hidden_units:

@@ -72,6 +72,22 @@ CASES += [
          batch_norm=False, use_wide=False, embedding_regularizer=0, net_regularizer=0),
 ]
 
+# RAT_m3 (parallel intra / cross attention sharing W_q, heads/2 heads of width 2*dim_head, mean fusion — RAT_m3.py)
+CASES += [
+    dict(name="m3_tiny_seq", model="RAT_m3", batch=6, topk=3, init_seed=2021, data_seed=101, weight_seed=102, full_limit=1 << 20,
+         fields=[_cat("a", 7), _cat("b", 5), _seq("c", 6), _cat("e", 9, padding_idx=8)],
+         embedding_dim=8, num_heads=2, dim_head=4, depth=2, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="m3_northstar_shape", model="RAT_m3", batch=3, topk=10, init_seed=2021, data_seed=111, weight_seed=112, full_limit=1024,
+         fields=[_cat("c%02d" % i, 37) for i in range(20)],
+         embedding_dim=64, num_heads=8, dim_head=10, depth=1, scale_dim=2, dnn_hidden_units=[16, 16],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.0005, net_regularizer=0),
+    dict(name="m3_mltag_shape", model="RAT_m3", batch=8, topk=5, init_seed=2021, data_seed=121, weight_seed=122, full_limit=4096,
+         fields=[_cat("user_id", 50), _cat("item_id", 40), _cat("tag_id", 30)],
+         embedding_dim=10, num_heads=2, dim_head=10, depth=2, scale_dim=4, dnn_hidden_units=[32, 16],
+         batch_norm=False, use_wide=True, embedding_regularizer=0.03, net_regularizer=0),
+]
+
 # The three shipped experiments (exps/RAT_m2/*/*.log "Total number of parameters").
 KNOWN_COUNT_CASES = [
     dict(name="count_mltag", expected_params=1337241, topk=5,

@@ -118,6 +118,56 @@ def check_attn(lib, dev, case, mode, seed=2):
             close(g, w.grad, 1e-4, 1e-4 * scale, name)
 
 
+def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed=5):
+    """rat_attn_fwd_ex / rat_attn_bwd_ex: y = out_scale * attention(LN(x)) + res with res in {none, a second tensor, the output
+    itself}, an explicit softmax scale; backward with the matching `add` term."""
+    B, T, S, d, heads, dh, proj = case
+    rs = np.random.RandomState(seed)
+    x = rnd(rs, B, T, S, d)
+    other = rnd(rs, B, T, S, d)
+    ws = attn_weights(rs, d, heads, dh, proj)
+    dy = rnd(rs, B, T, S, d)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) if w is not None else None for w in ws]
+    w = {"p.norm.weight": wr[0], "p.norm.bias": wr[1], "p.fn.to_qkv.weight": wr[2]}
+    if proj:
+        w["p.fn.to_out.0.weight"], w["p.fn.to_out.0.bias"] = wr[3], wr[4]
+    cfg = orc.Config(fields=[], embedding_dim=d, num_heads=heads, dim_head=dh)
+    if mode == "intra":
+        att = orc.attention(xr.reshape(B * T, S, d), w, "p.", cfg, scale=softmax_scale).reshape(B, T, S, d)
+    else:
+        att = orc.attention(xr.transpose(1, 2).reshape(B * S, T, d), w, "p.", cfg, scale=softmax_scale).reshape(B, S, T, d).transpose(1, 2)
+    ref = out_scale * att + (other.double() if res_mode != "none" else 0.0)
+    ref.backward(dy.double())
+    xd, dyd, od = x.to(dev), dy.to(dev), other.to(dev)
+    wd = [t.to(dev) if t is not None else None for t in ws]
+    params = ops.attn_params(*wd)
+    smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
+    if res_mode == "acc":                                   # accumulate onto a tensor that already holds `other`
+        y = od.clone()
+        y, o_save, lse = ops.attn_fwd_ex(xd, y, params, smap, d, heads, dh, softmax_scale or 0.0, out_scale, save=True, out=y, lib=lib)
+    else:
+        y, o_save, lse = ops.attn_fwd_ex(xd, od if res_mode == "other" else None, params, smap, d, heads, dh, softmax_scale or 0.0,
+                                         out_scale, save=True, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    gs = [torch.zeros_like(t) if t is not None else None for t in wd]
+    grads = ops.attn_params(*gs)
+    add = rnd(rs, B, T, S, d)
+    if res_mode == "none":
+        dx, _ = ops.attn_bwd_ex(xd, dyd, None, o_save, lse, params, grads, smap, d, heads, dh, softmax_scale or 0.0, out_scale, lib=lib)
+        want = xr.grad
+    else:                                                   # dx = add + ..., written in place over `add`
+        buf = add.clone().to(dev)             # .to("cpu") would alias `add`, which the in-place kernel overwrites
+        dx, _ = ops.attn_bwd_ex(xd, dyd, buf, o_save, lse, params, grads, smap, d, heads, dh, softmax_scale or 0.0, out_scale,
+                                out=buf, lib=lib)
+        want = xr.grad + add.double()
+    scale = max(1.0, (B * T * S) ** 0.5 / 4)
+    close(dx, want, 1e-4, 1e-4, "dx")
+    for name, g, wt in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, wr):
+        if wt is not None:
+            close(g, wt.grad, 1e-4, 1e-4 * scale, name)
+
+
 def check_ffn(lib, dev, ntok, d, hidden):
     rs = np.random.RandomState(3)
     x = rnd(rs, ntok, d)

@@ -52,6 +52,20 @@ def test_attn_fwd_bwd(emu, case, mode):
     kc.check_attn(emu, "cpu", case, mode)
 
 
+ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
+    ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
+    ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),
+    ((1, 2, 3, 64, 4, 20, True), "intra", "none", 0.5, 10 ** -0.5),       # RAT_m3 at the north-star widths: fast <64, 20>
+    ((1, 2, 3, 64, 4, 20, True), "cross", "acc", 0.5, 10 ** -0.5),
+    ((1, 3, 4, 16, 4, 20, True), "cross", "other", 1.0, None),            # generic geometry, compile-time dim_head 20
+]
+
+
+@pytest.mark.parametrize("case,mode,res_mode,out_scale,softmax_scale", ATTN_EX_CASES, ids=str)
+def test_attn_ex_fwd_bwd(emu, case, mode, res_mode, out_scale, softmax_scale):
+    kc.check_attn_ex(emu, "cpu", case, mode, res_mode, out_scale, softmax_scale)
+
+
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (77, 64, 128), (45, 16, 32)])
 def test_ffn_fwd_bwd(emu, ntok, d, hidden):
     kc.check_ffn(emu, "cpu", ntok, d, hidden)

@@ -43,6 +43,21 @@ def test_attn_fwd_bwd(lib, case, mode):
     kc.check_attn(lib, "cuda", case, mode)
 
 
+ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
+    ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
+    ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),
+    ((3, 11, 21, 64, 4, 20, True), "intra", "none", 0.5, 10 ** -0.5),     # RAT_m3 at the north-star shape: fast <64, 20>
+    ((3, 11, 21, 64, 4, 20, True), "cross", "acc", 0.5, 10 ** -0.5),
+    ((5, 6, 14, 40, 4, 20, True), "cross", "other", 1.0, None),           # generic geometry, compile-time dim_head 20
+    ((300, 6, 4, 10, 2, 10, True), "intra", "other", 0.25, 0.3),
+]
+
+
+@pytest.mark.parametrize("case,mode,res_mode,out_scale,softmax_scale", ATTN_EX_CASES, ids=str)
+def test_attn_ex_fwd_bwd(lib, case, mode, res_mode, out_scale, softmax_scale):
+    kc.check_attn_ex(lib, "cuda", case, mode, res_mode, out_scale, softmax_scale)
+
+
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (100000, 64, 128), (5000, 40, 80)])
 def test_ffn_fwd_bwd(lib, ntok, d, hidden):
     kc.check_ffn(lib, "cuda", ntok, d, hidden)

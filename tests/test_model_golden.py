@@ -24,18 +24,18 @@ def emu_lib():
     L._default = old
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m1_bare"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
 def test_init_matches_reference_bit_for_bit(name):
     mc.check_init(name, gpu=-1)
 
 
 # the emulator runs one OS thread per GPU thread: keep the CPU suite to the small cases (the GPU suite runs them all)
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "tmall_shape", "m1_tiny_seq", "m1_bare"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "tmall_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
 def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m1_bare"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
 def test_two_training_steps(name):
     mc.check_training(name, gpu=-1)
 

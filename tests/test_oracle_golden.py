@@ -18,14 +18,19 @@ def oracle_config(case):
                       dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=case["batch_norm"],
                       use_wide=case["use_wide"], embedding_regularizer=float(case["embedding_regularizer"] or 0.0),
                       net_regularizer=float(case["net_regularizer"] or 0.0),
-                      variant={"RAT_m2": "m2", "RAT_m1": "m1"}[case.get("model", "RAT_m2")])
+                      variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3"}[case.get("model", "RAT_m2")])
 
 
 def state_shapes(cfg):
     """Full state_dict shapes = trainable tensors + BatchNorm buffers, in registration order."""
     shapes = {}
+    aliases = orc.m3_state_aliases(cfg) if cfg.variant == "m3" else {}
     for k, s in orc.parameter_shapes(cfg).items():
         shapes[k] = s
+        if aliases and k.endswith("_attention.norm.bias"):      # RAT_m3: the shared projections reappear inside Attention
+            for alias, owner in aliases.items():
+                if alias.startswith(k[:-len("norm.bias")]):
+                    shapes[alias] = orc.parameter_shapes(cfg)[owner]
         if cfg.batch_norm and k.startswith("dnn.dnn.") and k.endswith(".bias") and len(s) == 1:
             pos = int(k.split(".")[2])
             layers, _ = orc.dnn_layout(cfg)
@@ -49,6 +54,9 @@ def load_case(name):
     cfg = oracle_config(case)
     gold = np.load(os.path.join(GOLD, name + ".npz"))
     w = {k: torch.from_numpy(np.asarray(v)) for k, v in gc.make_weights(case, state_shapes(cfg)).items()}
+    if cfg.variant == "m3":                                      # load_state_dict semantics: the last alias of a tensor wins
+        for alias, owner in orc.m3_state_aliases(cfg).items():
+            w[owner] = w.pop(alias)
     X, y, _, _ = gc.make_inputs(case)
     return case, cfg, gold, w, torch.from_numpy(X), torch.from_numpy(y)
 

@@ -36,13 +36,18 @@ constexpr int ATT_MT = ATT_ROWS / 16;
 constexpr int DH_MAX = 16;        // dim_head <= 16 (every shipped config uses 10)
 constexpr int QSLOTS = 8;         // persistent dW_qkv tiles per wave  (3I16/16 * D16/16 <= 64)
 constexpr int OSLOTS = 4;         // persistent dW_out tiles per wave  (D16/16 * I16/16 <= 32)
-constexpr int FAST_HEADS = 8;     // the compiled fast shapes fix heads = 8 (x dim_head = 10): the whole LDS geometry is then compile-time
+constexpr int FAST_INNER = 80;    // the compiled fast shapes fix heads x dim_head = 8 x 10 (or 4 x 20, RAT_m3): the whole LDS geometry is compile-time
+constexpr int fast_heads(int tdh) { return tdh > 0 ? FAST_INNER / tdh : 0; }
 constexpr int CORE_UNROLL = 3;    // keys (queries) per trip of the VALU attention-core loops
 
 struct AttnArgs {
     const float* x;
     const float* dy;
     float* y;            // forward output / backward dx
+    const float* res;    // forward: residual source (x for PreNorm(Attention) + x; y itself to accumulate; nullptr: none)
+    const float* add;    // backward: gradient added to the LayerNorm-backward result (dy for the residual; nullptr: none)
+    int add_lds;         // backward: add == dy and out_scale == 1 -> the residual gradient is the dy tile already in LDS
+    float out_scale;     // y = out_scale * to_out(...) + res   (RAT_m3's mean of two attentions: 0.5)
     float* o_save;
     float* lse_save;
     const float* ln_g;
@@ -99,7 +104,7 @@ __device__ __forceinline__ void map_rows(const AttnArgs& a, int64_t chunk, int64
 
 // load `width` floats per row from a token-indexed global array into an LDS tile (padding rows -> 0)
 __device__ __forceinline__ void load_rows(float* tile, int ld, const float* src, const int64_t* rowtok, int width,
-                                          bool vec) {
+                                          bool vec, float mul = 1.0f) {
     if (vec) {
         const int w4 = width >> 2;
         for (int e = threadIdx.x; e < ATT_ROWS * w4; e += ATT_THREADS) {
@@ -107,13 +112,14 @@ __device__ __forceinline__ void load_rows(float* tile, int ld, const float* src,
             const int64_t tok = rowtok[r];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (tok >= 0) v = *reinterpret_cast<const float4*>(src + tok * width + 4 * c4);
+            if (mul != 1.0f) { v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul; }
             *reinterpret_cast<float4*>(tile + (size_t)r * ld + 4 * c4) = v;
         }
     } else {
         for (int e = threadIdx.x; e < ATT_ROWS * width; e += ATT_THREADS) {
             const int r = e / width, c = e - r * width;
             const int64_t tok = rowtok[r];
-            tile[(size_t)r * ld + c] = tok >= 0 ? src[tok * width + c] : 0.f;
+            tile[(size_t)r * ld + c] = tok >= 0 ? src[tok * width + c] * mul : 0.f;
         }
     }
 }
@@ -193,23 +199,28 @@ __device__ __forceinline__ void layer_norm_rows(float* xs, int ld, int D, int ro
 }
 
 // tile[rows][0:width] (+ residual rows of `res`, token-indexed) -> dst rows, 16-byte coalesced when vec
+// dst = mul * tile + res (res may be nullptr, or dst itself: every element is read and written by the same thread)
 __device__ __forceinline__ void store_rows_residual(float* dst, const float* tile, int ld, const float* res,
-                                                    const int64_t* rowtok, int rows, int width, bool vec) {
+                                                    const int64_t* rowtok, int rows, int width, bool vec, float mul) {
     if (vec) {
         const int w4 = width >> 2;
         for (int e = threadIdx.x; e < rows * w4; e += ATT_THREADS) {
             const int r = e / w4, c4 = e - r * w4;
             const int64_t tok = rowtok[r];
             float4 v = *reinterpret_cast<const float4*>(tile + (size_t)r * ld + 4 * c4);
-            const float4 x = *reinterpret_cast<const float4*>(res + tok * width + 4 * c4);
-            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            if (mul != 1.0f) { v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul; }
+            if (res != nullptr) {
+                const float4 x = *reinterpret_cast<const float4*>(res + tok * width + 4 * c4);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
             *reinterpret_cast<float4*>(dst + tok * width + 4 * c4) = v;
         }
     } else {
         for (int e = threadIdx.x; e < rows * width; e += ATT_THREADS) {
             const int r = e / width, c = e - r * width;
             const int64_t tok = rowtok[r];
-            dst[tok * width + c] = tile[(size_t)r * ld + c] + res[tok * width + c];
+            const float v = tile[(size_t)r * ld + c] * mul;
+            dst[tok * width + c] = res != nullptr ? v + res[tok * width + c] : v;
         }
     }
 }
@@ -284,8 +295,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
     constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
     RAT_DYN_SMEM(smem);
-    const int heads_c = FAST ? FAST_HEADS : a.heads;
-    const AttnGeom g(FAST ? TD : a.d, heads_c, FAST && TDH > 0 ? TDH : a.dh);
+    const int heads_c = FAST ? fast_heads(TDH) : a.heads;
+    const AttnGeom g(FAST ? TD : a.d, heads_c, TDH > 0 ? TDH : a.dh);
     float* xs = reinterpret_cast<float*>(smem);
     float* qkv = xs + (size_t)ATT_ROWS * g.ldx;
     int64_t* rowtok = reinterpret_cast<int64_t*>(qkv + (size_t)ATT_ROWS * g.ldq);
@@ -419,9 +430,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
                 }
             });
             __syncthreads();
-            store_rows_residual(a.y, xs, ldx, a.x, rowtok, rows, D, FAST || a.vec_x != 0);
+            store_rows_residual(a.y, xs, ldx, a.res, rowtok, rows, D, FAST || a.vec_x != 0, a.out_scale);
         } else {
-            store_rows_residual(a.y, qkv, ldq, a.x, rowtok, rows, D, FAST || a.vec_x != 0);
+            store_rows_residual(a.y, qkv, ldq, a.res, rowtok, rows, D, FAST || a.vec_x != 0, a.out_scale);
         }
         __syncthreads();
 #ifndef RAT_EMU
@@ -438,8 +449,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
     constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
     RAT_DYN_SMEM(smem);
-    const AttnGeom g(FAST ? TD : a.d, FAST ? FAST_HEADS : a.heads, FAST && TDH > 0 ? TDH : a.dh);
-    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = FAST ? FAST_HEADS : a.heads;
+    const AttnGeom g(FAST ? TD : a.d, FAST ? fast_heads(TDH) : a.heads, TDH > 0 ? TDH : a.dh);
+    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = FAST ? fast_heads(TDH) : a.heads;
     const int ldx = g.ldx, ldq = g.ldq, ldt = g.ldt;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx]  LayerNorm(x)
     float* dys = xs + (size_t)ATT_ROWS * ldx;                   // [64][ldx]  dL/dy
@@ -492,7 +503,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         }
         RAT_PROF_MARK(0);
         load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
-        load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0);
+        load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0, a.out_scale);
         load_rows(ob, ldt, a.o_save, rowtok, I, FAST || ((I % 4) == 0 && a.vec_x != 0));
         for (int e = threadIdx.x; e < ATT_ROWS * H; e += ATT_THREADS) {
             const int64_t tok = rowtok[e / H];
@@ -684,8 +695,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             const bool valid = r < rows;
             const int64_t tok = valid ? rowtok[r] : 0;
             const float mean = mu[r], rstd = rs[r];
-            float xh[COLS], gg[COLS], out[COLS];
+            float xh[COLS], gg[COLS], out[COLS], ad[COLS];
             float s1 = 0.f, s2 = 0.f;
+            // the gradient added to the LayerNorm-backward result: the dy tile (PreNorm(Attention) + x), another tensor, or nothing
+#pragma unroll
+            for (int k = 0; k < COLS; ++k) {
+                const int c = c0 + k;
+                const bool in = (FAST || c < D) && valid;
+                if (a.add_lds) ad[k] = in ? dys[(size_t)r * ldx + c] : 0.f;
+                else ad[k] = (in && a.add != nullptr) ? a.add[tok * D + c] : 0.f;
+            }
             if (FAST && COLS % 4 == 0) {
 #pragma unroll
                 for (int k = 0; k < COLS; k += 4) {
@@ -724,7 +743,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 const int c = c0 + k;
                 const bool on = (FAST || c < D) && valid;
                 const float gw = on ? gg[k] * a.ln_g[c] : 0.f;
-                out[k] = on ? dys[(size_t)r * ldx + c] + rstd * (gw - s1 - xh[k] * s2) : 0.f;
+                out[k] = on ? ad[k] + rstd * (gw - s1 - xh[k] * s2) : 0.f;
                 dgam[k] += gg[k] * xh[k];
                 dbet[k] += gg[k];
             }
@@ -826,7 +845,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
 int check_dims(const RatSeqMap* map, int d, int heads, int dim_head, bool backward) {
     RAT_REQUIRE(map != nullptr, "null seq map");
     RAT_REQUIRE(d > 0 && heads > 0 && dim_head > 0, "bad dims");
-    RAT_REQUIRE(dim_head <= DH_MAX, "dim_head > 16 is not supported by this kernel");
+    RAT_REQUIRE(dim_head <= DH_MAX || dim_head == 20, "dim_head > 16 (other than 20) is not supported by this kernel");
     RAT_REQUIRE(d <= 128, "embedding_dim > 128 is not supported by this kernel");
     RAT_REQUIRE(map->L >= 1 && map->L <= ATT_ROWS, "sequence length (K+1 or F+1) must be in [1, 64]");
     RAT_REQUIRE(map->nseq >= 1 && map->q_div >= 1, "bad seq map");
@@ -864,6 +883,7 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
     a.dh = dim_head;
     a.eps = ln_eps;
     a.scale = 1.0f / sqrtf((float)dim_head);
+    a.out_scale = 1.0f;
     const int I = heads * dim_head;
     a.vec_wqkv = (d % 4 == 0) && aligned16(w->w_qkv);
     a.vec_wout = (I % 4 == 0) && aligned16(w->w_out);
@@ -872,7 +892,7 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
 
 // which compiled fast shape (if any) serves these dimensions
 int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
-    if (a.dh != 10 || a.heads != FAST_HEADS || a.w_out == nullptr) return 0;
+    if (!((a.dh == 10 || a.dh == 20) && a.heads == fast_heads(a.dh)) || a.w_out == nullptr) return 0;
     for (const void* p : ptrs)
         if (p != nullptr && !aligned16(p)) return 0;
     if (!aligned16(a.w_qkv) || !aligned16(a.w_out)) return 0;
@@ -883,25 +903,35 @@ int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
 
 extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                             const RatSeqMap* map_host, int d, int heads, int dim_head, float ln_eps, void* stream) {
+    return rat_attn_fwd_ex(x, x, y, o_save, lse_save, w_host, map_host, d, heads, dim_head, 0.f, 1.f, ln_eps, stream);
+}
+
+extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save,
+                               const RatAttnParams* w_host, const RatSeqMap* map_host, int d, int heads, int dim_head,
+                               float softmax_scale, float out_scale, float ln_eps, void* stream) {
     if (check_dims(map_host, d, heads, dim_head, false)) return -1;
     RAT_REQUIRE(x && y && w_host && w_host->ln_g && w_host->ln_b && w_host->w_qkv, "null pointer");
     RAT_REQUIRE(w_host->w_out != nullptr || heads * dim_head == d, "missing w_out");
     AttnArgs a{};
     fill_common(a, w_host, map_host, d, heads, dim_head, ln_eps);
+    if (softmax_scale > 0.f) a.scale = softmax_scale;
+    a.out_scale = out_scale;
+    a.res = res;
     a.x = x;
     a.y = y;
     a.o_save = o_save;
     a.lse_save = lse_save;
-    a.vec_x = (d % 4 == 0) && aligned16(x);
+    a.vec_x = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(res);
     const AttnGeom g(d, heads, dim_head);
     const size_t smem = g.fwd_smem();
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
     const unsigned blocks = (unsigned)(a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu);
-    switch (fast_dim(a, {x, y, o_save, lse_save})) {
-        case 64: RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a); break;
-        case 16: RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a); break;
-        default: RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a); break;
-    }
+    const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
+    if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
+    else if (dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
+    else RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
     return rat_check_launch("rat_attn_fwd");
 }
 
@@ -914,12 +944,24 @@ extern "C" int rat_attn_bwd(const float* x, const float* dy, const float* o_save
                             const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace,
                             size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
                             float ln_eps, void* stream) {
+    return rat_attn_bwd_ex(x, dy, dy, o_save, lse_save, dx, w_host, grads_host, workspace, workspace_bytes, map_host, d, heads,
+                           dim_head, 0.f, 1.f, ln_eps, stream);
+}
+
+extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save,
+                               float* dx, const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace,
+                               size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
+                               float softmax_scale, float out_scale, float ln_eps, void* stream) {
     if (check_dims(map_host, d, heads, dim_head, true)) return -1;
     RAT_REQUIRE(x && dy && o_save && lse_save && dx && w_host && grads_host && workspace, "null pointer");
     RAT_REQUIRE(w_host->w_out != nullptr || heads * dim_head == d, "missing w_out");
     RAT_REQUIRE(workspace_bytes >= rat_attn_bwd_workspace(d, heads, dim_head), "workspace too small");
     AttnArgs a{};
     fill_common(a, w_host, map_host, d, heads, dim_head, ln_eps);
+    if (softmax_scale > 0.f) a.scale = softmax_scale;
+    a.out_scale = out_scale;
+    a.add = add;
+    a.add_lds = (add == dy && out_scale == 1.0f) ? 1 : 0;
     a.x = x;
     a.dy = dy;
     a.y = dx;
@@ -931,11 +973,12 @@ extern "C" int rat_attn_bwd(const float* x, const float* dy, const float* o_save
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
     const size_t smem = g.bwd_smem(heads);
-    switch (fast_dim(a, {x, dy, o_save, dx})) {
-        case 64: RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a); break;
-        case 16: RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a); break;
-        default: RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a); break;
-    }
+    const int fast = fast_dim(a, {x, dy, add, o_save, dx});
+    if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
+    else if (dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
+    else RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
     if (rat_check_launch("rat_attn_bwd")) return -1;
     const int D = d, I = heads * dim_head;
     float* outs[5] = {grads_host->w_qkv, grads_host->w_out, grads_host->b_out, grads_host->ln_g, grads_host->ln_b};

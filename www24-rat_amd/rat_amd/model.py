@@ -95,6 +95,42 @@ class _Encoder(nn.Module):
         self.encoder = nn.ModuleList([_Block(dim, heads, dim_head, dropout, hidden) for _ in range(depth)])
 
 
+class _AttentionM3(nn.Module):
+    """RAT_m3's Attention (RAT_m3.py:164-178): the three projections are modules OWNED BY THE BLOCK and only referenced here
+    (so state_dict lists them again under fn.W_q / fn.W_k / fn.W_v); the output projection is its own."""
+
+    def __init__(self, W_q, W_k, W_v, dim, inner_dim, heads, dim_head, dropout):
+        super().__init__()
+        self.inner_dim = inner_dim
+        project_out = not (heads == 1 and dim_head == dim)
+        self.W_q, self.W_k, self.W_v = W_q, W_k, W_v
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
+
+
+class _BlockM3(nn.Module):
+    """CrossIntraEncoderBlock of RAT_m3 (RAT_m3.py:191-213): registration order W_q, W_k_s, W_v_s, W_k_t, W_v_t,
+    intra_attention, cross_attention, mlp."""
+
+    def __init__(self, dim, heads, dim_head, dropout, hidden):
+        super().__init__()
+        self.inner_dim = heads * dim_head
+        self.W_q = nn.Linear(dim, self.inner_dim, bias=False)
+        self.W_k_s = nn.Linear(dim, self.inner_dim, bias=False)
+        self.W_v_s = nn.Linear(dim, self.inner_dim, bias=False)
+        self.W_k_t = nn.Linear(dim, self.inner_dim, bias=False)
+        self.W_v_t = nn.Linear(dim, self.inner_dim, bias=False)
+        self.intra_attention = _PreNorm(dim, _AttentionM3(self.W_q, self.W_k_s, self.W_v_s, dim, self.inner_dim, heads, dim_head, dropout))
+        self.cross_attention = _PreNorm(dim, _AttentionM3(self.W_q, self.W_k_t, self.W_v_t, dim, self.inner_dim, heads, dim_head, dropout))
+        self.mlp = _FeedForward(dim, hidden)
+
+
+class _EncoderM3(nn.Module):
+    def __init__(self, dim, heads, dim_head, dropout, depth, hidden):
+        super().__init__()
+        self.encoder = nn.ModuleList([_BlockM3(dim, heads, dim_head, dropout, hidden) for _ in range(depth)])
+
+
 class _Transformer(nn.Module):
     """RAT_m1's Transformer (RAT_m1.py:194-203): `layers` is registered before `norm`; layers[i] = [PreNorm(Attention),
     PreNorm(FeedForward)]."""
@@ -589,3 +625,98 @@ class RAT_m1(RAT_m2):
         d = self._cfg["d"]
         dxi = self._stack_backward("cross_transformer", saved, dx, ops.intra_map(B, 1, T), T * d, (B, T, d), G)
         return self._stack_backward("intra_transformer", saved, dxi, ops.intra_map(B, T, S), S * d, (B, T, S, d), G)
+
+
+class RAT_m3(RAT_m2):
+    """RAT_m3 (fuxictr/pytorch/models/RAT_m3.py:27-243): intra and cross attention run IN PARALLEL on the block input,
+    share the query projection, use heads/2 heads of width 2*dim_head (softmax scale still dim_head^-0.5), carry no
+    residual of their own; their mean goes through the MLP, whose residual is the block input.  On the HIP path:
+        out  = 0.5 * intra(x)                 rat_attn_fwd_ex(res = NULL,  out_scale = 0.5)
+        out += 0.5 * cross(x)                 rat_attn_fwd_ex(res = out,   out_scale = 0.5)   (same memory, strided sequences)
+        x'   = FFN(out) + x                   rat_ffn_fwd_res(x = out, res = x)
+    The stacked [W_q; W_k; W_v] operand of each attention is assembled per step from the block's five projections."""
+
+    def __init__(self, feature_map, model_id="RAT_m3", **kwargs):
+        super().__init__(feature_map, model_id=model_id, **kwargs)
+
+    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
+        if num_heads < 2:
+            raise ValueError("RAT_m3 splits the projections into num_heads/2 heads (RAT_m3.py:181): num_heads must be >= 2")
+        self.encoder = _EncoderM3(d, num_heads, dim_head, dropout, depth, hidden)
+
+    def _build_encoder_descriptors(self):
+        c = self._cfg
+        inner = c["heads"] * c["dh"]
+        self._m3_heads = int(c["heads"] / 2)
+        self._m3_dh = inner // self._m3_heads
+        self._m3_scale = float(c["dh"]) ** -0.5
+        self._blocks = []
+        for i in range(c["depth"]):
+            p = "encoder.encoder.%d." % i
+            blk = {"proj": [p + n + ".weight" for n in ("W_q", "W_k_s", "W_v_s", "W_k_t", "W_v_t")],
+                   "ffn": [p + "mlp.net.%s" % n for n in ("0.weight", "0.bias", "3.weight", "3.bias")]}
+            for which in ("intra", "cross"):
+                q = p + which + "_attention."
+                has_out = (q + "fn.to_out.0.weight") in self._params
+                blk[which] = [q + "norm.weight", q + "norm.bias", q + "fn.to_out.0.weight" if has_out else None,
+                              q + "fn.to_out.0.bias" if has_out else None]
+            # stacked projection operands, refreshed from the parameters at every forward
+            blk["w_s"] = torch.empty((3 * inner, c["d"]), dtype=torch.float32, device=self.device)
+            blk["w_t"] = torch.empty((3 * inner, c["d"]), dtype=torch.float32, device=self.device)
+            self._blocks.append(blk)
+
+    def _m3_params(self, blk, which, w_qkv, source):
+        ln_g, ln_b, w_out, b_out = [source(n) if n else None for n in blk[which]]
+        return ops.attn_params(ln_g, ln_b, w_qkv, w_out, b_out)
+
+    def _encoder_forward(self, x, x0, dims, save, saved):
+        c, lib = self._cfg, self._lib
+        B, T, L, S = dims
+        d, H = c["d"], c["hidden"]
+        h, dh, sc = self._m3_heads, self._m3_dh, self._m3_scale
+        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        for blk in self._blocks:
+            wq, wks, wvs, wkt, wvt = [self._p(n) for n in blk["proj"]]
+            torch.cat([wq, wks, wvs], dim=0, out=blk["w_s"])
+            torch.cat([wq, wkt, wvt], dim=0, out=blk["w_t"])
+            ps = self._m3_params(blk, "intra", blk["w_s"], self._p)
+            pt = self._m3_params(blk, "cross", blk["w_t"], self._p)
+            out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, imap, d, h, dh, sc, 0.5, save=save, lib=lib)             # 0.5 * intra(x)
+            out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cmap, d, h, dh, sc, 0.5, save=save, out=out, lib=lib)     # += 0.5 * cross(x)
+            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+            xn = ops.ffn_fwd_res(out, x, w1, b1, w2, b2, d, H, lib=lib)                                           # mlp(out) + x
+            if save:
+                saved["blocks"].append((x, o_s, l_s, o_t, l_t, out))
+            x = xn
+        return x, T * S * d
+
+    def _encoder_backward(self, saved, dx, G):
+        c, lib = self._cfg, self._lib
+        B, T, L, S = saved["dims"]
+        d, H = c["d"], c["hidden"]
+        inner = c["heads"] * c["dh"]
+        h, dh, sc = self._m3_heads, self._m3_dh, self._m3_scale
+        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, h, dh))
+        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
+        g_s = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
+        g_t = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
+        for blk, (x_in, o_s, l_s, o_t, l_t, out) in zip(reversed(self._blocks), reversed(saved["blocks"])):
+            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+            gw = [G(n) for n in blk["ffn"]]
+            dout, _ = ops.ffn_bwd_res(out, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn, lib=lib)
+            ps = self._m3_params(blk, "intra", blk["w_s"], self._p)
+            pt = self._m3_params(blk, "cross", blk["w_t"], self._p)
+            gs = self._m3_params(blk, "intra", g_s, G)
+            gt = self._m3_params(blk, "cross", g_t, G)
+            # dx = dy (the MLP residual) + cross backward + intra backward, accumulated in place
+            dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, cmap, d, h, dh, sc, 0.5, workspace=ws_attn, lib=lib)
+            dxn, _ = ops.attn_bwd_ex(x_in, dout, dxn, o_s, l_s, ps, gs, imap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dxn, lib=lib)
+            gq, gks, gvs, gkt, gvt = [G(n) for n in blk["proj"]]
+            torch.add(g_s[:inner], g_t[:inner], out=gq)                    # W_q is used by both attentions
+            gks.copy_(g_s[inner:2 * inner])
+            gvs.copy_(g_s[2 * inner:])
+            gkt.copy_(g_t[inner:2 * inner])
+            gvt.copy_(g_t[2 * inner:])
+            dx = dxn
+        return dx

@@ -120,6 +120,37 @@ def attn_bwd(x, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=
     return dx, workspace
 
 
+def attn_fwd_ex(x, res, params, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, save=False, eps=1e-5, out=None,
+                lib=None):
+    """y = out_scale * attention(LayerNorm(x)) + res (res: a tensor laid out like x, the output itself, or None)."""
+    lib = lib or get_lib()
+    _chk(x, name="x")
+    y = out if out is not None else torch.empty_like(x)
+    ntok = x.numel() // d
+    o_save = lse = None
+    if save:
+        o_save = torch.empty((ntok, heads * dim_head), dtype=torch.float32, device=x.device)
+        lse = torch.empty((ntok, heads), dtype=torch.float32, device=x.device)
+    lib.call("rat_attn_fwd_ex", _p(x), _p(res), _p(y), _p(o_save), _p(lse), ctypes.byref(params), ctypes.byref(seqmap), d, heads,
+             dim_head, float(softmax_scale), float(out_scale), eps, _stream(x))
+    return y, o_save, lse
+
+
+def attn_bwd_ex(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, eps=1e-5,
+                workspace=None, out=None, lib=None):
+    """dx = add + LayerNorm-backward(... out_scale * dy ...) (add: tensor laid out like x, or None)."""
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy, name="dy")
+    need = lib.size("rat_attn_bwd_workspace", d, heads, dim_head)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = out if out is not None else torch.empty_like(x)
+    lib.call("rat_attn_bwd_ex", _p(x), _p(dy), _p(add), _p(o_save), _p(lse), _p(dx), ctypes.byref(params), ctypes.byref(grads),
+             _p(workspace), workspace.numel() * 4, ctypes.byref(seqmap), d, heads, dim_head, float(softmax_scale),
+             float(out_scale), eps, _stream(x))
+    return dx, workspace
+
+
 def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, lib=None):
     lib = lib or get_lib()
     _chk(x, name="x")
