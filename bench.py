@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="synthetic_F20_V1M_K10_d64_B4096")
-    ap.add_argument("--model", default="RAT_m2", choices=["RAT_m2", "RAT_m1", "RAT_m3"],
+    ap.add_argument("--model", default="RAT_m2", choices=["RAT_m2", "RAT_m1", "RAT_m3", "RAT_m0"],
                     help="RAT_m2 (default) is the BASELINE.json metric; RAT_m1 times the cascaded variant (SURVEY §8f rank 2) on the same workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256)
@@ -60,7 +60,7 @@ class KernelTimer:
     """HIP-event timing of every C-ABI launch on torch's current stream (the stream the kernels are launched on)."""
 
     HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
-             "rat_ffn_bwd_res")
+             "rat_ffn_bwd_res", "rat_attn_core_fwd", "rat_attn_core_bwd")
 
     def __init__(self, lib, everything=False):
         self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
@@ -80,6 +80,8 @@ class KernelTimer:
         if name in ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex"):
             smap = args[{"rat_attn_fwd": 5, "rat_attn_bwd": 9, "rat_attn_fwd_ex": 6, "rat_attn_bwd_ex": 10}[name]]._obj
             return "L%d" % smap.L
+        if name in ("rat_attn_core_fwd", "rat_attn_core_bwd"):           # RAT_m0: joint sequences of T*S tokens
+            return "L%d" % int(args[4 if name == "rat_attn_core_fwd" else 6])
         if name in ("rat_ffn_fwd_res", "rat_ffn_bwd_res"):               # RAT_m1 runs the block MLP at two token counts
             return "n%d" % int(args[7 if name == "rat_ffn_fwd_res" else 13])
         return ""
@@ -108,6 +110,9 @@ def algorithmic_work(spec, model="RAT_m2"):
         work[("rat_attn_bwd", "L%d" % L)] = work[("rat_attn_bwd_ex", "L%d" % L)] = ("mfma", 2 * f)
         work[("rat_ffn_fwd_res", "n%d" % n)] = ("mfma", n * 4 * d * H)
         work[("rat_ffn_bwd_res", "n%d" % n)] = ("mfma", 2 * n * 4 * d * H)
+    # RAT_m0's long-sequence core (fp32 VALU, priced against the same 157.3 TFLOP/s fp32 peak): scores + PV over L = T*S keys
+    work[("rat_attn_core_fwd", "L%d" % (T * S))] = ("mfma", tok * 4 * I * T * S)
+    work[("rat_attn_core_bwd", "L%d" % (T * S))] = ("mfma", 2 * tok * 4 * I * T * S)
     work[("rat_ffn_fwd", "")] = ("mfma", tok * 4 * d * H)
     work[("rat_ffn_bwd", "")] = ("mfma", 2 * tok * 4 * d * H)
     work[("rat_gather_fwd", "")] = ("hbm", B * (T * F * d * 4 + T * S * d * 4 + T * F * 4))
@@ -126,7 +131,7 @@ def cpu_baseline(spec, fm, batch_size, seed, model="RAT_m2"):
                      dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
                      dnn_hidden_units=tuple(spec["dnn_hidden_units"]), batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],
                      embedding_regularizer=0.0005, learning_rate=spec["learning_rate"],
-                     variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3"}[model])
+                     variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3", "RAT_m0": "m0"}[model])
     g = torch.Generator().manual_seed(seed)
     w = {}
     for name, shp in orc.parameter_shapes(cfg).items():         # reference-like init scales

@@ -115,6 +115,17 @@ int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const flo
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
                     float ln_eps, void* stream);
 
+/* ---- K2d: the attention core alone, for sequences longer than the fused kernel's 64-row tile — RAT_m0 attends jointly over all
+ * T*S tokens of a sample (RAT_m0.py:123-127; 231 at the north-star shape).  That variant runs LayerNorm as K2c and the two
+ * projections as rat_sgemm; this is softmax(Q K^T * scale) V on the projected rows: qkv [ntok][3*heads*dim_head] (the output of
+ * nn.Linear(d, 3I): Q | K | V, head-major), o [ntok][heads*dim_head], lse [ntok][heads] (log2-domain, as rat_attn_fwd saves it);
+ * sequence q owns tokens [q*L, (q+1)*L).  softmax_scale <= 0 selects dim_head^-0.5.  dim_head <= 32; one head's K, V (backward:
+ * also Q, dO) rows of a sequence must fit LDS (L * dim_head * 16 B <= 160 KB). */
+int rat_attn_core_fwd(const float* qkv, float* o, float* lse, int64_t nseq, int L, int heads, int dim_head, float softmax_scale,
+                      void* stream);
+int rat_attn_core_bwd(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv, int64_t nseq, int L,
+                      int heads, int dim_head, float softmax_scale, void* stream);
+
 /* ---- K2 (cont.): FeedForward + residual, y = W2 gelu_erf(W1 x + b1) + b2 + x (RAT_m2.py:163-174, 232) */
 int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                 int64_t ntok, int d, int hidden, void* stream);

@@ -69,6 +69,7 @@ class Config:
     bn_momentum: float = 0.1
     ln_eps: float = 1e-5
     variant: str = "m2"       # "m2": cross/intra encoder blocks (RAT_m2.py); "m1": cascaded transformers (RAT_m1.py);
+                              # "m0": ONE transformer over all T*S tokens of a sample (RAT_m0.py);
                               # "m3": parallel intra/cross attention with a shared query projection, mean fusion (RAT_m3.py)
 
     @property
@@ -133,10 +134,11 @@ def parameter_shapes(cfg: Config) -> "OrderedDict[str, Tuple[int, ...]]":
         shapes[p + "3.weight"] = (d, hid)
         shapes[p + "3.bias"] = (d,)
 
-    if cfg.variant == "m1":
-        # RAT_m1.__init__ (RAT_m1.py:71-72): intra_transformer, cross_transformer; Transformer registers `layers`
-        # before `norm` (RAT_m1.py:194-203): layers.i.0 = PreNorm(Attention), layers.i.1 = PreNorm(FeedForward)
-        for t in ("intra_transformer.", "cross_transformer."):
+    if cfg.variant in ("m1", "m0"):
+        # RAT_m1.__init__ (RAT_m1.py:71-72): intra_transformer, cross_transformer; RAT_m0.__init__ (RAT_m0.py:70): encoder.
+        # Transformer registers `layers` before `norm` (RAT_m1.py:194-203): layers.i.0 = PreNorm(Attention),
+        # layers.i.1 = PreNorm(FeedForward)
+        for t in (("intra_transformer.", "cross_transformer.") if cfg.variant == "m1" else ("encoder.",)):
             for i in range(cfg.depth):
                 attn_shapes(t + "layers.%d.0." % i)
                 shapes[t + "layers.%d.1.norm.weight" % i] = (d,)
@@ -389,7 +391,11 @@ def forward(w: Dict[str, Tensor], X: Tensor, y: Tensor, cfg: Config, training: b
             bn_state: Optional[Dict[str, Tensor]] = None, return_logit: bool = False):
     """RAT_m2.forward (RAT_m2.py:104-152) with dropout p=0.  Returns y_pred [B, 1]."""
     grid, target_fields = build_grid(X, y, w, cfg)
-    if cfg.variant == "m1":
+    if cfg.variant == "m0":
+        # RAT_m0.forward (RAT_m0.py:121-127): one joint sequence of T*S tokens per sample; [:, :, 0][:, 0] = token (t=0, n=0)
+        b, t, s, d = grid.shape
+        cls = transformer(grid.reshape(b, t * s, d), w, "encoder.", cfg)[:, 0]
+    elif cfg.variant == "m1":
         # RAT_m1.forward (RAT_m1.py:121-130): every sample's S tokens through the intra transformer, its label token
         # [:, 0] becomes that sample's vector; the T sample vectors go through the cross transformer; target = [:, 0]
         b, t, s, d = grid.shape

@@ -88,6 +88,18 @@ CASES += [
          batch_norm=False, use_wide=True, embedding_regularizer=0.03, net_regularizer=0),
 ]
 
+# RAT_m0 (one Transformer over the joint (t n) sequence of a sample — RAT_m0.py)
+CASES += [
+    dict(name="m0_tiny_seq", model="RAT_m0", batch=6, topk=3, init_seed=2021, data_seed=131, weight_seed=132, full_limit=1 << 20,
+         fields=[_cat("a", 7), _cat("b", 5), _seq("c", 6), _cat("e", 9, padding_idx=8)],
+         embedding_dim=8, num_heads=2, dim_head=4, depth=2, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="m0_northstar_shape", model="RAT_m0", batch=3, topk=10, init_seed=2021, data_seed=141, weight_seed=142, full_limit=1024,
+         fields=[_cat("c%02d" % i, 37) for i in range(20)],
+         embedding_dim=64, num_heads=8, dim_head=10, depth=1, scale_dim=2, dnn_hidden_units=[16, 16],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.0005, net_regularizer=0),
+]
+
 # The three shipped experiments (exps/RAT_m2/*/*.log "Total number of parameters").
 KNOWN_COUNT_CASES = [
     dict(name="count_mltag", expected_params=1337241, topk=5,

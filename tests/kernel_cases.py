@@ -168,6 +168,25 @@ def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed
             close(g, wt.grad, 1e-4, 1e-4 * scale, name)
 
 
+def check_attn_core(lib, dev, nseq, L, heads, dh, softmax_scale=None):
+    """rat_attn_core_fwd / bwd against float64 softmax attention on random projected rows."""
+    rs = np.random.RandomState(17)
+    I = heads * dh
+    qkv = rnd(rs, nseq * L, 3 * I)
+    dout = rnd(rs, nseq * L, I)
+    r = qkv.double().requires_grad_(True)
+    q, k, v = [t.reshape(nseq, L, heads, dh).permute(0, 2, 1, 3) for t in r.split(I, dim=-1)]
+    sc = dh ** -0.5 if softmax_scale is None else softmax_scale
+    p = torch.softmax((q @ k.transpose(-1, -2)) * sc, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(nseq * L, I)
+    ref.backward(dout.double())
+    qd = qkv.to(dev)
+    o, lse = ops.attn_core_fwd(qd, nseq, L, heads, dh, softmax_scale or 0.0, lib=lib)
+    close(o, ref, 2e-5, 2e-5, "o")
+    dqkv = ops.attn_core_bwd(qd, o, lse, dout.to(dev), nseq, L, heads, dh, softmax_scale or 0.0, lib=lib)
+    close(dqkv, r.grad, 1e-4, 1e-4, "dqkv")
+
+
 def check_ffn(lib, dev, ntok, d, hidden):
     rs = np.random.RandomState(3)
     x = rnd(rs, ntok, d)

@@ -52,6 +52,11 @@ def test_attn_fwd_bwd(emu, case, mode):
     kc.check_attn(emu, "cpu", case, mode)
 
 
+@pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (1, 70, 1, 10, None), (2, 33, 2, 7, 0.3)])
+def test_attn_core_fwd_bwd(emu, nseq, L, heads, dh, softmax_scale):
+    kc.check_attn_core(emu, "cpu", nseq, L, heads, dh, softmax_scale)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

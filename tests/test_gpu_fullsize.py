@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 NAME = "synthetic_F20_V1M_K10_d64_B4096"
 
 
-VARIANT = {"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3"}
+VARIANT = {"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3", "RAT_m0": "m0"}
 
 
-@pytest.fixture(scope="module", params=["RAT_m2", "RAT_m1", "RAT_m3"])
+@pytest.fixture(scope="module", params=["RAT_m2", "RAT_m1", "RAT_m3", "RAT_m0"])
 def setup(request):
     from rat_amd import models, synthetic
     from rat_amd.base_model import seed_everything

@@ -43,6 +43,11 @@ def test_attn_fwd_bwd(lib, case, mode):
     kc.check_attn(lib, "cuda", case, mode)
 
 
+@pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None)])
+def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale):
+    kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

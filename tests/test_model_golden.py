@@ -24,18 +24,18 @@ def emu_lib():
     L._default = old
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq", "m0_tiny_seq"])
 def test_init_matches_reference_bit_for_bit(name):
     mc.check_init(name, gpu=-1)
 
 
 # the emulator runs one OS thread per GPU thread: keep the CPU suite to the small cases (the GPU suite runs them all)
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "tmall_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "tmall_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq", "m0_tiny_seq"])
 def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m1_bare", "m3_tiny_seq", "m0_tiny_seq"])
 def test_two_training_steps(name):
     mc.check_training(name, gpu=-1)
 
@@ -80,3 +80,12 @@ def test_dropout_training_is_consistent():
     y = ops.dropout(x, 0.3, 77)
     kept = float((y != 0).float().mean())
     assert abs(kept - 0.7) < 0.01 and abs(float(y.max()) - 1 / 0.7) < 1e-6
+
+
+def test_m0_long_sequence_path(monkeypatch):
+    """RAT_m0 with the fused-kernel threshold lowered: the 20-token joint sequences of m0_tiny_seq take the long-sequence path
+    (K2c LayerNorm -> rat_sgemm -> K2d core -> rat_sgemm), which must reproduce the same golden vectors."""
+    from rat_amd import models
+    monkeypatch.setattr(models.RAT_m0, "FUSED_MAX_L", 8)
+    mc.check_eval("m0_tiny_seq", gpu=-1)
+    mc.check_training("m0_tiny_seq", gpu=-1)

@@ -18,7 +18,7 @@ def oracle_config(case):
                       dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=case["batch_norm"],
                       use_wide=case["use_wide"], embedding_regularizer=float(case["embedding_regularizer"] or 0.0),
                       net_regularizer=float(case["net_regularizer"] or 0.0),
-                      variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3"}[case.get("model", "RAT_m2")])
+                      variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3", "RAT_m0": "m0"}[case.get("model", "RAT_m2")])
 
 
 def state_shapes(cfg):

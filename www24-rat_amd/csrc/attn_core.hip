@@ -1,0 +1,255 @@
+// attn_core.hip — K2d: the softmax(Q K^T * scale) V core for LONG sequences, forward and backward, on projected Q|K|V rows.
+//
+// RAT_m0 (RAT_m0.py:123-127) attends jointly over all T*S tokens of a sample (231 at the north-star shape): a whole
+// sequence no longer fits the 64-row LDS tile of the fused kernel in attn.hip, so that variant runs the projections as
+// plain MFMA GEMMs (rat_sgemm) and LayerNorm as K2c, and only this core is new.  One work-group per (sequence, head):
+// the head's K and V rows (backward: also Q, dO, lse, delta) are staged in LDS once, one lane owns one query row (pass 2
+// of backward: one key row) and walks all keys with the online softmax of attn.hip — same log2-domain arithmetic, same
+// saved log-sum-exp convention (lse = m + log2(l) of the scores scaled by scale * log2(e)).
+//
+// qkv is [ntok][3*I] (I = heads*dh; Q | K | V, head-major inside each third, exactly nn.Linear(d, 3I)'s output), o and
+// do are [ntok][I], lse is [ntok][heads]; sequence q owns tokens [q*L, (q+1)*L).
+#include "rat_device.h"
+#include "../../include/rat_hip.h"
+
+namespace {
+
+constexpr int CORE_DH_MAX = 32;
+
+struct CoreArgs {
+    const float* qkv;
+    const float* o;
+    const float* dout;
+    const float* lse_in;
+    float* o_out;
+    float* lse_out;
+    float* dqkv;
+    int64_t nseq;
+    int L, heads, dh;
+    float scale;
+};
+
+template <int DH>
+struct Vec {
+    static constexpr int N = DH > 0 ? DH : CORE_DH_MAX;
+    float v[N];
+    __device__ __forceinline__ void load(const float* p, int dh) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = (DH > 0 || k < dh) ? p[k] : 0.f;
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = 0.f;
+    }
+    __device__ __forceinline__ float dot(const Vec& o) const {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s = fmaf(v[k], o.v[k], s);
+        return s;
+    }
+    __device__ __forceinline__ void axpy(float a, const Vec& x) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = fmaf(a, x.v[k], v[k]);
+    }
+    __device__ __forceinline__ void scale_axpy(float c, float a, const Vec& x) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = fmaf(a, x.v[k], v[k] * c);
+    }
+    __device__ __forceinline__ void store(float* p, int dh, float mul) const {
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (DH > 0 || k < dh) p[k] = v[k] * mul;
+    }
+};
+
+// LDS rows are unpadded [L][dh]: in the key / query walks every lane of a wave reads the SAME row (a broadcast, no bank
+// conflict), and the staging writes are contiguous.
+template <int DH>
+__global__ void __launch_bounds__(1024) core_fwd_kernel(CoreArgs a) {
+    RAT_DYN_SMEM(smem);
+    const int dh = DH > 0 ? DH : a.dh, L = a.L, I = a.heads * dh;
+    float* ks = reinterpret_cast<float*>(smem);          // [L][dh]
+    float* vs = ks + (size_t)L * dh;                     // [L][dh]
+    const float sl2 = a.scale * RAT_LOG2E;
+    for (int64_t task = blockIdx.x; task < a.nseq * a.heads; task += gridDim.x) {
+        const int64_t sq = task / a.heads;
+        const int h = (int)(task - sq * a.heads);
+        const float* base = a.qkv + sq * L * (int64_t)(3 * I) + h * dh;
+        for (int e = threadIdx.x; e < L * dh; e += blockDim.x) {
+            const int j = e / dh, c = e - j * dh;
+            const float* row = base + (int64_t)j * (3 * I);
+            ks[e] = row[I + c];
+            vs[e] = row[2 * I + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            Vec<DH> q, o, kv;
+            q.load(base + (int64_t)i * (3 * I), dh);
+            o.zero();
+            float m = -3.0e38f, l = 0.f;
+            for (int j = 0; j < L; ++j) {
+                kv.load(ks + (size_t)j * dh, dh);
+                const float s = q.dot(kv) * sl2;
+                const float mn = fmaxf(m, s);
+                const float corr = rat_exp2(m - mn), p = rat_exp2(s - mn);
+                l = l * corr + p;
+                kv.load(vs + (size_t)j * dh, dh);
+                o.scale_axpy(corr, p, kv);
+                m = mn;
+            }
+            const int64_t tok = sq * L + i;
+            o.store(a.o_out + tok * I + h * dh, dh, 1.0f / l);
+            if (a.lse_out != nullptr) a.lse_out[tok * a.heads + h] = m + rat_log2(l);
+        }
+        __syncthreads();
+    }
+}
+
+template <int DH>
+__global__ void __launch_bounds__(1024) core_bwd_kernel(CoreArgs a) {
+    RAT_DYN_SMEM(smem);
+    const int dh = DH > 0 ? DH : a.dh, L = a.L, I = a.heads * dh;
+    float* qs = reinterpret_cast<float*>(smem);          // [L][dh]
+    float* ks = qs + (size_t)L * dh;
+    float* vs = ks + (size_t)L * dh;
+    float* gs = vs + (size_t)L * dh;                     // dO
+    float* ls = gs + (size_t)L * dh;                     // [L] lse
+    float* ds = ls + L;                                  // [L] delta = dO . O
+    const float sl2 = a.scale * RAT_LOG2E;
+    for (int64_t task = blockIdx.x; task < a.nseq * a.heads; task += gridDim.x) {
+        const int64_t sq = task / a.heads;
+        const int h = (int)(task - sq * a.heads);
+        const float* base = a.qkv + sq * L * (int64_t)(3 * I) + h * dh;
+        const float* gbase = a.dout + sq * L * (int64_t)I + h * dh;
+        const float* obase = a.o + sq * L * (int64_t)I + h * dh;
+        for (int e = threadIdx.x; e < L * dh; e += blockDim.x) {
+            const int j = e / dh, c = e - j * dh;
+            const float* row = base + (int64_t)j * (3 * I);
+            qs[e] = row[c];
+            ks[e] = row[I + c];
+            vs[e] = row[2 * I + c];
+            gs[e] = gbase[(int64_t)j * I + c];
+        }
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            ls[i] = a.lse_in[(sq * L + i) * a.heads + h];
+            float dsum = 0.f;
+            for (int c = 0; c < dh; ++c) dsum = fmaf(gbase[(int64_t)i * I + c], obase[(int64_t)i * I + c], dsum);
+            ds[i] = dsum;
+        }
+        __syncthreads();
+        float* dbase = a.dqkv + sq * L * (int64_t)(3 * I) + h * dh;
+        // pass 1: one lane per query row -> dQ
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            Vec<DH> q, go, dq, kv;
+            q.load(qs + (size_t)i * dh, dh);
+            go.load(gs + (size_t)i * dh, dh);
+            dq.zero();
+            const float lse = ls[i], delta = ds[i];
+            for (int j = 0; j < L; ++j) {
+                kv.load(vs + (size_t)j * dh, dh);
+                const float dp = go.dot(kv);
+                kv.load(ks + (size_t)j * dh, dh);
+                const float p = rat_exp2(q.dot(kv) * sl2 - lse);
+                dq.axpy(p * (dp - delta), kv);
+            }
+            dq.store(dbase + (int64_t)i * (3 * I), dh, a.scale);
+        }
+        // pass 2: one lane per key row -> dK, dV
+        for (int j = threadIdx.x; j < L; j += blockDim.x) {
+            Vec<DH> kk, vv, dk, dv, t, qv;
+            kk.load(ks + (size_t)j * dh, dh);
+            vv.load(vs + (size_t)j * dh, dh);
+            dk.zero();
+            dv.zero();
+            for (int i = 0; i < L; ++i) {
+                t.load(gs + (size_t)i * dh, dh);
+                const float dp = t.dot(vv);
+                qv.load(qs + (size_t)i * dh, dh);
+                const float p = rat_exp2(qv.dot(kk) * sl2 - ls[i]);
+                dv.axpy(p, t);
+                dk.axpy(p * (dp - ds[i]), qv);
+            }
+            dk.store(dbase + (int64_t)j * (3 * I) + I, dh, a.scale);
+            dv.store(dbase + (int64_t)j * (3 * I) + 2 * I, dh, 1.0f);
+        }
+        __syncthreads();
+    }
+}
+
+int core_threads(int L) {
+    int t = (L + 63) / 64 * 64;
+    return t > 1024 ? 1024 : t;
+}
+
+int core_check(int64_t nseq, int L, int heads, int dh, size_t smem) {
+    RAT_REQUIRE(nseq > 0 && L > 0 && heads > 0 && dh > 0, "bad dims");
+    RAT_REQUIRE(dh <= CORE_DH_MAX, "dim_head > 32 is not supported by the long-sequence attention core");
+    RAT_REQUIRE(smem <= 160 * 1024, "sequence too long for the LDS staging of one head's K, V (and Q, dO) rows");
+    return 0;
+}
+
+template <template <int> class Launch>
+int core_dispatch(int dh, const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
+    switch (dh) {
+        case 4: return Launch<4>::go(a, grid, threads, smem, stream);
+        case 8: return Launch<8>::go(a, grid, threads, smem, stream);
+        case 10: return Launch<10>::go(a, grid, threads, smem, stream);
+        case 16: return Launch<16>::go(a, grid, threads, smem, stream);
+        case 20: return Launch<20>::go(a, grid, threads, smem, stream);
+        default: return Launch<0>::go(a, grid, threads, smem, stream);
+    }
+}
+template <int DH>
+struct LaunchFwd {
+    static int go(const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
+        RAT_LAUNCH((core_fwd_kernel<DH>), grid, threads, smem, stream, a);
+        return rat_check_launch("rat_attn_core_fwd");
+    }
+};
+template <int DH>
+struct LaunchBwd {
+    static int go(const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
+        RAT_LAUNCH((core_bwd_kernel<DH>), grid, threads, smem, stream, a);
+        return rat_check_launch("rat_attn_core_bwd");
+    }
+};
+
+unsigned core_grid(int64_t tasks) { return (unsigned)(tasks < 65536 ? tasks : 65536); }
+
+}  // namespace
+
+extern "C" int rat_attn_core_fwd(const float* qkv, float* o, float* lse, int64_t nseq, int L, int heads, int dim_head,
+                                 float softmax_scale, void* stream) {
+    const size_t smem = (size_t)2 * L * dim_head * sizeof(float);
+    if (core_check(nseq, L, heads, dim_head, smem)) return -1;
+    RAT_REQUIRE(qkv && o, "null pointer");
+    CoreArgs a{};
+    a.qkv = qkv;
+    a.o_out = o;
+    a.lse_out = lse;
+    a.nseq = nseq;
+    a.L = L;
+    a.heads = heads;
+    a.dh = dim_head;
+    a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
+    return core_dispatch<LaunchFwd>(dim_head, a, core_grid(nseq * heads), core_threads(L), smem, stream);
+}
+
+extern "C" int rat_attn_core_bwd(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv,
+                                 int64_t nseq, int L, int heads, int dim_head, float softmax_scale, void* stream) {
+    const size_t smem = ((size_t)4 * L * dim_head + 2 * (size_t)L) * sizeof(float);
+    if (core_check(nseq, L, heads, dim_head, smem)) return -1;
+    RAT_REQUIRE(qkv && o && lse && dout && dqkv, "null pointer");
+    CoreArgs a{};
+    a.qkv = qkv;
+    a.o = o;
+    a.lse_in = lse;
+    a.dout = dout;
+    a.dqkv = dqkv;
+    a.nseq = nseq;
+    a.L = L;
+    a.heads = heads;
+    a.dh = dim_head;
+    a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
+    return core_dispatch<LaunchBwd>(dim_head, a, core_grid(nseq * heads), core_threads(L), smem, stream);
+}

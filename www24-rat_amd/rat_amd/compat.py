@@ -1,6 +1,6 @@
 """Drop-in wiring for code written against the reference's package names.
 
-``install()`` makes ``fuxictr.pytorch.models.RAT_m2`` (and ``RAT_m1``, ``RAT_m3``) resolve to the HIP-backed plugins:
+``install()`` makes ``fuxictr.pytorch.models.RAT_m2`` (and ``RAT_m0``, ``RAT_m1``, ``RAT_m3``) resolve to the HIP-backed plugins:
   * if the real FuxiCTR fork is importable it only swaps those attributes (every other model stays the reference's);
   * otherwise it registers a minimal ``fuxictr`` namespace (version 1.2.3, ``fuxictr.pytorch.models``,
     ``fuxictr.pytorch.torch_utils.seed_everything``, ``fuxictr.features.FeatureMap``, ``fuxictr.utils``) backed by
@@ -16,6 +16,7 @@ def install():
         ref_models.RAT_m2 = models.RAT_m2
         ref_models.RAT_m1 = models.RAT_m1
         ref_models.RAT_m3 = models.RAT_m3
+        ref_models.RAT_m0 = models.RAT_m0
         return "patched"
     except Exception:
         pass

@@ -582,12 +582,12 @@ class RAT_m1(RAT_m2):
         layers, norm = self._stacks[which]
         rec = []
         for lay in layers:
-            xa, o, l = ops.attn_fwd(x, lay["attn"][1], smap, d, heads, dh, save=save, lib=lib)        # attn(norm(x)) + x
+            xa, att = self._attn_layer_forward(lay, x, smap, save)                                    # attn(norm(x)) + x
             xn = ops.layernorm_fwd(xa, d, ntok, self._p(lay["ln"][0]), self._p(lay["ln"][1]), d, lib=lib)
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
             xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, lib=lib)                               # ff(norm(x)) + x
             if save:
-                rec.append((x, o, l, xa, xn))
+                rec.append((x, att, xa, xn))
             x = xb
         out = ops.layernorm_fwd(x, cls_stride, ncls, self._p(norm[0]), self._p(norm[1]), d, lib=lib)
         if save:
@@ -599,18 +599,29 @@ class RAT_m1(RAT_m2):
         d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
         layers, norm = self._stacks[which]
         rec, x_last = saved[which]
-        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
         ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
         dx = torch.zeros(shape, dtype=torch.float32, device=dcls.device)          # only the class-token rows get a gradient
         ops.layernorm_bwd(x_last, cls_stride, dcls, self._p(norm[0]), dx, cls_stride, G(norm[0]), G(norm[1]), d, lib=lib)
-        for lay, (x_in, o, l, xa, xn) in zip(reversed(layers), reversed(rec)):
+        for lay, (x_in, att, xa, xn) in zip(reversed(layers), reversed(rec)):
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
             gw = [G(n) for n in lay["ffn"]]
             dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn, lib=lib)
             dxa = ops.layernorm_bwd(xa, d, dxn, self._p(lay["ln"][0]), dxn, d, G(lay["ln"][0]), G(lay["ln"][1]), d, add=dx, lib=lib)
-            names, params = lay["attn"]
-            grads = ops.attn_params(*[G(n) if n else None for n in names])
-            dx, _ = ops.attn_bwd(x_in, dxa, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+            dx = self._attn_layer_backward(lay, x_in, dxa, att, smap, G)
+        return dx
+
+    def _attn_layer_forward(self, lay, x, smap, save):
+        """x -> PreNorm(Attention)(x) + x; returns (y, whatever the backward needs)."""
+        c = self._cfg
+        y, o, l = ops.attn_fwd(x, lay["attn"][1], smap, c["d"], c["heads"], c["dh"], save=save, lib=self._lib)
+        return y, (o, l)
+
+    def _attn_layer_backward(self, lay, x_in, dy, att, smap, G):
+        c, lib = self._cfg, self._lib
+        ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", c["d"], c["heads"], c["dh"]))
+        names, params = lay["attn"]
+        grads = ops.attn_params(*[G(n) if n else None for n in names])
+        dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], params, grads, smap, c["d"], c["heads"], c["dh"], workspace=ws, lib=lib)
         return dx
 
     def _encoder_forward(self, x, x0, dims, save, saved):
@@ -720,3 +731,79 @@ class RAT_m3(RAT_m2):
             gvt.copy_(g_t[2 * inner:])
             dx = dxn
         return dx
+
+
+class RAT_m0(RAT_m1):
+    """RAT_m0 (fuxictr/pytorch/models/RAT_m0.py:24-141): ONE Transformer over the joint sequence of all T*S tokens of a sample
+    ('b t n d -> b (t n) d'), class token = token (t=0, n=0).  Sequences of up to 64 tokens run on the fused attention kernel
+    (K2a); longer ones (231 at the north-star shape) do not fit its LDS tile and run as K2c LayerNorm -> rat_sgemm QKV
+    projection -> K2d attention core (rat_attn_core_fwd/bwd) -> rat_sgemm output projection + bias + residual."""
+
+    FUSED_MAX_L = 64            # tests lower this to send short sequences through the long-sequence path as well
+
+    def __init__(self, feature_map, model_id="RAT_m0", **kwargs):
+        super().__init__(feature_map, model_id=model_id, **kwargs)
+
+    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
+        self.encoder = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)               # RAT_m0.py:70
+
+    def _build_encoder_descriptors(self):
+        layers = []
+        for i in range(self._cfg["depth"]):
+            p = "encoder.layers.%d." % i
+            layers.append(dict(attn=self._attn_descriptor(p + "0."), ln=[p + "1.norm.weight", p + "1.norm.bias"],
+                               ffn=[p + "1.fn.net.0.weight", p + "1.fn.net.0.bias", p + "1.fn.net.3.weight", p + "1.fn.net.3.bias"]))
+        self._stacks = {"encoder": (layers, ["encoder.norm.weight", "encoder.norm.bias"])}
+
+    def _encoder_forward(self, x, x0, dims, save, saved):
+        B, T, L, S = dims
+        d = self._cfg["d"]
+        xc = self._stack_forward("encoder", x, ops.intra_map(B, 1, T * S), B * T * S, T * S * d, B, save, saved)
+        return xc, d
+
+    def _encoder_backward(self, saved, dx, G):
+        B, T, L, S = saved["dims"]
+        d = self._cfg["d"]
+        return self._stack_backward("encoder", saved, dx, ops.intra_map(B, 1, T * S), T * S * d, (B, T, S, d), G)
+
+    # ---- PreNorm(Attention) + residual over long sequences, composed from K2c / rat_sgemm / K2d
+    def _attn_layer_forward(self, lay, x, smap, save):
+        if smap.L <= self.FUSED_MAX_L:
+            return super()._attn_layer_forward(lay, x, smap, save)
+        c, lib = self._cfg, self._lib
+        d, heads, dh = c["d"], c["heads"], c["dh"]
+        inner, nseq, L = heads * dh, int(smap.nseq), int(smap.L)
+        ntok = nseq * L
+        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in lay["attn"][0]]
+        if w_out is None:
+            raise NotImplementedError("RAT_m0 with heads == 1 and dim_head == embedding_dim (no output projection) and more than "
+                                      "%d tokens per sample is not implemented" % self.FUSED_MAX_L)
+        xn = ops.layernorm_fwd(x, d, ntok, ln_g, ln_b, d, lib=lib)
+        qkv = torch.empty((ntok, 3 * inner), dtype=torch.float32, device=x.device)
+        ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_qkv, d, qkv, 3 * inner, lib=lib)                     # to_qkv (no bias)
+        o, lse = ops.attn_core_fwd(qkv, nseq, L, heads, dh, save=True, lib=lib)
+        y = x.clone()                                                                                     # the residual, accumulated by beta = 1
+        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, lib=lib)      # to_out + x
+        return y, ((qkv, o, lse) if save else None)
+
+    def _attn_layer_backward(self, lay, x_in, dy, att, smap, G):
+        if smap.L <= self.FUSED_MAX_L:
+            return super()._attn_layer_backward(lay, x_in, dy, att, smap, G)
+        c, lib = self._cfg, self._lib
+        d, heads, dh = c["d"], c["heads"], c["dh"]
+        inner, nseq, L = heads * dh, int(smap.nseq), int(smap.L)
+        ntok = nseq * L
+        names = lay["attn"][0]
+        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
+        qkv, o, lse = att
+        dev = dy.device
+        xn = ops.layernorm_fwd(x_in, d, ntok, ln_g, ln_b, d, lib=lib)                                     # recomputed, not stored
+        do = torch.empty((ntok, inner), dtype=torch.float32, device=dev)
+        ops.sgemm(0, 0, ntok, inner, d, dy, d, w_out, inner, do, inner, lib=lib)                          # dO = dy W_out
+        ops.sgemm(1, 0, d, inner, ntok, dy, d, o, inner, G(names[3]), inner, lib=lib)                     # dW_out = dy^T O
+        ops.colsum(dy, d, G(names[4]), ntok, d, lib=lib)
+        dqkv = ops.attn_core_bwd(qkv, o, lse, do, nseq, L, heads, dh, lib=lib)
+        dxn = torch.empty((ntok, d), dtype=torch.float32, device=dev)
+        ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_qkv, d, dxn, d, lib=lib)                   # d(norm(x)) = dQKV W_qkv
+        ops.sgemm(1, 0, 3 * inner, d, ntok, dqkv, 3 * inner, xn, d, G(names[2]), d, lib=lib)              # dW_qkv = dQKV^T norm(x)
+        return ops.layernorm_bwd(x_in, d, dxn, ln_g, dxn, d, G(names[0]), G(names[1]), d, add=dy, lib=lib).view_as(x_in)

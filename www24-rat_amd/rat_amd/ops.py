@@ -151,6 +151,26 @@ def attn_bwd_ex(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_he
     return dx, workspace
 
 
+def attn_core_fwd(qkv, nseq, L, heads, dim_head, softmax_scale=0.0, save=True, lib=None):
+    """softmax(Q K^T * scale) V on projected rows qkv [nseq*L, 3*heads*dim_head] -> (o [ntok, heads*dim_head], lse [ntok, heads])."""
+    lib = lib or get_lib()
+    _chk(qkv, name="qkv")
+    ntok = nseq * L
+    o = torch.empty((ntok, heads * dim_head), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((ntok, heads), dtype=torch.float32, device=qkv.device) if save else None
+    lib.call("rat_attn_core_fwd", _p(qkv), _p(o), _p(lse), int(nseq), int(L), heads, dim_head, float(softmax_scale), _stream(qkv))
+    return o, lse
+
+
+def attn_core_bwd(qkv, o, lse, dout, nseq, L, heads, dim_head, softmax_scale=0.0, lib=None):
+    lib = lib or get_lib()
+    _chk(qkv, name="qkv"), _chk(o, name="o"), _chk(lse, name="lse"), _chk(dout, name="dout")
+    dqkv = torch.empty_like(qkv)
+    lib.call("rat_attn_core_bwd", _p(qkv), _p(o), _p(lse), _p(dout), _p(dqkv), int(nseq), int(L), heads, dim_head,
+             float(softmax_scale), _stream(qkv))
+    return dqkv
+
+
 def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, lib=None):
     lib = lib or get_lib()
     _chk(x, name="x")
