@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--workload", default="synthetic_F20_V1M_K10_d64_B4096")
     ap.add_argument("--model", default="RAT_m2", choices=["RAT_m2", "RAT_m1", "RAT_m3", "RAT_m0"],
                     help="RAT_m2 (default) is the BASELINE.json metric; RAT_m1 times the cascaded variant (SURVEY §8f rank 2) on the same workload")
+    ap.add_argument("--step-times", action="store_true", help="print the host-side issue time of every timed step to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -199,11 +200,18 @@ def main():
     for _ in range(args.warmup):
         model.train_step(batch)
     sync()
+    model.freeze_host_heap()          # what fit_generator does before its first batch (base_model.py): no full-heap GC walks mid-loop
     timer.enabled = True
     t0 = time.perf_counter()
+    stamps = []
     for _ in range(args.steps):
+        if args.step_times:
+            stamps.append(time.perf_counter())
         model.train_step(batch)
     sync()
+    if args.step_times:                # diagnostic: host-side issue time of every step (stderr), e.g. to spot interpreter stalls
+        stamps.append(time.perf_counter())
+        print("step issue times (ms): " + " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(stamps, stamps[1:])), file=sys.stderr)
     elapsed = time.perf_counter() - t0
     timer.enabled = False
     if world > 1:
