@@ -157,6 +157,18 @@ int rat_layernorm_bwd(const float* x, int64_t x_stride, const float* dy, const f
                       int64_t dx_stride, float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
                       int64_t nrows, int d, float eps, void* stream);
 
+/* ---- K6: BM25-style top-K retrieval pre-compute — the scoring / top-k / merge core of BM25_topk_retrieval_v4
+ * (fuxictr/datasets/data_utils.py:774-1064) on the `exact_match_cols: []` path of the shipped dataset configs:
+ *   score[b][n] = sum_f (qry_ids[b][f] == db[n][f]) * qry_idf[b][f]   (float64, f ascending)
+ *   out_values[b][0:K] = the K largest scores, descending; zero scores are dropped: out_indices = -1, out_values = 0;
+ *   out_lens[b] = number of entries kept (data_utils.py:786-818 padded_topk + sort_results).
+ * db_ids_field_major is [n_fields][n_db] int32 (the pool's id columns, transposed); qry_ids [n_qry][n_fields] int32; qry_idf
+ * [n_qry][n_fields] float64 = log(n_db / count of that id in the pool column), 0 for ids absent from the pool
+ * (data_utils.py:873-880,843-847).  Equal scores keep the lower pool index (torch.topk leaves that order unspecified).
+ * n_fields <= 32, topk <= 32. */
+int rat_bm25_topk(const int32_t* db_ids_field_major, const int32_t* qry_ids, const double* qry_idf, double* out_values,
+                  int64_t* out_indices, int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk, void* stream);
+
 /* ---- K3: prediction head -----------------------------------------------------------------------------
  * Plain fp32 GEMM on MFMA for MLP_Layer's nn.Linear (deep.py:126-141) forward / dgrad / wgrad:
  * C[M][N] = op(A) op(B) (+ bias[N]) (+ beta*C), row-major with leading dimensions, op = transpose flag. */

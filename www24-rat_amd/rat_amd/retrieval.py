@@ -1,0 +1,89 @@
+"""Top-K retrieval pre-compute on the device — the drop-in for ``BM25_topk_retrieval_v4``
+(fuxictr/datasets/data_utils.py:774-1064), which the reference's DataGenerator calls once per split to build
+``retrieval_{K}_{split}.h5`` (fuxictr/pytorch/data_generator.py:114-215).
+
+Same signature, same ``(values, indices, lens)`` named tuple of numpy arrays.  The host side keeps only what is host work in
+the reference too (the per-column IDF table: value counts of the pool, data_utils.py:873-880, and mapping the query ids to
+their weights, :843-847); scoring, top-k and the merge over the pool run in ONE kernel (rat_bm25_topk, csrc/retrieval.hip)
+that scans the pool once per tile of four queries — ``db_chunk_size`` is accepted and ignored (nothing is materialised),
+``qry_batch_size`` bounds the result buffers per launch.  ``exact_match_col_indices`` (unused by the shipped configs:
+``exact_match_cols: []``) is not implemented and raises.
+"""
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from ._lib import get_lib
+
+ResultsNamedTuple = namedtuple("ResultsNameTuple", ["values", "indices", "lens"])
+
+
+def idf_tables(db_np_data):
+    """per column: (sorted distinct ids, log(N / count)) — data_utils.py:873-880."""
+    n = len(db_np_data)
+    tables = []
+    for c in range(db_np_data.shape[1]):
+        vals, counts = np.unique(db_np_data[:, c], return_counts=True)
+        tables.append((vals, np.log(n / counts)))
+    return tables
+
+
+def map_data_to_idf(np_data, tables):
+    """ids of ONE query batch -> IDF weight, 0 for ids the pool column does not hold (map_data_to_IDF_v1,
+    data_utils.py:843-847).  Kept bug-compatible: the reference's ``np.vectorize(lambda x: stats.get(x, 0))`` takes its
+    output dtype from the first element, so a batch whose FIRST row carries an unseen id in a column gets that whole column
+    as int64 — every weight truncated toward zero.  The published ``retrieval_*.h5`` files embody this."""
+    out = np.zeros(np_data.shape, dtype=np.float64)
+    for c, (vals, idf) in enumerate(tables):
+        pos = np.minimum(np.searchsorted(vals, np_data[:, c]), len(vals) - 1)
+        hit = vals[pos] == np_data[:, c]
+        col = np.where(hit, idf[pos], 0.0)
+        if len(np_data) and not hit[0]:
+            col = col.astype(np.int64).astype(np.float64)
+        out[:, c] = col
+    return out
+
+
+def _as_int32(a, what):
+    a = np.asarray(a)
+    if a.size and (a.min() < np.iinfo(np.int32).min or a.max() > np.iinfo(np.int32).max):
+        raise ValueError("%s ids do not fit int32" % what)
+    return a.astype(np.int32)
+
+
+def BM25_topk_retrieval_v4(db_np_data, qry_np_data, exact_match_col_indices=None, qry_batch_size=None, db_chunk_size=None,
+                           device="cuda:0", topK=10, enable_clean=False, lib=None, **kwargs):
+    if exact_match_col_indices:
+        raise NotImplementedError("exact_match_col_indices is not implemented on the HIP path (the shipped configs use [])")
+    db_np_data, qry_np_data = np.asarray(db_np_data), np.asarray(qry_np_data)
+    assert db_np_data.ndim == 2 and qry_np_data.ndim == 2 and db_np_data.shape[1] == qry_np_data.shape[1]
+    lib = lib or get_lib()
+    dev = torch.device(device)
+    n_db, nf = db_np_data.shape
+    n_qry = len(qry_np_data)
+    values = np.zeros((n_qry, topK), dtype=np.float64)
+    indices = np.full((n_qry, topK), -1, dtype=np.int64)
+    lens = np.zeros(n_qry, dtype=np.int64)
+    if n_qry == 0 or n_db == 0:
+        return ResultsNamedTuple(values, indices, lens)
+    tables = idf_tables(db_np_data)
+    db_t = torch.from_numpy(np.ascontiguousarray(_as_int32(db_np_data, "pool").T)).to(dev)          # [F][N] field-major
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream) if dev.type == "cuda" else None
+    step = n_qry if qry_batch_size is None else int(qry_batch_size)
+    for q0 in range(0, n_qry, step):
+        q_np = qry_np_data[q0:q0 + step]
+        q_ids = torch.from_numpy(_as_int32(q_np, "query")).contiguous().to(dev)
+        q_idf = torch.from_numpy(map_data_to_idf(q_np, tables)).contiguous().to(dev)
+        b = len(q_np)
+        out_v = torch.empty((b, topK), dtype=torch.float64, device=dev)
+        out_i = torch.empty((b, topK), dtype=torch.int64, device=dev)
+        out_l = torch.empty((b,), dtype=torch.int64, device=dev)
+        lib.call("rat_bm25_topk", ctypes.c_void_p(db_t.data_ptr()), ctypes.c_void_p(q_ids.data_ptr()),
+                 ctypes.c_void_p(q_idf.data_ptr()), ctypes.c_void_p(out_v.data_ptr()), ctypes.c_void_p(out_i.data_ptr()),
+                 ctypes.c_void_p(out_l.data_ptr()), n_db, b, nf, int(topK), stream)
+        values[q0:q0 + b] = out_v.cpu().numpy()
+        indices[q0:q0 + b] = out_i.cpu().numpy()
+        lens[q0:q0 + b] = out_l.cpu().numpy()
+    return ResultsNamedTuple(values, indices, lens)
