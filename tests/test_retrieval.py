@@ -53,7 +53,8 @@ def check_product(name, device, lib):
         ro.assert_topk_equivalent(ro.scores(db, qry, qb), got, gold_of(name, tag))   # and equivalent to the reference's own output
 
 
-@pytest.mark.parametrize("name", list(rc.CASES))
+# the emulator runs one OS thread per GPU thread: two cases on the CPU (ties everywhere; topK > pool), all four on the GPU
+@pytest.mark.parametrize("name", ["mltag_like", "tiny_pool"])
 def test_kernel_emulated(name):
     import build_emu
     import rat_amd._lib as L
