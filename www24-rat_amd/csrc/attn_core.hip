@@ -34,8 +34,17 @@ struct Vec {
     static constexpr int N = DH > 0 ? DH : CORE_DH_MAX;
     float v[N];
     __device__ __forceinline__ void load(const float* p, int dh) {
+        if (DH > 0 && DH % 2 == 0) {                    // rows start on 8-byte boundaries for an even dim_head: 8-byte accesses
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] = (DH > 0 || k < dh) ? p[k] : 0.f;
+            for (int k = 0; k < N; k += 2) {
+                const float2 t = *reinterpret_cast<const float2*>(p + k);
+                v[k] = t.x;
+                v[k + 1] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = (DH > 0 || k < dh) ? p[k] : 0.f;
+        }
     }
     __device__ __forceinline__ void zero() {
 #pragma unroll
