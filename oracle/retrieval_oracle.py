@@ -89,3 +89,68 @@ def assert_topk_equivalent(score_matrix, got, want, atol=1e-12):
                 assert (np.abs(score_matrix[b] - gv[b, k]) <= atol).sum() > 1, (b, k, gi[b, k], wi[b, k])
         used = gi[b][gi[b] >= 0]
         assert len(set(used.tolist())) == len(used), "a pool row was returned twice"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def precompute(data, cfg, pool=None):
+    """DataGenerator's pre-retrieval branch (fuxictr/pytorch/data_generator.py:106-215) restated on top of ``topk``: pool "self"
+    = <X>-fold retrieval (every fold queries the others), otherwise a separate pool; ``label_wise`` = top-K among the pool's
+    positives and among its negatives.  Padded (-1) entries go through the reference's index arithmetic unchanged:
+    ``index_map[-1]`` is the LAST element of the map.  Returns (indices, values, lens, score) where score[b] maps a GLOBAL pool row
+    to its score for query b per label half (NaN where the row is not a candidate) — used to compare indices up to ties."""
+    import re
+    cols, k, qb, lw = cfg["used_col_indices"], cfg["topK"], cfg.get("qry_batch_size"), bool(cfg.get("label_wise"))
+
+    def one(db, db_labels, qry, index_map, n_global):
+        halves = [np.nonzero(db_labels)[0], np.nonzero(1 - db_labels)[0]] if lw else [np.arange(len(db))]
+        idx_parts, val_parts, len_parts, score_parts = [], [], [], []
+        for sel in halves:
+            v, i, ln = topk(db[sel], qry, k, qb)
+            g = sel[i]                                            # -1 -> sel[-1], as in the reference
+            g = g if index_map is None else index_map[g]
+            if not lw and index_map is None:
+                g = i                                             # data_generator.py:210: the raw result, -1 kept
+            sc = np.full((len(qry), n_global), np.nan)
+            cand = sel if index_map is None else index_map[sel]
+            sc[:, cand] = scores(db[sel], qry, qb)
+            idx_parts.append(g), val_parts.append(v), len_parts.append(ln), score_parts.append(sc)
+        if lw:
+            return np.concatenate(idx_parts, -1), np.concatenate(val_parts, -1), np.stack(len_parts, -1), score_parts
+        return idx_parts[0], val_parts[0], len_parts[0], score_parts
+
+    if pool is None:
+        ids = data[:, cols].astype(int)
+        labels = data[:, -1].astype(int)
+        fold_num = int(re.match(r"\d+-fold", cfg["split_type"]).group().split("-")[0])
+        fold_size = int(np.ceil(len(ids) / fold_num))
+        outs = []
+        for fi in range(fold_num):
+            lo, hi = fi * fold_size, (fi + 1) * fold_size
+            if len(ids[lo:hi]) == 0:
+                continue
+            db = np.concatenate([ids[:lo], ids[hi:]], 0)
+            index_map = np.concatenate([np.arange(lo), np.arange(min(hi, len(ids)), len(ids))], 0)
+            outs.append(one(db, np.concatenate([labels[:lo], labels[hi:]], 0), ids[lo:hi], index_map, len(ids)))
+        nh = len(outs[0][3])
+        return (np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]), np.concatenate([o[2] for o in outs]),
+                [np.concatenate([o[3][h] for o in outs], 0) for h in range(nh)])
+    return one(pool[:, cols].astype(int), pool[:, -1].astype(int), data[:, cols].astype(int), None, len(pool))
+
+
+def assert_driver_equivalent(got, want, score_halves, k, atol=1e-12):
+    """got / want: (indices, values, lens) as stored on disk; values and lens identical, indices identical up to ties: every
+    positive-valued entry must point at a candidate row with exactly that score, padded entries must be identical."""
+    gi, gv, gl = [np.asarray(x) for x in got]
+    wi, wv, wl = [np.asarray(x) for x in want]
+    np.testing.assert_allclose(gv, wv, rtol=0, atol=atol)
+    np.testing.assert_array_equal(gl, wl)
+    assert gi.shape == wi.shape
+    for h, sc in enumerate(score_halves):
+        sl = slice(h * k, (h + 1) * k)
+        for b in range(gi.shape[0]):
+            for idx_row, val_row in ((gi[b, sl], gv[b, sl]), (wi[b, sl], wv[b, sl])):
+                for idx, val in zip(idx_row, val_row):
+                    if val > 0:
+                        assert abs(sc[b, idx] - val) <= atol, (h, b, idx, val, sc[b, idx])
+            pad = gv[b, sl] == 0
+            np.testing.assert_array_equal(gi[b, sl][pad], wi[b, sl][pad])

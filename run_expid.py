@@ -48,16 +48,45 @@ def build_sources(params, feature_map, synthetic_rows):
                                                    seed=params.get("seed", 0))
         return out["train"], out["valid"], out["test"]
     data_dir = os.path.join(params["data_root"], params["dataset_id"])
+    rcfg = params["retrieval_configs"]
+    folds = "fold" in rcfg.get("split_type", "")
     out = []
     for split in ("train", "valid", "test"):
         dpath, rpath = _find(data_dir, split), _find(data_dir, "retrieval_%d_%s" % (topk, split))
-        if dpath is None or rpath is None:
-            raise RuntimeError("missing %s / retrieval_%d_%s under %s (pre-computed offline by the reference's "
-                               "build_dataset + BM25 retrieval, or pass --synthetic N)" % (split, topk, split, data_dir))
-        pool = _find(data_dir, "retrieval_pool") if split != "train" or "fold" not in params["retrieval_configs"].get("split_type", "") else None
+        if dpath is None:
+            if split == "test":
+                out.append(None)
+                continue
+            raise RuntimeError("missing %s.{npz,h5} under %s (encoded by the reference's build_dataset, or pass --synthetic N)" % (split, data_dir))
+        # pool per split as h5_generator chooses it (datasets/data_utils.py:1218-1226,1257-1262): <X>-fold -> the training split
+        # retrieves from its own other folds, valid / test from the training data; otherwise the separate retrieval pool
+        if folds:
+            pool = None if split == "train" else _find(data_dir, "train")
+        else:
+            pool = _find(data_dir, "retrieval_pool")
+        if rpath is None:
+            rpath = os.path.join(data_dir, "retrieval_%d_%s.npz" % (topk, split))
+            precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
         out.append(rat_data.batches_from_files(dpath, rpath, bs, pool_path=pool, shuffle=(split == "train") and params.get("shuffle", True),
                                                seed=params.get("seed", 0)))
     return out
+
+
+def precompute_retrieval_file(data_path, pool_path, save_path, rcfg, feature_map, params):
+    """DataGenerator's pre-retrieval branch (fuxictr/pytorch/data_generator.py:106-215) with the top-K search on the device
+    (rat_bm25_topk); the result is stored next to the data like the reference's retrieval_{K}_{split}.h5 (keys indices /
+    values / lens; .npz because this image has no h5py)."""
+    import numpy as np
+    from rat_amd import retrieval
+    if params["gpu"] < 0:
+        raise RuntimeError("%s does not exist and computing it needs a GPU (--gpu >= 0): the retrieval kernel has no CPU fallback" % save_path)
+    data = rat_data.load_array_file(data_path, ["data"])["data"]
+    pool = None if pool_path is None else rat_data.load_array_file(pool_path, ["data"])["data"]
+    logging.info("retrieval file %s not found: computing top-%d on the device (%d queries, pool %s)", save_path, rcfg["topK"], len(data),
+                 "self / %s" % rcfg.get("split_type") if pool is None else "%d rows" % len(pool))
+    cols = retrieval.used_col_indices(feature_map, rcfg)
+    indices, values, lens = retrieval.precompute_retrieval(data, rcfg, cols, pool_array=pool, device="cuda:%d" % params["gpu"])
+    np.savez_compressed(save_path, indices=indices, values=values, lens=lens)
 
 
 def main(argv=None):

@@ -28,3 +28,27 @@ def run_variants(case):
     first row of every batch, see oracle/retrieval_oracle.py:map_idf); the pool chunking only reorders ties."""
     return {"whole": dict(), "chunked": dict(qry_batch_size=8, db_chunk_size=50),
             "rechunked": dict(qry_batch_size=8, db_chunk_size=64, enable_clean=True)}
+
+
+# ---- the DataGenerator-level driver (fuxictr/pytorch/data_generator.py:106-215): fold / separate-pool / label-wise retrieval
+DRIVER_CASES = {
+    "fold3_self": dict(n=50, n_pool=None, vocab=[9, 7, 5], topk=4, split_type="3-fold", label_wise=False, seed=21, qry_batch_size=16),
+    "fold4_self_labelwise": dict(n=61, n_pool=None, vocab=[6, 5, 4], topk=3, split_type="4-fold", label_wise=True, seed=22, qry_batch_size=None),
+    "separate_pool": dict(n=23, n_pool=40, vocab=[8, 6], topk=5, split_type="random", label_wise=False, seed=23, qry_batch_size=10),
+    "separate_pool_labelwise": dict(n=19, n_pool=35, vocab=[5, 4, 3], topk=2, split_type="sequential", label_wise=True, seed=24, qry_batch_size=None),
+}
+
+
+def make_driver_case(case):
+    """-> (data [n, F+1] float64 with the label last, pool or None, retrieval_configs as h5_generator prepares them)"""
+    rs = np.random.RandomState(case["seed"])
+
+    def table(n):
+        ids = np.stack([rs.randint(0, v, size=n) for v in case["vocab"]], axis=1)
+        return np.concatenate([ids, rs.randint(0, 2, size=(n, 1))], axis=1).astype(np.float64)
+    data = table(case["n"])
+    pool = None if case["n_pool"] is None else table(case["n_pool"])
+    cfg = dict(pre_retrieval=True, split_type=case["split_type"], label_wise=case["label_wise"], topK=case["topk"],
+               used_col_indices=list(range(len(case["vocab"]))), exact_match_col_indices=None,
+               qry_batch_size=case["qry_batch_size"], db_chunk_size=17, device="cpu", enable_clean=False)
+    return data, pool, cfg

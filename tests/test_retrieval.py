@@ -94,3 +94,43 @@ def test_large_pool_properties_gpu(topk):
     np.testing.assert_allclose(got.values[sample], want[0], rtol=0, atol=1e-12)
     np.testing.assert_array_equal(got.lens[sample], want[2])
     ro.assert_topk_equivalent(s, (got.values[sample], got.indices[sample], got.lens[sample]), want)
+
+
+# ---- the driver: fold / separate-pool / label-wise pre-retrieval as DataGenerator runs it (data_generator.py:106-215)
+def gold_driver(name):
+    g = np.load(GOLD)
+    return g["driver/%s/indices" % name], g["driver/%s/values" % name], g["driver/%s/lens" % name]
+
+
+@pytest.mark.parametrize("name", list(rc.DRIVER_CASES))
+def test_driver_oracle_matches_reference(name):
+    case = rc.DRIVER_CASES[name]
+    data, pool, cfg = rc.make_driver_case(case)
+    idx, val, lens, sc = ro.precompute(data, cfg, pool)
+    ro.assert_driver_equivalent((idx, val, lens), gold_driver(name), sc, case["topk"])
+
+
+def check_driver_product(name, device, lib):
+    from rat_amd import retrieval
+    case = rc.DRIVER_CASES[name]
+    data, pool, cfg = rc.make_driver_case(case)
+    oi, ov, ol, sc = ro.precompute(data, cfg, pool)
+    gi, gv, gl = retrieval.precompute_retrieval(data, cfg, cfg["used_col_indices"], pool_array=pool, device=device, lib=lib)
+    np.testing.assert_array_equal(gi, oi)                       # same deterministic tie order as the oracle
+    np.testing.assert_allclose(gv, ov, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(gl, ol)
+    ro.assert_driver_equivalent((gi, gv, gl), gold_driver(name), sc, case["topk"])
+
+
+@pytest.mark.parametrize("name", ["fold3_self", "separate_pool_labelwise"])
+def test_driver_emulated(name):
+    import build_emu
+    import rat_amd._lib as L
+    check_driver_product(name, "cpu", L.RatLib(build_emu.build()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(rc.DRIVER_CASES))
+def test_driver_gpu(name):
+    import rat_amd._lib as L
+    check_driver_product(name, "cuda:0", L.get_lib())

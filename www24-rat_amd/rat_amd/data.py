@@ -5,8 +5,9 @@ The reference builds every sample in a Python ``__getitem__`` (``pool[retr_indic
 processes and collates float64 tensors; this class does the same gather with one vectorised fancy-index per batch and
 hands over int32 ids / float32 labels (the model converts once anyway).  On-disk formats: the reference's ``*.h5``
 (``data`` = float [N, L+1] with the label last; ``retrieval_{K}_{split}.h5`` with ``indices``/``values``/``lens``) are
-read when ``h5py`` is importable; ``.npz`` files with the same keys are always accepted.  BM25 retrieval itself is an
-offline pre-computation and out of scope."""
+read when ``h5py`` is importable; ``.npz`` files with the same keys are always accepted.  A missing retrieval file is
+computed on the device by ``rat_amd.retrieval.precompute_retrieval`` (run_expid.py), like the reference's DataGenerator does
+with BM25_topk_retrieval_v4."""
 import os
 
 import numpy as np

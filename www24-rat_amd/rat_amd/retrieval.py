@@ -87,3 +87,63 @@ def BM25_topk_retrieval_v4(db_np_data, qry_np_data, exact_match_col_indices=None
         indices[q0:q0 + b] = out_i.cpu().numpy()
         lens[q0:q0 + b] = out_l.cpu().numpy()
     return ResultsNamedTuple(values, indices, lens)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def used_col_indices(feature_map, retrieval_configs):
+    """h5_generator (fuxictr/datasets/data_utils.py:1193-1205): columns of the encoded array the retrieval compares."""
+    if retrieval_configs.get("exact_match_cols"):
+        raise NotImplementedError("exact_match_cols is not implemented on the HIP path (the shipped configs use [])")
+    return [feature_map.feature_specs[col]["index"] for col in retrieval_configs["used_cols"]]
+
+
+def precompute_retrieval(data_array, retrieval_configs, col_indices, pool_array=None, device="cuda:0", lib=None):
+    """What DataGenerator does when ``retrieval_{K}_{split}.h5`` does not exist yet (fuxictr/pytorch/data_generator.py:114-212).
+
+    data_array: the encoded split [Q, L+1] (label last).  pool_array None = pool "self": ``<X>-fold`` retrieval — every fold of
+    the split queries the other folds (data_generator.py:115-176); otherwise the split queries the separate pool
+    (:177-212).  ``label_wise`` retrieves top-K among the positives and top-K among the negatives (indices / values [Q, 2K],
+    lens [Q, 2]).  Returns (indices, values, lens) exactly as the reference stores them — including its index arithmetic on
+    padded entries: in the fold / label-wise paths a ``-1`` result indexes the LAST element of the index map
+    (``fold_db_indices[-1]``), which is what the reference writes to disk."""
+    import re
+    kw = dict(qry_batch_size=retrieval_configs.get("qry_batch_size"), topK=retrieval_configs["topK"], device=device, lib=lib)
+    label_wise = bool(retrieval_configs.get("label_wise", False))
+
+    def retrieve(db, qry):
+        return BM25_topk_retrieval_v4(db_np_data=db, qry_np_data=qry, **kw)
+
+    def one(db_data, db_labels, qry_data, index_map):
+        """-> (indices, values, lens) of one query set against one pool; index_map translates pool rows to global rows"""
+        if label_wise:
+            parts = []
+            for sel in (np.nonzero(db_labels)[0], np.nonzero(1 - db_labels)[0]):
+                r = retrieve(db_data[sel], qry_data)
+                idx = sel[r.indices]
+                parts.append((idx if index_map is None else index_map[idx], r.values, r.lens))
+            return (np.concatenate([parts[0][0], parts[1][0]], axis=-1), np.concatenate([parts[0][1], parts[1][1]], axis=-1),
+                    np.stack([parts[0][2], parts[1][2]], axis=-1))
+        r = retrieve(db_data, qry_data)
+        return (r.indices if index_map is None else index_map[r.indices]), r.values, r.lens
+
+    if pool_array is None:
+        ids = data_array[:, col_indices].astype(int)
+        labels = data_array[:, -1].astype(int) if label_wise else None
+        m = re.match(r"\d+-fold", retrieval_configs["split_type"])
+        assert m is not None, "pool 'self' needs split_type '<X>-fold'"
+        fold_num = int(m.group().split("-")[0])
+        fold_size = int(np.ceil(len(ids) / fold_num))
+        out = []
+        for fi in range(fold_num):
+            lo, hi = fi * fold_size, (fi + 1) * fold_size
+            qry = ids[lo:hi]
+            if len(qry) == 0:
+                continue
+            db = np.concatenate([ids[:lo], ids[hi:]], axis=0)
+            index_map = np.concatenate([np.arange(lo), np.arange(min(hi, len(ids)), len(ids))], axis=0)
+            db_labels = np.concatenate([labels[:lo], labels[hi:]], axis=0) if label_wise else None
+            out.append(one(db, db_labels, qry, index_map))
+        return tuple(np.concatenate([o[j] for o in out]) for j in range(3))
+    db = pool_array[:, col_indices].astype(int)
+    qry = data_array[:, col_indices].astype(int)
+    return one(db, pool_array[:, -1].astype(int) if label_wise else None, qry, None)
