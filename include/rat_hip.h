@@ -125,6 +125,15 @@ int rat_attn_core_fwd(const float* qkv, float* o, float* lse, int64_t nseq, int 
                       void* stream);
 int rat_attn_core_bwd(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv, int64_t nseq, int L,
                       int heads, int dim_head, float softmax_scale, void* stream);
+/* The same with RatSeqMap addressing (sequences strided through the token grid, e.g. the cross-sample phase) — the composed
+ * attention path for dimensions the fused kernels do not serve.  rat_attn_fused_supported tells which path applies: 0 for
+ * sequences above 64 tokens or heads*dim_head too wide for the fused LDS tile / weight-gradient accumulators (the shipped
+ * Tmall config, configs/RAT_m2/tmall_x1_002/model_config.yaml:23: 32 heads x 10). */
+int rat_attn_core_fwd_map(const float* qkv, float* o, float* lse, const RatSeqMap* map_host, int heads, int dim_head,
+                          float softmax_scale, void* stream);
+int rat_attn_core_bwd_map(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv,
+                          const RatSeqMap* map_host, int heads, int dim_head, float softmax_scale, void* stream);
+int rat_attn_fused_supported(int d, int heads, int dim_head, int L);
 
 /* ---- K2 (cont.): FeedForward + residual, y = W2 gelu_erf(W1 x + b1) + b2 + x (RAT_m2.py:163-174, 232) */
 int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,

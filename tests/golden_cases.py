@@ -56,6 +56,16 @@ CASES = [
          batch_norm=False, use_wide=False, embedding_regularizer=0, net_regularizer=0),
 ]
 
+# The REAL Tmall head geometry (configs/RAT_m2/tmall_x1_002/model_config.yaml: 32 heads x 10, d = 10): heads*dim_head = 320 is too
+# wide for the fused attention kernel's LDS tile -> the composed path (LayerNorm -> GEMM -> attention core with strided sequences
+# -> GEMM) serves both the intra and the cross phase.
+CASES += [
+    dict(name="tmall_real_heads", batch=4, topk=6, init_seed=2021, data_seed=151, weight_seed=152, full_limit=2048,
+         fields=[_cat("f%d" % i, 11 + 2 * i) for i in range(8)],
+         embedding_dim=10, num_heads=32, dim_head=10, depth=2, scale_dim=2, dnn_hidden_units=[20, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.07, net_regularizer=0),
+]
+
 # RAT_m1 (cascaded intra / cross transformers, RAT_m1.py) — same fields / seeds machinery.
 CASES += [
     dict(name="m1_tiny_seq", model="RAT_m1", batch=6, topk=3, init_seed=2021, data_seed=71, weight_seed=72, full_limit=1 << 20,

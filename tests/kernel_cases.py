@@ -187,6 +187,26 @@ def check_attn_core(lib, dev, nseq, L, heads, dh, softmax_scale=None):
     close(dqkv, r.grad, 1e-4, 1e-4, "dqkv")
 
 
+def check_attn_core_strided(lib, dev, B, T, S, heads, dh):
+    """rat_attn_core_*_map with the cross-sample map (sequences of T tokens strided by S through the [B,T,S] grid)."""
+    rs = np.random.RandomState(19)
+    I = heads * dh
+    qkv = rnd(rs, B * T * S, 3 * I)
+    dout = rnd(rs, B * T * S, I)
+    r = qkv.double().requires_grad_(True)
+    g = r.reshape(B, T, S, 3 * I).transpose(1, 2).reshape(B * S, T, 3 * I)               # what the reference's transpose copy holds
+    q, k, v = [t.reshape(B * S, T, heads, dh).permute(0, 2, 1, 3) for t in g.split(I, dim=-1)]
+    p = torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, S, T, I).transpose(1, 2).reshape(B * T * S, I)
+    ref.backward(dout.double())
+    smap = ops.cross_map(B, T, S)
+    qd = qkv.to(dev)
+    o, lse = ops.attn_core_fwd_map(qd, smap, heads, dh, lib=lib)
+    close(o, ref, 2e-5, 2e-5, "o")
+    dqkv = ops.attn_core_bwd_map(qd, o, lse, dout.to(dev), smap, heads, dh, lib=lib)
+    close(dqkv, r.grad, 1e-4, 1e-4, "dqkv")
+
+
 def check_ffn(lib, dev, ntok, d, hidden):
     rs = np.random.RandomState(3)
     x = rnd(rs, ntok, d)

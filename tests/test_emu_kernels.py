@@ -57,6 +57,11 @@ def test_attn_core_fwd_bwd(emu, nseq, L, heads, dh, softmax_scale):
     kc.check_attn_core(emu, "cpu", nseq, L, heads, dh, softmax_scale)
 
 
+@pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (1, 5, 3, 3, 10)])
+def test_attn_core_strided(emu, B, T, S, heads, dh):
+    kc.check_attn_core_strided(emu, "cpu", B, T, S, heads, dh)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

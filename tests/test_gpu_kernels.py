@@ -48,6 +48,11 @@ def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale):
     kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)
 
 
+@pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (64, 31, 9, 32, 10), (16, 11, 21, 8, 10)])
+def test_attn_core_strided(lib, B, T, S, heads, dh):
+    kc.check_attn_core_strided(lib, "cuda", B, T, S, heads, dh)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

@@ -30,13 +30,14 @@ def test_init_matches_reference_bit_for_bit(name):
 
 
 # the emulator runs one OS thread per GPU thread: keep the CPU suite to the small cases (the GPU suite runs them all)
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "tmall_shape", "m1_tiny_seq", "m1_bare", "m3_tiny_seq", "m0_tiny_seq"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m3_tiny_seq", "m0_tiny_seq"])
 def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
 
 # (RAT_m0's training steps run in test_m0_long_sequence_path: its fused-kernel path is RAT_m1's)
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m1_bare", "m3_tiny_seq"])
+# one case per variant on the emulator (35-40 s each); the GPU suite runs every case of golden_cases.CASES
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m3_tiny_seq"])
 def test_two_training_steps(name):
     mc.check_training(name, gpu=-1)
 
@@ -89,3 +90,16 @@ def test_m0_long_sequence_path(monkeypatch):
     from rat_amd import models
     monkeypatch.setattr(models.RAT_m0, "FUSED_MAX_L", 8)
     mc.check_training("m0_tiny_seq", gpu=-1)          # forward outputs, loss, every gradient, clip norm, post-Adam weights
+
+
+def test_wide_heads_select_the_composed_attention_path():
+    """32 heads x 10 (the shipped Tmall config) does not fit the fused attention kernel; the model-level parity of that geometry
+    (golden case tmall_real_heads) runs on the GPU (tests/test_gpu_model.py) — under the one-OS-thread-per-lane emulator its
+    ~1000 work-groups per launch take a quarter of an hour.  The composed path itself is emulated at kernel level
+    (tests/test_emu_kernels.py::test_attn_core_strided) and at model level by test_m0_long_sequence_path."""
+    import rat_amd._lib as L
+    from rat_amd import ops
+    assert not ops.attn_fused_supported(10, 32, 10, 9, lib=L._default)       # real Tmall heads
+    assert not ops.attn_fused_supported(64, 8, 10, 231, lib=L._default)      # RAT_m0's joint sequence
+    assert ops.attn_fused_supported(64, 8, 10, 21, lib=L._default)
+    assert ops.attn_fused_supported(40, 8, 10, 14, lib=L._default)           # KKBox

@@ -935,6 +935,18 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     return rat_check_launch("rat_attn_fwd");
 }
 
+// 1 when the fused kernels (forward AND backward) serve these dimensions, 0 when the caller has to take the composed path
+// (K2c LayerNorm -> rat_sgemm -> rat_attn_core_*_map -> rat_sgemm): sequences above 64 tokens, or heads*dim_head too wide for
+// the LDS tile / the in-register weight-gradient accumulators (the shipped Tmall config: 32 heads x 10).
+extern "C" int rat_attn_fused_supported(int d, int heads, int dim_head, int L) {
+    if (d <= 0 || heads <= 0 || dim_head <= 0 || L < 1 || L > ATT_ROWS) return 0;
+    if (!(dim_head <= DH_MAX || dim_head == 20) || d > 128) return 0;
+    const AttnGeom g(d, heads, dim_head);
+    if (g.fwd_smem() > 160 * 1024 || g.bwd_smem(heads) > 160 * 1024) return 0;
+    if ((g.Q16 / 16) * (g.D16 / 16) > QSLOTS * ATT_WAVES || (g.D16 / 16) * (g.I16 / 16) > OSLOTS * ATT_WAVES) return 0;
+    return 1;
+}
+
 extern "C" size_t rat_attn_bwd_workspace(int d, int heads, int dim_head) {
     const AttnGeom g(d, heads, dim_head);
     return (size_t)256 * (size_t)g.slab_floats() * sizeof(float);

@@ -24,10 +24,15 @@ struct CoreArgs {
     float* o_out;
     float* lse_out;
     float* dqkv;
-    int64_t nseq;
+    int64_t nseq, q_div, hi_stride, lo_stride, pos_stride;      // RatSeqMap: token of (sequence q, position p)
     int L, heads, dh;
     float scale;
 };
+
+// same addressing as attn.hip: sequences may be strided through the token grid (the cross-sample phase of RAT_m2)
+__device__ __forceinline__ int64_t core_token(const CoreArgs& a, int64_t q, int p) {
+    return (q / a.q_div) * a.hi_stride + (q % a.q_div) * a.lo_stride + (int64_t)p * a.pos_stride;
+}
 
 template <int DH>
 struct Vec {
@@ -83,17 +88,18 @@ __global__ void __launch_bounds__(1024) core_fwd_kernel(CoreArgs a) {
     for (int64_t task = blockIdx.x; task < a.nseq * a.heads; task += gridDim.x) {
         const int64_t sq = task / a.heads;
         const int h = (int)(task - sq * a.heads);
-        const float* base = a.qkv + sq * L * (int64_t)(3 * I) + h * dh;
+        const float* base = a.qkv + h * dh;
         for (int e = threadIdx.x; e < L * dh; e += blockDim.x) {
             const int j = e / dh, c = e - j * dh;
-            const float* row = base + (int64_t)j * (3 * I);
+            const float* row = base + core_token(a, sq, j) * (3 * I);
             ks[e] = row[I + c];
             vs[e] = row[2 * I + c];
         }
         __syncthreads();
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
             Vec<DH> q, o, kv;
-            q.load(base + (int64_t)i * (3 * I), dh);
+            const int64_t tok = core_token(a, sq, i);
+            q.load(base + tok * (3 * I), dh);
             o.zero();
             float m = -3.0e38f, l = 0.f;
             for (int j = 0; j < L; ++j) {
@@ -106,7 +112,6 @@ __global__ void __launch_bounds__(1024) core_fwd_kernel(CoreArgs a) {
                 o.scale_axpy(corr, p, kv);
                 m = mn;
             }
-            const int64_t tok = sq * L + i;
             o.store(a.o_out + tok * I + h * dh, dh, 1.0f / l);
             if (a.lse_out != nullptr) a.lse_out[tok * a.heads + h] = m + rat_log2(l);
         }
@@ -128,25 +133,27 @@ __global__ void __launch_bounds__(1024) core_bwd_kernel(CoreArgs a) {
     for (int64_t task = blockIdx.x; task < a.nseq * a.heads; task += gridDim.x) {
         const int64_t sq = task / a.heads;
         const int h = (int)(task - sq * a.heads);
-        const float* base = a.qkv + sq * L * (int64_t)(3 * I) + h * dh;
-        const float* gbase = a.dout + sq * L * (int64_t)I + h * dh;
-        const float* obase = a.o + sq * L * (int64_t)I + h * dh;
+        const float* base = a.qkv + h * dh;
+        const float* gbase = a.dout + h * dh;
+        const float* obase = a.o + h * dh;
         for (int e = threadIdx.x; e < L * dh; e += blockDim.x) {
             const int j = e / dh, c = e - j * dh;
-            const float* row = base + (int64_t)j * (3 * I);
+            const int64_t tok = core_token(a, sq, j);
+            const float* row = base + tok * (3 * I);
             qs[e] = row[c];
             ks[e] = row[I + c];
             vs[e] = row[2 * I + c];
-            gs[e] = gbase[(int64_t)j * I + c];
+            gs[e] = gbase[tok * I + c];
         }
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
-            ls[i] = a.lse_in[(sq * L + i) * a.heads + h];
+            const int64_t tok = core_token(a, sq, i);
+            ls[i] = a.lse_in[tok * a.heads + h];
             float dsum = 0.f;
-            for (int c = 0; c < dh; ++c) dsum = fmaf(gbase[(int64_t)i * I + c], obase[(int64_t)i * I + c], dsum);
+            for (int c = 0; c < dh; ++c) dsum = fmaf(gbase[tok * I + c], obase[tok * I + c], dsum);
             ds[i] = dsum;
         }
         __syncthreads();
-        float* dbase = a.dqkv + sq * L * (int64_t)(3 * I) + h * dh;
+        float* dbase = a.dqkv + h * dh;
         // pass 1: one lane per query row -> dQ
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
             Vec<DH> q, go, dq, kv;
@@ -161,7 +168,7 @@ __global__ void __launch_bounds__(1024) core_bwd_kernel(CoreArgs a) {
                 const float p = rat_exp2(q.dot(kv) * sl2 - lse);
                 dq.axpy(p * (dp - delta), kv);
             }
-            dq.store(dbase + (int64_t)i * (3 * I), dh, a.scale);
+            dq.store(dbase + core_token(a, sq, i) * (3 * I), dh, a.scale);
         }
         // pass 2: one lane per key row -> dK, dV
         for (int j = threadIdx.x; j < L; j += blockDim.x) {
@@ -178,8 +185,9 @@ __global__ void __launch_bounds__(1024) core_bwd_kernel(CoreArgs a) {
                 dv.axpy(p, t);
                 dk.axpy(p * (dp - ds[i]), qv);
             }
-            dk.store(dbase + (int64_t)j * (3 * I) + I, dh, a.scale);
-            dv.store(dbase + (int64_t)j * (3 * I) + 2 * I, dh, 1.0f);
+            const int64_t tokj = core_token(a, sq, j);
+            dk.store(dbase + tokj * (3 * I) + I, dh, a.scale);
+            dv.store(dbase + tokj * (3 * I) + 2 * I, dh, 1.0f);
         }
         __syncthreads();
     }
@@ -227,8 +235,39 @@ unsigned core_grid(int64_t tasks) { return (unsigned)(tasks < 65536 ? tasks : 65
 
 }  // namespace
 
+namespace {
+RatSeqMap contiguous_map(int64_t nseq, int L) {
+    RatSeqMap m{};
+    m.nseq = nseq;
+    m.L = L;
+    m.q_div = nseq;
+    m.hi_stride = 0;
+    m.lo_stride = L;
+    m.pos_stride = 1;
+    return m;
+}
+void fill_map(CoreArgs& a, const RatSeqMap* m) {
+    a.nseq = m->nseq;
+    a.L = m->L;
+    a.q_div = m->q_div;
+    a.hi_stride = m->hi_stride;
+    a.lo_stride = m->lo_stride;
+    a.pos_stride = m->pos_stride;
+}
+}  // namespace
+
 extern "C" int rat_attn_core_fwd(const float* qkv, float* o, float* lse, int64_t nseq, int L, int heads, int dim_head,
                                  float softmax_scale, void* stream) {
+    RAT_REQUIRE(nseq > 0 && L > 0, "bad dims");
+    const RatSeqMap m = contiguous_map(nseq, L);
+    return rat_attn_core_fwd_map(qkv, o, lse, &m, heads, dim_head, softmax_scale, stream);
+}
+
+extern "C" int rat_attn_core_fwd_map(const float* qkv, float* o, float* lse, const RatSeqMap* map_host, int heads, int dim_head,
+                                     float softmax_scale, void* stream) {
+    RAT_REQUIRE(map_host != nullptr && map_host->q_div >= 1, "bad seq map");
+    const int64_t nseq = map_host->nseq;
+    const int L = map_host->L;
     const size_t smem = (size_t)2 * L * dim_head * sizeof(float);
     if (core_check(nseq, L, heads, dim_head, smem)) return -1;
     RAT_REQUIRE(qkv && o, "null pointer");
@@ -236,8 +275,7 @@ extern "C" int rat_attn_core_fwd(const float* qkv, float* o, float* lse, int64_t
     a.qkv = qkv;
     a.o_out = o;
     a.lse_out = lse;
-    a.nseq = nseq;
-    a.L = L;
+    fill_map(a, map_host);
     a.heads = heads;
     a.dh = dim_head;
     a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
@@ -246,6 +284,16 @@ extern "C" int rat_attn_core_fwd(const float* qkv, float* o, float* lse, int64_t
 
 extern "C" int rat_attn_core_bwd(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv,
                                  int64_t nseq, int L, int heads, int dim_head, float softmax_scale, void* stream) {
+    RAT_REQUIRE(nseq > 0 && L > 0, "bad dims");
+    const RatSeqMap m = contiguous_map(nseq, L);
+    return rat_attn_core_bwd_map(qkv, o, lse, dout, dqkv, &m, heads, dim_head, softmax_scale, stream);
+}
+
+extern "C" int rat_attn_core_bwd_map(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv,
+                                     const RatSeqMap* map_host, int heads, int dim_head, float softmax_scale, void* stream) {
+    RAT_REQUIRE(map_host != nullptr && map_host->q_div >= 1, "bad seq map");
+    const int64_t nseq = map_host->nseq;
+    const int L = map_host->L;
     const size_t smem = ((size_t)4 * L * dim_head + 2 * (size_t)L) * sizeof(float);
     if (core_check(nseq, L, heads, dim_head, smem)) return -1;
     RAT_REQUIRE(qkv && o && lse && dout && dqkv, "null pointer");
@@ -255,8 +303,7 @@ extern "C" int rat_attn_core_bwd(const float* qkv, const float* o, const float* 
     a.lse_in = lse;
     a.dout = dout;
     a.dqkv = dqkv;
-    a.nseq = nseq;
-    a.L = L;
+    fill_map(a, map_host);
     a.heads = heads;
     a.dh = dim_head;
     a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);

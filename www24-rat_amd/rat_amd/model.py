@@ -216,6 +216,7 @@ class RAT_m2(BaseModel):
         self._lib = None
         self._last_gflat = None
         self._ws = {}
+        self._fused_cache = {}
         self.compile(kwargs["optimizer"], loss=kwargs["loss"], lr=learning_rate)
         self.reset_parameters()
         self.model_to_device()
@@ -231,6 +232,63 @@ class RAT_m2(BaseModel):
         names = [p + "norm.weight", p + "norm.bias", p + "fn.to_qkv.weight",
                  p + "fn.to_out.0.weight" if has_out else None, p + "fn.to_out.0.bias" if has_out else None]
         return names, ops.attn_params(*[self._p(n) if n else None for n in names])
+
+    # ---- one PreNorm(Attention)(x) + x layer: the fused kernel when it serves the dimensions, otherwise composed from K2c
+    #      LayerNorm -> rat_sgemm (to_qkv) -> K2d attention core (seq-map addressing) -> rat_sgemm (to_out + bias + residual)
+    FUSED_MAX_L = 64            # tests lower this to send short sequences through the composed path as well
+
+    def _attn_is_fused(self, smap):
+        key = (int(smap.L), self.FUSED_MAX_L)
+        hit = self._fused_cache.get(key)
+        if hit is None:
+            c = self._cfg
+            hit = self._fused_cache[key] = smap.L <= self.FUSED_MAX_L and ops.attn_fused_supported(c["d"], c["heads"], c["dh"], smap.L,
+                                                                                                  lib=self._lib)
+        return hit
+
+    def _attn_layer_forward(self, desc, x, smap, save, out=None):
+        """desc = (names, RatAttnParams) from _attn_descriptor; returns (y, whatever the backward needs)."""
+        c, lib = self._cfg, self._lib
+        d, heads, dh = c["d"], c["heads"], c["dh"]
+        if self._attn_is_fused(smap):
+            y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, lib=lib)
+            return y, (o, l)
+        inner, ntok = heads * dh, x.numel() // d
+        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in desc[0]]
+        if w_out is None:
+            raise NotImplementedError("attention without an output projection (heads == 1 and dim_head == embedding_dim) is only "
+                                      "implemented in the fused kernel (sequences up to 64 tokens)")
+        xn = ops.layernorm_fwd(x, d, ntok, ln_g, ln_b, d, lib=lib)
+        qkv = torch.empty((ntok, 3 * inner), dtype=torch.float32, device=x.device)
+        ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_qkv, d, qkv, 3 * inner, lib=lib)                     # to_qkv (no bias)
+        o, lse = ops.attn_core_fwd_map(qkv, smap, heads, dh, save=True, lib=lib)
+        y = x.clone()                                                                                     # the residual, accumulated by beta = 1
+        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, lib=lib)      # to_out + x
+        return y, ((qkv, o, lse) if save else None)
+
+    def _attn_layer_backward(self, desc, x_in, dy, att, smap, G):
+        c, lib = self._cfg, self._lib
+        d, heads, dh = c["d"], c["heads"], c["dh"]
+        names = desc[0]
+        if self._attn_is_fused(smap):
+            ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
+            grads = ops.attn_params(*[G(n) if n else None for n in names])
+            dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, lib=lib)
+            return dx
+        inner, ntok = heads * dh, x_in.numel() // d
+        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
+        qkv, o, lse = att
+        dev = dy.device
+        xn = ops.layernorm_fwd(x_in, d, ntok, ln_g, ln_b, d, lib=lib)                                     # recomputed, not stored
+        do = torch.empty((ntok, inner), dtype=torch.float32, device=dev)
+        ops.sgemm(0, 0, ntok, inner, d, dy, d, w_out, inner, do, inner, lib=lib)                          # dO = dy W_out
+        ops.sgemm(1, 0, d, inner, ntok, dy, d, o, inner, G(names[3]), inner, lib=lib)                     # dW_out = dy^T O
+        ops.colsum(dy, d, G(names[4]), ntok, d, lib=lib)
+        dqkv = ops.attn_core_bwd_map(qkv, o, lse, do, smap, heads, dh, lib=lib)
+        dxn = torch.empty((ntok, d), dtype=torch.float32, device=dev)
+        ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_qkv, d, dxn, d, lib=lib)                   # d(norm(x)) = dQKV W_qkv
+        ops.sgemm(1, 0, 3 * inner, d, ntok, dqkv, 3 * inner, xn, d, G(names[2]), d, lib=lib)              # dW_qkv = dQKV^T norm(x)
+        return ops.layernorm_bwd(x_in, d, dxn, ln_g, dxn, d, G(names[0]), G(names[1]), d, add=dy, lib=lib).view_as(x_in)
 
     def _build_encoder_descriptors(self):
         self._blocks = []
@@ -251,12 +309,12 @@ class RAT_m2(BaseModel):
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
         for bi, blk in enumerate(self._blocks):
             inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
-            xa, o1, l1 = ops.attn_fwd(x, blk["intra"][1], imap, d, heads, dh, save=save, out=x if inplace else None, lib=lib)
-            xb, o2, l2 = ops.attn_fwd(xa, blk["cross"][1], cmap, d, heads, dh, save=save, out=xa if not save else None, lib=lib)
+            xa, a1 = self._attn_layer_forward(blk["intra"], x, imap, save, out=x if inplace else None)
+            xb, a2 = self._attn_layer_forward(blk["cross"], xa, cmap, save, out=xa if not save else None)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, lib=lib)
             if save:
-                saved["blocks"].append((x, o1, l1, xa, o2, l2, xb))
+                saved["blocks"].append((x, a1, xa, a2, xb))
             x = xc
         return x, T * S * d
 
@@ -266,16 +324,13 @@ class RAT_m2(BaseModel):
         B, T, L, S = saved["dims"]
         d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
-        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
         ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
-        for blk, (x_in, o1, l1, xa, o2, l2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
+        for blk, (x_in, a1, xa, a2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             gw = [G(n) for n in blk["ffn"]]
             dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, lib=lib)
-            for which, xin, o, l, smap in (("cross", xa, o2, l2, cmap), ("intra", x_in, o1, l1, imap)):
-                names, params = blk[which]
-                grads = ops.attn_params(*[G(n) if n else None for n in names])
-                dx, _ = ops.attn_bwd(xin, dx, o, l, params, grads, smap, d, heads, dh, workspace=ws_attn, lib=lib)
+            dx = self._attn_layer_backward(blk["cross"], xa, dx, a2, cmap, G)
+            dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G)
         return dx
 
     # ------------------------------------------------------------------------------ flat parameter buffer
@@ -582,7 +637,7 @@ class RAT_m1(RAT_m2):
         layers, norm = self._stacks[which]
         rec = []
         for lay in layers:
-            xa, att = self._attn_layer_forward(lay, x, smap, save)                                    # attn(norm(x)) + x
+            xa, att = self._attn_layer_forward(lay["attn"], x, smap, save)                            # attn(norm(x)) + x
             xn = ops.layernorm_fwd(xa, d, ntok, self._p(lay["ln"][0]), self._p(lay["ln"][1]), d, lib=lib)
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
             xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, lib=lib)                               # ff(norm(x)) + x
@@ -607,21 +662,7 @@ class RAT_m1(RAT_m2):
             gw = [G(n) for n in lay["ffn"]]
             dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn, lib=lib)
             dxa = ops.layernorm_bwd(xa, d, dxn, self._p(lay["ln"][0]), dxn, d, G(lay["ln"][0]), G(lay["ln"][1]), d, add=dx, lib=lib)
-            dx = self._attn_layer_backward(lay, x_in, dxa, att, smap, G)
-        return dx
-
-    def _attn_layer_forward(self, lay, x, smap, save):
-        """x -> PreNorm(Attention)(x) + x; returns (y, whatever the backward needs)."""
-        c = self._cfg
-        y, o, l = ops.attn_fwd(x, lay["attn"][1], smap, c["d"], c["heads"], c["dh"], save=save, lib=self._lib)
-        return y, (o, l)
-
-    def _attn_layer_backward(self, lay, x_in, dy, att, smap, G):
-        c, lib = self._cfg, self._lib
-        ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", c["d"], c["heads"], c["dh"]))
-        names, params = lay["attn"]
-        grads = ops.attn_params(*[G(n) if n else None for n in names])
-        dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], params, grads, smap, c["d"], c["heads"], c["dh"], workspace=ws, lib=lib)
+            dx = self._attn_layer_backward(lay["attn"], x_in, dxa, att, smap, G)
         return dx
 
     def _encoder_forward(self, x, x0, dims, save, saved):
@@ -736,10 +777,8 @@ class RAT_m3(RAT_m2):
 class RAT_m0(RAT_m1):
     """RAT_m0 (fuxictr/pytorch/models/RAT_m0.py:24-141): ONE Transformer over the joint sequence of all T*S tokens of a sample
     ('b t n d -> b (t n) d'), class token = token (t=0, n=0).  Sequences of up to 64 tokens run on the fused attention kernel
-    (K2a); longer ones (231 at the north-star shape) do not fit its LDS tile and run as K2c LayerNorm -> rat_sgemm QKV
-    projection -> K2d attention core (rat_attn_core_fwd/bwd) -> rat_sgemm output projection + bias + residual."""
-
-    FUSED_MAX_L = 64            # tests lower this to send short sequences through the long-sequence path as well
+    (K2a); longer ones (231 at the north-star shape) do not fit its LDS tile and take the composed path of
+    RAT_m2._attn_layer_forward (K2c LayerNorm -> rat_sgemm -> K2d attention core -> rat_sgemm + bias + residual)."""
 
     def __init__(self, feature_map, model_id="RAT_m0", **kwargs):
         super().__init__(feature_map, model_id=model_id, **kwargs)
@@ -765,45 +804,3 @@ class RAT_m0(RAT_m1):
         B, T, L, S = saved["dims"]
         d = self._cfg["d"]
         return self._stack_backward("encoder", saved, dx, ops.intra_map(B, 1, T * S), T * S * d, (B, T, S, d), G)
-
-    # ---- PreNorm(Attention) + residual over long sequences, composed from K2c / rat_sgemm / K2d
-    def _attn_layer_forward(self, lay, x, smap, save):
-        if smap.L <= self.FUSED_MAX_L:
-            return super()._attn_layer_forward(lay, x, smap, save)
-        c, lib = self._cfg, self._lib
-        d, heads, dh = c["d"], c["heads"], c["dh"]
-        inner, nseq, L = heads * dh, int(smap.nseq), int(smap.L)
-        ntok = nseq * L
-        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in lay["attn"][0]]
-        if w_out is None:
-            raise NotImplementedError("RAT_m0 with heads == 1 and dim_head == embedding_dim (no output projection) and more than "
-                                      "%d tokens per sample is not implemented" % self.FUSED_MAX_L)
-        xn = ops.layernorm_fwd(x, d, ntok, ln_g, ln_b, d, lib=lib)
-        qkv = torch.empty((ntok, 3 * inner), dtype=torch.float32, device=x.device)
-        ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_qkv, d, qkv, 3 * inner, lib=lib)                     # to_qkv (no bias)
-        o, lse = ops.attn_core_fwd(qkv, nseq, L, heads, dh, save=True, lib=lib)
-        y = x.clone()                                                                                     # the residual, accumulated by beta = 1
-        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, lib=lib)      # to_out + x
-        return y, ((qkv, o, lse) if save else None)
-
-    def _attn_layer_backward(self, lay, x_in, dy, att, smap, G):
-        if smap.L <= self.FUSED_MAX_L:
-            return super()._attn_layer_backward(lay, x_in, dy, att, smap, G)
-        c, lib = self._cfg, self._lib
-        d, heads, dh = c["d"], c["heads"], c["dh"]
-        inner, nseq, L = heads * dh, int(smap.nseq), int(smap.L)
-        ntok = nseq * L
-        names = lay["attn"][0]
-        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
-        qkv, o, lse = att
-        dev = dy.device
-        xn = ops.layernorm_fwd(x_in, d, ntok, ln_g, ln_b, d, lib=lib)                                     # recomputed, not stored
-        do = torch.empty((ntok, inner), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, inner, d, dy, d, w_out, inner, do, inner, lib=lib)                          # dO = dy W_out
-        ops.sgemm(1, 0, d, inner, ntok, dy, d, o, inner, G(names[3]), inner, lib=lib)                     # dW_out = dy^T O
-        ops.colsum(dy, d, G(names[4]), ntok, d, lib=lib)
-        dqkv = ops.attn_core_bwd(qkv, o, lse, do, nseq, L, heads, dh, lib=lib)
-        dxn = torch.empty((ntok, d), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_qkv, d, dxn, d, lib=lib)                   # d(norm(x)) = dQKV W_qkv
-        ops.sgemm(1, 0, 3 * inner, d, ntok, dqkv, 3 * inner, xn, d, G(names[2]), d, lib=lib)              # dW_qkv = dQKV^T norm(x)
-        return ops.layernorm_bwd(x_in, d, dxn, ln_g, dxn, d, G(names[0]), G(names[1]), d, add=dy, lib=lib).view_as(x_in)

@@ -151,6 +151,32 @@ def attn_bwd_ex(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_he
     return dx, workspace
 
 
+def attn_fused_supported(d, heads, dim_head, L, lib=None):
+    """True when rat_attn_fwd / rat_attn_bwd serve these dimensions (else: the composed path, see model._attn_composed_*)."""
+    lib = lib or get_lib()
+    return bool(lib.size("rat_attn_fused_supported", int(d), int(heads), int(dim_head), int(L)))
+
+
+def attn_core_fwd_map(qkv, seqmap, heads, dim_head, softmax_scale=0.0, save=True, lib=None):
+    """attn_core_fwd with RatSeqMap addressing (strided sequences); qkv is [ntok, 3*heads*dim_head] over the WHOLE token grid."""
+    lib = lib or get_lib()
+    _chk(qkv, name="qkv")
+    ntok = qkv.shape[0]
+    o = torch.empty((ntok, heads * dim_head), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((ntok, heads), dtype=torch.float32, device=qkv.device) if save else None
+    lib.call("rat_attn_core_fwd_map", _p(qkv), _p(o), _p(lse), ctypes.byref(seqmap), heads, dim_head, float(softmax_scale), _stream(qkv))
+    return o, lse
+
+
+def attn_core_bwd_map(qkv, o, lse, dout, seqmap, heads, dim_head, softmax_scale=0.0, lib=None):
+    lib = lib or get_lib()
+    _chk(qkv, name="qkv"), _chk(o, name="o"), _chk(lse, name="lse"), _chk(dout, name="dout")
+    dqkv = torch.empty_like(qkv)
+    lib.call("rat_attn_core_bwd_map", _p(qkv), _p(o), _p(lse), _p(dout), _p(dqkv), ctypes.byref(seqmap), heads, dim_head,
+             float(softmax_scale), _stream(qkv))
+    return dqkv
+
+
 def attn_core_fwd(qkv, nseq, L, heads, dim_head, softmax_scale=0.0, save=True, lib=None):
     """softmax(Q K^T * scale) V on projected rows qkv [nseq*L, 3*heads*dim_head] -> (o [ntok, heads*dim_head], lse [ntok, heads])."""
     lib = lib or get_lib()
