@@ -16,6 +16,11 @@ WORKLOADS = {
     "mltag_like_K10_d16_B256": dict(F=3, total_vocab=90_000, K=10, d=16, batch=256, num_heads=2, dim_head=10, depth=4,
                                     scale_dim=4, dnn_hidden_units=[400, 400, 400], batch_norm=False, use_wide=True,
                                     learning_rate=1e-3),
+    # BASELINE.json configs[2] shape (KKBox: 13 fields, d = 64 as that config line states) and configs[4] shape (Tmall: 8 fields,
+    # K = 30 retrieved, the shipped 32 heads x 10 -> heads*dim_head = 320: served by the composed attention path); 1.5 M rows each
+    "kkbox_like_F13_K10_d64_B4096": dict(F=13, total_vocab=92_000, K=10, d=64, batch=4096, **KKBOX_HYPER),
+    "tmall_like_F8_K30_d64_h32_B4096": dict(F=8, total_vocab=1_500_000, K=30, d=64, batch=4096, num_heads=32, dim_head=10, depth=4,
+                                            scale_dim=2, dnn_hidden_units=[200, 80], batch_norm=True, use_wide=True, learning_rate=1e-3),
     # tiny: smoke / CI
     "tiny": dict(F=5, total_vocab=500, K=3, d=16, batch=32, num_heads=2, dim_head=10, depth=2, scale_dim=2,
                  dnn_hidden_units=[32, 16], batch_norm=True, use_wide=True, learning_rate=1e-3),
