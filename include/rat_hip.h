@@ -201,7 +201,9 @@ int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* b
 int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* workspace,
                     int M, int N, int use_bn, void* stream);
-/* column sums of a [M][N] matrix (bias gradients); workspace: rat_bn_workspace(N) bytes */
+/* column sums of a [M][N] matrix (bias gradients); workspace: rat_colsum_workspace(M, N) bytes (= rat_bn_workspace(N) up to
+ * M = 65536 rows; more row splits beyond, for the token-sized matrices of the composed attention path) */
+size_t rat_colsum_workspace(int M, int N);
 int rat_colsum(const float* a, int lda, float* out, float* workspace, int M, int N, void* stream);
 
 /* logit = fc(cls) + dnn_out + sum_f lr_table_f[idx] ; y_pred = sigmoid(logit)  (RAT_m2.py:138-150,

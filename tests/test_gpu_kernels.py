@@ -96,3 +96,15 @@ def test_logit_fwd_bwd(lib, with_dnn, with_lr):
 
 def test_l2_sumsq_clip_adam(lib):
     kc.check_optim(lib, "cuda", 1000003)
+
+
+@pytest.mark.parametrize("M,N", [(4096, 400), (1_000_003, 64), (70_000, 10)])
+def test_colsum_long_matrices(lib, M, N):
+    """token-sized matrices (composed attention path: bias gradient of to_out) use more row splits than the head's batches"""
+    import torch
+    from rat_amd import ops
+    a = torch.randn(M, N, device="cuda")
+    out = torch.empty(N, device="cuda")
+    ops.colsum(a, N, out, M, N, lib=lib)
+    ref = a.double().sum(0)
+    assert float((out.double() - ref).abs().max()) < 1e-4 * max(1.0, M ** 0.5)

@@ -2,7 +2,8 @@
 //
 // RAT_m0 (RAT_m0.py:123-127) attends jointly over all T*S tokens of a sample (231 at the north-star shape): a whole
 // sequence no longer fits the 64-row LDS tile of the fused kernel in attn.hip, so that variant runs the projections as
-// plain MFMA GEMMs (rat_sgemm) and LayerNorm as K2c, and only this core is new.  One work-group per (sequence, head):
+// plain MFMA GEMMs (rat_sgemm) and LayerNorm as K2c, and only this core is new.  One work-group per (sequence, head) —
+// several pairs per work-group when the sequences are short:
 // the head's K and V rows (backward: also Q, dO, lse, delta) are staged in LDS once, one lane owns one query row (pass 2
 // of backward: one key row) and walks all keys with the online softmax of attn.hip — same log2-domain arithmetic, same
 // saved log-sum-exp convention (lse = m + log2(l) of the scores scaled by scale * log2(e)).
@@ -76,40 +77,54 @@ struct Vec {
     }
 };
 
-// LDS rows are unpadded [L][dh]: in the key / query walks every lane of a wave reads the SAME row (a broadcast, no bank
-// conflict), and the staging writes are contiguous.
-template <int DH>
+// LDS rows are unpadded [L][dh]: in the key / query walks every lane of a (sequence, head) pair reads the SAME row (a
+// broadcast), and the staging writes are contiguous.  A work-group serves G = max(1, blockDim / L) (sequence, head) pairs per
+// pass — pair = task / L, row = task % L — so that short sequences (the 9- and 31-token phases of a wide-head RAT_m2) fill
+// the lanes instead of leaving most of each wave idle; consecutive pairs are consecutive heads of one sequence, i.e.
+// neighbouring slices of the same Q|K|V rows.
+template <int DH, bool MULTI>
 __global__ void __launch_bounds__(1024) core_fwd_kernel(CoreArgs a) {
     RAT_DYN_SMEM(smem);
     const int dh = DH > 0 ? DH : a.dh, L = a.L, I = a.heads * dh;
-    float* ks = reinterpret_cast<float*>(smem);          // [L][dh]
-    float* vs = ks + (size_t)L * dh;                     // [L][dh]
+    const int G = MULTI ? (int)blockDim.x / L : 1;        // MULTI = false: one pair per work-group, the pair arithmetic folds away
+    float* ks = reinterpret_cast<float*>(smem);          // [G][L][dh]
+    float* vs = ks + (size_t)G * L * dh;                 // [G][L][dh]
     const float sl2 = a.scale * RAT_LOG2E;
-    for (int64_t task = blockIdx.x; task < a.nseq * a.heads; task += gridDim.x) {
-        const int64_t sq = task / a.heads;
-        const int h = (int)(task - sq * a.heads);
-        const float* base = a.qkv + h * dh;
-        for (int e = threadIdx.x; e < L * dh; e += blockDim.x) {
-            const int j = e / dh, c = e - j * dh;
-            const float* row = base + core_token(a, sq, j) * (3 * I);
-            ks[e] = row[I + c];
-            vs[e] = row[2 * I + c];
+    const int64_t ntask = a.nseq * a.heads, ngroups = (ntask + G - 1) / G;
+    for (int64_t group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        for (int e = threadIdx.x; e < G * L * dh; e += blockDim.x) {
+            const int p = MULTI ? e / (L * dh) : 0, rem = e - p * (L * dh), j = rem / dh, c = rem - j * dh;
+            const int64_t task = group * G + p;
+            if (task < ntask) {
+                const int64_t sq = task / a.heads;
+                const int h = (int)(task - sq * a.heads);
+                const float* row = a.qkv + core_token(a, sq, j) * (3 * I) + h * dh;
+                ks[e] = row[I + c];
+                vs[e] = row[2 * I + c];
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        for (int w = threadIdx.x; w < G * L; w += blockDim.x) {
+            const int p = MULTI ? w / L : 0, i = w - p * L;
+            const int64_t task = group * G + p;
+            if (task >= ntask) continue;
+            const int64_t sq = task / a.heads;
+            const int h = (int)(task - sq * a.heads);
+            const float* kp = ks + (size_t)p * L * dh;
+            const float* vp = vs + (size_t)p * L * dh;
             Vec<DH> q, o, kv;
             const int64_t tok = core_token(a, sq, i);
-            q.load(base + tok * (3 * I), dh);
+            q.load(a.qkv + tok * (3 * I) + h * dh, dh);
             o.zero();
             float m = -3.0e38f, l = 0.f;
             for (int j = 0; j < L; ++j) {
-                kv.load(ks + (size_t)j * dh, dh);
+                kv.load(kp + (size_t)j * dh, dh);
                 const float s = q.dot(kv) * sl2;
                 const float mn = fmaxf(m, s);
-                const float corr = rat_exp2(m - mn), p = rat_exp2(s - mn);
-                l = l * corr + p;
-                kv.load(vs + (size_t)j * dh, dh);
-                o.scale_axpy(corr, p, kv);
+                const float corr = rat_exp2(m - mn), pr = rat_exp2(s - mn);
+                l = l * corr + pr;
+                kv.load(vp + (size_t)j * dh, dh);
+                o.scale_axpy(corr, pr, kv);
                 m = mn;
             }
             o.store(a.o_out + tok * I + h * dh, dh, 1.0f / l);
@@ -119,84 +134,105 @@ __global__ void __launch_bounds__(1024) core_fwd_kernel(CoreArgs a) {
     }
 }
 
-template <int DH>
+template <int DH, bool MULTI>
 __global__ void __launch_bounds__(1024) core_bwd_kernel(CoreArgs a) {
     RAT_DYN_SMEM(smem);
     const int dh = DH > 0 ? DH : a.dh, L = a.L, I = a.heads * dh;
-    float* qs = reinterpret_cast<float*>(smem);          // [L][dh]
-    float* ks = qs + (size_t)L * dh;
-    float* vs = ks + (size_t)L * dh;
-    float* gs = vs + (size_t)L * dh;                     // dO
-    float* ls = gs + (size_t)L * dh;                     // [L] lse
-    float* ds = ls + L;                                  // [L] delta = dO . O
+    const int G = MULTI ? (int)blockDim.x / L : 1;        // MULTI = false: one pair per work-group, the pair arithmetic folds away
+    const size_t plane = (size_t)G * L * dh;
+    float* qs = reinterpret_cast<float*>(smem);          // [G][L][dh]
+    float* ks = qs + plane;
+    float* vs = ks + plane;
+    float* gs = vs + plane;                              // dO
+    float* ls = gs + plane;                              // [G][L] lse
+    float* ds = ls + (size_t)G * L;                      // [G][L] delta = dO . O
     const float sl2 = a.scale * RAT_LOG2E;
-    for (int64_t task = blockIdx.x; task < a.nseq * a.heads; task += gridDim.x) {
-        const int64_t sq = task / a.heads;
-        const int h = (int)(task - sq * a.heads);
-        const float* base = a.qkv + h * dh;
-        const float* gbase = a.dout + h * dh;
-        const float* obase = a.o + h * dh;
-        for (int e = threadIdx.x; e < L * dh; e += blockDim.x) {
-            const int j = e / dh, c = e - j * dh;
-            const int64_t tok = core_token(a, sq, j);
-            const float* row = base + tok * (3 * I);
-            qs[e] = row[c];
-            ks[e] = row[I + c];
-            vs[e] = row[2 * I + c];
-            gs[e] = gbase[tok * I + c];
+    const int64_t ntask = a.nseq * a.heads, ngroups = (ntask + G - 1) / G;
+    for (int64_t group = blockIdx.x; group < ngroups; group += gridDim.x) {
+        for (int e = threadIdx.x; e < G * L * dh; e += blockDim.x) {
+            const int p = MULTI ? e / (L * dh) : 0, rem = e - p * (L * dh), j = rem / dh, c = rem - j * dh;
+            const int64_t task = group * G + p;
+            if (task < ntask) {
+                const int64_t sq = task / a.heads;
+                const int h = (int)(task - sq * a.heads);
+                const int64_t tok = core_token(a, sq, j);
+                const float* row = a.qkv + tok * (3 * I) + h * dh;
+                qs[e] = row[c];
+                ks[e] = row[I + c];
+                vs[e] = row[2 * I + c];
+                gs[e] = a.dout[tok * I + h * dh + c];
+            }
         }
-        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        for (int w = threadIdx.x; w < G * L; w += blockDim.x) {
+            const int p = MULTI ? w / L : 0, i = w - p * L;
+            const int64_t task = group * G + p;
+            if (task >= ntask) continue;
+            const int64_t sq = task / a.heads;
+            const int h = (int)(task - sq * a.heads);
             const int64_t tok = core_token(a, sq, i);
-            ls[i] = a.lse_in[tok * a.heads + h];
+            ls[w] = a.lse_in[tok * a.heads + h];
             float dsum = 0.f;
-            for (int c = 0; c < dh; ++c) dsum = fmaf(gbase[tok * I + c], obase[tok * I + c], dsum);
-            ds[i] = dsum;
+            for (int c = 0; c < dh; ++c) dsum = fmaf(a.dout[tok * I + h * dh + c], a.o[tok * I + h * dh + c], dsum);
+            ds[w] = dsum;
         }
         __syncthreads();
-        float* dbase = a.dqkv + h * dh;
         // pass 1: one lane per query row -> dQ
-        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        for (int w = threadIdx.x; w < G * L; w += blockDim.x) {
+            const int p = MULTI ? w / L : 0, i = w - p * L;
+            const int64_t task = group * G + p;
+            if (task >= ntask) continue;
+            const int64_t sq = task / a.heads;
+            const int h = (int)(task - sq * a.heads);
+            const size_t po = (size_t)p * L * dh;
             Vec<DH> q, go, dq, kv;
-            q.load(qs + (size_t)i * dh, dh);
-            go.load(gs + (size_t)i * dh, dh);
+            q.load(qs + po + (size_t)i * dh, dh);
+            go.load(gs + po + (size_t)i * dh, dh);
             dq.zero();
-            const float lse = ls[i], delta = ds[i];
+            const float lse = ls[w], delta = ds[w];
             for (int j = 0; j < L; ++j) {
-                kv.load(vs + (size_t)j * dh, dh);
+                kv.load(vs + po + (size_t)j * dh, dh);
                 const float dp = go.dot(kv);
-                kv.load(ks + (size_t)j * dh, dh);
-                const float p = rat_exp2(q.dot(kv) * sl2 - lse);
-                dq.axpy(p * (dp - delta), kv);
+                kv.load(ks + po + (size_t)j * dh, dh);
+                const float pr = rat_exp2(q.dot(kv) * sl2 - lse);
+                dq.axpy(pr * (dp - delta), kv);
             }
-            dq.store(dbase + core_token(a, sq, i) * (3 * I), dh, a.scale);
+            dq.store(a.dqkv + core_token(a, sq, i) * (3 * I) + h * dh, dh, a.scale);
         }
         // pass 2: one lane per key row -> dK, dV
-        for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        for (int w = threadIdx.x; w < G * L; w += blockDim.x) {
+            const int p = MULTI ? w / L : 0, j = w - p * L;
+            const int64_t task = group * G + p;
+            if (task >= ntask) continue;
+            const int64_t sq = task / a.heads;
+            const int h = (int)(task - sq * a.heads);
+            const size_t po = (size_t)p * L * dh;
             Vec<DH> kk, vv, dk, dv, t, qv;
-            kk.load(ks + (size_t)j * dh, dh);
-            vv.load(vs + (size_t)j * dh, dh);
+            kk.load(ks + po + (size_t)j * dh, dh);
+            vv.load(vs + po + (size_t)j * dh, dh);
             dk.zero();
             dv.zero();
             for (int i = 0; i < L; ++i) {
-                t.load(gs + (size_t)i * dh, dh);
+                t.load(gs + po + (size_t)i * dh, dh);
                 const float dp = t.dot(vv);
-                qv.load(qs + (size_t)i * dh, dh);
-                const float p = rat_exp2(qv.dot(kk) * sl2 - ls[i]);
-                dv.axpy(p, t);
-                dk.axpy(p * (dp - ds[i]), qv);
+                qv.load(qs + po + (size_t)i * dh, dh);
+                const float pr = rat_exp2(qv.dot(kk) * sl2 - ls[p * L + i]);
+                dv.axpy(pr, t);
+                dk.axpy(pr * (dp - ds[p * L + i]), qv);
             }
-            const int64_t tokj = core_token(a, sq, j);
-            dk.store(dbase + tokj * (3 * I) + I, dh, a.scale);
-            dv.store(dbase + tokj * (3 * I) + 2 * I, dh, 1.0f);
+            float* drow = a.dqkv + core_token(a, sq, j) * (3 * I) + h * dh;
+            dk.store(drow + I, dh, a.scale);
+            dv.store(drow + 2 * I, dh, 1.0f);
         }
         __syncthreads();
     }
 }
 
-int core_threads(int L) {
+int core_threads(int L) {                                  // short sequences share a 256-thread work-group (G pairs per pass)
+    if (L <= 256) return 256;
     int t = (L + 63) / 64 * 64;
     return t > 1024 ? 1024 : t;
 }
+int core_pairs(int L) { const int t = core_threads(L); return t >= L ? t / L : 1; }
 
 int core_check(int64_t nseq, int L, int heads, int dh, size_t smem) {
     RAT_REQUIRE(nseq > 0 && L > 0 && heads > 0 && dh > 0, "bad dims");
@@ -205,28 +241,33 @@ int core_check(int64_t nseq, int L, int heads, int dh, size_t smem) {
     return 0;
 }
 
-template <template <int> class Launch>
-int core_dispatch(int dh, const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
+template <template <int, bool> class Launch, bool MULTI>
+int core_dispatch_dh(int dh, const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
     switch (dh) {
-        case 4: return Launch<4>::go(a, grid, threads, smem, stream);
-        case 8: return Launch<8>::go(a, grid, threads, smem, stream);
-        case 10: return Launch<10>::go(a, grid, threads, smem, stream);
-        case 16: return Launch<16>::go(a, grid, threads, smem, stream);
-        case 20: return Launch<20>::go(a, grid, threads, smem, stream);
-        default: return Launch<0>::go(a, grid, threads, smem, stream);
+        case 4: return Launch<4, MULTI>::go(a, grid, threads, smem, stream);
+        case 8: return Launch<8, MULTI>::go(a, grid, threads, smem, stream);
+        case 10: return Launch<10, MULTI>::go(a, grid, threads, smem, stream);
+        case 16: return Launch<16, MULTI>::go(a, grid, threads, smem, stream);
+        case 20: return Launch<20, MULTI>::go(a, grid, threads, smem, stream);
+        default: return Launch<0, MULTI>::go(a, grid, threads, smem, stream);
     }
 }
-template <int DH>
+template <template <int, bool> class Launch>
+int core_dispatch(int dh, const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
+    return threads / a.L > 1 ? core_dispatch_dh<Launch, true>(dh, a, grid, threads, smem, stream)
+                             : core_dispatch_dh<Launch, false>(dh, a, grid, threads, smem, stream);
+}
+template <int DH, bool MULTI>
 struct LaunchFwd {
     static int go(const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
-        RAT_LAUNCH((core_fwd_kernel<DH>), grid, threads, smem, stream, a);
+        RAT_LAUNCH((core_fwd_kernel<DH, MULTI>), grid, threads, smem, stream, a);
         return rat_check_launch("rat_attn_core_fwd");
     }
 };
-template <int DH>
+template <int DH, bool MULTI>
 struct LaunchBwd {
     static int go(const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
-        RAT_LAUNCH((core_bwd_kernel<DH>), grid, threads, smem, stream, a);
+        RAT_LAUNCH((core_bwd_kernel<DH, MULTI>), grid, threads, smem, stream, a);
         return rat_check_launch("rat_attn_core_bwd");
     }
 };
@@ -268,7 +309,7 @@ extern "C" int rat_attn_core_fwd_map(const float* qkv, float* o, float* lse, con
     RAT_REQUIRE(map_host != nullptr && map_host->q_div >= 1, "bad seq map");
     const int64_t nseq = map_host->nseq;
     const int L = map_host->L;
-    const size_t smem = (size_t)2 * L * dim_head * sizeof(float);
+    const size_t smem = (size_t)2 * core_pairs(L) * L * dim_head * sizeof(float);
     if (core_check(nseq, L, heads, dim_head, smem)) return -1;
     RAT_REQUIRE(qkv && o, "null pointer");
     CoreArgs a{};
@@ -279,7 +320,7 @@ extern "C" int rat_attn_core_fwd_map(const float* qkv, float* o, float* lse, con
     a.heads = heads;
     a.dh = dim_head;
     a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
-    return core_dispatch<LaunchFwd>(dim_head, a, core_grid(nseq * heads), core_threads(L), smem, stream);
+    return core_dispatch<LaunchFwd>(dim_head, a, core_grid((nseq * heads + core_pairs(L) - 1) / core_pairs(L)), core_threads(L), smem, stream);
 }
 
 extern "C" int rat_attn_core_bwd(const float* qkv, const float* o, const float* lse, const float* dout, float* dqkv,
@@ -294,7 +335,7 @@ extern "C" int rat_attn_core_bwd_map(const float* qkv, const float* o, const flo
     RAT_REQUIRE(map_host != nullptr && map_host->q_div >= 1, "bad seq map");
     const int64_t nseq = map_host->nseq;
     const int L = map_host->L;
-    const size_t smem = ((size_t)4 * L * dim_head + 2 * (size_t)L) * sizeof(float);
+    const size_t smem = (size_t)core_pairs(L) * ((size_t)4 * L * dim_head + 2 * (size_t)L) * sizeof(float);
     if (core_check(nseq, L, heads, dim_head, smem)) return -1;
     RAT_REQUIRE(qkv && o && lse && dout && dqkv, "null pointer");
     CoreArgs a{};
@@ -307,5 +348,5 @@ extern "C" int rat_attn_core_bwd_map(const float* qkv, const float* o, const flo
     a.heads = heads;
     a.dh = dim_head;
     a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
-    return core_dispatch<LaunchBwd>(dim_head, a, core_grid(nseq * heads), core_threads(L), smem, stream);
+    return core_dispatch<LaunchBwd>(dim_head, a, core_grid((nseq * heads + core_pairs(L) - 1) / core_pairs(L)), core_threads(L), smem, stream);
 }

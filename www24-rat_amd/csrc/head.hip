@@ -311,9 +311,26 @@ extern "C" int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, con
     return rat_check_launch("rat_bn_relu_fwd");
 }
 
+namespace {
+// row splits of the column sum: 32 for the prediction head's batches; long token matrices (the composed attention path: M = all
+// tokens of the batch) get one split per ~2048 rows so that the partial-sum launch fills the chip
+int colsum_splits(int M) {
+    if (M < 64) return 1;
+    if (M < 1024) return 4;
+    const int s = M / 2048;
+    return s < BN_SPLITS ? BN_SPLITS : (s > 2048 ? 2048 : s);
+}
+}  // namespace
+
+extern "C" size_t rat_colsum_workspace(int M, int N) {
+    const size_t need = (size_t)colsum_splits(M) * (size_t)N * sizeof(float);
+    const size_t bn = rat_bn_workspace(N);
+    return need > bn ? need : bn;                                   // never below the BatchNorm workspace older callers pass
+}
+
 extern "C" int rat_colsum(const float* a, int lda, float* out, float* workspace, int M, int N, void* stream) {
-    RAT_REQUIRE(M > 0 && N > 0 && a && out && workspace, "bad args");     // workspace: rat_bn_workspace(N) bytes
-    const int splits = M >= 1024 ? BN_SPLITS : (M >= 64 ? 4 : 1);
+    RAT_REQUIRE(M > 0 && N > 0 && a && out && workspace, "bad args");     // workspace: rat_colsum_workspace(M, N) bytes
+    const int splits = colsum_splits(M);
     const int nblk = (N + HD_COLS - 1) / HD_COLS;
     RAT_LAUNCH(colsum_partial_kernel, nblk * splits, HD_THREADS, HD_THREADS * sizeof(float), stream, a, lda, workspace, M, N, splits);
     RAT_LAUNCH(colsum_final_kernel, (N + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 0, stream, workspace, out, N, splits);

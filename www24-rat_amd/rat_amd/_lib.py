@@ -52,6 +52,7 @@ _SIGNATURES = {
     "rat_attn_core_fwd_map": (c_int, [_P, _P, _P, POINTER(RatSeqMap), c_int, c_int, c_float, _P]),
     "rat_attn_core_bwd_map": (c_int, [_P, _P, _P, _P, _P, POINTER(RatSeqMap), c_int, c_int, c_float, _P]),
     "rat_attn_fused_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "rat_colsum_workspace": (c_size_t, [c_int, c_int]),
     "rat_bm25_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_ffn_fwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, c_int, _P]),

@@ -305,7 +305,7 @@ def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, li
 
 def colsum(a, lda, out, M, N, lib=None):
     lib = lib or get_lib()
-    ws = _bn_ws(N, out.device, lib)
+    ws = torch.empty((lib.size("rat_colsum_workspace", M, N) + 3) // 4, dtype=torch.float32, device=out.device)
     lib.call("rat_colsum", _p(a), lda, _p(out), _p(ws), M, N, _stream(out))
 
 
