@@ -185,11 +185,13 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
     RAT_PROF_FLUSH(a.prof, 24);
 }
 
-template <int TD>
+// generic shapes (any d, hidden up to the LDS tile): LDS-staged, weights streamed from L2 with guarded fragment loads.  The
+// compiled fast shapes (d, 2d) = (64, 128), (16, 32) run ffn_bwd_t_kernel below.
 __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
-    constexpr bool FAST = TD > 0;
+    constexpr bool FAST = false;
+    constexpr int TD = 0;
     RAT_DYN_SMEM(smem);
-    const FfnGeom g(FAST ? TD : a.d, FAST ? 2 * TD : a.hidden);      // fast shapes: hidden = 2 d (scale_dim 2), geometry is compile-time
+    const FfnGeom g(a.d, a.hidden);
     const int D = g.D, H = g.H;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx] x
     float* dys = xs + (size_t)FFN_ROWS * g.ldx;                 // [64][ldx] dL/dy
@@ -896,7 +898,7 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
     } else if (fast == 16 && hidden == 32) {
         RAT_LAUNCH((ffn_bwd_t_kernel<16, 32>), blocks, FB_THREADS, (FfnBTGeom<16, 32>::smem), stream, a);
     } else {
-        RAT_LAUNCH((ffn_bwd_kernel<0>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+        RAT_LAUNCH(ffn_bwd_kernel, blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     }
     if (rat_check_launch("rat_ffn_bwd")) return -1;
     float* outs[4] = {dw1, dw2, db1, db2};

@@ -340,35 +340,6 @@ __device__ __forceinline__ void rat_wave_gemm_col(f32x4 (&acc)[MT], const AF& af
     }
 }
 
-// B fragments of one 16-column tile held in registers for the life of the kernel ("persistent weight fragments"): a wave
-// that always owns the same column tile of a weight matrix loads its fragments ONCE, so the chunk loop issues no global
-// load for that product at all (no L2 round trip after every barrier, nothing for s_waitcnt vmcnt to queue behind).
-template <int KB>
-struct RatBFrags {
-    float4 f[KB];
-    // W[n][k] row-major (ld floats per row): tile nt, k-blocks kb0 .. kb0 + KB - 1
-    __device__ __forceinline__ void load(const float* w, int ld, int nt, int kb0 = 0) {
-        const int l = rat_lane();
-        const float* p = w + (size_t)(nt * 16 + (l & 15)) * ld + kb0 * 16 + 4 * (l >> 4);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) f[kb] = *reinterpret_cast<const float4*>(p + 16 * kb);
-    }
-};
-// acc[i] += A(tile mt0 + i, k-block kb0 + kb) * frag[kb], kb < nkb <= KB (nkb wave-uniform)
-template <int MT, int KB, class AF>
-__device__ __forceinline__ void rat_wave_gemm_regb(f32x4 (&acc)[MT], const AF& af, const RatBFrags<KB>& b, int mt0, int kb0 = 0,
-                                                   int nkb = KB) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        if (kb < nkb) {
-            float4 a[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = af(mt0 + i, kb0 + kb);
-            rat_mfma_block<MT>(acc, a, b.f[kb]);
-        }
-    }
-}
-
 // acc[i][j] += A(tile mt0+i) * B(tile nt0+j) over kblocks 16-wide k-blocks; tiles beyond mt_valid/nb_valid
 // are skipped (wave-uniform).  All 64 lanes of the wave must call this together.
 template <int MT, int NB, class AF, class BF>
