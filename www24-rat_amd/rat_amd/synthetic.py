@@ -21,6 +21,10 @@ WORKLOADS = {
     "kkbox_like_F13_K10_d64_B4096": dict(F=13, total_vocab=92_000, K=10, d=64, batch=4096, **KKBOX_HYPER),
     "tmall_like_F8_K30_d64_h32_B4096": dict(F=8, total_vocab=1_500_000, K=30, d=64, batch=4096, num_heads=32, dim_head=10, depth=4,
                                             scale_dim=2, dnn_hidden_units=[200, 80], batch_norm=True, use_wide=True, learning_rate=1e-3),
+    # BASELINE.json configs[3] shape per GPU (F = 40, global batch 8192 over 8 GPUs = 1024 per rank) at a tenth of its vocabulary:
+    # the full 100 M-row table (25.6 GB + 77 GB of gradient / Adam state per replica) fits one MI355X, but its DENSE gradient
+    # all-reduce does not scale — row-sparse exchange + lazy Adam for that config are future work
+    "synthetic_F40_V10M_K10_d64_B1024": dict(F=40, total_vocab=10_000_000, K=10, d=64, batch=1024, **KKBOX_HYPER),
     # tiny: smoke / CI
     "tiny": dict(F=5, total_vocab=500, K=3, d=16, batch=32, num_heads=2, dim_head=10, depth=2, scale_dim=2,
                  dnn_hidden_units=[32, 16], batch_norm=True, use_wide=True, learning_rate=1e-3),
