@@ -28,3 +28,22 @@ def test_eval_forward(name):
 @pytest.mark.parametrize("name", [c["name"] for c in gc.CASES])
 def test_two_training_steps(name):
     mc.check_training(name, gpu=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "northstar_shape", "kkbox_shape"])
+def test_composed_attention_path(name, monkeypatch):
+    """fused-kernel threshold lowered: every attention layer runs LayerNorm -> GEMM -> attention core (strided sequences in the
+    cross phase) -> GEMM; same golden vectors."""
+    from rat_amd import models
+    monkeypatch.setattr(models.RAT_m2, "FUSED_MAX_L", 3)
+    mc.check_eval(name, gpu=0)
+    mc.check_training(name, gpu=0)
+
+
+def test_grouped_heads_mode_is_selected_for_wide_heads():
+    """32 heads x 10: four launches of the fused kernel on 8 heads each (model._attn_mode)"""
+    import golden_cases as gc
+    from rat_amd import ops
+    model = mc.build_model(gc.case_by_name("tmall_real_heads"), gpu=0, seed=1)
+    assert model._attn_mode(ops.intra_map(4, 7, 9)) == ("grouped", 8)
+    assert model._attn_mode(ops.cross_map(4, 7, 9)) == ("grouped", 8)

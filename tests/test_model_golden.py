@@ -103,3 +103,12 @@ def test_wide_heads_select_the_composed_attention_path():
     assert not ops.attn_fused_supported(64, 8, 10, 231, lib=L._default)      # RAT_m0's joint sequence
     assert ops.attn_fused_supported(64, 8, 10, 21, lib=L._default)
     assert ops.attn_fused_supported(40, 8, 10, 14, lib=L._default)           # KKBox
+
+
+def test_m2_composed_attention_path(monkeypatch):
+    """RAT_m2 with the fused-kernel threshold lowered below both sequence lengths: the intra phase (contiguous sequences) and
+    the cross phase (sequences STRIDED through the grid, RatSeqMap addressing in the attention core) both take the composed
+    path (K2c LayerNorm -> rat_sgemm -> K2d core -> rat_sgemm) and must reproduce the golden vectors."""
+    from rat_amd import models
+    monkeypatch.setattr(models.RAT_m2, "FUSED_MAX_L", 3)
+    mc.check_training("tiny_seq_bn", gpu=-1)

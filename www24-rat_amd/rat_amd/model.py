@@ -237,22 +237,63 @@ class RAT_m2(BaseModel):
     #      LayerNorm -> rat_sgemm (to_qkv) -> K2d attention core (seq-map addressing) -> rat_sgemm (to_out + bias + residual)
     FUSED_MAX_L = 64            # tests lower this to send short sequences through the composed path as well
 
-    def _attn_is_fused(self, smap):
+    def _attn_mode(self, smap):
+        """-> ("fused", heads) | ("grouped", heads per group) | ("composed", None).
+
+        fused: the whole layer is one rat_attn_fwd / rat_attn_bwd launch.  grouped: heads*dim_head is too wide for the fused
+        kernel's LDS tile (the shipped Tmall config: 32 heads x 10) but the sequences are short: the heads are independent
+        given LayerNorm(x), so the layer runs as heads/g launches of the fused kernel on g heads each — every launch gets its
+        rows of W_q / W_k / W_v and its columns of W_out, the first one carries the bias and the residual, the others
+        accumulate onto its output (rat_attn_fwd_ex, res = y); backward chains the `add` term the same way.  composed: long
+        sequences (RAT_m0) — LayerNorm, GEMMs and the K2d core as separate launches."""
         key = (int(smap.L), self.FUSED_MAX_L)
         hit = self._fused_cache.get(key)
         if hit is None:
-            c = self._cfg
-            hit = self._fused_cache[key] = smap.L <= self.FUSED_MAX_L and ops.attn_fused_supported(c["d"], c["heads"], c["dh"], smap.L,
-                                                                                                  lib=self._lib)
+            c, L = self._cfg, int(smap.L)
+            ok = lambda h: L <= self.FUSED_MAX_L and ops.attn_fused_supported(c["d"], h, c["dh"], L, lib=self._lib)   # noqa: E731
+            if ok(c["heads"]):
+                hit = ("fused", c["heads"])
+            else:
+                per = next((h for h in (8, 4, 2, 1) if c["heads"] % h == 0 and h < c["heads"] and ok(h)), None)
+                hit = ("grouped", per) if per else ("composed", None)
+            self._fused_cache[key] = hit
         return hit
+
+    def _attn_is_fused(self, smap):
+        return self._attn_mode(smap)[0] == "fused"
+
+    def _group_weights(self, names, per):
+        """contiguous per-group copies of the projection weights: rows of Q | K | V and columns of to_out"""
+        c = self._cfg
+        d, dh, groups = c["d"], c["dh"], c["heads"] // per
+        ig = per * dh
+        ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
+        wq = w_qkv.view(3, groups, ig, d)
+        wo = w_out.view(d, groups, ig)
+        zero_bias = torch.zeros_like(b_out)
+        out = []
+        for g in range(groups):
+            w_g = wq[:, g].reshape(3 * ig, d).contiguous()
+            wo_g = wo[:, g].contiguous()
+            out.append((w_g, wo_g, ops.attn_params(ln_g, ln_b, w_g, wo_g, b_out if g == 0 else zero_bias), zero_bias))
+        return out
 
     def _attn_layer_forward(self, desc, x, smap, save, out=None):
         """desc = (names, RatAttnParams) from _attn_descriptor; returns (y, whatever the backward needs)."""
         c, lib = self._cfg, self._lib
         d, heads, dh = c["d"], c["heads"], c["dh"]
-        if self._attn_is_fused(smap):
+        mode, per = self._attn_mode(smap)
+        if mode == "fused":
             y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, lib=lib)
             return y, (o, l)
+        if mode == "grouped":
+            if desc[0][3] is None:
+                raise NotImplementedError("grouped attention needs an output projection")
+            y, kept = None, []
+            for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(desc[0], per)):
+                y, o, l = ops.attn_fwd_ex(x, x if g == 0 else y, params_g, smap, d, per, dh, 0.0, 1.0, save=save, out=y, lib=lib)
+                kept.append((w_g, wo_g, params_g, zb, o, l))
+            return y, (kept if save else None)
         inner, ntok = heads * dh, x.numel() // d
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in desc[0]]
         if w_out is None:
@@ -270,10 +311,31 @@ class RAT_m2(BaseModel):
         c, lib = self._cfg, self._lib
         d, heads, dh = c["d"], c["heads"], c["dh"]
         names = desc[0]
-        if self._attn_is_fused(smap):
+        mode, per = self._attn_mode(smap)
+        if mode == "fused":
             ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
             grads = ops.attn_params(*[G(n) if n else None for n in names])
             dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, lib=lib)
+            return dx
+        if mode == "grouped":
+            groups, ig = heads // per, per * dh
+            ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, per, dh))
+            g_lng, g_lnb, g_wqkv, g_wout, g_bout = [G(n) for n in names]
+            gq, go = g_wqkv.view(3, groups, ig, d), g_wout.view(d, groups, ig)
+            t_lng, t_lnb, t_b = torch.empty_like(g_lng), torch.empty_like(g_lnb), torch.empty_like(g_bout)
+            t_w = torch.empty((3 * ig, d), dtype=torch.float32, device=dy.device)
+            t_wo = torch.empty((d, ig), dtype=torch.float32, device=dy.device)
+            dx = None
+            for g, (w_g, wo_g, params_g, zb, o, l) in enumerate(att):
+                first = g == 0
+                grads_g = ops.attn_params(g_lng if first else t_lng, g_lnb if first else t_lnb, t_w, t_wo, g_bout if first else t_b)
+                dx, _ = ops.attn_bwd_ex(x_in, dy, dy if first else dx, o, l, params_g, grads_g, smap, d, per, dh, 0.0, 1.0,
+                                        workspace=ws, out=dx, lib=lib)                    # dx = dy + sum over groups, in place
+                gq[:, g].copy_(t_w.view(3, ig, d))
+                go[:, g].copy_(t_wo)
+                if not first:                                                              # LayerNorm sees every group's gradient
+                    g_lng.add_(t_lng)
+                    g_lnb.add_(t_lnb)
             return dx
         inner, ntok = heads * dh, x_in.numel() // d
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
