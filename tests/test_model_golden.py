@@ -35,7 +35,8 @@ def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
 
-# (RAT_m0's training steps run in test_m0_long_sequence_path: its fused-kernel path is RAT_m1's)
+# (RAT_m0 shares RAT_m1's transformer-stack code; its long-sequence composed path is exercised by
+# test_m2_composed_attention_path here and by the m0_northstar_shape golden case on the GPU)
 # one case per variant on the emulator (35-40 s each); the GPU suite runs every case of golden_cases.CASES
 @pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m3_tiny_seq"])
 def test_two_training_steps(name):
@@ -84,19 +85,11 @@ def test_dropout_training_is_consistent():
     assert abs(kept - 0.7) < 0.01 and abs(float(y.max()) - 1 / 0.7) < 1e-6
 
 
-def test_m0_long_sequence_path(monkeypatch):
-    """RAT_m0 with the fused-kernel threshold lowered: the 20-token joint sequences of m0_tiny_seq take the long-sequence path
-    (K2c LayerNorm -> rat_sgemm -> K2d core -> rat_sgemm), which must reproduce the same golden vectors."""
-    from rat_amd import models
-    monkeypatch.setattr(models.RAT_m0, "FUSED_MAX_L", 8)
-    mc.check_training("m0_tiny_seq", gpu=-1)          # forward outputs, loss, every gradient, clip norm, post-Adam weights
-
-
 def test_wide_heads_select_the_composed_attention_path():
     """32 heads x 10 (the shipped Tmall config) does not fit the fused attention kernel; the model-level parity of that geometry
     (golden case tmall_real_heads) runs on the GPU (tests/test_gpu_model.py) — under the one-OS-thread-per-lane emulator its
     ~1000 work-groups per launch take a quarter of an hour.  The composed path itself is emulated at kernel level
-    (tests/test_emu_kernels.py::test_attn_core_strided) and at model level by test_m0_long_sequence_path."""
+    (tests/test_emu_kernels.py::test_attn_core_strided) and at model level by test_m2_composed_attention_path."""
     import rat_amd._lib as L
     from rat_amd import ops
     assert not ops.attn_fused_supported(10, 32, 10, 9, lib=L._default)       # real Tmall heads
