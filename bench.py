@@ -255,7 +255,7 @@ def main():
                         traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1/r1_traffic_pmc.json)",
                         algorithmic=round(per_launch, 1), algorithmic_unit="FLOP/launch" if dom["bound"] == "mfma" else "bytes/launch",
                         avg_launch_ms=round(avg_s * 1e3, 4), launches_per_step=round(dom["n"], 2))
-        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64", value=round(B * world * args.steps / elapsed, 1),
+        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64; 1/2/4/8 MI355X", value=round(B * world * args.steps / elapsed, 1),
                       unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                       ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
                       dtype="f32", data="synthetic",
