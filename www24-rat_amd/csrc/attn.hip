@@ -289,6 +289,17 @@ struct HeadVec {
     }
 };
 
+// Width-20 heads (RAT_m3: heads/2 heads of 2*dim_head) on the fast geometry run as two 10-wide HALVES on adjacent lanes: the
+// per-(sequence, head, row) task count doubles back to what the 8 x 10 shape has (504 / 440 of 512 lanes instead of 252 /
+// 220), each lane keeps only its half of q / o / dq / dk / dv, and the one thing a score needs from the partner lane — the
+// other half of a dot product — is a single cross-lane add.
+template <bool PAIRED, class V>
+__device__ __forceinline__ float head_dot(const V& a, const V& b) {
+    float s = a.dot(b);
+    if (PAIRED) s += __shfl_xor(s, 1, 64);
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <int TD, int TDH>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
@@ -356,27 +367,35 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             if ((int)threadIdx.x < ATT_ROWS * nl && chunk + gridDim.x < a.nchunks)
                 pf = prefetch_lines_map(rowtok_buf[parity ^ 1], threadIdx.x, nl, a.x, D);
         }
-        const int ntasks = nsq * heads_c * L;
+        constexpr bool PAIRED = FAST && TDH == 20;
+        constexpr int VW = PAIRED ? 10 : TDH;                  // per-lane vector width
+        typedef HeadVec<VW> HV;
+        const int ntasks = nsq * heads_c * L * (PAIRED ? 2 : 1);
         const float sl2 = a.scale * RAT_LOG2E;
         // (A 4x4x1-MFMA formulation of this core — one block per (sequence, head, 4 queries) — and a 16x16x4 one were built
         //  and measured slower than this VALU loop at L = 11 / 21: tools/experiments/README.md.)
-        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
-            const int i = task % L;
-            const int h = (task / L) % heads_c;
-            const int sq = task / (L * heads_c);
+        // PAIRED: every lane of every wave runs every trip (idle lanes shadow the last task and store nothing) so that the
+        // cross-lane add in head_dot always sees a complete wave
+        for (int task0 = threadIdx.x; PAIRED ? task0 - (int)threadIdx.x < ntasks : task0 < ntasks; task0 += ATT_THREADS) {
+            const bool live = !PAIRED || task0 < ntasks;
+            const int task = live ? task0 : ntasks - 1;
+            const int half = PAIRED ? (task & 1) : 0, t2 = PAIRED ? task >> 1 : task;
+            const int i = t2 % L;
+            const int h = (t2 / L) % heads_c;
+            const int sq = t2 / (L * heads_c);
             const int row_i = sq * L + i;
-            float* qp = qkv + (size_t)row_i * ldq + h * dh;
-            HeadVec<TDH> q, o, kv;
+            float* qp = qkv + (size_t)row_i * ldq + h * dh + half * VW;
+            HV q, o, kv;
             q.load(qp, dh);
             o.zero();
             float m = -INFINITY, l = 0.f;
-            const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh;
+            const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh + half * VW;
             // keys three at a time: all six K / V rows are requested before anything waits (one exposed LDS latency per three
             // keys instead of two per key) and the three score dot products are independent chains; the online-softmax
             // recurrence itself runs in the original key order, so the result is bit-identical to the one-key loop
             int j = 0;
             for (; j + CORE_UNROLL <= L; j += CORE_UNROLL) {
-                HeadVec<TDH> kk[CORE_UNROLL], vv[CORE_UNROLL];
+                HV kk[CORE_UNROLL], vv[CORE_UNROLL];
 #pragma unroll
                 for (int u = 0; u < CORE_UNROLL; ++u) {
                     const float* kp = kbase + (size_t)(j + u) * ldq;
@@ -385,7 +404,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
                 }
                 float sc[CORE_UNROLL];
 #pragma unroll
-                for (int u = 0; u < CORE_UNROLL; ++u) sc[u] = q.dot(kk[u]) * sl2;   // scores in log2 units
+                for (int u = 0; u < CORE_UNROLL; ++u) sc[u] = head_dot<PAIRED>(q, kk[u]) * sl2;   // scores in log2 units
 #pragma unroll
                 for (int u = 0; u < CORE_UNROLL; ++u) {
                     const float mn = fmaxf(m, sc[u]);
@@ -399,7 +418,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             for (; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * ldq;
                 kv.load(kp, dh);
-                const float s = q.dot(kv) * sl2;
+                const float s = head_dot<PAIRED>(q, kv) * sl2;
                 const float mn = fmaxf(m, s);
                 const float corr = rat_exp2(m - mn);
                 const float p = rat_exp2(s - mn);
@@ -409,10 +428,12 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
                 m = mn;
             }
             const float inv = 1.0f / l;
-            o.store(qp, dh, inv);
-            const int64_t tok = rowtok[row_i];
-            if (a.o_save != nullptr) o.store(a.o_save + tok * I + h * dh, dh, inv);
-            if (a.lse_save != nullptr) a.lse_save[tok * heads_c + h] = m + rat_log2(l);   // log2-domain log-sum-exp
+            if (live) {
+                o.store(qp, dh, inv);
+                const int64_t tok = rowtok[row_i];
+                if (a.o_save != nullptr) o.store(a.o_save + tok * I + h * dh + half * VW, dh, inv);
+                if (a.lse_save != nullptr && half == 0) a.lse_save[tok * heads_c + h] = m + rat_log2(l);   // log2-domain log-sum-exp
+            }
         }
         __syncthreads();
         RAT_PROF_MARK(2);
@@ -564,7 +585,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         RAT_PROF_MARK(5);
 
         // (4) attention backward, pass 1: one lane per query row -> delta, dQ (written over O)
-        const int ntasks = nsq * H * L;
+        constexpr bool PAIRED = FAST && TDH == 20;
+        constexpr int VW = PAIRED ? 10 : TDH;
+        typedef HeadVec<VW> HV;
+        const int ntasks = nsq * H * L * (PAIRED ? 2 : 1);
         const float sl2 = a.scale * RAT_LOG2E;
         float pf = 0.f;
         {   // passes 1 and 2 touch LDS only: the next chunk's x / dy / O / lse lines travel HBM -> L2 meanwhile
@@ -578,41 +602,49 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 else if ((t -= ATT_ROWS * nlo) < ATT_ROWS) pf = prefetch_lines_map(nrt, t, 1, a.lse_save, H);
             }
         }
-        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
-            const int i = task % L;
-            const int h = (task / L) % H;
-            const int sq = task / (L * H);
+        for (int task0 = threadIdx.x; PAIRED ? task0 - (int)threadIdx.x < ntasks : task0 < ntasks; task0 += ATT_THREADS) {
+            const bool live = !PAIRED || task0 < ntasks;           // PAIRED: idle lanes shadow the last task (see forward)
+            const int task = live ? task0 : ntasks - 1;
+            const int half = PAIRED ? (task & 1) : 0, t2 = PAIRED ? task >> 1 : task;
+            const int i = t2 % L;
+            const int h = (t2 / L) % H;
+            const int sq = t2 / (L * H);
             const int row_i = sq * L + i;
-            float* op = ob + (size_t)row_i * ldt + h * dh;
-            HeadVec<TDH> q, go, dq, kv;
-            q.load(qkv + (size_t)row_i * ldq + h * dh, dh);
-            go.load(dob + (size_t)row_i * ldt + h * dh, dh);
+            const int ho = h * dh + half * VW;
+            float* op = ob + (size_t)row_i * ldt + ho;
+            HV q, go, dq, kv;
+            q.load(qkv + (size_t)row_i * ldq + ho, dh);
+            go.load(dob + (size_t)row_i * ldt + ho, dh);
             kv.load(op, dh);
-            const float delta = go.dot(kv);
+            const float delta = head_dot<PAIRED>(go, kv);
             dq.zero();
-            dlt[row_i * H + h] = delta;
+            if (live) dlt[row_i * H + h] = delta;                // (both halves write the same value)
             const float lse = lses[row_i * H + h];
-            const float* kbase = qkv + (size_t)(sq * L) * ldq + I + h * dh;
+            const float* kbase = qkv + (size_t)(sq * L) * ldq + I + ho;
             int j = 0;
             for (; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * ldq;
                 kv.load(kp + I, dh);
-                const float dp = go.dot(kv);
+                const float dp = head_dot<PAIRED>(go, kv);
                 kv.load(kp, dh);
-                const float p = rat_exp2(q.dot(kv) * sl2 - lse);
+                const float p = rat_exp2(head_dot<PAIRED>(q, kv) * sl2 - lse);
                 dq.axpy(p * (dp - delta), kv);
             }
-            dq.store(op, dh, a.scale);
+            if (live) dq.store(op, dh, a.scale);
         }
         __syncthreads();
         RAT_PROF_MARK(6);
         // pass 2: one lane per key row -> dK, dV (written over K, V)
-        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
-            const int j = task % L;
-            const int h = (task / L) % H;
-            const int sq = task / (L * H);
-            float* kp = qkv + (size_t)(sq * L + j) * ldq + I + h * dh;
-            HeadVec<TDH> kk, vv, dk, dv, t;
+        for (int task0 = threadIdx.x; PAIRED ? task0 - (int)threadIdx.x < ntasks : task0 < ntasks; task0 += ATT_THREADS) {
+            const bool live = !PAIRED || task0 < ntasks;
+            const int task = live ? task0 : ntasks - 1;
+            const int half = PAIRED ? (task & 1) : 0, t2 = PAIRED ? task >> 1 : task;
+            const int j = t2 % L;
+            const int h = (t2 / L) % H;
+            const int sq = t2 / (L * H);
+            const int ho = h * dh + half * VW;
+            float* kp = qkv + (size_t)(sq * L + j) * ldq + I + ho;
+            HV kk, vv, dk, dv, t;
             kk.load(kp, dh);
             vv.load(kp + I, dh);
             dk.zero();
@@ -620,17 +652,19 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             int i = 0;
             for (; i < L; ++i) {
                 const int row_i = sq * L + i;
-                t.load(dob + (size_t)row_i * ldt + h * dh, dh);
-                const float dp = t.dot(vv);
+                t.load(dob + (size_t)row_i * ldt + ho, dh);
+                const float dp = head_dot<PAIRED>(t, vv);
                 const float lse = lses[row_i * H + h], delta = dlt[row_i * H + h];
-                HeadVec<TDH> qv;
-                qv.load(qkv + (size_t)row_i * ldq + h * dh, dh);
-                const float p = rat_exp2(qv.dot(kk) * sl2 - lse);
+                HV qv;
+                qv.load(qkv + (size_t)row_i * ldq + ho, dh);
+                const float p = rat_exp2(head_dot<PAIRED>(qv, kk) * sl2 - lse);
                 dv.axpy(p, t);
                 dk.axpy(p * (dp - delta), qv);
             }
-            dk.store(kp, dh, a.scale);
-            dv.store(kp + I, dh, 1.0f);
+            if (live) {
+                dk.store(kp, dh, a.scale);
+                dv.store(kp + I, dh, 1.0f);
+            }
         }
         __syncthreads();
         // dQ (in ob) -> Q columns of qkv: qkv now holds d[Q|K|V]
@@ -698,12 +732,21 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             float xh[COLS], gg[COLS], out[COLS], ad[COLS];
             float s1 = 0.f, s2 = 0.f;
             // the gradient added to the LayerNorm-backward result: the dy tile (PreNorm(Attention) + x), another tensor, or nothing
+            if (FAST && COLS % 4 == 0 && !a.add_lds) {           // a separate gradient tensor: 16-byte loads of this lane's columns
 #pragma unroll
-            for (int k = 0; k < COLS; ++k) {
-                const int c = c0 + k;
-                const bool in = (FAST || c < D) && valid;
-                if (a.add_lds) ad[k] = in ? dys[(size_t)r * ldx + c] : 0.f;
-                else ad[k] = (in && a.add != nullptr) ? a.add[tok * D + c] : 0.f;
+                for (int k = 0; k < COLS; k += 4) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid && a.add != nullptr) t = *reinterpret_cast<const float4*>(a.add + tok * D + c0 + k);
+                    ad[k] = t.x; ad[k + 1] = t.y; ad[k + 2] = t.z; ad[k + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < COLS; ++k) {
+                    const int c = c0 + k;
+                    const bool in = (FAST || c < D) && valid;
+                    if (a.add_lds) ad[k] = in ? dys[(size_t)r * ldx + c] : 0.f;
+                    else ad[k] = (in && a.add != nullptr) ? a.add[tok * D + c] : 0.f;
+                }
             }
             if (FAST && COLS % 4 == 0) {
 #pragma unroll
