@@ -301,7 +301,8 @@ __device__ __forceinline__ float head_dot(const V& a, const V& b) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int TD, int TDH>
+// EX = false: the plain PreNorm(Attention)(x) + x layer (residual = x, output scale 1) — the _ex constants fold away
+template <int TD, int TDH, bool EX = true>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
     constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
@@ -451,9 +452,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
                 }
             });
             __syncthreads();
-            store_rows_residual(a.y, xs, ldx, a.res, rowtok, rows, D, FAST || a.vec_x != 0, a.out_scale);
+            store_rows_residual(a.y, xs, ldx, EX ? a.res : a.x, rowtok, rows, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f);
         } else {
-            store_rows_residual(a.y, qkv, ldq, a.res, rowtok, rows, D, FAST || a.vec_x != 0, a.out_scale);
+            store_rows_residual(a.y, qkv, ldq, EX ? a.res : a.x, rowtok, rows, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f);
         }
         __syncthreads();
 #ifndef RAT_EMU
@@ -465,7 +466,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- backward
-template <int TD, int TDH>
+template <int TD, int TDH, bool EX = true>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
     constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         }
         RAT_PROF_MARK(0);
         load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
-        load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0, a.out_scale);
+        load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f);
         load_rows(ob, ldt, a.o_save, rowtok, I, FAST || ((I % 4) == 0 && a.vec_x != 0));
         for (int e = threadIdx.x; e < ATT_ROWS * H; e += ATT_THREADS) {
             const int64_t tok = rowtok[e / H];
@@ -732,7 +733,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             float xh[COLS], gg[COLS], out[COLS], ad[COLS];
             float s1 = 0.f, s2 = 0.f;
             // the gradient added to the LayerNorm-backward result: the dy tile (PreNorm(Attention) + x), another tensor, or nothing
-            if (FAST && COLS % 4 == 0 && !a.add_lds) {           // a separate gradient tensor: 16-byte loads of this lane's columns
+            const bool add_lds = EX ? a.add_lds != 0 : true;
+            if (FAST && COLS % 4 == 0 && !add_lds) {           // a separate gradient tensor: 16-byte loads of this lane's columns
 #pragma unroll
                 for (int k = 0; k < COLS; k += 4) {
                     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 for (int k = 0; k < COLS; ++k) {
                     const int c = c0 + k;
                     const bool in = (FAST || c < D) && valid;
-                    if (a.add_lds) ad[k] = in ? dys[(size_t)r * ldx + c] : 0.f;
+                    if (add_lds) ad[k] = in ? dys[(size_t)r * ldx + c] : 0.f;
                     else ad[k] = (in && a.add != nullptr) ? a.add[tok * D + c] : 0.f;
                 }
             }
@@ -970,7 +972,9 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
     const unsigned blocks = (unsigned)(a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu);
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
-    if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
+    const bool plain = res == x && out_scale == 1.0f;
+    if (fast == 64 && dim_head == 10 && plain) RAT_LAUNCH((attn_fwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
@@ -1029,7 +1033,8 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
     const size_t smem = g.bwd_smem(heads);
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
-    if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
+    if (fast == 64 && dim_head == 10 && a.add_lds) RAT_LAUNCH((attn_bwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
