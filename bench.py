@@ -212,11 +212,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # W untimed warm-up steps.  The one-off host work (creating the timing events, gc.freeze() — what fit_generator does before
+    # its first batch: no full-heap GC walks mid-loop) happens BEFORE the last of them, so that the timed region starts on a busy
+    # device instead of one that idled (and clocked down) through ~100 ms of host-only set-up.
+    for _ in range(max(args.warmup - 1, 0)):
         model.train_step(batch)
     sync()
-    timer.prepare(args.steps, args.warmup)
-    model.freeze_host_heap()          # what fit_generator does before its first batch (base_model.py): no full-heap GC walks mid-loop
+    timer.prepare(args.steps, max(args.warmup - 1, 1))
+    model.freeze_host_heap()
+    if args.warmup > 0:
+        model.train_step(batch)
+    sync()
     timer.enabled = True
     t0 = time.perf_counter()
     stamps = []
