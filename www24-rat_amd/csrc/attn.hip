@@ -320,15 +320,17 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     RAT_PROF_DECL
 
-    int64_t* rowtok_buf[2] = {rowtok, rowtok + ATT_ROWS};     // double-buffered row maps: chunk c+1's map is written during chunk c
+    int64_t* const rowtok0 = rowtok;                          // double-buffered row maps (chunk c+1's map is written during chunk c),
+    //                                                           addressed as base + parity * 64 so that they stay provably-LDS pointers
+    //                                                           (an array of two pointers indexed by parity compiled to FLAT loads)
     {
         int nsq0, rows0;
-        map_rows(a, blockIdx.x, rowtok_buf[0], nsq0, rows0);
+        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
-        rowtok = rowtok_buf[parity];
+        rowtok = rowtok0 + parity * ATT_ROWS;
         int nsq, rows;
         {
             const int64_t q0 = chunk * a.nsq_chunk;
@@ -341,7 +343,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
-            map_rows(a, chunk + gridDim.x, rowtok_buf[parity ^ 1], nsq1, rows1);
+            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
@@ -366,7 +368,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         {
             const int nl = (D * 4 + 127) / 128;
             if ((int)threadIdx.x < ATT_ROWS * nl && chunk + gridDim.x < a.nchunks)
-                pf = prefetch_lines_map(rowtok_buf[parity ^ 1], threadIdx.x, nl, a.x, D);
+                pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, nl, a.x, D);
         }
         constexpr bool PAIRED = FAST && TDH == 20;
         constexpr int VW = PAIRED ? 10 : TDH;                  // per-lane vector width
@@ -507,15 +509,25 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
     RAT_PROF_DECL
 
-    int64_t* rowtok_buf[2] = {rowtok, rowtok + ATT_ROWS};     // row maps are double-buffered: chunk c+1's map is written during chunk c
+    int64_t* const rowtok0 = rowtok;                          // row maps are double-buffered (chunk c+1's map is written during chunk c);
+    //                                                           base + parity * 64 keeps them provably-LDS pointers (see forward)
     {
         int nsq0, rows0;
-        map_rows(a, blockIdx.x, rowtok_buf[0], nsq0, rows0);
+        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
+    // LayerNorm backward multiplies this lane's COLS columns by gamma in every chunk: the values are fetched ONCE here.  (Loaded
+    // inside the phase they compiled into COLS predicated single-dword loads, each in its own basic block behind a branch — a serial
+    // chain of L2 round trips per chunk.)
+    float lng[COLS];
+    {
+        const int c0g = (threadIdx.x & 7) * COLS;
+#pragma unroll
+        for (int k = 0; k < COLS; ++k) lng[k] = (FAST || c0g + k < D) ? a.ln_g[c0g + k] : 0.f;
+    }
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
-        rowtok = rowtok_buf[parity];
+        rowtok = rowtok0 + parity * ATT_ROWS;
         int nsq, rows;
         {
             const int64_t q0 = chunk * a.nsq_chunk;
@@ -536,7 +548,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, mu, rs);
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
-            map_rows(a, chunk + gridDim.x, rowtok_buf[parity ^ 1], nsq1, rows1);
+            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
         const int mt_valid = (rows + 15) / 16;
@@ -596,7 +608,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             const int nlx = (D * 4 + 127) / 128, nlo = (I * 4 + 127) / 128;
             int t = threadIdx.x;
             if (chunk + gridDim.x < a.nchunks) {
-                const int64_t* nrt = rowtok_buf[parity ^ 1];          // written before the barrier that opened this phase
+                const int64_t* nrt = (rowtok0 + (parity ^ 1) * ATT_ROWS);          // written before the barrier that opened this phase
                 if (t < ATT_ROWS * nlx) pf = prefetch_lines_map(nrt, t, nlx, a.x, D);
                 else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlx) pf = prefetch_lines_map(nrt, t, nlx, a.dy, D);
                 else if ((t -= ATT_ROWS * nlx) < ATT_ROWS * nlo) pf = prefetch_lines_map(nrt, t, nlo, a.o_save, I);
@@ -777,7 +789,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 const bool on = (FAST || c < D) && valid;
                 xh[k] = on ? (xh[k] - mean) * rstd : 0.f;
                 gg[k] = on ? gg[k] : 0.f;
-                const float gw = on ? gg[k] * a.ln_g[c] : 0.f;
+                const float gw = on ? gg[k] * lng[k] : 0.f;
                 s1 += gw;
                 s2 += gw * xh[k];
             }
@@ -787,7 +799,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             for (int k = 0; k < COLS; ++k) {
                 const int c = c0 + k;
                 const bool on = (FAST || c < D) && valid;
-                const float gw = on ? gg[k] * a.ln_g[c] : 0.f;
+                const float gw = on ? gg[k] * lng[k] : 0.f;
                 out[k] = on ? ad[k] + rstd * (gw - s1 - xh[k] * s2) : 0.f;
                 dgam[k] += gg[k] * xh[k];
                 dbet[k] += gg[k];
