@@ -124,6 +124,41 @@ __device__ __forceinline__ void load_rows(float* tile, int ld, const float* src,
     }
 }
 
+// Compile-time-width form for the fast shapes: a thread's items are staged in three sweeps — all row-map reads, then all
+// global loads, then all LDS writes — so that the tile costs ONE memory round trip.  (The run-time-width loop above compiles to
+// one LDS read -> global load -> LDS write dependency chain per item: seven serial round trips per chunk for x, dy and O.)
+template <int WIDTH>
+struct RowFetch {
+    static constexpr int W4 = WIDTH / 4;
+    static constexpr int NIT = (ATT_ROWS * W4 + ATT_THREADS - 1) / ATT_THREADS;
+    float4 v[NIT];
+    __device__ __forceinline__ void issue(const float* src, const int64_t* rowtok) {
+        int64_t tok[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            tok[it] = e < ATT_ROWS * W4 ? rowtok[e / W4] : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tok[it] >= 0) v[it] = *reinterpret_cast<const float4*>(src + tok[it] * WIDTH + 4 * (e % W4));
+        }
+    }
+    __device__ __forceinline__ void stash(float* tile, int ld, float mul = 1.0f) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            if (e < ATT_ROWS * W4) {
+                float4 t = v[it];
+                if (mul != 1.0f) { t.x *= mul; t.y *= mul; t.z *= mul; t.w *= mul; }
+                *reinterpret_cast<float4*>(tile + (size_t)(e / W4) * ld + 4 * (e % W4)) = t;
+            }
+        }
+    }
+};
+
 // Warm L2 with the NEXT chunk's rows: every thread touches one dword of one 128-byte line (64 rows x `bytes` per
 // source).  Issued at the start of a phase that performs no other global loads, so the HBM round trip hides behind it
 // and the next iteration's tile loads hit L2.  Returns the touched value; the caller keeps it alive until loop end.
@@ -338,7 +373,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
             rows = nsq * a.L;
         }
-        load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
+        if (FAST) {
+            RowFetch<FAST ? TD : 4> fx;
+            fx.issue(a.x, rowtok);
+            fx.stash(xs, ldx);
+        } else {
+            load_rows(xs, ldx, a.x, rowtok, D, a.vec_x != 0);
+        }
         __syncthreads();
         layer_norm_rows<COLS, FAST && (8 * COLS == TD)>(xs, ldx, D, rows, a.ln_g, a.ln_b, a.eps, nullptr, nullptr);
         if (chunk + gridDim.x < a.nchunks) {
@@ -536,9 +577,20 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             rows = nsq * a.L;
         }
         RAT_PROF_MARK(0);
-        load_rows(xs, ldx, a.x, rowtok, D, FAST || a.vec_x != 0);
-        load_rows(dys, ldx, a.dy, rowtok, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f);
-        load_rows(ob, ldt, a.o_save, rowtok, I, FAST || ((I % 4) == 0 && a.vec_x != 0));
+        if (FAST) {                                              // x, dy and O rows of the chunk in ONE memory round trip
+            RowFetch<FAST ? TD : 4> fx, fdy;
+            RowFetch<FAST ? FAST_INNER : 4> fo;
+            fx.issue(a.x, rowtok);
+            fdy.issue(a.dy, rowtok);
+            fo.issue(a.o_save, rowtok);
+            fx.stash(xs, ldx);
+            fdy.stash(dys, ldx, EX ? a.out_scale : 1.0f);
+            fo.stash(ob, ldt);
+        } else {
+            load_rows(xs, ldx, a.x, rowtok, D, a.vec_x != 0);
+            load_rows(dys, ldx, a.dy, rowtok, D, a.vec_x != 0, EX ? a.out_scale : 1.0f);
+            load_rows(ob, ldt, a.o_save, rowtok, I, (I % 4) == 0 && a.vec_x != 0);
+        }
         for (int e = threadIdx.x; e < ATT_ROWS * H; e += ATT_THREADS) {
             const int64_t tok = rowtok[e / H];
             lses[e] = tok >= 0 ? a.lse_save[tok * H + e % H] : 0.f;
