@@ -61,7 +61,8 @@ class KernelTimer:
     """HIP-event timing of every C-ABI launch on torch's current stream (the stream the kernels are launched on)."""
 
     HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
-             "rat_ffn_bwd_res", "rat_attn_core_fwd", "rat_attn_core_bwd")
+             "rat_ffn_bwd_res", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map")
+    ATTN_ARGS = {"rat_attn_fwd": (5, 7), "rat_attn_bwd": (9, 11), "rat_attn_fwd_ex": (6, 8), "rat_attn_bwd_ex": (10, 12)}   # (map, heads)
 
     def __init__(self, lib, everything=False):
         self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
@@ -93,11 +94,13 @@ class KernelTimer:
 
     @staticmethod
     def _tag(name, args):
-        if name in ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex"):
-            smap = args[{"rat_attn_fwd": 5, "rat_attn_bwd": 9, "rat_attn_fwd_ex": 6, "rat_attn_bwd_ex": 10}[name]]._obj
-            return "L%d" % smap.L
+        if name in KernelTimer.ATTN_ARGS:                                # "L<seq len>h<heads of this launch>" (grouped mode: heads / 4)
+            mi, hi = KernelTimer.ATTN_ARGS[name]
+            return "L%dh%d" % (args[mi]._obj.L, int(args[hi]))
         if name in ("rat_attn_core_fwd", "rat_attn_core_bwd"):           # RAT_m0: joint sequences of T*S tokens
             return "L%d" % int(args[4 if name == "rat_attn_core_fwd" else 6])
+        if name in ("rat_attn_core_fwd_map", "rat_attn_core_bwd_map"):
+            return "L%d" % args[3 if name == "rat_attn_core_fwd_map" else 5]._obj.L
         if name in ("rat_ffn_fwd_res", "rat_ffn_bwd_res"):               # RAT_m1 runs the block MLP at two token counts
             return "n%d" % int(args[7 if name == "rat_ffn_fwd_res" else 13])
         return ""
@@ -112,27 +115,34 @@ class KernelTimer:
 
 
 def algorithmic_work(spec, model="RAT_m2"):
-    """FLOPs / bytes per LAUNCH of each hot kernel (SURVEY.md §8d; padded MFMA lanes and recompute do not count;
-    backward = 2x forward)."""
+    """-> f(kernel name, tag) = (bound, FLOPs or bytes per LAUNCH) or None (padded MFMA lanes and recompute do not
+    count; backward = 2x forward).  Tags come from KernelTimer._tag."""
     B, F, K, d = spec["batch"], spec["F"], spec["K"], spec["d"]
     T, S = K + 1, F + 1
-    I, H = spec["num_heads"] * spec["dim_head"], d * spec["scale_dim"]
+    dh, H = spec["dim_head"], d * spec["scale_dim"]
     tok = B * T * S
-    work = {}
-    # RAT_m2: both attentions and the MLP see the whole grid; RAT_m1: the cross transformer sees one token per sample
-    for L, n in ((S, tok), (T, B * T if model == "RAT_m1" else tok)):
-        f = n * (8 * d * I + 4 * I * L)
-        work[("rat_attn_fwd", "L%d" % L)] = work[("rat_attn_fwd_ex", "L%d" % L)] = ("mfma", f)
-        work[("rat_attn_bwd", "L%d" % L)] = work[("rat_attn_bwd_ex", "L%d" % L)] = ("mfma", 2 * f)
-        work[("rat_ffn_fwd_res", "n%d" % n)] = ("mfma", n * 4 * d * H)
-        work[("rat_ffn_bwd_res", "n%d" % n)] = ("mfma", 2 * n * 4 * d * H)
-    # RAT_m0's long-sequence core (fp32 VALU, priced against the same 157.3 TFLOP/s fp32 peak): scores + PV over L = T*S keys
-    work[("rat_attn_core_fwd", "L%d" % (T * S))] = ("mfma", tok * 4 * I * T * S)
-    work[("rat_attn_core_bwd", "L%d" % (T * S))] = ("mfma", 2 * tok * 4 * I * T * S)
-    work[("rat_ffn_fwd", "")] = ("mfma", tok * 4 * d * H)
-    work[("rat_ffn_bwd", "")] = ("mfma", 2 * tok * 4 * d * H)
-    work[("rat_gather_fwd", "")] = ("hbm", B * (T * F * d * 4 + T * S * d * 4 + T * F * 4))
-    work[("rat_gather_bwd", "")] = ("hbm", B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4))
+
+    def tokens_of(L):                          # RAT_m1's cross transformer sees one token per sample; everything else the grid
+        return B * T if (model == "RAT_m1" and L == T) else tok
+
+    def work(name, tag):
+        bwd = 2 if "_bwd" in name else 1
+        if name in KernelTimer.ATTN_ARGS:                                # fused kernel: projections of `heads` heads + core
+            L, h = [int(v) for v in tag[1:].split("h")]
+            inner = h * dh
+            return "mfma", bwd * tokens_of(L) * (8 * d * inner + 4 * inner * L)
+        if name.startswith("rat_attn_core"):                             # core only (fp32 VALU, priced against the fp32 peak)
+            L = int(tag[1:])
+            return "mfma", bwd * tokens_of(L) * 4 * spec["num_heads"] * dh * L
+        if name in ("rat_ffn_fwd", "rat_ffn_bwd"):
+            return "mfma", bwd * tok * 4 * d * H
+        if name in ("rat_ffn_fwd_res", "rat_ffn_bwd_res"):
+            return "mfma", bwd * int(tag[1:]) * 4 * d * H
+        if name == "rat_gather_fwd":
+            return "hbm", B * (T * F * d * 4 + T * S * d * 4 + T * F * 4)
+        if name == "rat_gather_bwd":
+            return "hbm", B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4)
+        return None
     return work
 
 
@@ -249,8 +259,9 @@ def main():
         for key, st in sorted(ksum.items(), key=lambda kv: -kv[1]["ms_per_step"]):
             row = dict(kernel=key[0] + (":" + key[1] if key[1] else ""), launches_per_step=round(st["launches_per_step"], 2),
                        avg_ms=round(st["avg_ms"], 4), ms_per_step=round(st["ms_per_step"], 4))
-            if key in work:
-                bound, amount = work[key]
+            wk = work(*key)
+            if wk:
+                bound, amount = wk
                 if bound == "mfma":
                     row.update(bound="mfma", achieved=round(amount / (st["avg_ms"] * 1e-3) / 1e12, 3), unit="TFLOP/s")
                 else:
@@ -262,9 +273,10 @@ def main():
             p = pooled.setdefault(key[0], dict(ms=0.0, n=0.0, amount=0.0, bound=None))
             p["ms"] += st["ms_per_step"]
             p["n"] += st["launches_per_step"]
-            if key in work:
-                p["bound"] = work[key][0]
-                p["amount"] += work[key][1] * st["launches_per_step"]
+            wk = work(*key)
+            if wk:
+                p["bound"] = wk[0]
+                p["amount"] += wk[1] * st["launches_per_step"]
         dom_name, dom = max(((k, v) for k, v in pooled.items() if v["bound"]), key=lambda kv: kv[1]["ms"])
         avg_s = dom["ms"] / dom["n"] * 1e-3
         per_launch = dom["amount"] / dom["n"]
