@@ -25,6 +25,8 @@ WORKLOADS = {
     # the full 100 M-row table (25.6 GB + 77 GB of gradient / Adam state per replica) fits one MI355X, but its DENSE gradient
     # all-reduce does not scale — row-sparse exchange + lazy Adam for that config are future work
     "synthetic_F40_V10M_K10_d64_B1024": dict(F=40, total_vocab=10_000_000, K=10, d=64, batch=1024, **KKBOX_HYPER),
+    # the reference's own KKBox experiment (configs/RAT_m2/kkbox_x1/model_config.yaml: embedding_dim 40, K = 5): generic-geometry kernels
+    "kkbox_real_F13_K5_d40_B4096": dict(F=13, total_vocab=92_000, K=5, d=40, batch=4096, **KKBOX_HYPER),
     # tiny: smoke / CI
     "tiny": dict(F=5, total_vocab=500, K=3, d=16, batch=32, num_heads=2, dim_head=10, depth=2, scale_dim=2,
                  dnn_hidden_units=[32, 16], batch_norm=True, use_wide=True, learning_rate=1e-3),
