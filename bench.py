@@ -7,12 +7,24 @@
 
 One "step" = one full training iteration of BaseModel.train_one_epoch on one synthetic batch that is already
 resident in HBM: zero_grad -> forward -> BCE(+L2) -> backward -> [all-reduce] -> clip_grad_norm(10) -> Adam.
-Workload at every N: BASELINE.json configs[1] (F=20 fields, 1M-row vocab, K=10 retrieved, d=64, batch 4096 PER GPU,
-weak scaling), KKBox hyper-parameters for what BASELINE.json leaves open.  Rank 0 prints ONE JSON line.
+The timed loop rotates over NBATCH distinct batches (different ids every step).
+
+`--gpus N` without a torch.distributed launcher around it starts the N worker processes itself (children are spawned before
+this process touches the GPU; nothing is exec'ed) — one process per GPU, RCCL process group over 127.0.0.1.
+
+Workload: BASELINE.json configs[1] (F=20 fields, 1M-row vocab, K=10 retrieved, d=64), KKBox hyper-parameters for what
+BASELINE.json leaves open.  Partitioning at N > 1 (pure data parallelism over the batch):
+  * `value` / `ms_per_step`  — WEAK scaling: every rank trains on its own B = 4096 batch (global batch 4096 N);
+  * `strong_scaling`         — the SAME line also carries the strong-scaling measurement: ONE global batch of 4096 samples,
+                               rank r takes rows [r B/N, (r+1) B/N) — §8e's partitioning — timed right after the weak run.
+BatchNorm statistics are exchanged (SyncBN) so that N ranks compute what one device would on the global batch.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,65 +33,118 @@ for p in (ROOT, os.path.join(ROOT, "www24-rat_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, exact fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the sparsity figures are never used)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+NBATCH = 4                        # distinct batches rotated through the timed loop
 # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected with rocprofv3 in
 # separate runs (bench.py cannot host the profiler) and committed next to the kernel stats; valid for the north-star shapes only
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round1", "r1_traffic_pmc.json")
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "round2", "r2_traffic_pmc.json"),
+                 os.path.join(ROOT, "profiles", "round1", "r1_traffic_pmc.json")]
 
 
 def pmc_traffic(kernel, workload):
-    if workload != "synthetic_F20_V1M_K10_d64_B4096" or not os.path.exists(TRAFFIC_FILE):
-        return None
-    try:
-        with open(TRAFFIC_FILE) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (KeyError, ValueError):
-        return None
+    if workload != "synthetic_F20_V1M_K10_d64_B4096":
+        return None, None
+    for path in TRAFFIC_FILES:
+        try:
+            with open(path) as f:
+                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="synthetic_F20_V1M_K10_d64_B4096")
     ap.add_argument("--model", default="RAT_m2", choices=["RAT_m2", "RAT_m1", "RAT_m3", "RAT_m0"],
-                    help="RAT_m2 (default) is the BASELINE.json metric; RAT_m1 times the cascaded variant (SURVEY §8f rank 2) on the same workload")
+                    help="RAT_m2 (default) is the BASELINE.json metric; the others time the variants (SURVEY §8f rank 2) on the same workload")
+    ap.add_argument("--scaling", default="both", choices=["both", "weak", "strong"],
+                    help="N > 1 only.  both (default): `value` = weak scaling (batch per GPU fixed) and a `strong_scaling` object "
+                         "(one global batch split by rank) in the same line; weak / strong: only that measurement, as `value`")
+    ap.add_argument("--arith", default=None, choices=["f32", "bf16x3"],
+                    help="arithmetic of the encoder GEMMs (default: the library's default; both are timed when available)")
+    ap.add_argument("--embedding-grad", default=None, choices=["atomic", "sorted", "sparse"],
+                    help="how table gradients are produced (default: the workload's / the model's `auto` rule)")
     ap.add_argument("--step-times", action="store_true", help="print the host-side issue time of every timed step to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--time-all-kernels", action="store_true",
                     help="HIP-event timing around EVERY C-ABI launch (adds ~2 events x 60 launches of host work per step); "
-                         "default: only the encoder kernels (attention / FFN forward and backward), which hold >90 %% of the step")
-    return ap.parse_args()
+                         "default: the encoder kernels (attention / FFN forward and backward, >90 %% of the step) and the "
+                         "embedding gather / scatter")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="plumbing check without a GPU: gloo process group, the host-emulation build of the kernels (tests/emu), "
+                         "workload `dryrun`; the printed numbers mean nothing")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------- self-launch
+def self_launch(args):
+    """`python bench.py --gpus N` on its own: start N workers (this file, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment) as CHILD processes — before anything in this process has touched the GPU — wait for them, relay rank 0's
+    JSON line, exit with the worst return code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+# ------------------------------------------------------------------------------------------------- timing
+class _HostEvent:
+    """stand-in for torch.cuda.Event in --dry-run-cpu"""
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
 
 
 class KernelTimer:
-    """HIP-event timing of every C-ABI launch on torch's current stream (the stream the kernels are launched on)."""
+    """HIP-event timing of C-ABI launches on torch's current stream (the stream the kernels are launched on)."""
 
     HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
-             "rat_ffn_bwd_res", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map")
+             "rat_ffn_bwd_res", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map",
+             "rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted")
     ATTN_ARGS = {"rat_attn_fwd": (5, 7), "rat_attn_bwd": (9, 11), "rat_attn_fwd_ex": (6, 8), "rat_attn_bwd_ex": (10, 12)}   # (map, heads)
 
-    def __init__(self, lib, everything=False):
+    def __init__(self, lib, everything=False, host_events=False):
         self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
-        self.calls_seen, self.pool = 0, []
+        self.calls_seen, self.pool, self.host_events = 0, [], host_events
         lib.call = self._call
+
+    def _new(self):
+        import torch
+        return _HostEvent() if self.host_events else torch.cuda.Event(enable_timing=True)
 
     def prepare(self, steps, warmup_steps):
         """Create (and once record, which is what actually creates the HIP event) every event the timed region will need, from
         the launch count seen during warm-up: hipEventCreate inside the timed loop would be the benchmark timing itself."""
+        import torch
         need = 2 * (self.calls_seen // max(warmup_steps, 1) + 8) * steps
-        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(need)]
+        self.pool = [self._new() for _ in range(need)]
         for ev in self.pool:
             ev.record()
-        torch.cuda.synchronize()
+        if not self.host_events:
+            torch.cuda.synchronize()
 
     def _event(self):
-        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+        return self.pool.pop() if self.pool else self._new()
 
     def _call(self, name, *args):
         timed = self.everything or name in self.HEAVY
@@ -113,11 +178,14 @@ class KernelTimer:
             d[1] += s.elapsed_time(e)
         return {k: dict(launches_per_step=v[0] / steps, avg_ms=v[1] / v[0], ms_per_step=v[1] / steps) for k, v in out.items()}
 
+    def reset(self):
+        self.records = []
 
-def algorithmic_work(spec, model="RAT_m2"):
+
+def algorithmic_work(spec, batch, model="RAT_m2"):
     """-> f(kernel name, tag) = (bound, FLOPs or bytes per LAUNCH) or None (padded MFMA lanes and recompute do not
     count; backward = 2x forward).  Tags come from KernelTimer._tag."""
-    B, F, K, d = spec["batch"], spec["F"], spec["K"], spec["d"]
+    B, F, K, d = batch, spec["F"], spec["K"], spec["d"]
     T, S = K + 1, F + 1
     dh, H = spec["dim_head"], d * spec["scale_dim"]
     tok = B * T * S
@@ -140,15 +208,27 @@ def algorithmic_work(spec, model="RAT_m2"):
             return "mfma", bwd * int(tag[1:]) * 4 * d * H
         if name == "rat_gather_fwd":
             return "hbm", B * (T * F * d * 4 + T * S * d * 4 + T * F * 4)
-        if name == "rat_gather_bwd":
+        if name in ("rat_gather_bwd", "rat_gather_bwd_sorted"):
             return "hbm", B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4)
         return None
     return work
 
 
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(spec, fm, batch_size, seed, model="RAT_m2"):
     """The oracle (a port: oracle/rat_m2_oracle.py, pinned to the reference's golden vectors) timed on this box's host
     cores on a bounded sample of the same workload: full training steps at a reduced batch."""
+    import torch
     from oracle import rat_m2_oracle as orc
     from rat_amd import synthetic
     # many-core hosts thrash on these small ops with one thread per core; 32 threads is where the oracle peaks
@@ -184,77 +264,133 @@ def cpu_baseline(spec, fm, batch_size, seed, model="RAT_m2"):
     for s in range(nsteps):
         w, *_ = orc.train_step(w, X, y, cfg, state, 2 + s)
     dt = time.perf_counter() - t0
-    return dict(value=batch_size * nsteps / dt, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d full training steps (fwd+loss+bwd+clip+Adam) of the CPU oracle at batch %d of the same workload "
-                       "(F=%d, K=%d, d=%d, %d-row vocab), %d torch threads" % (nsteps, batch_size, spec["F"], spec["K"], spec["d"],
-                                                                                spec["total_vocab"], torch.get_num_threads()))
+    threads = torch.get_num_threads()
+    return dict(value=round(batch_size * nsteps / dt, 1), unit="samples/s", cores=threads, threads=threads,
+                host_cores=os.cpu_count(), cpu_model=host_cpu_model(), kind="port", sample_batch=batch_size,
+                sample="%d full training steps (fwd+loss+bwd+clip+Adam) of the CPU oracle at batch %d (NOT %d) of the same workload "
+                       "(F=%d, K=%d, d=%d, %d-row vocab), %d torch threads on a %d-core host"
+                       % (nsteps, batch_size, spec["batch"], spec["F"], spec["K"], spec["d"], spec["total_vocab"], threads,
+                          os.cpu_count() or 0))
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------- the worker
+def worker(args):
+    import torch
     import torch.distributed as dist
-    from rat_amd import synthetic
+    from rat_amd import models, synthetic
     from rat_amd.base_model import seed_everything
-    from rat_amd import models
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    dry = args.dry_run_cpu
+    if dry:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import build_emu
+        import rat_amd._lib as L
+        L._default = L.RatLib(build_emu.build())
+        args.workload = "dryrun"
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)
 
     spec = synthetic.WORKLOADS[args.workload]
     fm = synthetic.feature_map_for(args.workload, spec)
     seed_everything(2021)
-    model = getattr(models, args.model)(fm, **synthetic.model_kwargs(spec, gpu=local_rank))
-    batch = synthetic.make_batch(spec, fm, seed=1000 + rank, device=model.device)
+    gpu = -1 if dry else local_rank
+    kwargs = synthetic.model_kwargs(spec, gpu=gpu)
+    if args.embedding_grad is not None:
+        kwargs["embedding_grad"] = args.embedding_grad
+        if args.embedding_grad == "sparse":
+            kwargs["embedding_regularizer"] = 0.0          # lazy row updates cannot carry the dense lambda*W term (declared)
+    model = getattr(models, args.model)(fm, **kwargs)
+    if args.arith is not None:
+        model.set_arith(args.arith)
+    B = spec["batch"]
+    dev = model.device if not dry else None
     model.train()
-    timer = KernelTimer(model._lib, everything=args.time_all_kernels)
+    timer = KernelTimer(model._lib, everything=args.time_all_kernels, host_events=dry)
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    # W untimed warm-up steps.  The one-off host work (creating the timing events, gc.freeze() — what fit_generator does before
-    # its first batch: no full-heap GC walks mid-loop) happens BEFORE the last of them, so that the timed region starts on a busy
-    # device instead of one that idled (and clocked down) through ~100 ms of host-only set-up.
-    for _ in range(max(args.warmup - 1, 0)):
-        model.train_step(batch)
-    sync()
-    timer.prepare(args.steps, max(args.warmup - 1, 1))
-    model.freeze_host_heap()
-    if args.warmup > 0:
-        model.train_step(batch)
-    sync()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    stamps = []
-    for _ in range(args.steps):
-        if args.step_times:
+    def make(seed, lo=None, hi=None):
+        b = synthetic.make_batch(spec, fm, seed=seed, device=dev, as_float64=False)
+        return b if lo is None else tuple(t[lo:hi].contiguous() for t in b)
+
+    def timed_region(batches, steps, warmup, label):
+        """W untimed warm-up steps, then K steps between barrier + synchronize.  The one-off host work (creating the timing
+        events, gc.freeze() — what fit_generator does before its first batch) happens BEFORE the last warm-up step, so that the
+        timed region starts on a busy device instead of one that idled (and clocked down) through ~100 ms of host-only set-up."""
+        timer.enabled = False
+        timer.reset()
+        nb = len(batches)
+        for i in range(max(warmup - 1, 0)):
+            model.train_step(batches[i % nb])
+        sync()
+        timer.prepare(steps, max(warmup - 1, 1))
+        model.freeze_host_heap()
+        if warmup > 0:
+            model.train_step(batches[(warmup - 1) % nb])
+        sync()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        stamps = []
+        for i in range(steps):
+            if args.step_times:
+                stamps.append(time.perf_counter())
+            model.train_step(batches[i % nb])
+        sync()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+        if args.step_times:                # diagnostic: host-side issue time of every step (stderr), e.g. to spot interpreter stalls
             stamps.append(time.perf_counter())
-        model.train_step(batch)
-    sync()
-    if args.step_times:                # diagnostic: host-side issue time of every step (stderr), e.g. to spot interpreter stalls
-        stamps.append(time.perf_counter())
-        print("step issue times (ms): " + " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(stamps, stamps[1:])), file=sys.stderr)
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=model.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+            print("%s step issue times (ms): %s" % (label, " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(stamps, stamps[1:]))),
+                  file=sys.stderr)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=model.device if not dry else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        model.check_id_errors()
+        return elapsed, timer.summary(steps)
+
+    want_weak = world == 1 or args.scaling in ("both", "weak")
+    want_strong = world > 1 and args.scaling in ("both", "strong")
+    weak = strong = None
+    if want_weak:                                  # every rank its own batches of B samples
+        batches = [make(1000 + 16 * rank + i) for i in range(NBATCH)]
+        weak = timed_region(batches, args.steps, args.warmup, "weak")
+        del batches
+    if want_strong:                                # one global batch of B samples, rank r takes rows [r B/N, (r+1) B/N)
+        per = B // world
+        batches = [make(2000 + i, rank * per, (rank + 1) * per) for i in range(NBATCH)]
+        strong = timed_region(batches, args.steps, max(args.warmup, 2) if weak is None else 2, "strong")
+        del batches
+
+    # exact-fp32 arithmetic timed beside the default one in the SAME invocation (VERDICT r1 item 4 (ii)); N = 1 only
+    alt = None
+    if world == 1 and args.arith is None and hasattr(model, "arith_modes") and len(model.arith_modes()) > 1:
+        default_arith = model.arith
+        other = [m for m in model.arith_modes() if m != default_arith][0]
+        model.set_arith(other)
+        batches = [make(1000 + i) for i in range(NBATCH)]
+        el, ks = timed_region(batches, args.steps, 2, other)
+        alt = dict(arith=other, value=round(B * args.steps / el, 1), ms_per_step=round(el / args.steps * 1e3, 3),
+                   kernels={k[0] + (":" + k[1] if k[1] else ""): round(v["avg_ms"], 4) for k, v in ks.items()})
+        model.set_arith(default_arith)
+        del batches
 
     if rank == 0:
-        B = spec["batch"]
-        ksum = timer.summary(args.steps)
-        work = algorithmic_work(spec, args.model)
+        primary, per_rank_batch, scaling = (weak, B, "weak") if weak is not None else (strong, B // world, "strong")
+        elapsed, ksum = primary
+        work = algorithmic_work(spec, per_rank_batch, args.model)
+        arith = getattr(model, "arith", "f32")
         kernels = []
         for key, st in sorted(ksum.items(), key=lambda kv: -kv[1]["ms_per_step"]):
             row = dict(kernel=key[0] + (":" + key[1] if key[1] else ""), launches_per_step=round(st["launches_per_step"], 2),
@@ -263,9 +399,11 @@ def main():
             if wk:
                 bound, amount = wk
                 if bound == "mfma":
-                    row.update(bound="mfma", achieved=round(amount / (st["avg_ms"] * 1e-3) / 1e12, 3), unit="TFLOP/s")
+                    tf = amount / (st["avg_ms"] * 1e-3) / 1e12
+                    row.update(bound="mfma", achieved=round(tf, 3), unit="TFLOP/s", frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
                 else:
-                    row.update(bound="hbm", achieved=round(amount / (st["avg_ms"] * 1e-3) / 1e9, 1), unit="GB/s")
+                    gbs = amount / (st["avg_ms"] * 1e-3) / 1e9
+                    row.update(bound="hbm", achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
             kernels.append(row)
         # dominant kernel = the C-ABI entry point with the most time per step (all its launches, both attention phases pooled)
         pooled = {}
@@ -284,30 +422,81 @@ def main():
             achieved, peak, unit = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        traffic, traffic_src = pmc_traffic(dom_name, args.workload) if (args.model == "RAT_m2" and per_rank_batch == B) else (None, None)
         roofline = dict(kernel=dom_name, bound=dom["bound"], achieved=round(achieved, 3), peak=peak, unit=unit,
-                        frac=round(achieved / peak, 4), traffic=pmc_traffic(dom_name, args.workload) if args.model == "RAT_m2" else None,
-                        traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1/r1_traffic_pmc.json)",
+                        frac=round(achieved / peak, 4), traffic=traffic,
+                        traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, %s)" % traffic_src,
                         algorithmic=round(per_launch, 1), algorithmic_unit="FLOP/launch" if dom["bound"] == "mfma" else "bytes/launch",
                         avg_launch_ms=round(avg_s * 1e3, 4), launches_per_step=round(dom["n"], 2))
-        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64; 1/2/4/8 MI355X", value=round(B * world * args.steps / elapsed, 1),
+        if dom["bound"] == "mfma" and arith == "bf16x3":
+            # 3-way bf16 split, 6 of the 9 cross products, fp32 accumulate: `peak` stays the exact-fp32 MFMA peak (continuity
+            # with round 1); `peak_effective` = dense bf16 MFMA peak / 6 products per fp32-equivalent FLOP
+            eff = PEAK_BF16_MFMA_TFLOPS / 6.0
+            roofline.update(peak_effective=round(eff, 1), frac_effective=round(achieved / eff, 4),
+                            peak_effective_note="bf16 MFMA dense peak 2500 TFLOP/s / 6 bf16 products per fp32 product")
+        # north_star's two named targets, from the same HIP-event records
+        targets = {}
+        for nm in ("rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted"):
+            p = pooled.get(nm)
+            if p and p["n"] > 0 and p["bound"] == "hbm":
+                gbs = p["amount"] / p["n"] / (p["ms"] / p["n"] * 1e-3) / 1e9
+                targets[nm] = dict(bound="hbm", avg_launch_ms=round(p["ms"] / p["n"], 4), algorithmic_bytes=round(p["amount"] / p["n"]),
+                                   achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4))
+        T = spec["K"] + 1
+        cross_ms = cross_fl = 0.0
+        for key, st in ksum.items():
+            if key[0] in KernelTimer.ATTN_ARGS and key[1].startswith("L%dh" % T) and T != spec["F"] + 1:
+                cross_ms += st["ms_per_step"]
+                cross_fl += work(*key)[1] * st["launches_per_step"]
+        if cross_ms > 0:
+            tf = cross_fl / (cross_ms * 1e-3) / 1e12
+            targets["cross_attention"] = dict(bound="mfma", what="all L=T=%d fused-attention launches of a step, fwd + bwd" % T,
+                                              ms_per_step=round(cross_ms, 4), algorithmic_flop_per_step=round(cross_fl),
+                                              achieved_TFLOPs=round(tf, 2), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+        gbatch = per_rank_batch * world
+        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64; 1/2/4/8 MI355X",
+                      value=round(gbatch * args.steps / elapsed, 1),
                       unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                      ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
-                      dtype="f32", data="synthetic",
+                      ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling=scaling, vs_baseline=None,
+                      dtype="f32", arith={"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
+                                          "bf16x3": "bf16x3-split MFMA, fp32 accumulate"}.get(arith, arith),
+                      data="synthetic (%d distinct batches rotated)" % NBATCH,
                       config=dict(workload=args.workload, fields=spec["F"], vocab_rows=spec["total_vocab"], retrieved=spec["K"],
-                                  embedding_dim=spec["d"], batch_per_gpu=B, global_batch=B * world, heads=spec["num_heads"],
+                                  embedding_dim=spec["d"], batch_per_gpu=per_rank_batch, global_batch=gbatch, heads=spec["num_heads"],
                                   dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
-                                  dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam",
+                                  dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam", embedding_grad=model._grad_mode,
+                                  embedding_regularizer=model._cfg["lam_emb"], sync_batch_norm=bool(world > 1 and spec["batch_norm"]),
                                   parallelism="dp%d" % world),
-                      roofline=roofline, kernels=kernels)
+                      roofline=roofline, targets=targets, kernels=kernels)
+        if strong is not None and weak is not None:
+            el, _ = strong
+            result["strong_scaling"] = dict(value=round(B * args.steps / el, 1), unit="samples/s", ms_per_step=round(el / args.steps * 1e3, 3),
+                                            global_batch=B, batch_per_gpu=B // world,
+                                            partitioning="one global batch of %d samples, rank r trains on rows [r*%d, (r+1)*%d)" % (B, B // world, B // world))
+        if alt is not None:
+            result["exact_f32" if alt["arith"] == "f32" else "alt_arith"] = alt
         if args.model != "RAT_m2":
             result["config"]["variant"] = args.model
-        if world == 1 and not args.no_cpu_baseline:
+        if dry:
+            result["dry_run_cpu"] = True
+        if world == 1 and not args.no_cpu_baseline and not dry:
             result["cpu_baseline"] = cpu_baseline(spec, fm, args.cpu_batch, seed=1000, model=args.model)
         print(json.dumps(result))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

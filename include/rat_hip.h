@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 1
+#define RAT_ABI_VERSION 2
 
 int rat_version(void);
 const char* rat_last_error(void);
@@ -56,6 +56,13 @@ int rat_gather_fwd(const int32_t* idx, const int32_t* label_ids, const RatField*
 int rat_gather_bwd(const float* dgrid, const float* dflat, const int32_t* idx, const int32_t* label_ids,
                    const RatField* grad_fields_dev, int nfields, float* dlabel_table,
                    int B, int T, int L, int d, void* stream);
+
+/* nn.Embedding raises IndexError for an id outside [0, vocab) (embedding.py:158-178 -> F.embedding); the kernels above
+ * clamp such ids (and labels outside {0,1,2}) for memory safety only.  rat_check_ids makes the error visible without a
+ * per-step host synchronisation: counts[0] += number of feature ids outside their table, counts[1] += number of label ids
+ * outside {0,1,2} (device int32[2], caller zeroes it once and reads it at its next synchronisation point). */
+int rat_check_ids(const int32_t* idx, const int32_t* label_ids, const RatField* fields_dev, int nfields, int B, int T,
+                  int L, int32_t* counts, void* stream);
 
 /* ---- K0: device-side batch assembly ---------------------------------------------------------------------
  * replaces Dataset.__getitem__ + default_collate + inputs_to_device for retrieval-augmented batches
@@ -201,6 +208,23 @@ int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* b
 int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* workspace,
                     int M, int N, int use_bn, void* stream);
+/* SyncBN for data parallelism (deep.py:128-132 evaluated over the GLOBAL batch, i.e. exactly what the
+ * reference's single-device BatchNorm1d sees).  The collectives between the calls belong to the caller (RCCL):
+ *   fwd:  rat_bn_local_stats -> all_gather(stats, 2N+1 floats per rank) -> rat_bn_relu_fwd_sync
+ *   bwd:  rat_bn_bwd_local_sums -> all_reduce_sum(copy of sums, 2N floats) -> rat_bn_relu_bwd_sync
+ * stats = [mean_r (N) | sum (z-mean_r)^2 (N) | row count (1)]; all_stats = [world] such records, combined in rank order
+ * (Chan's update: stable, the same bits on every rank).  dgamma / dbeta receive this rank's LOCAL sums (the gradient
+ * bucket's all-reduce adds the ranks); the backward reads the global row count from the forward's all_stats.
+ * workspace: rat_bn_workspace(N) bytes. */
+int rat_bn_local_stats(const float* z, float* stats, float* workspace, int M, int N, void* stream);
+int rat_bn_relu_fwd_sync(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* save_mean, float* save_rstd, const float* all_stats, int world,
+                         int M, int N, float eps, float momentum, void* stream);
+int rat_bn_bwd_local_sums(const float* z, const float* a, const float* da, const float* save_mean, const float* save_rstd,
+                          float* sums, float* workspace, int M, int N, void* stream);
+int rat_bn_relu_bwd_sync(const float* z, const float* a, const float* da, float* dz, const float* gamma,
+                         const float* save_mean, const float* save_rstd, const float* local_sums, const float* global_sums,
+                         float* dgamma, float* dbeta, const float* all_stats, int world, int M, int N, void* stream);
 /* column sums of a [M][N] matrix (bias gradients); workspace: rat_colsum_workspace(M, N) bytes (= rat_bn_workspace(N) up to
  * M = 65536 rows; more row splits beyond, for the token-sized matrices of the composed attention path) */
 size_t rat_colsum_workspace(int M, int N);
@@ -214,19 +238,61 @@ int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* fc_w, const
                   const float* dnn_out, const RatField* lr_fields_dev, int nfields, const int32_t* idx,
                   int64_t idx_stride, const float* y_true, float* y_pred, float* loss_sum, int B, int d,
                   void* stream);
-/* dlogit[b] = gscale * (y_pred - y_true)/B ; dcls row b (written at dcls + b*dcls_stride) = dlogit*fc_w ;
- * dfc_w, dfc_b and the LR grad tables are ACCUMULATED into (caller zeroes them). */
+/* dlogit[b] = gscale * (gscale_dev ? *gscale_dev : 1) * (y_pred - y_true)/B ; dcls row b (written at
+ * dcls + b*dcls_stride) = dlogit*fc_w ; dfc_w, dfc_b and the LR grad tables are ACCUMULATED into (caller zeroes them).
+ * gscale_dev (nullable): a DEVICE scalar — autograd's incoming loss gradient — so that backward needs no host read-back. */
 int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride,
                   const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
                   float* dfc_b, const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx,
-                  int64_t idx_stride, float gscale, int B, int d, void* stream);
+                  int64_t idx_stride, float gscale, const float* gscale_dev, int B, int d, void* stream);
+
+/* ---- K1s: row-sparse / deterministic embedding gradients (BASELINE.json configs[3]; SURVEY.md §2a rows H/I, §7 hard parts 3, 7)
+ * replaces, for tables too large for dense semantics, embedding_dense_backward + the dense clip/Adam pass over the tables
+ * (embedding.py:158-178 with sparse=False; base_model.py:221-225; torch_utils.py:41-49) and, for every table size, the fp32
+ * atomics of rat_gather_bwd by a bit-reproducible sorted segmented reduction.
+ *   plan   : (sample, id column) pairs -> key = global row = (fields[f].table - flat_base)/width + id (padding ids, ids outside the
+ *            vocabulary and columns with col2field < 0 take no part); stable radix sort; *count_out = number of unique rows U
+ *            (device int32; never read back by the library).  target_only: only the t == 0 rows of idx (the LR tables).
+ *   reduce : segment sums in sorted (= batch) order -> out_rows [U] int32, out_grads [U][d] (either may be NULL) and / or straight
+ *            into a dense gradient block (dense_base + row*d; plain stores, untouched rows are the caller's zeros).
+ *            _grid: source rows dgrid [B][T][1+nfields][d] (+ dflat [B][nfields*d] on target rows, as rat_gather_bwd);
+ *            _rows: source = gathered lists of `world` ranks, each `cap` entries long with counts_dev[r] valid (all-gather);
+ *            _scalar: width-1 tables, source = one value per sample (dlogit [B]; plan built with target_only).
+ *   rat_sumsq_rows / rat_adam_rows: gradient-norm contribution and clip + Adam of the U listed rows only ("lazy" Adam: moments
+ *            of untouched rows do not decay — declared deviation, exact when every row is touched every step).
+ * workspace: rat_sparse_workspace(n) bytes for n = pairs (B*T*L, or B*L with target_only, or cap*world); the same workspace is
+ * handed to the matching reduce call. */
+/* deterministic gradient of the 3-row label table (RAT_m2.py:64-65): dlabel_table [3][d] += per-block partial sums combined in
+ * block order (rat_gather_bwd's version reduces through LDS / global atomics).  workspace: rat_label_grad_workspace(d) bytes. */
+size_t rat_label_grad_workspace(int d);
+int rat_label_grad(const float* dgrid, const int32_t* label_ids, float* dlabel_table, float* workspace, int64_t nbt, int S,
+                   int d, void* stream);
+size_t rat_sparse_workspace(int64_t n);
+int rat_sparse_plan_ids(const int32_t* idx, const RatField* fields_dev, const int32_t* col2field_dev, int nfields,
+                        const float* flat_base, int width, int64_t total_rows, int B, int T, int L, int target_only,
+                        void* workspace, size_t workspace_bytes, int32_t* count_out, void* stream);
+int rat_sparse_plan_rows(const int32_t* rows, const int32_t* counts_dev, int64_t cap, int world, int64_t total_rows,
+                         void* workspace, size_t workspace_bytes, int32_t* count_out, void* stream);
+int rat_sparse_reduce_grid(const void* workspace, const int32_t* count_dev, const float* dgrid, const float* dflat,
+                           const int32_t* col2field_dev, int B, int T, int L, int nfields, int d, int target_only,
+                           int32_t* out_rows, float* out_grads, float* dense_base, void* stream);
+int rat_sparse_reduce_rows(const void* workspace, const int32_t* count_dev, const float* src_rows, int64_t cap, int world,
+                           int d, int32_t* out_rows, float* out_grads, void* stream);
+int rat_sparse_reduce_scalar(const void* workspace, const int32_t* count_dev, const float* per_sample, int B, int L,
+                             int32_t* out_rows, float* out_vals, float* dense_base, void* stream);
+int rat_sumsq_rows(const float* grads, const int32_t* count_dev, int64_t max_rows, int d, float* norm_sq_out, void* stream);
+int rat_adam_rows(float* w_base, float* m_base, float* v_base, const int32_t* rows, const float* grads,
+                  const int32_t* count_dev, int64_t max_rows, int d, const float* norm_sq, float max_norm, float lr,
+                  float beta1, float beta2, float eps, int step, void* stream);
 
 /* ---- K4/K5: regulariser + clip_grad_norm_ + Adam over flat buffers -----------------------------------
  * base_model.py:79-94,224-225; torch_utils.py:41-49,65-81.
- * rat_l2_reg: for i<n: g[i] += lambda*w[i]; reg_out += (lambda/2)*sum w^2   (the "embedding_layer" tensors).
+ * rat_l2_reg: for i<n: g[i] += lambda*w[i]; reg_out += (lambda/2)*sum w^2   (the "embedding_layer" tensors);
+ *             lambda is multiplied by *lambda_scale_dev when that (device scalar, nullable) is given.
  * rat_sumsq : norm_sq_out += sum g^2 (fp32 partials, fp64-free two-stage tree; caller zeroes the scalar).
  * rat_clip_adam: coef = min(1, max_norm/(sqrt(*norm_sq)+1e-6)); g*=coef; Adam(lr,b1,b2,eps,step), in place. */
-int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, float* reg_out, void* stream);
+int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, const float* lambda_scale_dev, float* reg_out,
+               void* stream);
 int rat_sumsq(const float* g, int64_t n, float* norm_sq_out, void* stream);
 int rat_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* norm_sq,
                   float max_norm, float lr, float beta1, float beta2, float eps, int step, void* stream);

@@ -1,0 +1,30 @@
+"""bench.py's contract around the measurement: `python bench.py --gpus N` (the form the driver uses) must start its N worker
+processes itself, run the weak- AND the strong-scaling region and print ONE JSON line.  There is no GPU here, so the workers
+run `--dry-run-cpu`: gloo process group, the host-emulation build of the kernel sources, a toy workload — the numbers mean
+nothing, the plumbing (self-launch, rank environment, SyncBN collectives, batch rotation, JSON schema) is what is checked."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus2_self_launch_dry_run():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["scaling"] == "weak" and out["dry_run_cpu"] is True
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"] and out["config"]["sync_batch_norm"] is True
+    st = out["strong_scaling"]
+    assert st["global_batch"] == out["config"]["batch_per_gpu"] and st["batch_per_gpu"] * 2 == st["global_batch"]
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "arith", "data", "roofline",
+                "targets", "kernels"):
+        assert key in out, key
+    assert out["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    assert {"rat_gather_fwd", "rat_gather_bwd", "cross_attention"} <= set(out["targets"])
+    assert "cpu_baseline" not in out                      # N = 1 only (and never in a dry run)

@@ -1,0 +1,88 @@
+"""Row-sparse / deterministic embedding-gradient path on the MI355X (-m gpu): rocPRIM's device radix sort + scan under the plan,
+the hand-written segmented reduction, the row optimizer — against CPU autograd and against the dense (atomic) path."""
+import numpy as np
+import pytest
+import torch
+
+import sparse_cases as sc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rat_amd._lib import get_lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return get_lib()
+
+
+@pytest.mark.parametrize("d", [8, 64])
+@pytest.mark.parametrize("B,T", [(5, 4), (257, 11)])
+def test_sorted_segmented_reduce(lib, d, B, T):
+    sc.check_sorted_reduce(lib, "cuda", d, B=B, T=T)
+
+
+def test_scalar_reduce_for_the_wide_tables(lib):
+    sc.check_scalar_reduce(lib, "cuda")
+    sc.check_scalar_reduce(lib, "cuda", B=700, T=5)
+
+
+def test_merge_of_gathered_row_lists_and_row_adam(lib):
+    sc.check_merge_rows(lib, "cuda")
+
+
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "kkbox_shape", "northstar_shape"])
+def test_sorted_mode_equals_atomic_mode_and_is_reproducible(lib, name):
+    if sc.gc.case_by_name(name)["embedding_dim"] % 4:
+        pytest.skip("sorted / sparse modes need embedding_dim % 4 == 0")
+    sc.check_model_sorted_equals_atomic(name, gpu=0)
+
+
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "northstar_shape"])
+def test_sparse_training_equals_dense_training(lib, name):
+    sc.check_model_sparse_training(name, gpu=0, steps=3)
+
+
+def _run(workload, mode, steps, batch_rows):
+    from rat_amd import models, synthetic
+    from rat_amd.base_model import seed_everything
+    spec = dict(synthetic.WORKLOADS[workload])
+    fm = synthetic.feature_map_for(workload, spec)
+    seed_everything(2021)
+    model = models.RAT_m2(fm, **synthetic.model_kwargs(spec, gpu=0, embedding_regularizer=0.0), embedding_grad=mode)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.startswith("embedding_layer.") and p.shape[-1] == spec["d"]:
+                p.mul_(3000.0)
+    batch = tuple(t[:batch_rows] for t in synthetic.make_batch(spec, fm, seed=3))
+    model.train()
+    losses = [float(model.train_step(batch)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    model.check_id_errors()
+    return model, losses
+
+
+def test_sparse_equals_dense_at_the_config3_rank_shape(lib):
+    """BASELINE.json configs[3] per-rank shape (F = 40, B = 1024) at a tenth of its vocabulary: three steps on the same batch —
+    sparse row lists + lazy row Adam against the dense atomic path + dense Adam (identical when the same rows recur)."""
+    name = "synthetic_F40_V10M_K10_d64_B1024"
+    dense, ld = _run(name, "atomic", 3, 1024)
+    flat_d = dense._flat.detach().cpu()
+    offs, order, nt = dict(dense._offsets), list(dense._order), dense._n_tab
+    del dense
+    torch.cuda.empty_cache()
+    sparse, ls = _run(name, "sparse", 3, 1024)
+    assert sparse._grad_mode == "sparse"
+    flat_s = sparse._flat.detach().cpu()
+    np.testing.assert_allclose(ls, ld, rtol=0, atol=3e-6)
+    noise = sc.mc.noise_tensors(sparse)
+    keep = torch.ones_like(flat_s, dtype=torch.bool)
+    for n in noise:
+        keep[offs[n]:offs[n] + sparse._params[n].numel()] = False
+    diff = (flat_s - flat_d).abs()
+    tol = 2e-6 + 2e-4 * flat_d.abs()
+    bad = (diff > tol) & keep
+    # Adam's first steps are sign-like (+-lr per element): an element whose gradient is rounding-level zero may step the other way;
+    # bound their number and size instead of loosening the tolerance for everything
+    assert float(bad.float().mean()) < 1e-5 and float(diff[keep].max()) <= 2.1e-3, (int(bad.sum()), float(diff[keep].max()))
+    assert order == list(sparse._order) and nt == sparse._n_tab

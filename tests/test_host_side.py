@@ -70,7 +70,8 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(DEFAULT_LIB)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.rat_version() == 1
+    from rat_amd._lib import ABI_VERSION
+    assert lib.rat_version() == ABI_VERSION == 2
 
 
 def test_no_silent_fallback_when_library_is_missing(tmp_path, monkeypatch):

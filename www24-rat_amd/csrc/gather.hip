@@ -40,7 +40,9 @@ gather_fwd_vec_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict
                 const int64_t bt = row / S;
                 const int s = (int)(row - bt * S);
                 if (s == 0) {
-                    src[u] = reinterpret_cast<const float4*>(label_table + (int64_t)label_ids[bt] * d) + piece;
+                    int lab = label_ids[bt];
+                    lab = lab < 0 ? 0 : (lab > 2 ? 2 : lab);  // memory safety only: rat_check_ids REPORTS such labels
+                    src[u] = reinterpret_cast<const float4*>(label_table + (int64_t)lab * d) + piece;
                 } else {
                     const RatField f = fields[s - 1];
                     const int32_t* ids = idx + bt * L + f.col;
@@ -87,7 +89,9 @@ gather_fwd_scalar_kernel(const int32_t* __restrict__ idx, const int32_t* __restr
         const int s = (int)(row - bt * S);
         float v;
         if (s == 0) {
-            v = label_table[(int64_t)label_ids[bt] * d + c];
+            int lab = label_ids[bt];
+            lab = lab < 0 ? 0 : (lab > 2 ? 2 : lab);
+            v = label_table[(int64_t)lab * d + c];
         } else {
             const RatField f = fields[s - 1];
             const int32_t* ids = idx + bt * L + f.col;
@@ -148,6 +152,73 @@ gather_bwd_label_kernel(const float* __restrict__ dgrid, const int32_t* __restri
         if (part[i] != 0.f) atomicAdd(&dlabel[i], part[i]);
 }
 
+// deterministic variant of the label-row gradient: every block owns a fixed slice of the (sample, target/retrieved) rows, thread =
+// (column, row group) accumulates its three label rows in registers, row groups are combined through LDS in a fixed order and
+// the per-block partials [blocks][3][d] are summed in block order by a second launch: bit-reproducible, no atomics.
+constexpr int LABEL_BLOCKS = 256;
+
+__global__ void __launch_bounds__(GATHER_THREADS)
+label_grad_partial_kernel(const float* __restrict__ dgrid, const int32_t* __restrict__ label_ids, float* __restrict__ part,
+                          int64_t nbt, int S, int d) {
+    RAT_DYN_SMEM(smem);
+    float* red = reinterpret_cast<float*>(smem);              // [groups][3][d]
+    const int groups = GATHER_THREADS / d;
+    const int c = threadIdx.x % d, rg = threadIdx.x / d;
+    const int64_t per = (nbt + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < nbt ? r0 + per : nbt;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (rg < groups)
+        for (int64_t bt = r0 + rg; bt < r1; bt += groups) {
+            const float g = dgrid[(bt * S) * d + c];
+            const int lab = label_ids[bt];
+            a0 += lab <= 0 ? g : 0.f;
+            a1 += lab == 1 ? g : 0.f;
+            a2 += lab >= 2 ? g : 0.f;
+        }
+    if (rg < groups) {
+        red[(rg * 3 + 0) * d + c] = a0;
+        red[(rg * 3 + 1) * d + c] = a1;
+        red[(rg * 3 + 2) * d + c] = a2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) {
+        float sacc = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) sacc += red[g2 * 3 * d + i];
+        part[(int64_t)blockIdx.x * 3 * d + i] = sacc;
+    }
+}
+
+__global__ void __launch_bounds__(GATHER_THREADS)
+label_grad_final_kernel(const float* __restrict__ part, float* __restrict__ dlabel, int nblocks, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * d) return;
+    float sacc = 0.f;
+    for (int b = 0; b < nblocks; ++b) sacc += part[(int64_t)b * 3 * d + i];
+    dlabel[i] += sacc;
+}
+
+// nn.Embedding raises IndexError on an id outside [0, vocab); the kernels above clamp for memory safety, so the error would
+// be silent.  This pass COUNTS the offenders instead (counts[0]: feature ids, counts[1]: label ids outside {0, 1, 2}); the
+// host reads the two counters at its next natural synchronisation point and raises.
+__global__ void __launch_bounds__(GATHER_THREADS)
+check_ids_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ label_ids, const RatField* __restrict__ fields,
+                 int nfields, int64_t nbt, int L, int* __restrict__ counts) {
+    int bad_id = 0, bad_lab = 0;
+    for (int64_t bt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; bt < nbt; bt += (int64_t)gridDim.x * blockDim.x) {
+        const int lab = label_ids[bt];
+        bad_lab += (lab < 0 || lab > 2) ? 1 : 0;
+        for (int f = 0; f < nfields; ++f) {
+            const RatField fd = fields[f];
+            for (int j = 0; j < fd.ncols; ++j) {
+                const int id = idx[bt * L + fd.col + j];
+                bad_id += (id < 0 || id >= fd.vocab) ? 1 : 0;
+            }
+        }
+    }
+    if (bad_id) atomicAdd(&counts[0], bad_id);
+    if (bad_lab) atomicAdd(&counts[1], bad_lab);
+}
+
 int pick_blocks(int64_t nitems, int per_thread) {
     int64_t want = (nitems + (int64_t)GATHER_THREADS * per_thread - 1) / ((int64_t)GATHER_THREADS * per_thread);
     if (want < 1) want = 1;
@@ -193,4 +264,26 @@ extern "C" int rat_gather_bwd(const float* dgrid, const float* dflat, const int3
                    label_ids, dlabel_table, nbt, S, d);
     }
     return rat_check_launch("rat_gather_bwd");
+}
+
+extern "C" int rat_check_ids(const int32_t* idx, const int32_t* label_ids, const RatField* fields_dev, int nfields, int B, int T,
+                             int L, int32_t* counts, void* stream) {
+    RAT_REQUIRE(B > 0 && T > 0 && L > 0 && nfields >= 0 && idx && label_ids && counts && (fields_dev || nfields == 0), "bad args");
+    const int64_t nbt = (int64_t)B * T;
+    RAT_LAUNCH(check_ids_kernel, pick_blocks(nbt, 1), GATHER_THREADS, 0, stream, idx, label_ids, fields_dev, nfields, nbt, L,
+               reinterpret_cast<int*>(counts));
+    return rat_check_launch("rat_check_ids");
+}
+
+extern "C" size_t rat_label_grad_workspace(int d) { return (size_t)LABEL_BLOCKS * 3 * (size_t)(d > 0 ? d : 1) * sizeof(float); }
+
+extern "C" int rat_label_grad(const float* dgrid, const int32_t* label_ids, float* dlabel_table, float* workspace, int64_t nbt,
+                              int S, int d, void* stream) {
+    RAT_REQUIRE(dgrid && label_ids && dlabel_table && workspace && nbt > 0 && S > 0 && d > 0 && d <= GATHER_THREADS, "bad args");
+    const int groups = GATHER_THREADS / d;
+    RAT_LAUNCH(label_grad_partial_kernel, LABEL_BLOCKS, GATHER_THREADS, (size_t)groups * 3 * d * sizeof(float), stream, dgrid,
+               label_ids, workspace, nbt, S, d);
+    RAT_LAUNCH(label_grad_final_kernel, (3 * d + GATHER_THREADS - 1) / GATHER_THREADS, GATHER_THREADS, 0, stream, workspace,
+               dlabel_table, LABEL_BLOCKS, d);
+    return rat_check_launch("rat_label_grad");
 }

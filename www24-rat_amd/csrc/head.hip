@@ -160,6 +160,104 @@ bn_relu_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ 
     }
 }
 
+// ---- SyncBN (data parallelism): BatchNorm1d statistics over the GLOBAL batch.  Each rank reduces its own
+// rows to (mean_r, M2_r = sum (z - mean_r)^2, count_r) per column, the host all-gathers the 2N+1 floats, and every rank combines
+// them in rank order with Chan's pairwise update (stable, and bit-identical on every rank).  Backward: local (sum g, sum g*xhat)
+// per column, all-reduced (sum) by the host; dgamma / dbeta stay LOCAL sums (the gradient bucket's all-reduce adds the ranks).
+__global__ void __launch_bounds__(HD_THREADS)
+bn_local_finalize_kernel(const float* __restrict__ z, const float* __restrict__ ws, float* __restrict__ stats, int M, int N) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col == 0) stats[2 * (size_t)N] = (float)M;
+    if (col >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < BN_SPLITS; ++w) {
+        s1 += ws[(size_t)w * N + col];
+        s2 += ws[(size_t)(BN_SPLITS + w) * N + col];
+    }
+    const float d1 = s1 / (float)M;
+    const float m2 = s2 - s1 * d1;
+    stats[col] = z[col] + d1;
+    stats[(size_t)N + col] = m2 > 0.f ? m2 : 0.f;
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_relu_apply_sync_kernel(const float* __restrict__ z, float* __restrict__ a, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                          const float* __restrict__ all_stats, int world, int M, int N, float eps, float momentum) {
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    if (col >= N) return;
+    const size_t rec = 2 * (size_t)N + 1;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int r = 0; r < world; ++r) {                                  // fixed rank order -> the same bits on every rank
+        const float* st = all_stats + (size_t)r * rec;
+        const float nr = st[2 * (size_t)N];
+        if (nr <= 0.f) continue;
+        const float delta = st[col] - mean, nt = n + nr;
+        mean += delta * (nr / nt);
+        m2 += st[(size_t)N + col] + delta * delta * (n * nr / nt);
+        n = nt;
+    }
+    float var = m2 / n;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (split == 0 && rg == 0) {
+        save_mean[col] = mean;
+        save_rstd[col] = rstd;
+        const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+        running_mean[col] = (1.f - momentum) * running_mean[col] + momentum * mean;
+        running_var[col] = (1.f - momentum) * running_var[col] + momentum * unbiased;
+    }
+    const float gam = gamma[col], bet = beta[col];
+    const int per = (M + BN_SPLITS - 1) / BN_SPLITS;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
+    for (int m = r0 + rg; m < r1; m += HD_RG) {
+        const float y = (z[(size_t)m * N + col] - mean) * rstd * gam + bet;
+        a[(size_t)m * N + col] = y > 0.f ? y : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_bwd_sums_final_kernel(const float* __restrict__ ws, float* __restrict__ sums, int N) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int w = 0; w < BN_SPLITS; ++w) {
+        s1 += ws[(size_t)w * N + col];
+        s2 += ws[(size_t)(BN_SPLITS + w) * N + col];
+    }
+    sums[col] = s1;
+    sums[(size_t)N + col] = s2;
+}
+
+__global__ void __launch_bounds__(HD_THREADS)
+bn_relu_bwd_apply_sync_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
+                              float* __restrict__ dz, const float* gamma, const float* save_mean, const float* save_rstd,
+                              const float* local_sums, const float* global_sums, float* dgamma, float* dbeta,
+                              const float* __restrict__ all_stats, int world, int M, int N) {
+    const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
+    const int nblk = (N + HD_COLS - 1) / HD_COLS;
+    const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
+    if (col >= N) return;
+    if (split == 0 && rg == 0) {
+        dbeta[col] = local_sums[col];
+        dgamma[col] = local_sums[(size_t)N + col];
+    }
+    const float mean = save_mean[col], rstd = save_rstd[col], gam = gamma[col];
+    float total_count = 0.f;                                           // global row count, from the forward's gathered records
+    for (int r = 0; r < world; ++r) total_count += all_stats[(size_t)r * (2 * (size_t)N + 1) + 2 * (size_t)N];
+    const float m1 = global_sums[col] / total_count, m2 = global_sums[(size_t)N + col] / total_count;
+    const int per = (M + BN_SPLITS - 1) / BN_SPLITS;
+    const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
+    for (int m = r0 + rg; m < r1; m += HD_RG) {
+        const size_t o = (size_t)m * N + col;
+        const float xh = (z[o] - mean) * rstd;
+        const float g = a[o] > 0.f ? da[o] : 0.f;
+        dz[o] = gam * rstd * (g - m1 - xh * m2);
+    }
+}
+
 // column sums, two stages when the matrix is tall: (column block x row split) partials into `ws`, then a fixed-order
 // combine — deterministic, and 32x more blocks in flight than one block per 32 columns.
 __global__ void __launch_bounds__(HD_THREADS)
@@ -238,7 +336,7 @@ __global__ void __launch_bounds__(HD_THREADS)
 logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ cls,
                  int64_t cls_stride, const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
                  float* dfc_b, const RatField* lr_grad_fields, int nfields, const int32_t* idx, int64_t idx_stride,
-                 float gscale, int B, int d) {
+                 float gscale, const float* gscale_dev, int B, int d) {
     // One block = LB_SAMPLES samples.  Phase 1: one thread per sample (dlogit, LR-table atomics, dfc_b partial).  Phase 2:
     // thread = (column k, sample group): dcls rows and the dfc_w partial sums are produced column-parallel — no LDS atomics
     // (the first version issued d LDS atomics per sample onto the same d addresses and ran on B/256 CUs only).
@@ -247,6 +345,7 @@ logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_t
     float* part = dls + LB_SAMPLES;                           // [groups][d] partial dfc_w
     const int b0 = blockIdx.x * LB_SAMPLES;
     const int nb = B - b0 < LB_SAMPLES ? B - b0 : LB_SAMPLES;
+    if (gscale_dev != nullptr) gscale *= *gscale_dev;         // the incoming loss gradient stays on the device (no host read-back)
     float dbias = 0.f;
     if ((int)threadIdx.x < LB_SAMPLES) {
         float dl = 0.f;
@@ -350,13 +449,13 @@ extern "C" int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* 
 extern "C" int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride,
                              const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w, float* dfc_b,
                              const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx, int64_t idx_stride,
-                             float gscale, int B, int d, void* stream) {
+                             float gscale, const float* gscale_dev, int B, int d, void* stream) {
     RAT_REQUIRE(B > 0 && d > 0 && y_pred && y_true && cls && fc_w && dlogit && dcls && dfc_w && dfc_b, "bad args");
     RAT_REQUIRE(lr_grad_fields_dev == nullptr || idx != nullptr, "LR term needs idx");
     RAT_REQUIRE(d <= HD_THREADS, "embedding_dim above the block size");
     RAT_LAUNCH(logit_bwd_kernel, (B + LB_SAMPLES - 1) / LB_SAMPLES, HD_THREADS, (size_t)(LB_SAMPLES + HD_THREADS) * sizeof(float), stream,
                y_pred, y_true, cls, cls_stride, fc_w, dlogit, dcls, dcls_stride, dfc_w, dfc_b, lr_grad_fields_dev, nfields,
-               idx, idx_stride, gscale, B, d);
+               idx, idx_stride, gscale, gscale_dev, B, d);
     return rat_check_launch("rat_logit_bwd");
 }
 
@@ -373,4 +472,46 @@ extern "C" int rat_bn_relu_bwd(const float* z, const float* a, const float* da, 
     RAT_LAUNCH(bn_relu_bwd_apply_kernel, blocks, HD_THREADS, 0, stream, z, a, da, dz, gamma, save_mean, save_rstd, dgamma,
                dbeta, workspace, M, N, use_bn);
     return rat_check_launch("rat_bn_relu_bwd");
+}
+
+// ---- SyncBN entry points (see the kernels above; the collectives between them are the caller's: torch.distributed / RCCL)
+extern "C" int rat_bn_local_stats(const float* z, float* stats, float* workspace, int M, int N, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && stats && workspace, "bad args");
+    const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
+    RAT_LAUNCH(bn_stats_kernel, blocks, HD_THREADS, HD_THREADS * sizeof(float), stream, z, workspace, M, N);
+    RAT_LAUNCH(bn_local_finalize_kernel, (N + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 0, stream, z, workspace, stats, M, N);
+    return rat_check_launch("rat_bn_local_stats");
+}
+
+extern "C" int rat_bn_relu_fwd_sync(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, float* save_mean, float* save_rstd, const float* all_stats, int world,
+                                    int M, int N, float eps, float momentum, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && world >= 1 && z && a && gamma && beta && running_mean && running_var && save_mean && save_rstd &&
+                all_stats, "bad args");
+    const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
+    RAT_LAUNCH(bn_relu_apply_sync_kernel, blocks, HD_THREADS, 0, stream, z, a, gamma, beta, running_mean, running_var, save_mean,
+               save_rstd, all_stats, world, M, N, eps, momentum);
+    return rat_check_launch("rat_bn_relu_fwd_sync");
+}
+
+extern "C" int rat_bn_bwd_local_sums(const float* z, const float* a, const float* da, const float* save_mean,
+                                     const float* save_rstd, float* sums, float* workspace, int M, int N, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && a && da && save_mean && save_rstd && sums && workspace, "bad args");
+    const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
+    RAT_LAUNCH(bn_bwd_stats_kernel, blocks, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, da, save_mean, save_rstd,
+               workspace, M, N);
+    RAT_LAUNCH(bn_bwd_sums_final_kernel, (N + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 0, stream, workspace, sums, N);
+    return rat_check_launch("rat_bn_bwd_local_sums");
+}
+
+extern "C" int rat_bn_relu_bwd_sync(const float* z, const float* a, const float* da, float* dz, const float* gamma,
+                                    const float* save_mean, const float* save_rstd, const float* local_sums,
+                                    const float* global_sums, float* dgamma, float* dbeta, const float* all_stats, int world,
+                                    int M, int N, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && world >= 1 && z && a && da && dz && gamma && save_mean && save_rstd && local_sums &&
+                global_sums && dgamma && dbeta && all_stats, "bad args");
+    const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
+    RAT_LAUNCH(bn_relu_bwd_apply_sync_kernel, blocks, HD_THREADS, 0, stream, z, a, da, dz, gamma, save_mean, save_rstd, local_sums,
+               global_sums, dgamma, dbeta, all_stats, world, M, N);
+    return rat_check_launch("rat_bn_relu_bwd_sync");
 }

@@ -18,9 +18,11 @@ __device__ __forceinline__ float opt_block_sum(float v, float* scratch) {
 }
 
 __global__ void __launch_bounds__(OPT_THREADS)
-l2_reg_kernel(const float* __restrict__ w, float* __restrict__ g, int64_t n, float lambda, float* reg_out) {
+l2_reg_kernel(const float* __restrict__ w, float* __restrict__ g, int64_t n, float lambda, const float* lambda_scale_dev,
+              float* reg_out) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
+    if (lambda_scale_dev != nullptr) lambda *= *lambda_scale_dev;
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float wv = w[i];
@@ -75,9 +77,10 @@ int opt_blocks(int64_t n) {
 
 }  // namespace
 
-extern "C" int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, float* reg_out, void* stream) {
+extern "C" int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, const float* lambda_scale_dev, float* reg_out,
+                          void* stream) {
     RAT_REQUIRE(n > 0 && w && g, "bad args");
-    RAT_LAUNCH(l2_reg_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, w, g, n, lambda, reg_out);
+    RAT_LAUNCH(l2_reg_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, w, g, n, lambda, lambda_scale_dev, reg_out);
     return rat_check_launch("rat_l2_reg");
 }
 

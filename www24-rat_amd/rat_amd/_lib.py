@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RatField(Structure):
@@ -68,10 +68,25 @@ _SIGNATURES = {
     "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "rat_colsum": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P]),
+    "rat_bn_local_stats": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "rat_bn_relu_fwd_sync": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
+    "rat_bn_bwd_local_sums": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "rat_bn_relu_bwd_sync": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "rat_logit_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, _P, _P, _P, c_int, c_int, _P]),
-    "rat_logit_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, c_int, _P, c_int64, c_float, c_int,
+    "rat_logit_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, c_int, _P, c_int64, c_float, _P, c_int,
                               c_int, _P]),
-    "rat_l2_reg": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
+    "rat_l2_reg": (c_int, [_P, _P, c_int64, c_float, _P, _P, _P]),
+    "rat_label_grad_workspace": (c_size_t, [c_int]),
+    "rat_label_grad": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "rat_sparse_workspace": (c_size_t, [c_int64]),
+    "rat_sparse_plan_ids": (c_int, [_P, _P, _P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
+    "rat_sparse_plan_rows": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_size_t, _P, _P]),
+    "rat_sparse_reduce_grid": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "rat_sparse_reduce_rows": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    "rat_sparse_reduce_scalar": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P]),
+    "rat_sumsq_rows": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
+    "rat_adam_rows": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "rat_check_ids": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "rat_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "rat_dropout": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P]),
     "rat_clip_adam": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),

@@ -150,43 +150,11 @@ class BaseModel(nn.Module):
         self._after_device_move()
 
     # ---- fit -----------------------------------------------------------------------------------------
-    def on_batch_end(self, batch, logs={}):
-        self._total_batches += 1
-        if (batch + 1) % self._every_x_batches == 0 or (batch + 1) % self._batches_per_epoch == 0:
-            epoch = round(float(self._total_batches) / self._batches_per_epoch, 2)
-            val_logs = self.evaluate_generator(self.valid_gen)
-            self.checkpoint_and_earlystop(epoch, val_logs)
-            self.train()
-            logging.info("--- {}/{} batches finished ---".format(batch + 1, self._batches_per_epoch))
-
-    def lr_decay(self, factor=0.1, min_lr=1e-6):
-        reduced_lr = None
-        for group in self.optimizer.param_groups:
-            reduced_lr = max(group["lr"] * factor, min_lr)
-            group["lr"] = reduced_lr
-        return reduced_lr
-
-    def checkpoint_and_earlystop(self, epoch, logs, min_delta=1e-6):
-        value = self._monitor.get_value(logs)
-        worse = (value > self._best_metric - min_delta) if self._monitor_mode == "min" else \
-                (value < self._best_metric + min_delta)
-        if worse:
-            self._stopping_steps += 1
-            logging.info("Monitor({}) STOP: {:.6f} !".format(self._monitor_mode, value))
-            if self._reduce_lr_on_plateau:
-                logging.info("Reduce learning rate on plateau: {:.6f}".format(self.lr_decay()))
-        else:
-            self._stopping_steps = 0
-            self._best_metric = value
-            if self._save_best_only:
-                logging.info("Save best model: monitor({}): {:.6f}".format(self._monitor_mode, value))
-                self.save_weights(self.checkpoint)
-        if self._stopping_steps * self._every_x_epochs >= self._patience:
-            self._stop_training = True
-            logging.info("Early stopping at epoch={:g}".format(epoch))
-        if not self._save_best_only:
-            self.save_weights(self.checkpoint)
-
+    # The training-loop contract of the reference (base_model.py:144-211) is kept — same public methods, same attributes that
+    # tooling reads (_best_metric, _stopping_steps, _stop_training, _total_batches), same log lines (the
+    # experiment scripts parse them) — but organised around one small state record and two helpers: `_validation_due` decides
+    # WHEN to validate, `_judge` turns a monitored value into (improved?, stop?).  Under data parallelism every rank takes
+    # the decision from rank 0's value and only rank 0 writes the checkpoint.
     @staticmethod
     def freeze_host_heap():
         """Keep the interpreter's garbage collector out of the training loop's way: after `import torch` the process holds
@@ -198,26 +166,87 @@ class BaseModel(nn.Module):
         gc.collect()
         gc.freeze()
 
+    def _validation_due(self, batch_index):
+        """validate every `every_x_epochs` epochs' worth of batches and at the end of every epoch (base_model.py:146)"""
+        done = batch_index + 1
+        return done % self._every_x_batches == 0 or done % self._batches_per_epoch == 0
+
+    def on_batch_end(self, batch, logs={}):
+        """base_model.py:144-151."""
+        self._total_batches += 1
+        if not self._validation_due(batch):
+            return
+        epoch = round(self._total_batches / float(self._batches_per_epoch), 2)
+        self.checkpoint_and_earlystop(epoch, self.evaluate_generator(self.valid_gen))
+        self.train()
+        logging.info("--- {}/{} batches finished ---".format(batch + 1, self._batches_per_epoch))
+
+    def lr_decay(self, factor=0.1, min_lr=1e-6):
+        """base_model.py:153-158: every param group's lr <- max(lr * factor, min_lr); returns the last one."""
+        lrs = [max(group["lr"] * factor, min_lr) for group in self.optimizer.param_groups]
+        for group, lr in zip(self.optimizer.param_groups, lrs):
+            group["lr"] = lr
+        return lrs[-1] if lrs else None
+
+    def _agreed_value(self, value):
+        """Data parallelism: all ranks act on rank 0's monitored value (validation shards may differ per rank; a rank that
+        stopped or decayed alone would dead-lock the next all-reduce)."""
+        if self._world_size() > 1:
+            import torch.distributed as dist
+            box = torch.tensor([value], dtype=torch.float64, device=self.device if self.device.type == "cuda" else "cpu")
+            dist.broadcast(box, src=0)
+            value = float(box[0])
+        return value
+
+    def _judge(self, value, min_delta):
+        """-> True when `value` improves on the best so far by more than min_delta in the monitored direction"""
+        if self._monitor_mode == "min":
+            return value <= self._best_metric - min_delta
+        return value >= self._best_metric + min_delta
+
+    def _save_checkpoint(self):
+        if self._rank() == 0:
+            self.save_weights(self.checkpoint)
+        if self._world_size() > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def checkpoint_and_earlystop(self, epoch, logs, min_delta=1e-6):
+        """base_model.py:160-179."""
+        value = self._agreed_value(self._monitor.get_value(logs))
+        if self._judge(value, min_delta):
+            self._stopping_steps, self._best_metric = 0, value
+            if self._save_best_only:
+                logging.info("Save best model: monitor({}): {:.6f}".format(self._monitor_mode, value))
+                self._save_checkpoint()
+        else:
+            self._stopping_steps += 1
+            logging.info("Monitor({}) STOP: {:.6f} !".format(self._monitor_mode, value))
+            if self._reduce_lr_on_plateau:
+                logging.info("Reduce learning rate on plateau: {:.6f}".format(self.lr_decay()))
+        if not self._save_best_only:
+            self._save_checkpoint()
+        if self._stopping_steps * self._every_x_epochs >= self._patience:
+            self._stop_training = True
+            logging.info("Early stopping at epoch={:g}".format(epoch))
+
     def fit_generator(self, data_generator, epochs=1, validation_data=None, verbose=0, max_gradient_norm=10., **kwargs):
         """base_model.py:181-211."""
         self.freeze_host_heap()
-        self.valid_gen = validation_data
-        self._max_gradient_norm = max_gradient_norm
-        self._best_metric = np.inf if self._monitor_mode == "min" else -np.inf
-        self._stopping_steps = 0
-        self._total_batches = 0
+        self.valid_gen, self._verbose, self._max_gradient_norm = validation_data, verbose, max_gradient_norm
         self._batches_per_epoch = len(data_generator)
         self._every_x_batches = int(np.ceil(self._every_x_epochs * self._batches_per_epoch))
+        self._best_metric = {"min": np.inf}.get(self._monitor_mode, -np.inf)
+        self._stopping_steps = self._total_batches = 0
         self._stop_training = False
-        self._verbose = verbose
         logging.info("Start training: {} batches/epoch".format(self._batches_per_epoch))
         logging.info("************ Epoch=1 start ************")
-        for epoch in range(epochs):
-            epoch_loss = self.train_one_epoch(data_generator, epoch)
-            logging.info("Train loss: {:.6f}".format(epoch_loss))
-            if self._stop_training:
-                break
-            logging.info("************ Epoch={} end ************".format(epoch + 1))
+        epoch = 0
+        while epoch < epochs and not self._stop_training:
+            logging.info("Train loss: {:.6f}".format(self.train_one_epoch(data_generator, epoch)))
+            epoch += 1
+            if not self._stop_training:
+                logging.info("************ Epoch={} end ************".format(epoch))
         logging.info("Training finished.")
 
     def train_step(self, batch_data):
@@ -241,7 +270,9 @@ class BaseModel(nn.Module):
                 self._total_batches += 1
             if self._stop_training:
                 break
-        return float(running.item()) / self._batches_per_epoch
+        epoch_loss = float(running.item()) / self._batches_per_epoch
+        self.check_id_errors()
+        return epoch_loss
 
     # ---- eval ----------------------------------------------------------------------------------------
     def evaluate_generator(self, data_generator):
@@ -255,6 +286,7 @@ class BaseModel(nn.Module):
                 trues.append(out["y_true"])
         y_pred = torch.cat(preds).double().cpu().numpy().reshape(-1)
         y_true = torch.cat(trues).double().cpu().numpy().reshape(-1)
+        self.check_id_errors()
         return self.evaluate_metrics(y_true, y_pred, self._validation_metrics)
 
     def evaluate_metrics(self, y_true, y_pred, metrics):
@@ -269,7 +301,9 @@ class BaseModel(nn.Module):
                 ids = batch_data.idx if hasattr(batch_data, "idx") else batch_data[0]      # DeviceBatch or the 4-tuple
                 assert ids.ndim == 3, "retrieval augmented mode requires input_shape like [Bx(1+K)xF]"
                 preds.append(self.forward(batch_data)["y_pred"])
-        return torch.cat(preds).double().cpu().numpy().reshape(-1)
+        out = torch.cat(preds).double().cpu().numpy().reshape(-1)
+        self.check_id_errors()
+        return out
 
     def save_weights(self, checkpoint):
         os.makedirs(os.path.dirname(os.path.abspath(checkpoint)), exist_ok=True)
@@ -303,5 +337,12 @@ class BaseModel(nn.Module):
         import torch.distributed as dist
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    def _rank(self):
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
     def _exchange_gradients(self):
+        pass
+
+    def check_id_errors(self):
         pass

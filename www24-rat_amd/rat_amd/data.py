@@ -50,6 +50,9 @@ class RetrievalBatches:
 
     def to_device(self, device, lib=None):
         """The same dataset, HBM-resident: batches are then assembled by ``rat_batch_assemble`` (same order for the same seed)."""
+        # the check RAT_m2.forward makes on every host batch (RAT_m2.py:109 `retrieved_lens.ndim == 1`): a label-wise retrieval
+        # file ([Q, 2] lens, [Q, 2K] indices) must be rejected here too, the device batches no longer carry the lens
+        assert self.retr_lens.ndim == 1, "RIM does not support label-wise retrieval-enhanced training"
         src = DeviceRetrievalBatches.__new__(DeviceRetrievalBatches)
         src._init_from_arrays(self.ids, self.labels, self.pool_ids, self.pool_labels, self.retr_indices, self.batch_size, device,
                               self.shuffle, self.drop_last, lib)
@@ -89,7 +92,10 @@ class DeviceRetrievalBatches:
     launch over the batch's row ids.  Yields ``DeviceBatch`` objects.  Same ordering rule as ``RetrievalBatches`` (a numpy
     permutation per epoch when ``shuffle``), so both sources produce identical batches for the same seed."""
 
-    def __init__(self, data, pool, retr_indices, batch_size, device, shuffle=False, seed=0, drop_last=False, lib=None):
+    def __init__(self, data, pool, retr_indices, batch_size, device, shuffle=False, seed=0, drop_last=False, lib=None,
+                 retr_lens=None):
+        if retr_lens is not None:                       # same rejection of label-wise retrieval files as the host path
+            assert np.asarray(retr_lens).ndim == 1, "RIM does not support label-wise retrieval-enhanced training"
         data, pool_arr = np.asarray(data), np.asarray(pool)
         same = pool is data
         ids, labels = data[:, :-1].astype(np.int32), data[:, -1].astype(np.float32)

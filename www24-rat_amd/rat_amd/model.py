@@ -179,7 +179,9 @@ class _RATFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _g_pred, g_loss, g_reg):
-        grads = ctx.model._run_backward(ctx.saved_state, float(g_loss), float(g_reg) if ctx.with_reg else 0.0)
+        # the incoming gradients stay DEVICE scalars (the kernels multiply them in): no host read-back, so the host can enqueue
+        # the whole backward while the forward is still running
+        grads = ctx.model._run_backward(ctx.saved_state, g_loss, g_reg if ctx.with_reg else None)
         ctx.saved_state = None
         return (None, None, None) + tuple(grads)
 
@@ -215,11 +217,36 @@ class RAT_m2(BaseModel):
         self._flat = None
         self._lib = None
         self._last_gflat = None
+        self._gbuf = None              # persistent flat gradient buffer + the gradient field tables that point into it
+        self._sync_bn = bool(kwargs.get("sync_batch_norm", True))     # under data parallelism: BatchNorm over the GLOBAL batch
+        # how the embedding-table gradients are produced:
+        #   "atomic" fp32 atomics into dense tables (fastest, not run-to-run reproducible); "sorted" the same dense tables from a
+        #   stable sort + segmented reduction (bit-reproducible); "sparse" (unique rows, gradient rows) lists + lazy row Adam, no
+        #   dense table gradient at all (BASELINE configs[3]); "auto" = sparse above 8 GB of tables when embedding_regularizer
+        #   is 0, else atomic
+        self._embedding_grad = str(kwargs.get("embedding_grad", "auto"))
+        if self._embedding_grad not in ("auto", "atomic", "sorted", "sparse"):
+            raise ValueError("embedding_grad=%r" % self._embedding_grad)
+        self._sparse = None
+        self._validate_ids = bool(kwargs.get("validate_ids", True))
+        self._id_errors = None
         self._ws = {}
         self._fused_cache = {}
         self.compile(kwargs["optimizer"], loss=kwargs["loss"], lr=learning_rate)
         self.reset_parameters()
         self.model_to_device()
+
+    # ------------------------------------------------------------------------------ arithmetic of the encoder GEMMs
+    arith = "f32"
+
+    def arith_modes(self):
+        """arithmetic variants the loaded library offers for the encoder GEMMs ("f32" = exact fp32 MFMA, always present)"""
+        return ["f32"]
+
+    def set_arith(self, mode):
+        if mode not in self.arith_modes():
+            raise ValueError("arith=%r is not available (have %s)" % (mode, self.arith_modes()))
+        self.arith = mode
 
     # ------------------------------------------------------------------------------ encoder (overridden by the variants)
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
@@ -401,6 +428,10 @@ class RAT_m2(BaseModel):
         named = [(n, p) for n, p in self.named_parameters() if p.requires_grad and not n.startswith("query_proj")]
         emb = [(n, p) for n, p in named if "embedding_layer" in n]
         rest = [(n, p) for n, p in named if "embedding_layer" not in n]
+        # inside the "embedding_layer" block: feature tables, then the LR ("wide") tables, then the label table — the two table
+        # families are what the row-sparse gradient path covers, so they form one contiguous prefix of the buffer
+        rank = lambda n: 0 if n.startswith("embedding_layer.") else (1 if n.startswith("lr_layer.") else 2)   # noqa: E731
+        emb.sort(key=lambda np_: rank(np_[0]))
         return emb, rest
 
     def _after_device_move(self):
@@ -423,6 +454,23 @@ class RAT_m2(BaseModel):
         self._flat, self._offsets, self._order = flat, offsets, [n for n, _ in emb + rest]
         self._params = OrderedDict(emb + rest)
         self._lib = get_lib() if self._lib is None else self._lib
+        # table families at the head of the buffer: [0, _n_feat) feature tables (rows of d floats), [_n_feat, _n_tab) LR tables
+        self._n_feat = sum((p.numel() + 3) // 4 * 4 for n, p in emb if n.startswith("embedding_layer."))
+        self._n_tab = self._n_feat + sum((p.numel() + 3) // 4 * 4 for n, p in emb if n.startswith("lr_layer."))
+        mode = self._embedding_grad
+        d = self._cfg["d"]
+        row_aligned = d % 4 == 0 and all(self._offsets[n] % d == 0 for n, _ in emb if n.startswith("embedding_layer."))
+        if mode == "auto":
+            big = self._n_feat * 4 > (8 << 30)
+            mode = "sparse" if (big and self._cfg["lam_emb"] == 0 and row_aligned) else "atomic"
+        if mode in ("sorted", "sparse") and not row_aligned:
+            raise NotImplementedError("embedding_grad=%r needs embedding_dim %% 4 == 0 (table rows on 16-byte boundaries)" % mode)
+        if mode == "sparse" and self._cfg["lam_emb"] != 0:
+            raise NotImplementedError("embedding_grad='sparse' touches only the rows of the batch: the reference's dense L2 term "
+                                      "(lambda*W on EVERY row, base_model.py:79-94) cannot be carried — use embedding_regularizer=0")
+        self._grad_mode = mode
+        self._n_sparse = self._n_tab if mode == "sparse" else 0
+        self._gbuf = None
         self._build_descriptors()
 
     def _p(self, name):
@@ -439,6 +487,7 @@ class RAT_m2(BaseModel):
             self._lr_ftab = ops.field_table(self._fields, self._lr_tables, dev)
         else:
             self._lr_tables, self._lr_ftab = None, None
+        self._col2field = None                                  # built on first use (needs the batch's column count)
         self._build_encoder_descriptors()
         # DNN head layout: [(linear_idx, bn_idx or None, dropout_p)], out linear idx
         self._dnn_layers, self._dnn_out = [], None
@@ -458,37 +507,114 @@ class RAT_m2(BaseModel):
                 self._dnn_layers.append((lin, bn, pdrop))
             self._dnn_out = len(mods) - 1
 
+    def _grad_buffer(self):
+        """-> (zeroed flat gradient buffer, its embedding / LR gradient field tables).  ONE persistent buffer is reused (so the
+        RatField tables that point into it are built and uploaded once) whenever the previous step's gradients were released
+        (optimizer.zero_grad()); if some p.grad still aliases it — gradient accumulation over several backward calls — a fresh
+        buffer is used so that autograd's `p.grad += new` never adds a tensor to itself."""
+        dev = self._flat.device
+        emb_prefix = "embedding_layer.embedding_layer.embedding_layer."
+        lr_prefix = "lr_layer.embedding_layer.embedding_layer.embedding_layer."
+
+        def tables(g):
+            view = lambda n: self._gflat_view(g, n)           # noqa: E731
+            gft = ops.field_table(self._fields, [view(emb_prefix + f.name + ".weight") for f in self._fields], dev)
+            lft = ops.field_table(self._fields, [view(lr_prefix + f.name + ".weight") for f in self._fields], dev) \
+                if self._cfg["use_wide"] else None
+            return gft, lft
+        held = any(p.grad is not None for p in self._params.values())
+        size = self._flat.numel() - self._n_sparse
+        if self._gbuf is not None and not held and self._gbuf[0].numel() == size and self._gbuf[0].device == dev:
+            g, gft, lft = self._gbuf
+            g.zero_()
+            return g, gft, lft
+        g = torch.zeros(size, dtype=torch.float32, device=dev)
+        gft, lft = tables(g) if self._n_sparse == 0 else (None, None)
+        if not held:
+            self._gbuf = (g, gft, lft)
+        return g, gft, lft
+
     def _gflat_view(self, gflat, name):
+        """view of parameter `name`'s gradient inside the flat gradient buffer (which, in sparse mode, starts BEHIND the tables)"""
         p = self._params[name]
-        o = self._offsets[name]
+        o = self._offsets[name] - self._n_sparse
+        assert o >= 0, "the tables have no dense gradient in sparse mode"
         return gflat[o:o + p.numel()].view_as(p)
+
+    def _dense_names(self):
+        return [n for n in self._order if self._offsets[n] >= self._n_sparse]
 
     def _gather_flat_grad(self):
         """The flat gradient the last backward produced, or one assembled from p.grad if autograd copied them."""
         g = self._last_gflat
-        names = self._order
+        names = self._dense_names()
         if g is not None and all(self._params[n].grad is not None and
-                                 self._params[n].grad.data_ptr() == g.data_ptr() + 4 * self._offsets[n] for n in names):
+                                 self._params[n].grad.data_ptr() == g.data_ptr() + 4 * (self._offsets[n] - self._n_sparse) for n in names):
             return g
         if all(self._params[n].grad is None for n in names):
             return None
-        g = torch.zeros_like(self._flat)
+        g = torch.zeros(self._flat.numel() - self._n_sparse, dtype=torch.float32, device=self._flat.device)
         for n in names:
             if self._params[n].grad is not None:
                 self._gflat_view(g, n).copy_(self._params[n].grad)
         return g
 
     def _exchange_gradients(self):
-        """Data parallelism: ONE all-reduce (RCCL over xGMI) of the whole flat gradient bucket."""
+        """Data parallelism: ONE all-reduce (RCCL over xGMI) of the flat gradient bucket; in sparse mode the bucket holds only the
+        dense net (+ label table) and the table gradients travel as all-gathered (row ids, gradient rows) lists that every rank
+        merges with the same deterministic plan + segmented reduction."""
         import torch.distributed as dist
         if self._world_size() > 1:
             g = self._gather_flat_grad()
             if g is not None:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
                 if g is not self._last_gflat:
-                    for n in self._order:
+                    for n in self._dense_names():
                         self._params[n].grad = self._gflat_view(g, n)
                     self._last_gflat = g
+            if self._sparse is not None:
+                self._sparse = [self._merge_sparse(part) for part in self._sparse]
+
+    def _merge_sparse(self, part):
+        """all-gather one family's (rows, grads, count) at capacity and reduce the union: -> the same record, global"""
+        lib, world = self._lib, self._world_size()
+        rows, grads, count, width, total_rows, base_off = part
+        cap = rows.numel()
+        all_rows = self._all_gather_flat(rows)
+        all_grads = self._all_gather_flat(grads.reshape(-1))
+        all_counts = self._all_gather_flat(count)
+        plan = ops.sparse_plan_rows(all_rows, all_counts, cap, world, total_rows, plan=self._ws.get(("merge", width)), lib=lib)
+        self._ws[("merge", width)] = plan
+        ncap = min(cap * world, total_rows)
+        out_rows = torch.empty(ncap, dtype=torch.int32, device=rows.device)
+        out_grads = torch.empty((ncap, width), dtype=torch.float32, device=rows.device)
+        ops.sparse_reduce_rows(plan, all_grads, cap, world, width, out_rows, out_grads, lib=lib)
+        return (out_rows, out_grads, plan.count.clone(), width, total_rows, base_off)
+
+    def _all_gather_flat(self, t):
+        """[n] -> [world * n], ranks in order (RCCL all-gather on the GPU, gloo in the CPU tests)."""
+        import torch.distributed as dist
+        out = torch.empty(self._world_size() * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t) if t.is_cuda else dist.all_gather(list(out.view(self._world_size(), -1).unbind(0)), t)
+        return out
+
+    def _all_reduce_sum(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def check_id_errors(self):
+        """nn.Embedding raises IndexError on an out-of-vocabulary id (embedding.py:158-178); the kernels clamp for memory safety
+        and rat_check_ids counts the offenders on the device.  This reads the counters (ONE host synchronisation — called where
+        the training loop synchronises anyway: end of an epoch / of an evaluation) and raises like the reference would."""
+        if self._id_errors is None:
+            return
+        bad_ids, bad_labels = [int(v) for v in self._id_errors.tolist()]
+        if bad_ids or bad_labels:
+            self._id_errors.zero_()
+            raise IndexError("index out of range in self: %d feature id(s) outside their embedding table and %d label id(s) "
+                             "outside {0, 1} were fed to the model since the last check (feature_map / data mismatch?)"
+                             % (bad_ids, bad_labels))
 
     # ------------------------------------------------------------------------------ batch plumbing
     def _prepare_batch(self, inputs):
@@ -548,6 +674,10 @@ class RAT_m2(BaseModel):
         d, F, H, heads, dh = c["d"], c["nf"], c["hidden"], c["heads"], c["dh"]
         S = F + 1
         training = self.training
+        if self._validate_ids:
+            if self._id_errors is None:
+                self._id_errors = torch.zeros(2, dtype=torch.int32, device=idx.device)
+            ops.check_ids(idx, labels, self._ftab, F, self._id_errors, B, T, L, lib=lib)
         x0 = ops.gather_fwd(idx, labels, self._ftab, F, self._p("label_embedding_layer.weight"), B, T, L, d, lib=lib)
         saved = {"batch": batch, "dims": (B, T, L, S), "blocks": [], "dnn": []}
         # dropout seeds come from torch's CPU generator, so seed_everything() governs them (masks are re-derived in backward)
@@ -566,8 +696,13 @@ class RAT_m2(BaseModel):
                 ops.sgemm(0, 1, B, N, K, a_prev, lda, W, K, z, N, bias=bvec, lib=lib)
                 if bn is not None:
                     m = mods[bn]
-                    a, sm, sr = ops.bn_relu_fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
-                                                eps=m.eps, momentum=m.momentum, lib=lib)
+                    if training and self._sync_bn and self._world_size() > 1:         # SyncBN: statistics of the GLOBAL batch
+                        a, sm, sr, gstats = ops.bn_relu_fwd_sync(z, m.weight.data, m.bias.data, m.running_mean, m.running_var,
+                                                                 self._all_gather_flat, eps=m.eps, momentum=m.momentum, lib=lib)
+                        sm = (sm, gstats)
+                    else:
+                        a, sm, sr = ops.bn_relu_fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
+                                                    eps=m.eps, momentum=m.momentum, lib=lib)
                     if training:
                         m.num_batches_tracked += 1
                 else:
@@ -605,23 +740,27 @@ class RAT_m2(BaseModel):
         return ws
 
     def _run_backward(self, saved, g_loss, g_reg):
+        """g_loss / g_reg: DEVICE scalars (autograd's incoming gradients of the loss / regulariser outputs; g_reg None = no
+        regulariser term) — multiplied in by rat_logit_bwd / rat_l2_reg, never read on the host."""
         c, lib = self._cfg, self._lib
         idx, labels, y_true = saved["batch"]
         B, T, L, S = saved["dims"]
         d, F, H, heads, dh = c["d"], c["nf"], c["hidden"], c["heads"], c["dh"]
         dev = self._flat.device
-        gflat = torch.zeros_like(self._flat)
+        gflat, gftab, lr_gftab = self._grad_buffer()
+        mode = self._grad_mode
+        if mode != "atomic":
+            lr_gftab = None                                     # the LR rows come from the sorted reduction below, not from atomics
+            if self._col2field is None or self._col2field.numel() != L:
+                self._col2field = ops.col2field_table(self._fields, L, dev)
         G = lambda name: self._gflat_view(gflat, name)          # noqa: E731
         x_final, y_pred = saved["x_final"], saved["y_pred"]
+        g_loss = g_loss.reshape(1).to(torch.float32).contiguous()
         # ---- head
         dx = torch.zeros_like(x_final)
-        lr_gftab = None
-        if c["use_wide"]:
-            lr_prefix = "lr_layer.embedding_layer.embedding_layer.embedding_layer."
-            lr_gftab = ops.field_table(self._fields, [G(lr_prefix + f.name + ".weight") for f in self._fields], dev)
         cs = saved["cls_stride"]
         dlogit = ops.logit_bwd(y_pred, y_true, x_final, cs, self.fc.weight.data, dx, cs, G("fc.weight"),
-                               G("fc.bias"), lr_gftab, F, idx, T * L, g_loss, B, d, lib=lib)
+                               G("fc.bias"), lr_gftab, F, idx, T * L, 1.0, B, d, gscale_dev=g_loss, lib=lib)
         dflat = None
         if self.dnn is not None:
             mods = self.dnn.dnn
@@ -637,7 +776,11 @@ class RAT_m2(BaseModel):
                 N = z.shape[1]
                 if seeds is not None and pdrop > 0:
                     da = ops.dropout(da, pdrop, seeds[1 + li], out=da, lib=lib)
-                if bn is not None:
+                if bn is not None and isinstance(sm, tuple):                       # SyncBN (see _run_forward)
+                    m = mods[bn]
+                    dz = ops.bn_relu_bwd_sync(z, a, da, m.weight.data, sm[0], sr, G("dnn.dnn.%d.weight" % bn),
+                                              G("dnn.dnn.%d.bias" % bn), self._all_reduce_sum, sm[1], lib=lib)
+                elif bn is not None:
                     m = mods[bn]
                     dz = ops.bn_relu_bwd(z, a, da, m.weight.data, sm, sr, G("dnn.dnn.%d.weight" % bn), G("dnn.dnn.%d.bias" % bn),
                                          True, lib=lib)
@@ -654,17 +797,58 @@ class RAT_m2(BaseModel):
         if saved["seeds"] is not None and c["emb_dropout"] > 0:
             dx = ops.dropout(dx, c["emb_dropout"], saved["seeds"][0], out=dx, lib=lib)
         # ---- embedding tables
-        emb_prefix = "embedding_layer.embedding_layer.embedding_layer."
-        gftab = ops.field_table(self._fields, [G(emb_prefix + f.name + ".weight") for f in self._fields], dev)
-        ops.gather_bwd(dx, dflat, idx, labels, gftab, F, G("label_embedding_layer.weight"), B, T, L, d, lib=lib)
+        if mode == "atomic":
+            ops.gather_bwd(dx, dflat, idx, labels, gftab, F, G("label_embedding_layer.weight"), B, T, L, d, lib=lib)
+            self._sparse = None
+        else:
+            self._table_gradients_sorted(dx, dflat, dlogit, idx, labels, gflat, (B, T, L, S), mode)
+            ops.label_grad(dx, labels, G("label_embedding_layer.weight"), B * T, S, d, lib=lib)
         # ---- L2 regulariser gradient (base_model.py:79-94): lambda * W on the "embedding_layer" tensors
-        if g_reg != 0.0:
+        if g_reg is not None:
+            g_reg = g_reg.reshape(1).to(torch.float32).contiguous()
             if c["lam_emb"] > 0 and self._n_emb > 0:
-                ops.l2_reg(self._flat[:self._n_emb], gflat[:self._n_emb], c["lam_emb"] * g_reg, None, lib=lib)
+                ops.l2_reg(self._flat[:self._n_emb], gflat[:self._n_emb], c["lam_emb"], None, lam_scale_dev=g_reg, lib=lib)
             if c["lam_net"] > 0:
-                ops.l2_reg(self._flat[self._n_emb:], gflat[self._n_emb:], c["lam_net"] * g_reg, None, lib=lib)
+                ops.l2_reg(self._flat[self._n_emb:], gflat[self._n_emb:], c["lam_net"], None, lam_scale_dev=g_reg, lib=lib)
         self._last_gflat = gflat
-        return [self._gflat_view(gflat, n) for n in self._order]
+        return [self._gflat_view(gflat, n) if self._offsets[n] >= self._n_sparse else None for n in self._order]
+
+    def _table_gradients_sorted(self, dx, dflat, dlogit, idx, labels, gflat, dims, mode):
+        """K1s: stable sort of the batch's (sample, id column) pairs by table row + segmented reduction in batch order.
+        mode "sorted": sums land in the dense gradient tables (bit-reproducible replacement of the fp32 atomics);
+        mode "sparse": (unique rows, gradient rows, count) lists per table family, consumed by rat_adam_rows."""
+        c, lib = self._cfg, self._lib
+        B, T, L, S = dims
+        d, F = c["d"], c["nf"]
+        dev = dx.device
+        rows_feat = self._n_feat // d
+        plan = ops.sparse_plan_ids(idx, self._ftab, self._col2field, F, self._flat, d, rows_feat, B, T, L,
+                                   plan=self._ws.get(("plan", 0)), lib=lib)
+        self._ws[("plan", 0)] = plan
+        sparse = []
+        if mode == "sorted":
+            ops.sparse_reduce_grid(plan, dx, dflat, self._col2field, B, T, L, F, d, dense_base=gflat, lib=lib)
+        else:
+            cap = min(B * T * L, rows_feat)
+            rows = torch.empty(cap, dtype=torch.int32, device=dev)
+            grads = torch.empty((cap, d), dtype=torch.float32, device=dev)
+            ops.sparse_reduce_grid(plan, dx, dflat, self._col2field, B, T, L, F, d, out_rows=rows, out_grads=grads, lib=lib)
+            sparse.append((rows, grads, plan.count.clone(), d, rows_feat, 0))
+        if c["use_wide"]:                                       # LR tables: width-1 rows, gradient = dlogit of the TARGET sample
+            rows_lr = self._n_tab - self._n_feat
+            lr_base = self._flat[self._n_feat:]
+            plan_lr = ops.sparse_plan_ids(idx, self._lr_ftab, self._col2field, F, lr_base, 1, rows_lr, B, T, L, target_only=True,
+                                          plan=self._ws.get(("plan", 1)), lib=lib)
+            self._ws[("plan", 1)] = plan_lr
+            if mode == "sorted":
+                ops.sparse_reduce_scalar(plan_lr, dlogit, B, L, dense_base=gflat[self._n_feat:], lib=lib)
+            else:
+                cap = min(B * L, rows_lr)
+                rows = torch.empty(cap, dtype=torch.int32, device=dev)
+                vals = torch.empty((cap, 1), dtype=torch.float32, device=dev)
+                ops.sparse_reduce_scalar(plan_lr, dlogit, B, L, out_rows=rows, out_vals=vals, lib=lib)
+                sparse.append((rows, vals, plan_lr.count.clone(), 1, rows_lr, self._n_feat))
+        self._sparse = sparse if mode == "sparse" else None
 
 
 class RAT_m1(RAT_m2):

@@ -86,11 +86,101 @@ def gather_fwd(idx, label_ids, ftab, nfields, label_table, B, T, L, d, lib=None)
     return grid
 
 
+def check_ids(idx, label_ids, ftab, nfields, counts, B, T, L, lib=None):
+    """counts (device int32[2]) += [feature ids outside their table, label ids outside {0,1,2}] — see rat_check_ids."""
+    lib = lib or get_lib()
+    _chk(idx, torch.int32, "idx"), _chk(label_ids, torch.int32, "label_ids"), _chk(counts, torch.int32, "counts")
+    lib.call("rat_check_ids", _p(idx), _p(label_ids), _p(ftab), nfields, B, T, L, _p(counts), _stream(idx))
+
+
 def gather_bwd(dgrid, dflat, idx, label_ids, gftab, nfields, dlabel_table, B, T, L, d, lib=None):
     lib = lib or get_lib()
     _chk(dgrid, name="dgrid"), _chk(dflat, name="dflat"), _chk(dlabel_table, name="dlabel_table")
     lib.call("rat_gather_bwd", _p(dgrid), _p(dflat), _p(idx), _p(label_ids), _p(gftab), nfields, _p(dlabel_table),
              B, T, L, d, _stream(dgrid))
+
+
+# ----------------------------------------------------------------------------- K1s (row-sparse / deterministic table gradients)
+def col2field_table(fields, L, device):
+    """int32 [L]: the field that owns each id column of idx (-1: no field reads it)"""
+    arr = np.full(L, -1, dtype=np.int32)
+    for i, f in enumerate(fields):
+        arr[f.col:f.col + f.ncols] = i
+    return torch.from_numpy(arr).to(device)
+
+
+class SparsePlan:
+    """Workspace + device-side unique-row count of one rat_sparse_plan_* call (what the matching reduce call needs)."""
+
+    __slots__ = ("ws", "count", "n")
+
+    def __init__(self, n, device, lib):
+        self.n = int(n)
+        self.ws = torch.empty(lib.size("rat_sparse_workspace", self.n), dtype=torch.uint8, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def sparse_plan_ids(idx, ftab, col2field, nfields, flat_base, width, total_rows, B, T, L, target_only=False, plan=None, lib=None):
+    """flat_base: the tensor whose first element is row 0 of the table block the RatField pointers of `ftab` point into."""
+    lib = lib or get_lib()
+    _chk(idx, torch.int32, "idx"), _chk(col2field, torch.int32, "col2field")
+    n = (B if target_only else B * T) * L
+    if plan is None or plan.n != n:
+        plan = SparsePlan(n, idx.device, lib)
+    lib.call("rat_sparse_plan_ids", _p(idx), _p(ftab), _p(col2field), nfields, _p(flat_base), int(width), int(total_rows), B, T, L,
+             int(bool(target_only)), _p(plan.ws), plan.ws.numel(), _p(plan.count), _stream(idx))
+    return plan
+
+
+def sparse_plan_rows(rows, counts, cap, world, total_rows, plan=None, lib=None):
+    lib = lib or get_lib()
+    _chk(rows, torch.int32, "rows"), _chk(counts, torch.int32, "counts")
+    n = cap * world
+    if plan is None or plan.n != n:
+        plan = SparsePlan(n, rows.device, lib)
+    lib.call("rat_sparse_plan_rows", _p(rows), _p(counts), int(cap), int(world), int(total_rows), _p(plan.ws), plan.ws.numel(),
+             _p(plan.count), _stream(rows))
+    return plan
+
+
+def sparse_reduce_grid(plan, dgrid, dflat, col2field, B, T, L, nfields, d, out_rows=None, out_grads=None, dense_base=None,
+                       target_only=False, lib=None):
+    lib = lib or get_lib()
+    _chk(dgrid, name="dgrid"), _chk(dflat, name="dflat"), _chk(out_grads, name="out_grads"), _chk(out_rows, torch.int32, "out_rows")
+    lib.call("rat_sparse_reduce_grid", _p(plan.ws), _p(plan.count), _p(dgrid), _p(dflat), _p(col2field), B, T, L, nfields, d,
+             int(bool(target_only)), _p(out_rows), _p(out_grads), _p(dense_base), _stream(dgrid))
+
+
+def sparse_reduce_rows(plan, src_rows, cap, world, d, out_rows, out_grads, lib=None):
+    lib = lib or get_lib()
+    _chk(src_rows, name="src_rows"), _chk(out_grads, name="out_grads"), _chk(out_rows, torch.int32, "out_rows")
+    lib.call("rat_sparse_reduce_rows", _p(plan.ws), _p(plan.count), _p(src_rows), int(cap), int(world), d, _p(out_rows), _p(out_grads),
+             _stream(src_rows))
+
+
+def sparse_reduce_scalar(plan, per_sample, B, L, out_rows=None, out_vals=None, dense_base=None, lib=None):
+    lib = lib or get_lib()
+    _chk(per_sample, name="per_sample"), _chk(out_vals, name="out_vals"), _chk(out_rows, torch.int32, "out_rows")
+    lib.call("rat_sparse_reduce_scalar", _p(plan.ws), _p(plan.count), _p(per_sample), B, L, _p(out_rows), _p(out_vals), _p(dense_base),
+             _stream(per_sample))
+
+
+def sumsq_rows(grads, count, max_rows, d, out, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_sumsq_rows", _p(grads), _p(count), int(max_rows), d, _p(out), _stream(grads))
+
+
+def adam_rows(w_base, m_base, v_base, rows, grads, count, max_rows, d, norm_sq, max_norm, lr, beta1, beta2, eps, step, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_adam_rows", _p(w_base), _p(m_base), _p(v_base), _p(rows), _p(grads), _p(count), int(max_rows), d, _p(norm_sq),
+             float(max_norm), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream(grads))
+
+
+def label_grad(dgrid, label_ids, dlabel, nbt, S, d, lib=None):
+    """deterministic gradient of the 3-row label table: per-block partial sums + fixed-order combine (no atomics)"""
+    lib = lib or get_lib()
+    ws = torch.empty(lib.size("rat_label_grad_workspace", d) // 4, dtype=torch.float32, device=dgrid.device)
+    lib.call("rat_label_grad", _p(dgrid), _p(label_ids), _p(dlabel), _p(ws), int(nbt), S, d, _stream(dgrid))
 
 
 # ----------------------------------------------------------------------------- K2
@@ -303,6 +393,40 @@ def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, li
     return dz
 
 
+def bn_relu_fwd_sync(z, gamma, beta, running_mean, running_var, all_gather, eps=1e-5, momentum=0.1, lib=None):
+    """SyncBN training forward: local (mean, M2, count) -> `all_gather(stats) -> [world, 2N+1]` (the caller's
+    collective: torch.distributed over RCCL / gloo) -> normalise with the GLOBAL batch statistics + ReLU."""
+    lib = lib or get_lib()
+    _chk(z, name="z")
+    M, N = z.shape
+    stats = torch.empty(2 * N + 1, dtype=torch.float32, device=z.device)
+    ws = _bn_ws(N, z.device, lib)
+    lib.call("rat_bn_local_stats", _p(z), _p(stats), _p(ws), M, N, _stream(z))
+    all_stats = all_gather(stats)
+    _chk(all_stats, name="all_stats")
+    world = all_stats.numel() // (2 * N + 1)
+    a = torch.empty_like(z)
+    save_mean = torch.empty(N, dtype=torch.float32, device=z.device)
+    save_rstd = torch.empty(N, dtype=torch.float32, device=z.device)
+    lib.call("rat_bn_relu_fwd_sync", _p(z), _p(a), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(save_mean),
+             _p(save_rstd), _p(all_stats), world, M, N, eps, momentum, _stream(z))
+    return a, save_mean, save_rstd, all_stats
+
+
+def bn_relu_bwd_sync(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, all_reduce_sum, all_stats, lib=None):
+    """SyncBN backward: local (sum g, sum g*xhat) -> `all_reduce_sum(copy)` (caller's collective) -> dz; dgamma/dbeta = LOCAL sums."""
+    lib = lib or get_lib()
+    M, N = z.shape
+    local = torch.empty(2 * N, dtype=torch.float32, device=z.device)
+    ws = _bn_ws(N, z.device, lib)
+    lib.call("rat_bn_bwd_local_sums", _p(z), _p(a), _p(da), _p(save_mean), _p(save_rstd), _p(local), _p(ws), M, N, _stream(z))
+    glob = all_reduce_sum(local.clone())
+    dz = torch.empty_like(z)
+    lib.call("rat_bn_relu_bwd_sync", _p(z), _p(a), _p(da), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd), _p(local), _p(glob),
+             _p(dgamma), _p(dbeta), _p(all_stats), all_stats.numel() // (2 * N + 1), M, N, _stream(z))
+    return dz
+
+
 def colsum(a, lda, out, M, N, lib=None):
     lib = lib or get_lib()
     ws = torch.empty((lib.size("rat_colsum_workspace", M, N) + 3) // 4, dtype=torch.float32, device=out.device)
@@ -318,18 +442,19 @@ def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_s
 
 
 def logit_bwd(y_pred, y_true, cls, cls_stride, fc_w, dcls, dcls_stride, dfc_w, dfc_b, lr_gftab, nfields, idx, idx_stride,
-              gscale, B, d, lib=None):
+              gscale, B, d, gscale_dev=None, lib=None):
+    """gscale: host factor; gscale_dev: optional DEVICE scalar multiplied in by the kernel (autograd's incoming gradient)."""
     lib = lib or get_lib()
     dlogit = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
     lib.call("rat_logit_bwd", _p(y_pred), _p(y_true), _p(cls), cls_stride, _p(fc_w), _p(dlogit), _p(dcls), dcls_stride,
-             _p(dfc_w), _p(dfc_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), B, d, _stream(fc_w))
+             _p(dfc_w), _p(dfc_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), _p(gscale_dev), B, d, _stream(fc_w))
     return dlogit
 
 
 # ----------------------------------------------------------------------------- K4 / K5
-def l2_reg(w, g, lam, reg_out, lib=None):
+def l2_reg(w, g, lam, reg_out, lam_scale_dev=None, lib=None):
     lib = lib or get_lib()
-    lib.call("rat_l2_reg", _p(w), _p(g), w.numel(), float(lam), _p(reg_out), _stream(w))
+    lib.call("rat_l2_reg", _p(w), _p(g), w.numel(), float(lam), _p(lam_scale_dev), _p(reg_out), _stream(w))
 
 
 def sumsq(g, out, lib=None):

@@ -31,19 +31,28 @@ class FusedClipAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def clip_and_step(self, max_norm=None):
         model = self._model
-        grad = model._gather_flat_grad()
-        if grad is None:
+        grad = model._gather_flat_grad()                 # the dense part of the bucket (everything, unless the tables are sparse)
+        sparse = getattr(model, "_sparse", None) or []
+        if grad is None and not sparse:
             return None
         m, v = self._buffers()
         group = self.param_groups[0]
+        lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
         self._step += 1
+        ns = getattr(model, "_n_sparse", 0)
         norm_sq = None
-        if max_norm is not None:
+        if max_norm is not None:                         # ONE global norm over dense gradients and sparse row lists alike
             self._norm_sq.zero_()
-            ops.sumsq(grad, self._norm_sq, lib=model._lib)
+            if grad is not None:
+                ops.sumsq(grad, self._norm_sq, lib=model._lib)
+            for rows, g, count, width, _total, _base in sparse:
+                ops.sumsq_rows(g, count, rows.numel(), width, self._norm_sq, lib=model._lib)
             norm_sq = self._norm_sq
-        ops.clip_adam(model._flat, grad, m, v, norm_sq, max_norm or 0.0, group["lr"], group["betas"][0], group["betas"][1],
-                      group["eps"], self._step, lib=model._lib)
+        if grad is not None:
+            ops.clip_adam(model._flat[ns:], grad, m[ns:], v[ns:], norm_sq, max_norm or 0.0, lr, b1, b2, eps, self._step, lib=model._lib)
+        for rows, g, count, width, _total, base in sparse:   # lazy Adam on the touched table rows (rat_adam_rows)
+            ops.adam_rows(model._flat[base:], m[base:], v[base:], rows, g, count, rows.numel(), width, norm_sq, max_norm or 0.0,
+                          lr, b1, b2, eps, self._step, lib=model._lib)
         return norm_sq
 
     def step(self, closure=None):

@@ -25,8 +25,15 @@ WORKLOADS = {
     # the full 100 M-row table (25.6 GB + 77 GB of gradient / Adam state per replica) fits one MI355X, but its DENSE gradient
     # all-reduce does not scale — row-sparse exchange + lazy Adam for that config are future work
     "synthetic_F40_V10M_K10_d64_B1024": dict(F=40, total_vocab=10_000_000, K=10, d=64, batch=1024, **KKBOX_HYPER),
+    # BASELINE.json configs[3] per GPU at its FULL vocabulary: 100 M rows x 64 floats = 25.6 GB of feature tables (+ 51.2 GB of Adam
+    # moments; no dense gradient: row-sparse lists + rat_adam_rows), global batch 8192 over 8 GPUs = 1024 per rank
+    "synthetic_F40_V100M_K10_d64_B1024": dict(F=40, total_vocab=100_000_000, K=10, d=64, batch=1024, embedding_regularizer=0.0,
+                                              embedding_grad="sparse", **KKBOX_HYPER),
     # the reference's own KKBox experiment (configs/RAT_m2/kkbox_x1/model_config.yaml: embedding_dim 40, K = 5): generic-geometry kernels
     "kkbox_real_F13_K5_d40_B4096": dict(F=13, total_vocab=92_000, K=5, d=40, batch=4096, **KKBOX_HYPER),
+    # bench.py --dry-run-cpu (plumbing check of the multi-process launch over gloo + the host-emulated kernels)
+    "dryrun": dict(F=3, total_vocab=90, K=2, d=16, batch=8, num_heads=2, dim_head=10, depth=1, scale_dim=2,
+                   dnn_hidden_units=[16], batch_norm=True, use_wide=True, learning_rate=1e-3),
     # tiny: smoke / CI
     "tiny": dict(F=5, total_vocab=500, K=3, d=16, batch=32, num_heads=2, dim_head=10, depth=2, scale_dim=2,
                  dnn_hidden_units=[32, 16], batch_norm=True, use_wide=True, learning_rate=1e-3),
@@ -42,7 +49,9 @@ def feature_map_for(name, spec):
 
 
 def model_kwargs(spec, gpu, embedding_regularizer=0.0005, model_root="/tmp/rat_amd_models/"):
-    return dict(model_id="RAT_m2_bench", gpu=gpu, task="binary_classification", learning_rate=spec["learning_rate"],
+    embedding_regularizer = spec.get("embedding_regularizer", embedding_regularizer)
+    extra = {"embedding_grad": spec["embedding_grad"]} if "embedding_grad" in spec else {}
+    return dict(**extra, model_id="RAT_m2_bench", gpu=gpu, task="binary_classification", learning_rate=spec["learning_rate"],
                 embedding_dim=spec["d"], dnn_hidden_units=list(spec["dnn_hidden_units"]), dnn_activations="relu",
                 num_heads=spec["num_heads"], dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
                 dropout=0.0, emb_dropout=0.0, net_dropout=0, batch_norm=spec["batch_norm"], use_wide=spec["use_wide"],
