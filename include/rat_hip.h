@@ -113,14 +113,26 @@ int rat_attn_bwd(const float* x, const float* dy, const float* o_save, const flo
  *   y = out_scale * to_out(softmax(Q K^T * softmax_scale) V) + res
  * res: residual source — x (rat_attn_fwd), y itself (accumulate onto the first attention's result), or NULL;
  * softmax_scale <= 0 selects dim_head^-0.5.  Backward: the gradient through the projection is out_scale * dy and
- * dx = add + LayerNorm-backward(...), add = dy (rat_attn_bwd), another tensor laid out like dx (may alias dx), or NULL. */
+ * dx = add + LayerNorm-backward(...), add = dy (rat_attn_bwd), another tensor laid out like dx (may alias dx), or NULL.
+ *
+ * arith selects the arithmetic of the projections (the GEMMs; the softmax core is the same fp32 VALU code either way):
+ *   RAT_ARITH_F32     v_mfma_f32_16x16x4_f32: exact fp32, bit-identical to a k-ordered fmaf chain (what rat_attn_fwd / _bwd use);
+ *   RAT_ARITH_BF16X3  v_mfma_f32_16x16x32_bf16 on operands split EXACTLY into three bf16 chunks, the six cross products of weight
+ *                     >= 2^-16, fp32 accumulation: fp32-class accuracy (the dropped terms are <= 2^-23 of each product — one fp32
+ *                     rounding; measured against fp64 in tools/probes/bf16x3_probe.hip) at 2.4x the fp32-MFMA rate.  Compiled for
+ *                     the north-star geometry (embedding_dim 64, 8 heads x 10); any other shape runs RAT_ARITH_F32 regardless.
+ * The forward needs rat_attn_fwd_workspace() bytes of workspace for the pre-split weight fragments under RAT_ARITH_BF16X3
+ * (NULL / too small: exact fp32); the backward's rat_attn_bwd_workspace() already covers its own. */
+#define RAT_ARITH_F32 0
+#define RAT_ARITH_BF16X3 1
+size_t rat_attn_fwd_workspace(int d, int heads, int dim_head);
 int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
-                    float ln_eps, void* stream);
+                    float ln_eps, int arith, float* workspace, size_t workspace_bytes, void* stream);
 int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save, float* dx,
                     const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace, size_t workspace_bytes,
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
-                    float ln_eps, void* stream);
+                    float ln_eps, int arith, void* stream);
 
 /* ---- K2d: the attention core alone, for sequences longer than the fused kernel's 64-row tile — RAT_m0 attends jointly over all
  * T*S tokens of a sample (RAT_m0.py:123-127; 231 at the north-star shape).  That variant runs LayerNorm as K2c and the two

@@ -22,6 +22,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
         }
         blk.xa.assign(nwaves * 64, 0.f);
         blk.xb.assign(nwaves * 64, 0.f);
+        blk.xw.assign(nwaves * 64 * 8, 0u);
         blk.smem.assign(smem + 64, 0x7f);   // poison: uninitialised LDS reads show up as NaN-ish garbage
         std::vector<std::thread> threads;
         threads.reserve(nthreads);

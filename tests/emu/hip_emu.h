@@ -49,6 +49,7 @@ struct Block {
     std::vector<std::unique_ptr<std::barrier<>>> wave_barrier;
     std::vector<float> xa, xb;          // per-wave 64-entry exchange buffers
     std::vector<unsigned long long> xu;
+    std::vector<unsigned> xw;           // per-wave 64 x 8-dword exchange buffer (bf16 MFMA fragments, transposed LDS reads)
     std::vector<char> smem;
 };
 extern thread_local Block* g_block;
@@ -123,6 +124,59 @@ static inline f32x4 emu_mfma_f32_4x4x1f32(float a, float b, f32x4 c) {
     for (int r = 0; r < 4; ++r) c[r] = std::fmaf(wa[(l & ~3) + r], b, c[r]);
     emu::wave_sync();
     return c;
+}
+
+// ---- bf16 MFMA and the transposed LDS read of gfx950 (cdna_hip_programming.md §3 / T10) -------------------------------
+typedef short bf16x8 __attribute__((vector_size(16)));
+typedef short s16x4 __attribute__((vector_size(8)));
+
+static inline float emu_bf16_to_f32(short v) {
+    const unsigned u = ((unsigned)(unsigned short)v) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// v_mfma_f32_16x16x32_bf16: A: lane l holds A[row l & 15][k = 8 (l >> 4) + j]; B: lane l holds B[k = 8 (l >> 4) + j][col l & 15];
+// C/D: col = l & 15, row = 4 (l >> 4) + reg.  bf16 x bf16 products are exact in fp32; they are summed in k order in fp32.
+static inline f32x4 emu_mfma_f32_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    unsigned* w = &emu::g_block->xw[emu::wave() * 64 * 8];
+    const int l = emu::lane();
+    std::memcpy(&w[l * 8], &a, 16);
+    std::memcpy(&w[l * 8 + 4], &b, 16);
+    emu::wave_sync();
+    const int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (l >> 4) * 4 + r;
+        float s = c[r];
+        for (int g = 0; g < 4; ++g) {
+            short av[8], bv[8];
+            std::memcpy(av, &w[(g * 16 + row) * 8], 16);
+            std::memcpy(bv, &w[(g * 16 + col) * 8 + 4], 16);
+            for (int j = 0; j < 8; ++j) s += emu_bf16_to_f32(av[j]) * emu_bf16_to_f32(bv[j]);
+        }
+        c[r] = s;
+    }
+    emu::wave_sync();
+    return c;
+}
+
+// ds_read_b64_tr_b16: within every group of 16 consecutive lanes, lane 4q + p supplies the address of 4 consecutive 16-bit
+// elements (row q of a 4 x 16 block, columns 4p .. 4p+3); lane i of the group receives column i: element q = row q.
+static inline s16x4 emu_lds_tr16(const unsigned short* p) {
+    unsigned* w = &emu::g_block->xw[emu::wave() * 64 * 8];
+    const int l = emu::lane();
+    std::memcpy(&w[l * 8], &p, sizeof(p));
+    emu::wave_sync();
+    const int base = l & ~15, i = l & 15;
+    s16x4 r;
+    for (int q = 0; q < 4; ++q) {
+        const unsigned short* src;
+        std::memcpy(&src, &w[(base + 4 * q + (i >> 2)) * 8], sizeof(src));
+        r[q] = (short)src[i & 3];
+    }
+    emu::wave_sync();
+    return r;
 }
 
 #define RAT_LAUNCH(kernel, grid, block, smem, stream, ...) \

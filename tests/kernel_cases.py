@@ -92,7 +92,9 @@ def attn_weights(rs, d, heads, dh, proj):
             rnd(rs, d, inner, scale=inner ** -0.5) if proj else None, 0.1 * rnd(rs, d) if proj else None)
 
 
-def check_attn(lib, dev, case, mode, seed=2):
+def check_attn(lib, dev, case, mode, seed=2, arith="f32"):
+    """arith "bf16x3": the split-operand bf16 MFMA kernels — SAME tolerances against the float64 reference as the exact-fp32
+    kernels, plus a direct comparison of the two arithmetic variants (they must agree to fp32 rounding level)."""
     B, T, S, d, heads, dh, proj = case
     rs = np.random.RandomState(seed)
     x = rnd(rs, B, T, S, d)
@@ -106,16 +108,24 @@ def check_attn(lib, dev, case, mode, seed=2):
     wd = [w.to(dev) if w is not None else None for w in ws]
     params = ops.attn_params(*wd)
     smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
-    y, o_save, lse = ops.attn_fwd(xd, params, smap, d, heads, dh, save=True, lib=lib)
+    y, o_save, lse = ops.attn_fwd(xd, params, smap, d, heads, dh, save=True, arith=arith, lib=lib)
     close(y, ref, 2e-5, 2e-5, "y")
     gs = [torch.zeros_like(w) if w is not None else None for w in wd]
     grads = ops.attn_params(*gs)
-    dx, _ = ops.attn_bwd(xd, dyd, o_save, lse, params, grads, smap, d, heads, dh, lib=lib)
+    dx, _ = ops.attn_bwd(xd, dyd, o_save, lse, params, grads, smap, d, heads, dh, arith=arith, lib=lib)
     scale = max(1.0, (B * T * S) ** 0.5 / 4)
     close(dx, xr.grad, 1e-4, 1e-4, "dx")
     for name, g, w in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, wr):
         if w is not None:
             close(g, w.grad, 1e-4, 1e-4 * scale, name)
+    if arith != "f32":                                          # the two arithmetic variants side by side
+        y0, o0, l0 = ops.attn_fwd(xd, params, smap, d, heads, dh, save=True, lib=lib)
+        g0 = [torch.zeros_like(w) if w is not None else None for w in wd]
+        dx0, _ = ops.attn_bwd(xd, dyd, o0, l0, params, ops.attn_params(*g0), smap, d, heads, dh, lib=lib)
+        for name, a_, b_ in [("y", y, y0), ("o_save", o_save, o0), ("lse", lse, l0), ("dx", dx, dx0)] + \
+                [(n, ga, gb) for n, ga, gb in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, g0) if ga is not None]:
+            err = float((a_ - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
+            assert err < 4e-6, ("bf16x3 vs exact fp32", name, err)
 
 
 def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed=5):

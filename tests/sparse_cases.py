@@ -53,7 +53,9 @@ def check_sorted_reduce(lib, dev, d, B=5, T=4, dup_vocab=3):
     U = int(plan.count.cpu()[0])
     touched = (ref_dense.view(total_rows, d).abs().sum(1) > 0)
     assert U >= int(touched.sum()) and U <= cap
-    close(dense, ref_dense, 1e-5, 1e-6, "dense sums")
+    # a row collects up to B*T*3 / vocab terms of size ~1 in a different (sorted) order than CPU autograd: fp32 rounding of the
+    # partial sums grows with the term count
+    close(dense, ref_dense, 1e-5, 1e-6 + 1e-7 * B * T, "dense sums")
     r = rows[:U].cpu().long()
     assert bool((r[1:] > r[:-1]).all()), "unique rows come out sorted"
     assert not bool(((r == 6 + fields[0].vocab - 1 + 0) & False).any())

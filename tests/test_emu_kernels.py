@@ -52,6 +52,13 @@ def test_attn_fwd_bwd(emu, case, mode):
     kc.check_attn(emu, "cpu", case, mode)
 
 
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attn_fwd_bwd_bf16x3(emu, mode):
+    """the split-operand bf16 MFMA kernels (plane images in LDS, transposed block reads, pre-split weight fragments) through the
+    emulated v_mfma_f32_16x16x32_bf16 / ds_read_b64_tr_b16; two chunks in one phase, three in the other, ragged tails"""
+    kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), mode, arith="bf16x3")
+
+
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (1, 70, 1, 10, None), (2, 33, 2, 7, 0.3)])
 def test_attn_core_fwd_bwd(emu, nseq, L, heads, dh, softmax_scale):
     kc.check_attn_core(emu, "cpu", nseq, L, heads, dh, softmax_scale)

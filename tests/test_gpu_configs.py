@@ -101,6 +101,25 @@ def test_auc_and_logloss_match_the_oracle_within_1e4(fwd_setup):
     assert abs(mine["AUC"] - want["AUC"]) < 1e-4 and abs(mine["logloss"] - want["logloss"]) < 1e-4, (mine, want)
 
 
+def _relu_safe_rows(orc, w, X, y, cfg, margin=1e-5):
+    """Rows whose DNN pre-activations all stay `margin` away from 0 (float64 evaluation of the head on the target sample's field
+    embeddings).  A hidden unit within rounding distance of 0 lands on either side of the ReLU depending on the GEMM's summation
+    order; ONE such flip changes that sample's whole DNN-branch gradient (every row of the first weight matrix, its table rows) by
+    far more than any tolerance — an artefact of the comparison, not of either implementation (the reference itself is not
+    reproducible there), so those few samples are left out of the slice."""
+    w64 = {k: v.double() for k, v in w.items() if k.startswith(("dnn.", "embedding_layer.", "label_embedding_layer."))}
+    _, target_fields = orc.build_grid(X, y, w64, cfg)
+    a = target_fields.reshape(target_fields.shape[0], -1)
+    layers, out_pos = orc.dnn_layout(cfg)
+    ok = torch.ones(a.shape[0], dtype=torch.bool)
+    for lin, bn in layers:
+        assert bn is None
+        z = a @ w64["dnn.dnn.%d.weight" % lin].t() + w64["dnn.dnn.%d.bias" % lin]
+        ok &= z.abs().min(dim=1).values > margin
+        a = torch.relu(z)
+    return ok
+
+
 def _chunks_per_group(n, T, S):
     """chunks per work-group (256 of them) of the fused attention backward, both phases: a chunk = floor(64 / L) sequences"""
     intra = -(-(n * T) // (64 // S)) / 256.0
@@ -113,18 +132,21 @@ def test_gradients_of_a_full_size_slice_match_the_oracle(name, nslice):
     from oracle import rat_m2_oracle as orc
     spec, fm, model, batch = _build(name, batch_norm=False)
     T, S = spec["K"] + 1, spec["F"] + 1
+    cfg = _oracle_cfg(orc, spec, fm, batch_norm=False, embedding_regularizer=0.0)
+    w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    take = min(spec["batch"], nslice + nslice // 4)                          # head-room for the rows dropped below
+    keep = _relu_safe_rows(orc, w, batch[0][:take], batch[1][:take], cfg).nonzero().reshape(-1)[:nslice]
+    assert keep.numel() >= min(nslice, spec["batch"]) * 0.7, keep.numel()
     if nslice < spec["batch"]:
-        intra, cross = _chunks_per_group(nslice, T, S)
+        intra, cross = _chunks_per_group(int(keep.numel()), T, S)
         assert intra >= 4 and cross >= 4, "slice too small: every work-group must loop over >= 4 chunks (%s)" % ((intra, cross),)
-    sub = tuple(t[:nslice] for t in batch)
+    sub = tuple(t[keep] for t in batch)
     model.train()
     model.optimizer.zero_grad()
     loss = model.get_total_loss(sub)
     loss.backward()
     torch.cuda.synchronize()
     model.check_id_errors()
-    w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    cfg = _oracle_cfg(orc, spec, fm, batch_norm=False, embedding_regularizer=0.0)
     ref_loss, _ref_pred, ref_grads, _ = orc.loss_and_grads(w, sub[0], sub[1], cfg, training=True)
     assert abs(float(loss) - float(ref_loss)) < 2e-6, (float(loss), float(ref_loss))
     worst = {}
@@ -135,7 +157,7 @@ def test_gradients_of_a_full_size_slice_match_the_oracle(name, nslice):
         got, ref = p.grad.detach().cpu().double(), ref_grads[k].double()
         scale = float(ref.abs().max())
         assert scale > 0, k
-        err = float((got - ref).abs().max()) / scale
-        worst[k] = err
-        assert err < GRAD_RTOL, (k, err, scale)
+        worst[k] = (float((got - ref).abs().max()) / scale, scale)
+    bad = {k: v for k, v in worst.items() if not v[0] < GRAD_RTOL}
+    assert not bad, "gradients outside %g of their tensor's largest element: %s" % (GRAD_RTOL, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
     assert len(worst) >= 20

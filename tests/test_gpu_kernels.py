@@ -43,6 +43,19 @@ def test_attn_fwd_bwd(lib, case, mode):
     kc.check_attn(lib, "cuda", case, mode)
 
 
+# bf16x3 arithmetic (north-star geometry only): one chunk, many chunks per work-group with a ragged last one, both sequence
+# lengths of the north star, the KKBox-like S = 14 and Tmall-like T = 31 lengths — same tolerances as the exact-fp32 kernels, plus
+# agreement of the two arithmetic variants to 4e-6 of each tensor's largest element
+B3_CASES = [(3, 11, 21, 64, 8, 10, True), (300, 11, 21, 64, 8, 10, True), (37, 11, 14, 64, 8, 10, True), (29, 31, 9, 64, 8, 10, True),
+            (1, 2, 64, 64, 8, 10, True)]
+
+
+@pytest.mark.parametrize("case", B3_CASES, ids=str)
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attn_fwd_bwd_bf16x3(lib, case, mode):
+    kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
+
+
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None)])
 def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale):
     kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)

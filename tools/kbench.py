@@ -35,6 +35,7 @@ def main():
     ap.add_argument("which", nargs="*", default=["ffn_fwd", "ffn_bwd", "attn_fwd", "attn_bwd"])
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--B", type=int, default=4096)
+    ap.add_argument("--arith", default="f32", choices=["f32", "bf16x3", "both"])
     args = ap.parse_args()
     dev = "cuda"
     B, T, S, d, heads, dh, H = args.B, 11, 21, 64, 8, 10, 128
@@ -66,20 +67,21 @@ def main():
         params = ops.attn_params(ln_g, ln_b, w_qkv, w_out, b_out)
         gsl = [torch.zeros_like(t) for t in (ln_g, ln_b, w_qkv, w_out, b_out)]
         grads = ops.attn_params(*gsl)
-        for mode, smap, L in (("intra", ops.intra_map(B, T, S), S), ("cross", ops.cross_map(B, T, S), T)):
+        for arith in (["f32", "bf16x3"] if args.arith == "both" else [args.arith]):
+          for mode, smap, L in (("intra", ops.intra_map(B, T, S), S), ("cross", ops.cross_map(B, T, S), T)):
             y = torch.empty_like(x)
             fl = tok * (8 * d * I + 4 * I * L)
-            y, o_save, lse = ops.attn_fwd(x, params, smap, d, heads, dh, save=True, out=y)
+            y, o_save, lse = ops.attn_fwd(x, params, smap, d, heads, dh, save=True, out=y, arith=arith)
             if "attn_fwd" in args.which:
-                ms = timeit(lambda: ops.attn_fwd(x, params, smap, d, heads, dh, save=True, out=y), args.reps)
-                print("attn_fwd L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (L, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
+                ms = timeit(lambda: ops.attn_fwd(x, params, smap, d, heads, dh, save=True, out=y, arith=arith), args.reps)
+                print("attn_fwd %-6s L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (arith, L, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
             if "attn_bwd" in args.which:
                 ws = [None]
 
                 def run():
-                    _, ws[0] = ops.attn_bwd(x, dy, o_save, lse, params, grads, smap, d, heads, dh, workspace=ws[0])
+                    _, ws[0] = ops.attn_bwd(x, dy, o_save, lse, params, grads, smap, d, heads, dh, workspace=ws[0], arith=arith)
                 ms = timeit(run, args.reps)
-                print("attn_bwd L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (L, ms, 2 * fl / ms / 1e9, 100 * 2 * fl / ms / 1e9 / PEAK))
+                print("attn_bwd %-6s L%-2d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (arith, L, ms, 2 * fl / ms / 1e9, 100 * 2 * fl / ms / 1e9 / PEAK))
 
 
 if __name__ == "__main__" and "sgemm" not in sys.argv:

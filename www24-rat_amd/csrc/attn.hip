@@ -951,6 +951,587 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     }
 }
 
+// =============================================================================================================================
+// bf16x3 variants of the north-star geometry (embedding_dim 64, 8 heads x 10): every projection runs on v_mfma_f32_16x16x32_bf16
+// with 3-way split operands (rat_device.h "bf16x3": fp32-class accuracy at 2.7x the fp32-MFMA rate).  What changes against the
+// kernels above is only how the GEMM operands are held and fetched:
+//   * activations that feed a GEMM live in LDS as three bf16 PLANES, split ONCE by the thread that produces them (LayerNorm
+//     output, the dy tile, the attention output O, dQ|dK|dV) — the GEMM loops contain no VALU work, only 16-byte LDS reads (row
+//     operands), transposed 4 x 16 block reads (ds_read_b64_tr_b16: the token-contraction operands of the weight gradients) and
+//     16-byte L2 loads of pre-split weight fragments;
+//   * Q|K|V, dO and O stay fp32 tiles for the VALU attention core, which is unchanged (same instruction sequence => the softmax
+//     statistics, the saved O / log-sum-exp and the pass structure are those of the exact-fp32 kernels).
+constexpr int B3_D = 64, B3_I = 80, B3_Q3 = 240, B3_H = 8, B3_DH = 10;
+constexpr int B3_LDQ = B3_Q3 + 4;                      // fp32 Q|K|V tile row (floats)
+constexpr int B3_XP = 64 * 128;                         // one plane of a [64][64] tile (128-byte rows, swizzled)
+constexpr int B3_OP = 64 * 160 + 64;                    // one plane of a [64][80] tile (160-byte rows) + slack for the padded K step
+constexpr int B3_QP = 64 * 480;                         // one plane of a [64][240] tile (480-byte rows)
+typedef RatPlanes<128, true, B3_XP> PlanesX;
+typedef RatPlanes<160, false, B3_OP> PlanesO;
+typedef RatPlanes<480, false, B3_QP> PlanesQ;
+
+struct Attn3W {                                         // pre-split weight fragments (rat_launch_split_weights)
+    RatWPlanes qkv;      // B[k = d][n = qkv col]      = w_qkv[n][k]      N 240, K 64   (Q|K|V projection)
+    RatWPlanes out;      // B[k = inner][n = d]        = w_out[n][k]      N 64,  K 80   (output projection, forward)
+    RatWPlanes outT;     // B[k = d][n = inner]        = w_out[k][n]      N 80,  K 64   (dO = dy W_out, backward)
+    RatWPlanes qkvT;     // B[k = qkv col][n = d]      = w_qkv[k][n]      N 64,  K 240  (d LN-out = dQKV W_qkv, backward)
+};
+constexpr size_t B3_W_QKV = (size_t)15 * 2 * 3 * 1024, B3_W_OUT = (size_t)4 * 3 * 3 * 1024, B3_W_OUTT = (size_t)5 * 2 * 3 * 1024,
+                 B3_W_QKVT = (size_t)4 * 8 * 3 * 1024;
+constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
+
+constexpr size_t b3_fwd_smem() { return (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8; }
+
+// LayerNorm of the chunk's rows straight from global memory into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns
+// [8 sub, 8 sub + 8) = exactly one 16-byte piece; same arithmetic, in the same order, as layer_norm_rows above.
+__device__ __forceinline__ void b3_layer_norm_to_planes(const AttnArgs& a, const int64_t* rowtok, const PlanesX& xp, const float (&gam)[8],
+                                                        const float (&bet)[8], float* mu_out, float* rs_out) {
+    const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    const int64_t tok = rowtok[r];
+    float xv[8];
+    {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (tok >= 0) {
+            v0 = *reinterpret_cast<const float4*>(a.x + tok * B3_D + 8 * sub);
+            v1 = *reinterpret_cast<const float4*>(a.x + tok * B3_D + 8 * sub + 4);
+        }
+        xv[0] = v0.x; xv[1] = v0.y; xv[2] = v0.z; xv[3] = v0.w; xv[4] = v1.x; xv[5] = v1.y; xv[6] = v1.z; xv[7] = v1.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += xv[k];
+    const float mean = rat_group_sum<8>(s) / (float)B3_D;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = xv[k] - mean;
+        v += t * t;
+    }
+    const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / (float)B3_D + a.eps);
+    float y[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] = tok >= 0 ? (xv[k] - mean) * rstd * gam[k] + bet[k] : 0.f;
+    rat_u4 h, m, l;
+    rat_split8(make_float4(y[0], y[1], y[2], y[3]), make_float4(y[4], y[5], y[6], y[7]), h, m, l);
+    xp.store(r, sub, h, m, l);
+    if (mu_out != nullptr && sub == 0) {
+        mu_out[r] = mean;
+        rs_out[r] = rstd;
+    }
+}
+
+// C[64][16 NT] = A (planes, row operand, KS K-steps) x B (weight fragments).  Wave w owns the row-tile pair {2 (w >> 2), +1} and the
+// column tiles (w & 3) + 4 i: its A fragments are read once; the B fragment of the NEXT (column tile, K step) is requested before
+// the MFMAs of the current one (one fragment in flight: 12 VGPRs instead of a whole column tile's).
+template <int KS, class PA, class Epi>
+__device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
+    const int w = rat_wave(), mt0 = 2 * (w >> 2);
+    RatB3 a[2][KS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[i][s] = A.row_frag(mt0 + i, s);
+    int nt = w & 3;
+    if (nt >= n_tiles) return;
+    RatB3 b = Bw(nt, 0);
+    for (; nt < n_tiles; nt += 4) {
+        f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool last = s == KS - 1;
+            const RatB3 bn = Bw(last ? (nt + 4 < n_tiles ? nt + 4 : nt) : nt, last ? 0 : s + 1);
+            const RatB3 as[2] = {a[0][s], a[1][s]};
+            rat_mfma3_block<2>(acc, as, b);
+            b = bn;
+        }
+        epi(mt0, nt, acc[0]);
+        epi(mt0 + 1, nt, acc[1]);
+    }
+}
+
+template <bool EX>
+__global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
+    RAT_DYN_SMEM(smem);
+    const PlanesX xp{smem};                                                 // LayerNorm(x) planes; later the fp32 output staging tile
+    float* qkv = reinterpret_cast<float*>(smem + 3 * B3_XP);                // [64][244] fp32 Q|K|V; O overwrites Q
+    const PlanesO op{smem + 3 * B3_XP + 64 * B3_LDQ * 4};                   // O planes (row operand of the output projection)
+    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(smem + 3 * B3_XP + 64 * B3_LDQ * 4 + 3 * B3_OP);
+    float* ys = reinterpret_cast<float*>(smem);                             // [64][68] over the (then dead) x planes
+    constexpr int LDY = B3_D + 4;
+    const int L = a.L;
+
+    for (int e = threadIdx.x; e < 3 * B3_OP / 4; e += ATT_THREADS) reinterpret_cast<float*>(op.base)[e] = 0.f;   // incl. the slack
+    for (int e = threadIdx.x; e < 64 * (B3_LDQ - B3_Q3); e += ATT_THREADS) qkv[(e >> 2) * B3_LDQ + B3_Q3 + (e & 3)] = 0.f;
+    float gam[8], bet[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        gam[k] = a.ln_g[8 * (threadIdx.x & 7) + k];
+        bet[k] = a.ln_b[8 * (threadIdx.x & 7) + k];
+    }
+    {
+        int nsq0, rows0;
+        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
+    }
+    __syncthreads();
+    int parity = 0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
+        const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
+        int nsq, rows;
+        {
+            const int64_t q0 = chunk * a.nsq_chunk;
+            const int64_t left = a.nseq - q0;
+            nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+            rows = nsq * a.L;
+        }
+        b3_layer_norm_to_planes(a, rowtok, xp, gam, bet, nullptr, nullptr);
+        if (chunk + gridDim.x < a.nchunks) {
+            int nsq1, rows1;
+            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
+        }
+        __syncthreads();
+        // Q|K|V = LN(x) W_qkv^T
+        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
+        });
+        __syncthreads();
+        // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>
+        float pf = 0.f;
+        if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)
+            pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
+        typedef HeadVec<B3_DH> HV;
+        const int ntasks = nsq * B3_H * L;
+        const float sl2 = a.scale * RAT_LOG2E;
+        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
+            const int i = task % L;
+            const int h = (task / L) % B3_H;
+            const int sq = task / (L * B3_H);
+            const int row_i = sq * L + i;
+            float* qp = qkv + (size_t)row_i * B3_LDQ + h * B3_DH;
+            HV q, o, kv;
+            q.load(qp, B3_DH);
+            o.zero();
+            float m = -INFINITY, l = 0.f;
+            const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + h * B3_DH;
+            int j = 0;
+            for (; j + CORE_UNROLL <= L; j += CORE_UNROLL) {
+                HV kk[CORE_UNROLL], vv[CORE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CORE_UNROLL; ++u) {
+                    const float* kp = kbase + (size_t)(j + u) * B3_LDQ;
+                    kk[u].load(kp, B3_DH);
+                    vv[u].load(kp + B3_I, B3_DH);
+                }
+                float sc[CORE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CORE_UNROLL; ++u) sc[u] = q.dot(kk[u]) * sl2;
+#pragma unroll
+                for (int u = 0; u < CORE_UNROLL; ++u) {
+                    const float mn = fmaxf(m, sc[u]);
+                    const float corr = rat_exp2(m - mn);
+                    const float p = rat_exp2(sc[u] - mn);
+                    l = l * corr + p;
+                    o.scale_axpy(corr, p, vv[u]);
+                    m = mn;
+                }
+            }
+            for (; j < L; ++j) {
+                const float* kp = kbase + (size_t)j * B3_LDQ;
+                kv.load(kp, B3_DH);
+                const float sv = q.dot(kv) * sl2;
+                const float mn = fmaxf(m, sv);
+                const float corr = rat_exp2(m - mn);
+                const float p = rat_exp2(sv - mn);
+                l = l * corr + p;
+                kv.load(kp + B3_I, B3_DH);
+                o.scale_axpy(corr, p, kv);
+                m = mn;
+            }
+            const float inv = 1.0f / l;
+            o.store(qp, B3_DH, inv);
+            const int64_t tok = rowtok[row_i];
+            if (a.o_save != nullptr) o.store(a.o_save + tok * B3_I + h * B3_DH, B3_DH, inv);
+            if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = m + rat_log2(l);
+        }
+        __syncthreads();
+        // O (the Q columns of the valid rows; padding rows are exact zeros) -> planes
+        for (int e = threadIdx.x; e < ATT_ROWS * (B3_I / 8); e += ATT_THREADS) {
+            const int r = e / (B3_I / 8), o8 = e - r * (B3_I / 8);
+            const float* src = qkv + (size_t)r * B3_LDQ + 8 * o8;
+            rat_u4 h, m, l;
+            rat_split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, m, l);
+            op.store(r, o8, h, m, l);
+        }
+        __syncthreads();
+        // y = O W_out^T + b_out (+ residual), staged through LDS for whole-row stores
+        b3_gemm_rows<3>(op, W.out, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
+            const float bias = a.b_out[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ys[(size_t)rat_acc_row(mt, r) * LDY + col] = acc[r] + bias;
+        });
+        __syncthreads();
+        store_rows_residual(a.y, ys, LDY, EX ? a.res : a.x, rowtok, rows, B3_D, true, EX ? a.out_scale : 1.0f);
+        __syncthreads();
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));
+#endif
+    }
+}
+
+// ---- backward, bf16x3.  LDS map (bytes): [x planes 24576][dy planes 24576][Q|K|V fp32 62464][O fp32 21504][dO fp32 21504][misc];
+// the three fp32 tiles are contiguous: once the attention core is done, d(Q|K|V) is re-written over them as planes (3 x 30720),
+// and the dy planes (dead after dO / dW_out) become the fp32 tile of d(LayerNorm out).
+constexpr int B3_LDT = B3_I + 4;                        // fp32 O / dO tile row (floats)
+constexpr int B3_LDN = B3_D + 4;                        // fp32 d(LN out) tile row
+constexpr size_t B3_OFF_DYP = (size_t)3 * B3_XP, B3_OFF_QKV = 2 * B3_OFF_DYP, B3_OFF_OB = B3_OFF_QKV + (size_t)64 * B3_LDQ * 4,
+                 B3_OFF_DOB = B3_OFF_OB + (size_t)64 * B3_LDT * 4, B3_OFF_MISC = B3_OFF_DOB + (size_t)64 * B3_LDT * 4;
+constexpr size_t b3_bwd_smem() { return B3_OFF_MISC + (size_t)64 * (2 + 2 * B3_H) * 4 + 2 * 64 * 8 + 2 * B3_D * 4; }
+static_assert(B3_OFF_MISC - B3_OFF_QKV >= (size_t)3 * B3_QP + 64, "d(Q|K|V) planes overlay the three fp32 tiles");
+static_assert((size_t)64 * B3_LDN * 4 <= (size_t)3 * B3_XP, "d(LN out) overlays the dy planes");
+
+// C[64][64] = A (planes, row operand, KS K-steps) x B: wave w owns row tiles {2 (w >> 2), +1} x column tile (w & 3); operands of
+// step s + 1 are requested before the MFMAs of step s
+template <int KS, class PA, class Epi>
+__device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes& Bw, const Epi& epi) {
+    const int w = rat_wave(), mt0 = 2 * (w >> 2), nt = w & 3;
+    f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+    RatB3 a[2] = {A.row_frag(mt0, 0), A.row_frag(mt0 + 1, 0)};
+    RatB3 b = Bw(nt, 0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int sn = s + 1 < KS ? s + 1 : s;
+        const RatB3 an[2] = {A.row_frag(mt0, sn), A.row_frag(mt0 + 1, sn)};
+        const RatB3 bn = Bw(nt, sn);
+        rat_mfma3_block<2>(acc, a, b);
+        a[0] = an[0];
+        a[1] = an[1];
+        b = bn;
+    }
+    epi(mt0, nt, acc[0]);
+    epi(mt0 + 1, nt, acc[1]);
+}
+
+template <bool EX>
+__global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
+    RAT_DYN_SMEM(smem);
+    const PlanesX xp{smem};                                                  // LayerNorm(x)
+    const PlanesX dyp{smem + B3_OFF_DYP};                                    // dy (x out_scale)
+    float* dxn = reinterpret_cast<float*>(smem + B3_OFF_DYP);                // [64][68] d(LN out), over the dead dy planes
+    float* qkv = reinterpret_cast<float*>(smem + B3_OFF_QKV);                // [64][244] Q|K|V, then dK|dV in place
+    const PlanesQ dqp{smem + B3_OFF_QKV};                                    // d(Q|K|V) planes, over qkv / ob / dob
+    float* ob = reinterpret_cast<float*>(smem + B3_OFF_OB);                  // [64][84] O, then dQ
+    float* dob = reinterpret_cast<float*>(smem + B3_OFF_DOB);                // [64][84] dO
+    float* mu = reinterpret_cast<float*>(smem + B3_OFF_MISC);
+    float* rs = mu + ATT_ROWS;
+    float* lses = rs + ATT_ROWS;                                             // [64][8]
+    float* dlt = lses + ATT_ROWS * B3_H;                                     // [64][8]
+    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(dlt + ATT_ROWS * B3_H);
+    const int L = a.L;
+    const int r_own = threadIdx.x >> 3, sub = threadIdx.x & 7;               // this thread's (row slot, 8-column piece)
+
+    f32x4 accq[QSLOTS], acco[OSLOTS];                                        // persistent dW_qkv / dW_out^T tiles
+#pragma unroll
+    for (int i = 0; i < QSLOTS; ++i) accq[i] = rat_zero4();
+#pragma unroll
+    for (int i = 0; i < OSLOTS; ++i) acco[i] = rat_zero4();
+    float dgam[8], dbet[8], dbo[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dgam[k] = dbet[k] = dbo[k] = 0.f;
+    float* const lnw = reinterpret_cast<float*>(rowtok0 + 2 * ATT_ROWS);     // [2][64] LayerNorm gamma | beta (kept out of the registers)
+    if (threadIdx.x < 2 * B3_D) lnw[threadIdx.x] = threadIdx.x < B3_D ? a.ln_g[threadIdx.x] : a.ln_b[threadIdx.x - B3_D];
+    for (int e = threadIdx.x; e < (int)((B3_OFF_MISC - B3_OFF_QKV) / 4); e += ATT_THREADS) qkv[e] = 0.f;   // pad columns, slack
+    {
+        int nsq0, rows0;
+        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
+    }
+    __syncthreads();
+    int parity = 0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
+        const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
+        int nsq, rows;
+        {
+            const int64_t q0 = chunk * a.nsq_chunk;
+            const int64_t left = a.nseq - q0;
+            nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+            rows = nsq * a.L;
+        }
+        const int64_t tok_own = rowtok[r_own];
+        // ---- P0: x -> LayerNorm -> planes; dy -> planes (+ db_out partials); O, lse -> fp32 tiles
+        {
+            RowFetch<B3_I> fo;
+            fo.issue(a.o_save, rowtok);
+            float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
+            if (tok_own >= 0) {
+                d0 = *reinterpret_cast<const float4*>(a.dy + tok_own * B3_D + 8 * sub);
+                d1 = *reinterpret_cast<const float4*>(a.dy + tok_own * B3_D + 8 * sub + 4);
+            }
+            {
+                float gam[8], bet[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    gam[k] = lnw[8 * sub + k];
+                    bet[k] = lnw[B3_D + 8 * sub + k];
+                }
+                b3_layer_norm_to_planes(a, rowtok, xp, gam, bet, mu, rs);
+            }
+            if (EX && a.out_scale != 1.0f) {
+                const float m_ = a.out_scale;
+                d0.x *= m_; d0.y *= m_; d0.z *= m_; d0.w *= m_; d1.x *= m_; d1.y *= m_; d1.z *= m_; d1.w *= m_;
+            }
+            dbo[0] += d0.x; dbo[1] += d0.y; dbo[2] += d0.z; dbo[3] += d0.w; dbo[4] += d1.x; dbo[5] += d1.y; dbo[6] += d1.z; dbo[7] += d1.w;
+            rat_u4 h, m, l;
+            rat_split8(d0, d1, h, m, l);
+            dyp.store(r_own, sub, h, m, l);
+            fo.stash(ob, B3_LDT);
+            {
+                const int r = threadIdx.x >> 3;                              // 512 threads = 64 rows x 8 heads
+                const int64_t tok = rowtok[r];
+                lses[threadIdx.x] = tok >= 0 ? a.lse_save[tok * B3_H + (threadIdx.x & 7)] : 0.f;
+            }
+        }
+        if (chunk + gridDim.x < a.nchunks) {
+            int nsq1, rows1;
+            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
+        }
+        __syncthreads();
+        // ---- P1: Q|K|V = LN(x) W_qkv^T   P2: dO = dy W_out   P2b: dW_out^T += O^T dy
+        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
+        });
+        RAT_SCHED_FENCE();
+        b3_gemm_rows<2>(dyp, W.outT, B3_I / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * B3_LDT + col] = acc[r];
+        });
+        RAT_SCHED_FENCE();
+        if (rat_wave() < B3_I / 16) {                                        // wave = inner-dimension tile of O^T
+            const int mt = rat_wave(), l = rat_lane(), g = l >> 4, col = 16 * mt + (l & 15);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ob[(size_t)rat_col_slot_row(s, g, j) * B3_LDT + col];
+                const RatB3 af = rat_split8_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+#pragma unroll
+                for (int nt = 0; nt < OSLOTS; ++nt) {
+                    acco[nt] = rat_mfma3(af, dyp.col_frag(nt, s), acco[nt]);
+                    RAT_SCHED_FENCE();
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P3: attention backward on the VALU — the two passes of attn_bwd_kernel<64, 10>
+        typedef HeadVec<B3_DH> HV;
+        const int ntasks = nsq * B3_H * L;
+        const float sl2 = a.scale * RAT_LOG2E;
+        float pf = 0.f;
+        {
+            int t = threadIdx.x;
+            if (chunk + gridDim.x < a.nchunks) {
+                const int64_t* nrt = (rowtok0 + (parity ^ 1) * ATT_ROWS);
+                if (t < ATT_ROWS * 2) pf = prefetch_lines_map(nrt, t, 2, a.x, B3_D);
+                else if ((t -= ATT_ROWS * 2) < ATT_ROWS * 2) pf = prefetch_lines_map(nrt, t, 2, a.dy, B3_D);
+                else if ((t -= ATT_ROWS * 2) < ATT_ROWS * 3) pf = prefetch_lines_map(nrt, t, 3, a.o_save, B3_I);
+                else if ((t -= ATT_ROWS * 3) < ATT_ROWS) pf = prefetch_lines_map(nrt, t, 1, a.lse_save, B3_H);
+            }
+        }
+        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
+            const int i = task % L;
+            const int h = (task / L) % B3_H;
+            const int sq = task / (L * B3_H);
+            const int row_i = sq * L + i;
+            const int ho = h * B3_DH;
+            float* opp = ob + (size_t)row_i * B3_LDT + ho;
+            HV q, go, dq, kv;
+            q.load(qkv + (size_t)row_i * B3_LDQ + ho, B3_DH);
+            go.load(dob + (size_t)row_i * B3_LDT + ho, B3_DH);
+            kv.load(opp, B3_DH);
+            const float delta = go.dot(kv);
+            dq.zero();
+            dlt[row_i * B3_H + h] = delta;
+            const float lse = lses[row_i * B3_H + h];
+            const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + ho;
+            for (int j = 0; j < L; ++j) {
+                const float* kp = kbase + (size_t)j * B3_LDQ;
+                kv.load(kp + B3_I, B3_DH);
+                const float dp = go.dot(kv);
+                kv.load(kp, B3_DH);
+                const float p = rat_exp2(q.dot(kv) * sl2 - lse);
+                dq.axpy(p * (dp - delta), kv);
+            }
+            dq.store(opp, B3_DH, a.scale);
+        }
+        __syncthreads();
+        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
+            const int j = task % L;
+            const int h = (task / L) % B3_H;
+            const int sq = task / (L * B3_H);
+            const int ho = h * B3_DH;
+            float* kp = qkv + (size_t)(sq * L + j) * B3_LDQ + B3_I + ho;
+            HV kk, vv, dk, dv, t;
+            kk.load(kp, B3_DH);
+            vv.load(kp + B3_I, B3_DH);
+            dk.zero();
+            dv.zero();
+            for (int i = 0; i < L; ++i) {
+                const int row_i = sq * L + i;
+                t.load(dob + (size_t)row_i * B3_LDT + ho, B3_DH);
+                const float dp = t.dot(vv);
+                const float lse = lses[row_i * B3_H + h], delta = dlt[row_i * B3_H + h];
+                HV qv;
+                qv.load(qkv + (size_t)row_i * B3_LDQ + ho, B3_DH);
+                const float p = rat_exp2(qv.dot(kk) * sl2 - lse);
+                dv.axpy(p, t);
+                dk.axpy(p * (dp - delta), qv);
+            }
+            dk.store(kp, B3_DH, a.scale);
+            dv.store(kp + B3_I, B3_DH, 1.0f);
+        }
+        __syncthreads();
+        // ---- P3c: d(Q|K|V) = [dQ (in ob) | dK | dV (in qkv)] -> planes over the three fp32 tiles: all reads, barrier, all writes
+        {
+            constexpr int NP = B3_Q3 / 8;                                    // 30 pieces per row
+            constexpr int NIT = (ATT_ROWS * NP + ATT_THREADS - 1) / ATT_THREADS;
+            float4 lo[NIT], hi[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + ATT_THREADS * it;
+                lo[it] = hi[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < ATT_ROWS * NP) {
+                    const int r = e / NP, o = e - r * NP;
+                    const float* src = o < B3_I / 8 ? ob + (size_t)r * B3_LDT + 8 * o : qkv + (size_t)r * B3_LDQ + 8 * o;
+                    lo[it] = *reinterpret_cast<const float4*>(src);
+                    hi[it] = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = threadIdx.x + ATT_THREADS * it;
+                if (e < ATT_ROWS * NP) {
+                    const int r = e / NP, o = e - r * NP;
+                    rat_u4 h, m, l;
+                    rat_split8(lo[it], hi[it], h, m, l);
+                    dqp.store(r, o, h, m, l);
+                }
+            }
+            // the padded last K step of P4 reads 32 bytes past each plane's last row: for the first two planes that is the next
+            // plane's first row (finite), behind the third it is stale fp32 data whose halves may look like bf16 NaNs — clear it
+            if (threadIdx.x < 8) reinterpret_cast<float*>(smem + B3_OFF_QKV + (size_t)3 * B3_QP)[threadIdx.x] = 0.f;
+        }
+        __syncthreads();
+        // ---- P4: d(LN out) = dQKV W_qkv   P5: dW_qkv += dQKV^T LN(x)
+        b3_gemm_rows_longk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col] = acc[r];
+        });
+        RAT_SCHED_FENCE();
+        {
+            const int w = rat_wave(), nt = w & 3;
+            const RatB3 b0 = xp.col_frag(nt, 0), b1 = xp.col_frag(nt, 1);
+#pragma unroll
+            for (int i = 0; i < QSLOTS; ++i) {
+                const int mt = (w >> 2) + 2 * i;
+                if (mt < B3_Q3 / 16) {
+                    accq[i] = rat_mfma3(dqp.col_frag(mt, 0), b0, accq[i]);
+                    accq[i] = rat_mfma3(dqp.col_frag(mt, 1), b1, accq[i]);
+                }
+                RAT_SCHED_FENCE();
+            }
+        }
+        __syncthreads();
+        // ---- P6: LayerNorm backward + the added gradient: dx = add + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma
+        {
+            const bool valid = tok_own >= 0;
+            const float mean = mu[r_own], rstd = rs[r_own];
+            const float* addp = EX ? a.add : a.dy;
+            float xh[8], gg[8], ad[8], out[8], gam[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gam[k] = lnw[8 * sub + k];
+#pragma unroll
+            for (int k = 0; k < 8; k += 4) {
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), av = xv;
+                if (valid) xv = *reinterpret_cast<const float4*>(a.x + tok_own * B3_D + 8 * sub + k);
+                if (valid && addp != nullptr) av = *reinterpret_cast<const float4*>(addp + tok_own * B3_D + 8 * sub + k);
+                const float4 gv = *reinterpret_cast<const float4*>(dxn + (size_t)r_own * B3_LDN + 8 * sub + k);
+                xh[k] = xv.x; xh[k + 1] = xv.y; xh[k + 2] = xv.z; xh[k + 3] = xv.w;
+                ad[k] = av.x; ad[k + 1] = av.y; ad[k + 2] = av.z; ad[k + 3] = av.w;
+                gg[k] = gv.x; gg[k + 1] = gv.y; gg[k + 2] = gv.z; gg[k + 3] = gv.w;
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                xh[k] = valid ? (xh[k] - mean) * rstd : 0.f;
+                gg[k] = valid ? gg[k] : 0.f;
+                const float gw = valid ? gg[k] * gam[k] : 0.f;
+                s1 += gw;
+                s2 += gw * xh[k];
+            }
+            s1 = rat_group_sum<8>(s1) / (float)B3_D;
+            s2 = rat_group_sum<8>(s2) / (float)B3_D;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float gw = valid ? gg[k] * gam[k] : 0.f;
+                out[k] = valid ? ad[k] + rstd * (gw - s1 - xh[k] * s2) : 0.f;
+                dgam[k] += gg[k] * xh[k];
+                dbet[k] += gg[k];
+            }
+            if (valid) {
+                *reinterpret_cast<float4*>(a.y + tok_own * B3_D + 8 * sub) = make_float4(out[0], out[1], out[2], out[3]);
+                *reinterpret_cast<float4*>(a.y + tok_own * B3_D + 8 * sub + 4) = make_float4(out[4], out[5], out[6], out[7]);
+            }
+        }
+        __syncthreads();
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));
+#endif
+    }
+
+    // ---- this work-group's parameter-gradient slab: [dW_qkv | dW_out | db_out | dgamma | dbeta]
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+    float* s_wqkv = slab;
+    float* s_wout = s_wqkv + (int64_t)B3_Q3 * B3_D;
+    float* s_bout = s_wout + (int64_t)B3_D * B3_I;
+    float* s_gam = s_bout + B3_D;
+    float* s_bet = s_gam + B3_D;
+    {
+        const int w = rat_wave(), col = rat_acc_col(w & 3);
+#pragma unroll
+        for (int i = 0; i < QSLOTS; ++i) {
+            const int mt = (w >> 2) + 2 * i;
+            if (mt < B3_Q3 / 16)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_wqkv[(int64_t)rat_acc_row(mt, r) * B3_D + col] = accq[i][r];
+        }
+        if (w < B3_I / 16)
+#pragma unroll
+            for (int nt = 0; nt < OSLOTS; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_wout[(int64_t)rat_acc_col(nt) * B3_I + rat_acc_row(w, r)] = acco[nt][r];
+    }
+    // db_out / dgamma / dbeta: 64 row-slot partials per column -> LDS -> fixed-order column sums
+    float* red = reinterpret_cast<float*>(smem);                             // [64][68]
+    float* const outs[3] = {s_bout, s_gam, s_bet};
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[(size_t)r_own * B3_LDN + 8 * sub + k] = which == 0 ? dbo[k] : (which == 1 ? dgam[k] : dbet[k]);
+        __syncthreads();
+        if (threadIdx.x < B3_D) {
+            float sacc = 0.f;
+            for (int rr = 0; rr < ATT_ROWS; ++rr) sacc += red[(size_t)rr * B3_LDN + threadIdx.x];
+            outs[which][threadIdx.x] = sacc;
+        }
+    }
+}
+
 int check_dims(const RatSeqMap* map, int d, int heads, int dim_head, bool backward) {
     RAT_REQUIRE(map != nullptr, "null seq map");
     RAT_REQUIRE(d > 0 && heads > 0 && dim_head > 0, "bad dims");
@@ -1012,12 +1593,23 @@ int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
 
 extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                             const RatSeqMap* map_host, int d, int heads, int dim_head, float ln_eps, void* stream) {
-    return rat_attn_fwd_ex(x, x, y, o_save, lse_save, w_host, map_host, d, heads, dim_head, 0.f, 1.f, ln_eps, stream);
+    return rat_attn_fwd_ex(x, x, y, o_save, lse_save, w_host, map_host, d, heads, dim_head, 0.f, 1.f, ln_eps, RAT_ARITH_F32, nullptr, 0,
+                           stream);
+}
+
+// bf16x3 kernels exist for the north-star geometry only; every other shape runs the exact-fp32 kernels whatever `arith` says
+static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
+    return d == B3_D && heads == B3_H && dim_head == B3_DH && w->w_out != nullptr;
+}
+
+extern "C" size_t rat_attn_fwd_workspace(int d, int heads, int dim_head) {
+    return (d == B3_D && heads == B3_H && dim_head == B3_DH) ? B3_W_QKV + B3_W_OUT : 0;
 }
 
 extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save,
                                const RatAttnParams* w_host, const RatSeqMap* map_host, int d, int heads, int dim_head,
-                               float softmax_scale, float out_scale, float ln_eps, void* stream) {
+                               float softmax_scale, float out_scale, float ln_eps, int arith, float* workspace,
+                               size_t workspace_bytes, void* stream) {
     if (check_dims(map_host, d, heads, dim_head, false)) return -1;
     RAT_REQUIRE(x && y && w_host && w_host->ln_g && w_host->ln_b && w_host->w_qkv, "null pointer");
     RAT_REQUIRE(w_host->w_out != nullptr || heads * dim_head == d, "missing w_out");
@@ -1037,6 +1629,19 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     const unsigned blocks = (unsigned)(a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu);
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
     const bool plain = res == x && out_scale == 1.0f;
+    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && workspace != nullptr &&
+        workspace_bytes >= B3_W_QKV + B3_W_OUT && aligned16(workspace)) {
+        char* ws = reinterpret_cast<char*>(workspace);
+        if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
+            rat_launch_split_weights(w_host->w_out, B3_D, B3_I, B3_I, 0, ws + B3_W_QKV, stream)) return -1;
+        Attn3W W{};
+        W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
+        W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 3};
+        const unsigned b3_blocks = (unsigned)(a.nchunks < 256 ? a.nchunks : 256);
+        if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        return rat_check_launch("rat_attn_fwd (bf16x3)");
+    }
     if (fast == 64 && dim_head == 10 && plain) RAT_LAUNCH((attn_fwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
@@ -1061,7 +1666,9 @@ extern "C" int rat_attn_fused_supported(int d, int heads, int dim_head, int L) {
 
 extern "C" size_t rat_attn_bwd_workspace(int d, int heads, int dim_head) {
     const AttnGeom g(d, heads, dim_head);
-    return (size_t)256 * (size_t)g.slab_floats() * sizeof(float);
+    const size_t slabs = (size_t)256 * (size_t)g.slab_floats() * sizeof(float);
+    const bool b3 = d == B3_D && heads == B3_H && dim_head == B3_DH;         // + the pre-split weight fragments of the bf16x3 kernel
+    return slabs + (b3 ? B3_W_QKV + B3_W_OUTT + B3_W_QKVT : 0);
 }
 
 extern "C" int rat_attn_bwd(const float* x, const float* dy, const float* o_save, const float* lse_save, float* dx,
@@ -1069,13 +1676,13 @@ extern "C" int rat_attn_bwd(const float* x, const float* dy, const float* o_save
                             size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
                             float ln_eps, void* stream) {
     return rat_attn_bwd_ex(x, dy, dy, o_save, lse_save, dx, w_host, grads_host, workspace, workspace_bytes, map_host, d, heads,
-                           dim_head, 0.f, 1.f, ln_eps, stream);
+                           dim_head, 0.f, 1.f, ln_eps, RAT_ARITH_F32, stream);
 }
 
 extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save,
                                float* dx, const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace,
                                size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
-                               float softmax_scale, float out_scale, float ln_eps, void* stream) {
+                               float softmax_scale, float out_scale, float ln_eps, int arith, void* stream) {
     if (check_dims(map_host, d, heads, dim_head, true)) return -1;
     RAT_REQUIRE(x && dy && o_save && lse_save && dx && w_host && grads_host && workspace, "null pointer");
     RAT_REQUIRE(w_host->w_out != nullptr || heads * dim_head == d, "missing w_out");
@@ -1098,6 +1705,19 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
     const size_t smem = g.bwd_smem(heads);
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
+    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && aligned16(workspace) &&
+        (a.slab_stride * 256 * 4) % 16 == 0) {
+        char* ws = reinterpret_cast<char*>(workspace) + (size_t)256 * a.slab_stride * sizeof(float);
+        if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
+            rat_launch_split_weights(w_host->w_out, B3_I, B3_D, B3_I, 1, ws + B3_W_QKV, stream) ||
+            rat_launch_split_weights(w_host->w_qkv, B3_D, B3_Q3, B3_D, 1, ws + B3_W_QKV + B3_W_OUTT, stream)) return -1;
+        Attn3W W{};
+        W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
+        W.outT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 2};
+        W.qkvT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV + B3_W_OUTT), 8};
+        if (add == dy && out_scale == 1.0f) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+    } else
     if (fast == 64 && dim_head == 10 && a.add_lds) RAT_LAUNCH((attn_bwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);

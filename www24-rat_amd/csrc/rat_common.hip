@@ -95,3 +95,31 @@ int rat_launch_transpose(const float* src, float* dst, int R, int C, void* strea
     RAT_LAUNCH(rat_transpose_kernel, (unsigned)(blocks < 256 ? blocks : 256), 256, 0, stream, src, dst, R, C);
     return rat_check_launch("rat_transpose");
 }
+
+// weights -> fragment-major bf16x3 planes (rat_device.h RatWPlanes): one thread per (n tile, K step, lane)
+__global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __restrict__ w, int N, int K, int ld, int transpose,
+                                                                rat_u4* __restrict__ out, int ntiles, int steps) {
+    const int total = ntiles * steps * 64;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int lane = e & 63, fs = e >> 6, nt = fs / steps, s = fs - nt * steps;
+        const int n = 16 * nt + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            v[j] = (n < N && k < K) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
+        }
+        rat_u4 h, m, l;
+        rat_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
+        rat_u4* o = out + ((size_t)fs * 3) * 64 + lane;
+        o[0] = h;
+        o[64] = m;
+        o[128] = l;
+    }
+}
+int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream) {
+    const int ntiles = (N + 15) / 16, steps = (K + 31) / 32;
+    const int blocks = (ntiles * steps * 64 + 255) / 256;
+    RAT_LAUNCH(rat_split_weights_kernel, (unsigned)blocks, 256, 0, stream, w, N, K, ld, transpose, static_cast<rat_u4*>(out), ntiles, steps);
+    return rat_check_launch("rat_split_weights");
+}

@@ -509,6 +509,152 @@ __device__ __forceinline__ void rat_wave_gemm_ct(f32x4 (&acc)[SL], const AF& af,
     }
 }
 
+// ============================================================================================================================
+// bf16x3: fp32 GEMMs on the bf16 matrix instruction (v_mfma_f32_16x16x32_bf16, 16x the fp32 MFMA rate per FLOP).
+//
+//   x = h + m + l EXACTLY, with h, m, l the three 8-bit chunks of x's 24-bit significand as bf16 numbers (truncation split: h = x
+//   with the low 16 bits cleared, m = the same of x - h, l = x - h - m; every subtraction is exact).  A product a*b is evaluated
+//   as the six cross terms of weight >= 2^-16:  al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh  (each bf16 x bf16 product is exact
+//   in fp32; the MFMA accumulates in fp32).  Dropped: am*bl + al*bm + al*bl <= 2^-23 |a b| — the size of ONE fp32 rounding of the
+//   product, so the result has fp32-class accuracy (measured: tools/probes/bf16x3_probe.hip) while costing 6 x 16 cycles per
+//   K = 32 step of a 16x16 tile instead of 8 x 32 cycles on v_mfma_f32_16x16x4_f32.
+// Lane maps (cdna_hip_programming.md §3): A: lane l holds A[row l & 15][k = 8 (l >> 4) + j], j = 0..7 (one 16-byte fragment);
+// B: lane l holds B[k = 8 (l >> 4) + j][col l & 15]; C/D as the fp32 form.  As everywhere in this file the k order inside a
+// step may be permuted as long as A and B agree.
+#ifdef RAT_EMU
+#define RAT_MFMA_BF16(a, b, c) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
+#define RAT_LDS_TR16(p) emu_lds_tr16((const unsigned short*)(p))
+struct rat_u4 { unsigned x, y, z, w; };
+#else
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define RAT_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// ds_read_b64_tr_b16: lane 4q + p of every 16-lane group supplies the address of (row q, columns 4p..4p+3) of a 4 x 16 block of
+// 16-bit elements; lane i of the group receives column i, row q in element q (cdna_hip_programming.md T10; probe (e))
+#define RAT_LDS_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p))
+typedef uint4 rat_u4;
+#endif
+
+struct RatB3 {                       // one operand fragment in its three planes
+    bf16x8 h, m, l;
+};
+
+__device__ __forceinline__ unsigned rat_fbits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float rat_bitsf(unsigned u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ bf16x8 rat_as_bf16x8(const rat_u4& v) { return __builtin_bit_cast(bf16x8, v); }
+
+// two floats -> their packed (low half = x0, high half = x1) bf16 chunks
+__device__ __forceinline__ void rat_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned h0 = rat_fbits(x0) & 0xffff0000u, h1 = rat_fbits(x1) & 0xffff0000u;
+    const float r0 = x0 - rat_bitsf(h0), r1 = x1 - rat_bitsf(h1);
+    const unsigned m0 = rat_fbits(r0) & 0xffff0000u, m1 = rat_fbits(r1) & 0xffff0000u;
+    const float s0 = r0 - rat_bitsf(m0), s1 = r1 - rat_bitsf(m1);
+    h = (h0 >> 16) | h1;
+    m = (m0 >> 16) | m1;
+    l = (rat_fbits(s0) >> 16) | (rat_fbits(s1) & 0xffff0000u);
+}
+// eight floats (two float4: elements 0..3, 4..7) -> three 16-byte pieces
+__device__ __forceinline__ void rat_split8(const float4& a, const float4& b, rat_u4& h, rat_u4& m, rat_u4& l) {
+    rat_split2(a.x, a.y, h.x, m.x, l.x);
+    rat_split2(a.z, a.w, h.y, m.y, l.y);
+    rat_split2(b.x, b.y, h.z, m.z, l.z);
+    rat_split2(b.z, b.w, h.w, m.w, l.w);
+}
+__device__ __forceinline__ RatB3 rat_split8_frag(const float4& a, const float4& b) {
+    rat_u4 h, m, l;
+    rat_split8(a, b, h, m, l);
+    return RatB3{rat_as_bf16x8(h), rat_as_bf16x8(m), rat_as_bf16x8(l)};
+}
+// value of element e (0..7) of a 16-byte piece triple: h + m + l is exact, in this order
+__device__ __forceinline__ float rat_join(unsigned h, unsigned m, unsigned l, int hi) {
+    const unsigned sh = hi ? 0u : 16u, mk = hi ? 0xffff0000u : 0xffffffffu;
+    return (rat_bitsf((h << sh) & mk | 0u) + rat_bitsf((m << sh) & mk)) + rat_bitsf((l << sh) & mk);
+}
+
+// c += a * b, six cross products, small terms first
+__device__ __forceinline__ f32x4 rat_mfma3(const RatB3& a, const RatB3& b, f32x4 c) {
+    c = RAT_MFMA_BF16(a.l, b.h, c);
+    c = RAT_MFMA_BF16(a.h, b.l, c);
+    c = RAT_MFMA_BF16(a.m, b.m, c);
+    c = RAT_MFMA_BF16(a.m, b.h, c);
+    c = RAT_MFMA_BF16(a.h, b.m, c);
+    c = RAT_MFMA_BF16(a.h, b.h, c);
+    return c;
+}
+// MT row tiles against one B fragment: the MT independent accumulator chains interleave product by product
+template <int MT>
+__device__ __forceinline__ void rat_mfma3_block(f32x4 (&acc)[MT], const RatB3 (&a)[MT], const RatB3& b) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA_BF16(a[i].l, b.h, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA_BF16(a[i].h, b.l, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA_BF16(a[i].m, b.m, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA_BF16(a[i].m, b.h, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA_BF16(a[i].h, b.m, acc[i]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = RAT_MFMA_BF16(a[i].h, b.h, acc[i]);
+}
+
+// ---- an activation tile [64 rows][W columns] held in LDS as three bf16 planes.  Unit = a 16-byte PIECE (8 consecutive columns
+// of one row); rows are RS bytes apart; SWZ: the piece index is XORed with (row & 7), which makes the 16-byte row reads of an
+// MFMA fragment AND the transposed 4-row block reads below bank-conflict free for 128-byte rows (W = 64).
+template <int RS, bool SWZ, int PLANE_BYTES>
+struct RatPlanes {
+    char* base;
+    __device__ __forceinline__ int off(int r, int o) const { return r * RS + 16 * (SWZ ? (o ^ (r & 7)) : o); }
+    __device__ __forceinline__ void store(int r, int o, const rat_u4& h, const rat_u4& m, const rat_u4& l) const {
+        const int a = off(r, o);
+        *reinterpret_cast<rat_u4*>(base + a) = h;
+        *reinterpret_cast<rat_u4*>(base + PLANE_BYTES + a) = m;
+        *reinterpret_cast<rat_u4*>(base + 2 * PLANE_BYTES + a) = l;
+    }
+    // the tile as a ROW operand (A[row][k] of C = A B): fragment of row tile `mt`, K-step `s` (columns 32 s .. 32 s + 31)
+    __device__ __forceinline__ RatB3 row_frag(int mt, int s) const {
+        const int l = rat_lane(), a = off(16 * mt + (l & 15), 4 * s + (l >> 4));
+        return RatB3{rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(base + a)),
+                     rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(base + PLANE_BYTES + a)),
+                     rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(base + 2 * PLANE_BYTES + a))};
+    }
+    // the tile as a COLUMN operand (contraction over the 64 rows): fragment for column tile `ct` (columns 16 ct .. +15), K-step s
+    // = rows 32 s .. 32 s + 31.  k slot j of lane group g <-> row 32 s + 4 g + j (j < 4), 32 s + 16 + 4 g + (j - 4) (j >= 4):
+    // two transposed 4 x 16 block reads per plane.  Every col_frag of every tile uses this same row order.
+    __device__ __forceinline__ bf16x8 col_plane(const char* pl, int ct, int s) const {
+        const int l = rat_lane(), g = l >> 4, q = (l >> 2) & 3, p = l & 3;
+        const int o = 2 * ct + (p >> 1), hb = 8 * (p & 1);
+        const s16x4 lo = RAT_LDS_TR16(pl + off(32 * s + 4 * g + q, o) + hb);
+        const s16x4 hi = RAT_LDS_TR16(pl + off(32 * s + 16 + 4 * g + q, o) + hb);
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r[e] = lo[e];
+            r[4 + e] = hi[e];
+        }
+        return r;
+    }
+    __device__ __forceinline__ RatB3 col_frag(int ct, int s) const {
+        return RatB3{col_plane(base, ct, s), col_plane(base + PLANE_BYTES, ct, s), col_plane(base + 2 * PLANE_BYTES, ct, s)};
+    }
+};
+// the row order of col_frag, for operands that are fetched some other way (fp32 column reads + split)
+__device__ __forceinline__ int rat_col_slot_row(int s, int g, int j) { return 32 * s + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)); }
+
+// ---- weights as B operands: pre-split by rat_launch_split_weights into FRAGMENT-MAJOR planes in global memory —
+// [n tile][K step][plane][lane] x 16 bytes — so that a wave's fragment is one coalesced 1 KB load per plane (L2-resident)
+struct RatWPlanes {
+    const rat_u4* base;
+    int steps;
+    __device__ __forceinline__ RatB3 operator()(int nt, int s) const {
+        const rat_u4* p = base + ((size_t)(nt * steps + s) * 3) * 64 + rat_lane();
+        return RatB3{rat_as_bf16x8(p[0]), rat_as_bf16x8(p[64]), rat_as_bf16x8(p[128])};
+    }
+};
+// B[k][n] = transpose ? w[k * ld + n] : w[n * ld + k] for n < N, k < K (zero beyond); out: rat_wplanes_bytes(N, K) bytes
+inline size_t rat_wplanes_bytes(int N, int K) { return (size_t)((N + 15) / 16) * ((K + 31) / 32) * 3 * 64 * 16; }
+int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream);
+
 // row/col of accumulator register r of a 16x16 tile
 __device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 16 + (rat_lane() >> 4) * 4 + r; }
 __device__ __forceinline__ int rat_acc_col(int tile_n) { return tile_n * 16 + (rat_lane() & 15); }

@@ -224,6 +224,7 @@ class RAT_m2(BaseModel):
         #   stable sort + segmented reduction (bit-reproducible); "sparse" (unique rows, gradient rows) lists + lazy row Adam, no
         #   dense table gradient at all (BASELINE configs[3]); "auto" = sparse above 8 GB of tables when embedding_regularizer
         #   is 0, else atomic
+        self._arith_request = str(kwargs.get("arith", "auto"))
         self._embedding_grad = str(kwargs.get("embedding_grad", "auto"))
         if self._embedding_grad not in ("auto", "atomic", "sorted", "sparse"):
             raise ValueError("embedding_grad=%r" % self._embedding_grad)
@@ -237,15 +238,26 @@ class RAT_m2(BaseModel):
         self.model_to_device()
 
     # ------------------------------------------------------------------------------ arithmetic of the encoder GEMMs
+    # "f32": v_mfma_f32_16x16x4_f32, exact fp32 (bit-identical to a k-ordered fmaf chain).  "bf16x3": operands split exactly into
+    # three bf16 chunks, six cross products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation — fp32-class accuracy (every parity
+    # gate of tests/ holds at unchanged tolerances) at ~2.4x the MFMA rate; compiled for embedding_dim 64 with 8 heads x 10, other
+    # shapes run exact fp32 whatever is selected.  kwarg / attribute `arith`: "auto" (= bf16x3 where compiled), "f32", "bf16x3".
     arith = "f32"
 
     def arith_modes(self):
-        """arithmetic variants the loaded library offers for the encoder GEMMs ("f32" = exact fp32 MFMA, always present)"""
-        return ["f32"]
+        """arithmetic variants the loaded library offers for THIS model's encoder shapes ("f32" is always present)"""
+        c = self._cfg
+        modes = ["f32"]
+        ok = lambda h: self._lib.size("rat_attn_fwd_workspace", c["d"], h, c["dh"]) > 0            # noqa: E731
+        if self._lib is not None and (ok(c["heads"]) or (c["heads"] % 8 == 0 and ok(8))):       # (wide heads run in groups of 8)
+            modes.append("bf16x3")
+        return modes
 
     def set_arith(self, mode):
+        if mode == "auto":
+            mode = self.arith_modes()[-1]
         if mode not in self.arith_modes():
-            raise ValueError("arith=%r is not available (have %s)" % (mode, self.arith_modes()))
+            raise ValueError("arith=%r is not available for this shape (have %s)" % (mode, self.arith_modes()))
         self.arith = mode
 
     # ------------------------------------------------------------------------------ encoder (overridden by the variants)
@@ -311,14 +323,15 @@ class RAT_m2(BaseModel):
         d, heads, dh = c["d"], c["heads"], c["dh"]
         mode, per = self._attn_mode(smap)
         if mode == "fused":
-            y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, lib=lib)
+            y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, arith=self.arith, lib=lib)
             return y, (o, l)
         if mode == "grouped":
             if desc[0][3] is None:
                 raise NotImplementedError("grouped attention needs an output projection")
             y, kept = None, []
             for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(desc[0], per)):
-                y, o, l = ops.attn_fwd_ex(x, x if g == 0 else y, params_g, smap, d, per, dh, 0.0, 1.0, save=save, out=y, lib=lib)
+                y, o, l = ops.attn_fwd_ex(x, x if g == 0 else y, params_g, smap, d, per, dh, 0.0, 1.0, save=save, out=y,
+                                          arith=self.arith, lib=lib)
                 kept.append((w_g, wo_g, params_g, zb, o, l))
             return y, (kept if save else None)
         inner, ntok = heads * dh, x.numel() // d
@@ -342,7 +355,7 @@ class RAT_m2(BaseModel):
         if mode == "fused":
             ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
             grads = ops.attn_params(*[G(n) if n else None for n in names])
-            dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, lib=lib)
+            dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, arith=self.arith, lib=lib)
             return dx
         if mode == "grouped":
             groups, ig = heads // per, per * dh
@@ -357,7 +370,7 @@ class RAT_m2(BaseModel):
                 first = g == 0
                 grads_g = ops.attn_params(g_lng if first else t_lng, g_lnb if first else t_lnb, t_w, t_wo, g_bout if first else t_b)
                 dx, _ = ops.attn_bwd_ex(x_in, dy, dy if first else dx, o, l, params_g, grads_g, smap, d, per, dh, 0.0, 1.0,
-                                        workspace=ws, out=dx, lib=lib)                    # dx = dy + sum over groups, in place
+                                        workspace=ws, out=dx, arith=self.arith, lib=lib)  # dx = dy + sum over groups, in place
                 gq[:, g].copy_(t_w.view(3, ig, d))
                 go[:, g].copy_(t_wo)
                 if not first:                                                              # LayerNorm sees every group's gradient
@@ -472,6 +485,7 @@ class RAT_m2(BaseModel):
         self._n_sparse = self._n_tab if mode == "sparse" else 0
         self._gbuf = None
         self._build_descriptors()
+        self.set_arith(self._arith_request)
 
     def _p(self, name):
         return self._params[name].data
