@@ -26,6 +26,8 @@ extern "C" {
 #endif
 
 #define RAT_ABI_VERSION 2
+#define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
+#define RAT_ARITH_BF16X3 1
 
 int rat_version(void);
 const char* rat_last_error(void);
@@ -123,8 +125,6 @@ int rat_attn_bwd(const float* x, const float* dy, const float* o_save, const flo
  *                     the north-star geometry (embedding_dim 64, 8 heads x 10); any other shape runs RAT_ARITH_F32 regardless.
  * The forward needs rat_attn_fwd_workspace() bytes of workspace for the pre-split weight fragments under RAT_ARITH_BF16X3
  * (NULL / too small: exact fp32); the backward's rat_attn_bwd_workspace() already covers its own. */
-#define RAT_ARITH_F32 0
-#define RAT_ARITH_BF16X3 1
 size_t rat_attn_fwd_workspace(int d, int heads, int dim_head);
 int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
@@ -165,12 +165,14 @@ int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, con
 /* The same block MLP with the residual taken from a SEPARATE tensor: y = W2 gelu_erf(W1 x + b1) + b2 + res (res == x gives
  * rat_ffn_fwd; res == NULL: no residual).  RAT_m1's PreNorm(FeedForward) (RAT_m1.py:143-161,201,207: ff(norm(x)) + x) is
  * rat_layernorm_fwd followed by this with x = norm(x), res = x.  Backward: add_dy = 1 adds dy to dx (residual from x
- * itself), add_dy = 0 returns only the gradient through the two Linear layers. */
+ * itself), add_dy = 0 returns only the gradient through the two Linear layers.
+ * arith: RAT_ARITH_F32 (what rat_ffn_fwd / rat_ffn_bwd use) or RAT_ARITH_BF16X3 (see rat_attn_fwd_ex; compiled for d = 64,
+ * hidden = 128, every other shape runs exact fp32). */
 int rat_ffn_fwd_res(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2,
-                    const float* b2, int64_t ntok, int d, int hidden, void* stream);
+                    const float* b2, int64_t ntok, int d, int hidden, int arith, void* stream);
 int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
-                    size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, void* stream);
+                    size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, int arith, void* stream);
 
 /* ---- K2c: stand-alone nn.LayerNorm(d) (biased variance, affine) over selected token rows — RAT_m1's PreNorm in front of
  * FeedForward and the final `self.norm` of each Transformer (RAT_m1.py:137-141,198,209), of which only token 0 of every

@@ -217,7 +217,7 @@ def check_attn_core_strided(lib, dev, B, T, S, heads, dh):
     close(dqkv, r.grad, 1e-4, 1e-4, "dqkv")
 
 
-def check_ffn(lib, dev, ntok, d, hidden):
+def check_ffn(lib, dev, ntok, d, hidden, arith="f32"):
     rs = np.random.RandomState(3)
     x = rnd(rs, ntok, d)
     ws = (rnd(rs, hidden, d, scale=d ** -0.5), 0.1 * rnd(rs, hidden), rnd(rs, d, hidden, scale=hidden ** -0.5), 0.1 * rnd(rs, d))
@@ -228,14 +228,21 @@ def check_ffn(lib, dev, ntok, d, hidden):
     ref.backward(dy.double())
     xd, dyd = x.to(dev), dy.to(dev)
     wd = [w.to(dev) for w in ws]
-    y = ops.ffn_fwd(xd, *wd, d, hidden, lib=lib)
+    y = ops.ffn_fwd(xd, *wd, d, hidden, arith=arith, lib=lib)
     close(y, ref, 2e-5, 2e-5, "y")
     gs = [torch.zeros_like(w) for w in wd]
-    dx, _ = ops.ffn_bwd(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, lib=lib)
+    dx, _ = ops.ffn_bwd(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, arith=arith, lib=lib)
     scale = max(1.0, ntok ** 0.5 / 4)
     close(dx, xr.grad, 1e-4, 1e-4, "dx")
     for g, w in zip(gs, wr):
         close(g, w.grad, 1e-4, 1e-4 * scale)
+    if arith != "f32":                                          # the two arithmetic variants side by side
+        y0 = ops.ffn_fwd(xd, *wd, d, hidden, lib=lib)
+        g0 = [torch.zeros_like(w) for w in wd]
+        dx0, _ = ops.ffn_bwd(xd, dyd, *wd, g0[0], g0[1], g0[2], g0[3], d, hidden, lib=lib)
+        for name, a_, b_ in [("y", y, y0), ("dx", dx, dx0)] + [("g%d" % i, ga, gb) for i, (ga, gb) in enumerate(zip(gs, g0))]:
+            err = float((a_ - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
+            assert err < 4e-6, ("bf16x3 vs exact fp32", name, err)
 
 
 def check_ffn_res(lib, dev, ntok, d, hidden, with_res):

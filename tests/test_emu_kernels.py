@@ -52,11 +52,24 @@ def test_attn_fwd_bwd(emu, case, mode):
     kc.check_attn(emu, "cpu", case, mode)
 
 
+@pytest.fixture()
+def two_blocks(monkeypatch):
+    monkeypatch.setenv("RAT_MAX_BLOCKS", "2")
+
+
 @pytest.mark.parametrize("mode", ["intra", "cross"])
-def test_attn_fwd_bwd_bf16x3(emu, mode):
+def test_attn_fwd_bwd_bf16x3(emu, mode, two_blocks):
     """the split-operand bf16 MFMA kernels (plane images in LDS, transposed block reads, pre-split weight fragments) through the
-    emulated v_mfma_f32_16x16x32_bf16 / ds_read_b64_tr_b16; two chunks in one phase, three in the other, ragged tails"""
+    emulated v_mfma_f32_16x16x32_bf16 / ds_read_b64_tr_b16.  RAT_MAX_BLOCKS=2 (test knob of the library): two work-groups loop over 4-5 chunks each — persistent weight-gradient accumulators, double-buffered row maps, load-ahead, a ragged
+    last chunk."""
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), mode, arith="bf16x3")
+
+
+def test_persistent_kernels_loop_over_several_chunks(emu, two_blocks):
+    """exact-fp32 fast kernels and the FFN with every work-group looping over several chunks (RAT_MAX_BLOCKS=2)"""
+    kc.check_attn(emu, "cpu", (2, 5, 9, 64, 8, 10, True), "intra")
+    kc.check_ffn(emu, "cpu", 200, 64, 128)
+    kc.check_ffn(emu, "cpu", 200, 64, 128, arith="bf16x3")
 
 
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (1, 70, 1, 10, None), (2, 33, 2, 7, 0.3)])

@@ -24,9 +24,10 @@ PHASES = {
                       "pass2 (dK,dV) + copy", "dXn gemm (wave 0)", "dWqkv + barrier", "LN bwd + store"]),
     24: ("ffn_fwd", ["load", "W1 gemm + gelu", "W2 gemm + store"]),
     36: ("ffn_bwd", ["load", "W1 gemm + gelu", "dW2", "dh gemm", "dx gemm + dW1"]),
-    48: ("attn2_fwd", ["load+LN (+prev out-proj tail)", "QKV gemm", "core 4x4", "out-proj+store (wave 0)"]),
+    48: ("attn_fwd bf16x3", ["LN -> planes", "QKV gemm", "softmax(QK)V valu", "O -> planes", "out-proj", "store"]),
     72: ("ffn_bwd_t (wave 0)", ["consume + stage", "h / dh chain + gelu", "dx partial", "barrier 1", "dx store + prefetch issue", "dW1, dW2", "barrier 2"]),
-    60: ("attn2_core_fwd(wave0)", ["loads issue", "S mfma", "softmax", "PV", "stores", "-", "-", "-", "-", "-", "-", "loop"]),
+    60: ("attn_bwd bf16x3", ["loads, LN, planes", "QKV gemm (wave 0)", "dO gemm (wave 0)", "dW_out + barrier", "pass1 (dQ)", "pass2 (dK,dV)",
+                             "dQKV -> planes", "dXn gemm (wave 0)", "dW_qkv + barrier", "LN bwd + store"]),
 }
 
 

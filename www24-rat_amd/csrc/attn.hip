@@ -87,6 +87,10 @@ struct AttnGeom {
 };
 
 __device__ __forceinline__ int64_t seq_token(const AttnArgs& a, int64_t q, int p) {
+    if (a.nseq <= 0x7fffffffLL && a.q_div <= 0x7fffffffLL) {          // 32-bit divide (a 64-bit one is a ~200-instruction sequence)
+        const unsigned qq = (unsigned)q, dv = (unsigned)a.q_div, hi = qq / dv;
+        return (int64_t)hi * a.hi_stride + (int64_t)(qq - hi * dv) * a.lo_stride + (int64_t)p * a.pos_stride;
+    }
     return (q / a.q_div) * a.hi_stride + (q % a.q_div) * a.lo_stride + (int64_t)p * a.pos_stride;
 }
 
@@ -966,9 +970,9 @@ constexpr int B3_LDQ = B3_Q3 + 4;                      // fp32 Q|K|V tile row (f
 constexpr int B3_XP = 64 * 128;                         // one plane of a [64][64] tile (128-byte rows, swizzled)
 constexpr int B3_OP = 64 * 160 + 64;                    // one plane of a [64][80] tile (160-byte rows) + slack for the padded K step
 constexpr int B3_QP = 64 * 480;                         // one plane of a [64][240] tile (480-byte rows)
-typedef RatPlanes<128, true, B3_XP> PlanesX;
-typedef RatPlanes<160, false, B3_OP> PlanesO;
-typedef RatPlanes<480, false, B3_QP> PlanesQ;
+typedef RatPlanes<128, 7, B3_XP> PlanesX;
+typedef RatPlanes<160, 0, B3_OP> PlanesO;
+typedef RatPlanes<480, 0, B3_QP> PlanesQ;
 
 struct Attn3W {                                         // pre-split weight fragments (rat_launch_split_weights)
     RatWPlanes qkv;      // B[k = d][n = qkv col]      = w_qkv[n][k]      N 240, K 64   (Q|K|V projection)
@@ -982,21 +986,13 @@ constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
 
 constexpr size_t b3_fwd_smem() { return (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8; }
 
-// LayerNorm of the chunk's rows straight from global memory into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns
-// [8 sub, 8 sub + 8) = exactly one 16-byte piece; same arithmetic, in the same order, as layer_norm_rows above.
-__device__ __forceinline__ void b3_layer_norm_to_planes(const AttnArgs& a, const int64_t* rowtok, const PlanesX& xp, const float (&gam)[8],
-                                                        const float (&bet)[8], float* mu_out, float* rs_out) {
+// LayerNorm of one row piece into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns [8 sub, 8 sub + 8) = exactly
+// one 16-byte piece, handed over in two float4 (loaded by the caller, usually a whole chunk ahead); same arithmetic, in the same
+// order, as layer_norm_rows above.
+__device__ __forceinline__ void b3_layer_norm_to_planes(bool valid, const float4& v0, const float4& v1, float eps, const PlanesX& xp,
+                                                        const float (&gam)[8], const float (&bet)[8], float* mu_out, float* rs_out) {
     const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    const int64_t tok = rowtok[r];
-    float xv[8];
-    {
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (tok >= 0) {
-            v0 = *reinterpret_cast<const float4*>(a.x + tok * B3_D + 8 * sub);
-            v1 = *reinterpret_cast<const float4*>(a.x + tok * B3_D + 8 * sub + 4);
-        }
-        xv[0] = v0.x; xv[1] = v0.y; xv[2] = v0.z; xv[3] = v0.w; xv[4] = v1.x; xv[5] = v1.y; xv[6] = v1.z; xv[7] = v1.w;
-    }
+    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += xv[k];
@@ -1007,10 +1003,10 @@ __device__ __forceinline__ void b3_layer_norm_to_planes(const AttnArgs& a, const
         const float t = xv[k] - mean;
         v += t * t;
     }
-    const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / (float)B3_D + a.eps);
+    const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / (float)B3_D + eps);
     float y[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) y[k] = tok >= 0 ? (xv[k] - mean) * rstd * gam[k] + bet[k] : 0.f;
+    for (int k = 0; k < 8; ++k) y[k] = valid ? (xv[k] - mean) * rstd * gam[k] + bet[k] : 0.f;
     rat_u4 h, m, l;
     rat_split8(make_float4(y[0], y[1], y[2], y[3]), make_float4(y[4], y[5], y[6], y[7]), h, m, l);
     xp.store(r, sub, h, m, l);
@@ -1019,23 +1015,63 @@ __device__ __forceinline__ void b3_layer_norm_to_planes(const AttnArgs& a, const
         rs_out[r] = rstd;
     }
 }
+// this thread's piece of a token-indexed [.][64] tensor for the chunk whose row map is `rowtok` (zeros for padding rows)
+__device__ __forceinline__ void b3_load_piece(const float* src, const int64_t* rowtok, float4& v0, float4& v1) {
+    const int64_t tok = rowtok[threadIdx.x >> 3];
+    v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tok >= 0) {
+        v0 = *reinterpret_cast<const float4*>(src + tok * B3_D + 8 * (threadIdx.x & 7));
+        v1 = *reinterpret_cast<const float4*>(src + tok * B3_D + 8 * (threadIdx.x & 7) + 4);
+    }
+}
 
 // C[64][16 NT] = A (planes, row operand, KS K-steps) x B (weight fragments).  Wave w owns the row-tile pair {2 (w >> 2), +1} and the
-// column tiles (w & 3) + 4 i: its A fragments are read once; the B fragment of the NEXT (column tile, K step) is requested before
-// the MFMAs of the current one (one fragment in flight: 12 VGPRs instead of a whole column tile's).
-template <int KS, class PA, class Epi>
+// column tiles (w & 3) + 4 i: its A fragments are read once; B fragments are requested ahead of their MFMAs — B3_PREFETCH_TILE 1:
+// the whole next column tile (KS fragments in flight), 0: one fragment (12 VGPRs) ahead.
+#ifndef B3_PREFETCH_TILE
+#define B3_PREFETCH_TILE 0
+#endif
+#ifndef B3_LONGK_DEPTH
+#define B3_LONGK_DEPTH 1
+#endif
+#ifndef B3_P5_PREFETCH
+#define B3_P5_PREFETCH 1
+#endif
+#ifndef B3_P2_REV
+#define B3_P2_REV 1
+#endif
+// REV: column tiles are dealt from the other end ((3 - w & 3) + 4 i), so that two back-to-back phases with 4 k + 3 and 4 k + 1 column
+// tiles (Q|K|V: 15, dO: 5) give every wave the same number of tiles in total
+template <int KS, bool REV = false, class PA, class Epi>
 __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
     const int w = rat_wave(), mt0 = 2 * (w >> 2);
+    int nt = REV ? 3 - (w & 3) : (w & 3);
+    if (nt >= n_tiles) return;
+#if B3_PREFETCH_TILE
+    RatB3 b[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[s] = Bw(nt, s);
+#else
+    RatB3 b = Bw(nt, 0);
+#endif
     RatB3 a[2][KS];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[i][s] = A.row_frag(mt0 + i, s);
-    int nt = w & 3;
-    if (nt >= n_tiles) return;
-    RatB3 b = Bw(nt, 0);
     for (; nt < n_tiles; nt += 4) {
         f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+#if B3_PREFETCH_TILE
+        RatB3 bn[KS];
+        const int nn = nt + 4 < n_tiles ? nt + 4 : nt;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bn[s] = Bw(nn, s);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const RatB3 as[2] = {a[0][s], a[1][s]};
+            rat_mfma3_block<2>(acc, as, b[s]);
+        }
+#else
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bool last = s == KS - 1;
@@ -1044,8 +1080,13 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, 
             rat_mfma3_block<2>(acc, as, b);
             b = bn;
         }
+#endif
         epi(mt0, nt, acc[0]);
         epi(mt0 + 1, nt, acc[1]);
+#if B3_PREFETCH_TILE
+#pragma unroll
+        for (int s = 0; s < KS; ++s) b[s] = bn[s];
+#endif
     }
 }
 
@@ -1073,6 +1114,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
+    RAT_PROF_DECL
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
         const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
@@ -1083,12 +1125,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
             rows = nsq * a.L;
         }
-        b3_layer_norm_to_planes(a, rowtok, xp, gam, bet, nullptr, nullptr);
+        float4 x0, x1;                                           // kept: the residual of the plain PreNorm(Attention)(x) + x layer
+        b3_load_piece(a.x, rowtok, x0, x1);
+        b3_layer_norm_to_planes(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr);
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
             map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
+        RAT_PROF_MARK(0);
         // Q|K|V = LN(x) W_qkv^T
         b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
@@ -1096,6 +1141,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
         });
         __syncthreads();
+        RAT_PROF_MARK(1);
         // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>
         float pf = 0.f;
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)
@@ -1155,6 +1201,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = m + rat_log2(l);
         }
         __syncthreads();
+        RAT_PROF_MARK(2);
         // O (the Q columns of the valid rows; padding rows are exact zeros) -> planes
         for (int e = threadIdx.x; e < ATT_ROWS * (B3_I / 8); e += ATT_THREADS) {
             const int r = e / (B3_I / 8), o8 = e - r * (B3_I / 8);
@@ -1164,6 +1211,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             op.store(r, o8, h, m, l);
         }
         __syncthreads();
+        RAT_PROF_MARK(3);
         // y = O W_out^T + b_out (+ residual), staged through LDS for whole-row stores
         b3_gemm_rows<3>(op, W.out, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
@@ -1172,12 +1220,26 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             for (int r = 0; r < 4; ++r) ys[(size_t)rat_acc_row(mt, r) * LDY + col] = acc[r] + bias;
         });
         __syncthreads();
-        store_rows_residual(a.y, ys, LDY, EX ? a.res : a.x, rowtok, rows, B3_D, true, EX ? a.out_scale : 1.0f);
+        RAT_PROF_MARK(4);
+        if (EX) {
+            store_rows_residual(a.y, ys, LDY, a.res, rowtok, rows, B3_D, true, a.out_scale);
+        } else {                                                 // y = tile + x, the x piece still in registers: no global re-read
+            const int r = threadIdx.x >> 3, sb = threadIdx.x & 7;
+            const int64_t tok = rowtok[r];
+            if (tok >= 0) {
+                const float4 t0 = *reinterpret_cast<const float4*>(ys + (size_t)r * LDY + 8 * sb);
+                const float4 t1 = *reinterpret_cast<const float4*>(ys + (size_t)r * LDY + 8 * sb + 4);
+                *reinterpret_cast<float4*>(a.y + tok * B3_D + 8 * sb) = make_float4(t0.x + x0.x, t0.y + x0.y, t0.z + x0.z, t0.w + x0.w);
+                *reinterpret_cast<float4*>(a.y + tok * B3_D + 8 * sb + 4) = make_float4(t1.x + x1.x, t1.y + x1.y, t1.z + x1.z, t1.w + x1.w);
+            }
+        }
         __syncthreads();
 #ifndef RAT_EMU
         asm volatile("" ::"v"(pf));
 #endif
+        RAT_PROF_MARK(5);
     }
+    RAT_PROF_FLUSH(a.prof, 48);
 }
 
 // ---- backward, bf16x3.  LDS map (bytes): [x planes 24576][dy planes 24576][Q|K|V fp32 62464][O fp32 21504][dO fp32 21504][misc];
@@ -1191,23 +1253,33 @@ constexpr size_t b3_bwd_smem() { return B3_OFF_MISC + (size_t)64 * (2 + 2 * B3_H
 static_assert(B3_OFF_MISC - B3_OFF_QKV >= (size_t)3 * B3_QP + 64, "d(Q|K|V) planes overlay the three fp32 tiles");
 static_assert((size_t)64 * B3_LDN * 4 <= (size_t)3 * B3_XP, "d(LN out) overlays the dy planes");
 
-// C[64][64] = A (planes, row operand, KS K-steps) x B: wave w owns row tiles {2 (w >> 2), +1} x column tile (w & 3); operands of
-// step s + 1 are requested before the MFMAs of step s
+// C[64][64] = A (planes, row operand, KS K-steps) x B: wave w owns row tiles {2 (w >> 2), +1} x column tile (w & 3); the weight
+// fragment (L2) is requested B3_LONGK_DEPTH steps, the LDS fragments one step ahead of their MFMAs
 template <int KS, class PA, class Epi>
 __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes& Bw, const Epi& epi) {
     const int w = rat_wave(), mt0 = 2 * (w >> 2), nt = w & 3;
     f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+    RatB3 b0 = Bw(nt, 0);
+#if B3_LONGK_DEPTH > 1
+    RatB3 b1 = Bw(nt, KS > 1 ? 1 : 0);
+#endif
     RatB3 a[2] = {A.row_frag(mt0, 0), A.row_frag(mt0 + 1, 0)};
-    RatB3 b = Bw(nt, 0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int sn = s + 1 < KS ? s + 1 : s;
+#if B3_LONGK_DEPTH > 1
+        const RatB3 b2 = Bw(nt, s + 2 < KS ? s + 2 : KS - 1);
+#else
+        const RatB3 b1 = Bw(nt, sn);
+#endif
         const RatB3 an[2] = {A.row_frag(mt0, sn), A.row_frag(mt0 + 1, sn)};
-        const RatB3 bn = Bw(nt, sn);
-        rat_mfma3_block<2>(acc, a, b);
+        rat_mfma3_block<2>(acc, a, b0);
         a[0] = an[0];
         a[1] = an[1];
-        b = bn;
+        b0 = b1;
+#if B3_LONGK_DEPTH > 1
+        b1 = b2;
+#endif
     }
     epi(mt0, nt, acc[0]);
     epi(mt0 + 1, nt, acc[1]);
@@ -1247,6 +1319,24 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
+    RAT_PROF_DECL
+#ifndef B3_LOAD_AHEAD
+#define B3_LOAD_AHEAD 1
+#endif
+    // this thread's loads of a chunk (x / dy piece, O items, lse).  vmcnt retires in order, so loads that may miss to HBM must never
+    // sit in front of a GEMM phase's operand loads: the NEXT chunk's are issued at the start of P6 (the last phase, LayerNorm
+    // backward — whose own loads are issued first) and consumed by P0
+    float4 xn0, xn1, dn0, dn1;
+    RowFetch<B3_I> fo;
+    float lsen;
+    auto issue_loads = [&](const int64_t* rt) {
+        b3_load_piece(a.x, rt, xn0, xn1);
+        b3_load_piece(a.dy, rt, dn0, dn1);
+        fo.issue(a.o_save, rt);
+        const int64_t tk = rt[r_own];
+        lsen = tk >= 0 ? a.lse_save[tk * B3_H + sub] : 0.f;
+    };
+    if (B3_LOAD_AHEAD) issue_loads(rowtok0);
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
         const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
@@ -1260,13 +1350,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         const int64_t tok_own = rowtok[r_own];
         // ---- P0: x -> LayerNorm -> planes; dy -> planes (+ db_out partials); O, lse -> fp32 tiles
         {
-            RowFetch<B3_I> fo;
-            fo.issue(a.o_save, rowtok);
-            float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0;
-            if (tok_own >= 0) {
-                d0 = *reinterpret_cast<const float4*>(a.dy + tok_own * B3_D + 8 * sub);
-                d1 = *reinterpret_cast<const float4*>(a.dy + tok_own * B3_D + 8 * sub + 4);
-            }
+            if (!B3_LOAD_AHEAD) issue_loads(rowtok);
+            float4 x0 = xn0, x1 = xn1, d0 = dn0, d1 = dn1;
             {
                 float gam[8], bet[8];
 #pragma unroll
@@ -1274,7 +1359,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                     gam[k] = lnw[8 * sub + k];
                     bet[k] = lnw[B3_D + 8 * sub + k];
                 }
-                b3_layer_norm_to_planes(a, rowtok, xp, gam, bet, mu, rs);
+                b3_layer_norm_to_planes(tok_own >= 0, x0, x1, a.eps, xp, gam, bet, mu, rs);
             }
             if (EX && a.out_scale != 1.0f) {
                 const float m_ = a.out_scale;
@@ -1285,17 +1370,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             rat_split8(d0, d1, h, m, l);
             dyp.store(r_own, sub, h, m, l);
             fo.stash(ob, B3_LDT);
-            {
-                const int r = threadIdx.x >> 3;                              // 512 threads = 64 rows x 8 heads
-                const int64_t tok = rowtok[r];
-                lses[threadIdx.x] = tok >= 0 ? a.lse_save[tok * B3_H + (threadIdx.x & 7)] : 0.f;
-            }
+            lses[threadIdx.x] = lsen;                                        // 512 threads = 64 rows x 8 heads
         }
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
             map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
+        RAT_PROF_MARK(0);
         // ---- P1: Q|K|V = LN(x) W_qkv^T   P2: dO = dy W_out   P2b: dW_out^T += O^T dy
         b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
@@ -1303,12 +1385,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
         });
         RAT_SCHED_FENCE();
-        b3_gemm_rows<2>(dyp, W.outT, B3_I / 16, [&](int mt, int nt, const f32x4& acc) {
+        RAT_PROF_MARK(1);
+        b3_gemm_rows<2, B3_P2_REV != 0>(dyp, W.outT, B3_I / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
 #pragma unroll
             for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * B3_LDT + col] = acc[r];
         });
         RAT_SCHED_FENCE();
+        RAT_PROF_MARK(2);
         if (rat_wave() < B3_I / 16) {                                        // wave = inner-dimension tile of O^T
             const int mt = rat_wave(), l = rat_lane(), g = l >> 4, col = 16 * mt + (l & 15);
 #pragma unroll
@@ -1325,12 +1409,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             }
         }
         __syncthreads();
+        RAT_PROF_MARK(3);
         // ---- P3: attention backward on the VALU — the two passes of attn_bwd_kernel<64, 10>
         typedef HeadVec<B3_DH> HV;
         const int ntasks = nsq * B3_H * L;
         const float sl2 = a.scale * RAT_LOG2E;
         float pf = 0.f;
-        {
+        {   // the next chunk's lines travel HBM -> L2 behind the two passes; the loads proper are issued at P4
             int t = threadIdx.x;
             if (chunk + gridDim.x < a.nchunks) {
                 const int64_t* nrt = (rowtok0 + (parity ^ 1) * ATT_ROWS);
@@ -1367,6 +1452,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             dq.store(opp, B3_DH, a.scale);
         }
         __syncthreads();
+        RAT_PROF_MARK(4);
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int j = task % L;
             const int h = (task / L) % B3_H;
@@ -1393,6 +1479,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             dv.store(kp + B3_I, B3_DH, 1.0f);
         }
         __syncthreads();
+        RAT_PROF_MARK(5);
         // ---- P3c: d(Q|K|V) = [dQ (in ob) | dK | dV (in qkv)] -> planes over the three fp32 tiles: all reads, barrier, all writes
         {
             constexpr int NP = B3_Q3 / 8;                                    // 30 pieces per row
@@ -1425,6 +1512,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             if (threadIdx.x < 8) reinterpret_cast<float*>(smem + B3_OFF_QKV + (size_t)3 * B3_QP)[threadIdx.x] = 0.f;
         }
         __syncthreads();
+        RAT_PROF_MARK(6);
         // ---- P4: d(LN out) = dQKV W_qkv   P5: dW_qkv += dQKV^T LN(x)
         b3_gemm_rows_longk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
@@ -1432,9 +1520,25 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             for (int r = 0; r < 4; ++r) dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col] = acc[r];
         });
         RAT_SCHED_FENCE();
+        RAT_PROF_MARK(7);
         {
             const int w = rat_wave(), nt = w & 3;
             const RatB3 b0 = xp.col_frag(nt, 0), b1 = xp.col_frag(nt, 1);
+#if B3_P5_PREFETCH
+            RatB3 a0 = dqp.col_frag(w >> 2, 0), a1 = dqp.col_frag(w >> 2, 1);
+#pragma unroll
+            for (int i = 0; i < QSLOTS; ++i) {
+                const int mt = (w >> 2) + 2 * i;
+                const int mn = mt + 2 < B3_Q3 / 16 ? mt + 2 : mt;
+                const RatB3 n0 = dqp.col_frag(mn, 0), n1 = dqp.col_frag(mn, 1);
+                if (mt < B3_Q3 / 16) {
+                    accq[i] = rat_mfma3(a0, b0, accq[i]);
+                    accq[i] = rat_mfma3(a1, b1, accq[i]);
+                }
+                a0 = n0;
+                a1 = n1;
+            }
+#else
 #pragma unroll
             for (int i = 0; i < QSLOTS; ++i) {
                 const int mt = (w >> 2) + 2 * i;
@@ -1444,21 +1548,29 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 }
                 RAT_SCHED_FENCE();
             }
+#endif
         }
         __syncthreads();
+        RAT_PROF_MARK(8);
         // ---- P6: LayerNorm backward + the added gradient: dx = add + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma
         {
             const bool valid = tok_own >= 0;
             const float mean = mu[r_own], rstd = rs[r_own];
             const float* addp = EX ? a.add : a.dy;
             float xh[8], gg[8], ad[8], out[8], gam[8];
+            float4 xv2[2], av2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                xv2[k] = av2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) xv2[k] = *reinterpret_cast<const float4*>(a.x + tok_own * B3_D + 8 * sub + 4 * k);
+                if (valid && addp != nullptr) av2[k] = *reinterpret_cast<const float4*>(addp + tok_own * B3_D + 8 * sub + 4 * k);
+            }
+            if (B3_LOAD_AHEAD && chunk + gridDim.x < a.nchunks) issue_loads(rowtok0 + (parity ^ 1) * ATT_ROWS);
 #pragma unroll
             for (int k = 0; k < 8; ++k) gam[k] = lnw[8 * sub + k];
 #pragma unroll
             for (int k = 0; k < 8; k += 4) {
-                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), av = xv;
-                if (valid) xv = *reinterpret_cast<const float4*>(a.x + tok_own * B3_D + 8 * sub + k);
-                if (valid && addp != nullptr) av = *reinterpret_cast<const float4*>(addp + tok_own * B3_D + 8 * sub + k);
+                const float4 xv = xv2[k >> 2], av = av2[k >> 2];
                 const float4 gv = *reinterpret_cast<const float4*>(dxn + (size_t)r_own * B3_LDN + 8 * sub + k);
                 xh[k] = xv.x; xh[k + 1] = xv.y; xh[k + 2] = xv.z; xh[k + 3] = xv.w;
                 ad[k] = av.x; ad[k + 1] = av.y; ad[k + 2] = av.z; ad[k + 3] = av.w;
@@ -1491,7 +1603,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
 #ifndef RAT_EMU
         asm volatile("" ::"v"(pf));
 #endif
+        RAT_PROF_MARK(9);
     }
+    RAT_PROF_FLUSH(a.prof, 60);
 
     // ---- this work-group's parameter-gradient slab: [dW_qkv | dW_out | db_out | dgamma | dbeta]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
@@ -1626,7 +1740,7 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     const AttnGeom g(d, heads, dim_head);
     const size_t smem = g.fwd_smem();
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
-    const unsigned blocks = (unsigned)(a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu);
+    const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() * per_cu ? a.nchunks : rat_max_blocks() * per_cu);
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
     const bool plain = res == x && out_scale == 1.0f;
     if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && workspace != nullptr &&
@@ -1637,7 +1751,7 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         Attn3W W{};
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 3};
-        const unsigned b3_blocks = (unsigned)(a.nchunks < 256 ? a.nchunks : 256);
+        const unsigned b3_blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
         if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         return rat_check_launch("rat_attn_fwd (bf16x3)");
@@ -1702,7 +1816,7 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     const AttnGeom g(d, heads, dim_head);
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
-    const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
+    const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const size_t smem = g.bwd_smem(heads);
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
     if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && aligned16(workspace) &&

@@ -524,6 +524,110 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t_kernel(FfnArgs a) {
     }
 }
 
+// ---- bf16x3 variant of the token-on-lanes forward (D = 64, H = 128): both weight matrices live in LDS as three bf16 planes
+// (rat_device.h "bf16x3"), split once per work-group; the token fragments are split in registers (x: once per tile, gelu(h): once
+// per pair of hidden tiles) — each split feeds 8 resp. 4 row tiles.  W2 is stored with the hidden index PERMUTED so that the
+// accumulators of hidden tiles (2 t, 2 t + 1) are, as they stand, the B fragment of K step t:
+//     k slot j of lane group g  <->  hidden 32 t + 4 g + j (j < 4),  32 t + 16 + 4 g + (j - 4) (j >= 4).
+constexpr int F3_D = 64, F3_H = 128;
+typedef RatPlanes<128, 7, F3_H * 128> PlanesW1;          // [128 hidden][64 d]
+typedef RatPlanes<256, 15, F3_D * 256> PlanesW2;         // [64 d][128 hidden, permuted]
+constexpr size_t f3_fwd_smem() { return (size_t)3 * F3_H * 128 + (size_t)3 * F3_D * 256 + (size_t)(F3_H + F3_D) * 4; }
+
+__device__ __forceinline__ void f3_stage_weights(const FfnArgs& a, const PlanesW1& w1p, const PlanesW2& w2p, int nthreads) {
+    for (int e = threadIdx.x; e < F3_H * (F3_D / 8); e += nthreads) {
+        const int r = e / (F3_D / 8), o = e - r * (F3_D / 8);
+        rat_u4 h, m, l;
+        rat_split8(ld4(a.w1 + (size_t)r * F3_D + 8 * o), ld4(a.w1 + (size_t)r * F3_D + 8 * o + 4), h, m, l);
+        w1p.store(r, o, h, m, l);
+    }
+    for (int e = threadIdx.x; e < F3_D * (F3_H / 8); e += nthreads) {
+        const int r = e / (F3_H / 8), o = e - r * (F3_H / 8), t = o >> 2, g = o & 3;
+        rat_u4 h, m, l;
+        rat_split8(ld4(a.w2 + (size_t)r * F3_H + 32 * t + 4 * g), ld4(a.w2 + (size_t)r * F3_H + 32 * t + 16 + 4 * g), h, m, l);
+        w2p.store(r, o, h, m, l);
+    }
+}
+
+template <bool XRES>
+__global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t3_kernel(FfnArgs a) {
+    constexpr int D = F3_D, H = F3_H;
+    RAT_DYN_SMEM(smem);
+    const PlanesW1 w1p{smem};
+    const PlanesW2 w2p{smem + 3 * H * 128};
+    float* b1s = reinterpret_cast<float*>(smem + 3 * H * 128 + 3 * D * 256);
+    float* b2s = b1s + H;
+    f3_stage_weights(a, w1p, w2p, FT_THREADS);
+    for (int e = threadIdx.x; e < H; e += FT_THREADS) b1s[e] = a.b1[e];
+    for (int e = threadIdx.x; e < D; e += FT_THREADS) b2s[e] = a.b2[e];
+    __syncthreads();
+
+    const int l = rat_lane(), n = l & 15, g = l >> 4;
+    const int64_t ntiles = (a.ntok + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * FT_WAVES;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t t = (int64_t)blockIdx.x * FT_WAVES + rat_wave();
+    float4 xN[4];                                             // x[token n][32 s + 8 g .. + 7] for s = 0, 1 (two float4 each)
+    {
+        const int64_t tk = t * 16 + n;
+        const bool ok = t < ntiles && tk < a.ntok;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+    }
+    for (; t < ntiles; t += stride) {
+        const int64_t tok = t * 16 + n;
+        RatB3 xb[2];
+        {
+            float4 xT[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xT[q] = rat_consume4(xN[q]);
+            xb[0] = rat_split8_frag(xT[0], xT[1]);
+            xb[1] = rat_split8_frag(xT[2], xT[3]);
+        }
+        {   // next tile's fragments: in flight behind this tile's MFMAs
+            const int64_t tk = (t + stride) * 16 + n;
+            const bool ok = t + stride < ntiles && tk < a.ntok;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+        }
+        f32x4 yo[D / 16];
+#pragma unroll
+        for (int c = 0; c < D / 16; ++c) {
+            float4 r0 = zero4;
+            const float* rp = XRES ? a.x : a.res;
+            if (rp != nullptr && tok < a.ntok) r0 = ld4(rp + tok * D + 16 * c + 4 * g);
+            const float4 bs = ld4(b2s + 16 * c + 4 * g);
+            yo[c] = f32x4{bs.x + r0.x, bs.y + r0.y, bs.z + r0.z, bs.w + r0.w};
+        }
+#pragma unroll
+        for (int p = 0; p < H / 32; ++p) {
+            f32x4 c0 = as_v4(ld4(b1s + 32 * p + 4 * g)), c1 = as_v4(ld4(b1s + 32 * p + 16 + 4 * g));
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const RatB3 a0 = w1p.row_frag(2 * p, s), a1 = w1p.row_frag(2 * p + 1, s);
+                f32x4 cc[2] = {c0, c1};
+                const RatB3 aa[2] = {a0, a1};
+                rat_mfma3_block<2>(cc, aa, xb[s]);
+                c0 = cc[0];
+                c1 = cc[1];
+            }
+            const RatB3 gb = rat_split8_frag(gelu4(c0), gelu4(c1));
+#pragma unroll
+            for (int c = 0; c < D / 16; c += 2) {
+                f32x4 cc[2] = {yo[c], yo[c + 1]};
+                const RatB3 aa[2] = {w2p.row_frag(c, p), w2p.row_frag(c + 1, p)};
+                rat_mfma3_block<2>(cc, aa, gb);
+                yo[c] = cc[0];
+                yo[c + 1] = cc[1];
+            }
+        }
+        if (tok < a.ntok) {
+#pragma unroll
+            for (int m = 0; m < D / 16; ++m) st4(a.y + tok * D + 16 * m + 4 * g, as_f4(yo[m]));
+        }
+    }
+}
+
 // backward, same formulation.  512 threads (8 waves, one work-group per CU), 64 tokens per iteration: wave (tt, half) =
 // (wave & 3, wave >> 2) owns token tile tt and one half of the hidden tiles.  Chain phase (no barrier): h^T and dh^T
 // (shared token B fragments x^T / dy^T, weights W1 / W2^T rows as A operands straight from L2), gelu / gelu' on the
@@ -802,11 +906,11 @@ int ffn_check(int64_t ntok, int d, int hidden, bool backward) {
 
 extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                            int64_t ntok, int d, int hidden, void* stream) {
-    return rat_ffn_fwd_res(x, x, y, w1, b1, w2, b2, ntok, d, hidden, stream);
+    return rat_ffn_fwd_res(x, x, y, w1, b1, w2, b2, ntok, d, hidden, RAT_ARITH_F32, stream);
 }
 
 extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2,
-                               const float* b2, int64_t ntok, int d, int hidden, void* stream) {
+                               const float* b2, int64_t ntok, int d, int hidden, int arith, void* stream) {
     if (ffn_check(ntok, d, hidden, false)) return -1;
     RAT_REQUIRE(x && y && w1 && b1 && w2 && b2, "null pointer");
     FfnArgs a{};
@@ -830,12 +934,15 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
     int per_cu = (int)((160 * 1024) / smem);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    const int64_t blocks = a.nchunks < 256 * per_cu ? a.nchunks : 256 * per_cu;
+    const int64_t blocks = a.nchunks < rat_max_blocks() * per_cu ? a.nchunks : rat_max_blocks() * per_cu;
     const int fast = ffn_fast_dim(a, {x, y, b1, b2, res});
     const int64_t wtiles = ((ntok + 15) / 16 + FT_WAVES - 1) / FT_WAVES;
-    const unsigned tgrid = (unsigned)(wtiles < 256 ? wtiles : 256);
+    const unsigned tgrid = (unsigned)(wtiles < rat_max_blocks() ? wtiles : rat_max_blocks());
     const bool xres = res == x;
-    if (fast == 64 && hidden == 128) {
+    if (fast == 64 && hidden == 128 && arith == RAT_ARITH_BF16X3) {
+        if (xres) RAT_LAUNCH((ffn_fwd_t3_kernel<true>), tgrid, FT_THREADS, f3_fwd_smem(), stream, a);
+        else RAT_LAUNCH((ffn_fwd_t3_kernel<false>), tgrid, FT_THREADS, f3_fwd_smem(), stream, a);
+    } else if (fast == 64 && hidden == 128) {
         if (xres) RAT_LAUNCH((ffn_fwd_t_kernel<64, 128, true>), tgrid, FT_THREADS, (FfnTGeom<64, 128>::fwd_smem), stream, a);
         else RAT_LAUNCH((ffn_fwd_t_kernel<64, 128, false>), tgrid, FT_THREADS, (FfnTGeom<64, 128>::fwd_smem), stream, a);
     } else if (fast == 16 && hidden == 32) {
@@ -855,12 +962,13 @@ extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
 extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                            const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                            size_t workspace_bytes, int64_t ntok, int d, int hidden, void* stream) {
-    return rat_ffn_bwd_res(x, dy, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, ntok, d, hidden, 1, stream);
+    return rat_ffn_bwd_res(x, dy, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, ntok, d, hidden, 1, RAT_ARITH_F32,
+                           stream);
 }
 
 extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                                const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
-                               size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, void* stream) {
+                               size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, int arith, void* stream) {
     if (ffn_check(ntok, d, hidden, true)) return -1;
     RAT_REQUIRE(x && dy && dx && w1 && b1 && w2 && b2 && dw1 && db1 && dw2 && db2 && workspace, "null pointer");
     RAT_REQUIRE(workspace_bytes >= rat_ffn_bwd_workspace(d, hidden), "workspace too small");
@@ -884,7 +992,7 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
     const FfnGeom g(d, hidden);
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
-    const int blocks = (int)(a.nchunks < 256 ? a.nchunks : 256);
+    const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const int fast = ffn_fast_dim(a, {x, dy, dx, b1});
     if (fast) {
         float* w1t = workspace + (size_t)256 * a.slab_stride;

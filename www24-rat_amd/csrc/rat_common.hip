@@ -1,5 +1,6 @@
 // rat_common.hip — error reporting, ABI version, slab reduction shared by the backward kernels.
 #include "rat_device.h"
+#include <stdlib.h>
 #include "../../include/rat_hip.h"
 
 static thread_local std::string g_last_error;
@@ -16,6 +17,14 @@ int rat_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return rat_fail(std::string(what) + ": " + hipGetErrorString(e));
     return 0;
+}
+
+// Test knob (never set by the product): RAT_MAX_BLOCKS=<n> caps the grid of the persistent encoder kernels so that small test
+// problems make every work-group loop over SEVERAL chunks (persistent accumulators, double-buffered row maps, load-ahead).
+int rat_max_blocks() {
+    const char* e = getenv("RAT_MAX_BLOCKS");            // read per launch: tests set and clear it around single calls
+    const int n = e ? atoi(e) : 0;
+    return n > 0 && n < 256 ? n : 256;
 }
 
 static unsigned long long* g_prof = nullptr;

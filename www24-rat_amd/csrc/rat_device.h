@@ -52,6 +52,7 @@ unsigned long long* rat_prof_buffer();                // device pointer set by r
 const char* rat_set_error(const std::string& msg);   // stores thread-local, returns c_str
 int rat_fail(const std::string& msg);                 // sets error, returns -1
 int rat_check_launch(const char* what);               // hipGetLastError -> 0 / -1
+int rat_max_blocks();                                 // 256 (one work-group per CU) unless the RAT_MAX_BLOCKS test knob lowers it
 
 #define RAT_REQUIRE(cond, msg)                  \
     do {                                        \
@@ -599,12 +600,13 @@ __device__ __forceinline__ void rat_mfma3_block(f32x4 (&acc)[MT], const RatB3 (&
 }
 
 // ---- an activation tile [64 rows][W columns] held in LDS as three bf16 planes.  Unit = a 16-byte PIECE (8 consecutive columns
-// of one row); rows are RS bytes apart; SWZ: the piece index is XORed with (row & 7), which makes the 16-byte row reads of an
-// MFMA fragment AND the transposed 4-row block reads below bank-conflict free for 128-byte rows (W = 64).
-template <int RS, bool SWZ, int PLANE_BYTES>
+// of one row); rows are RS bytes apart; SWZ (0, 7 or 15): the piece index is XORed with (row & SWZ), which makes the 16-byte row
+// reads of an MFMA fragment AND the transposed 4-row block reads below bank-conflict free for 128-byte rows (SWZ 7, W = 64) and
+// the row reads for 256-byte rows (SWZ 15, W = 128).
+template <int RS, int SWZ, int PLANE_BYTES>
 struct RatPlanes {
     char* base;
-    __device__ __forceinline__ int off(int r, int o) const { return r * RS + 16 * (SWZ ? (o ^ (r & 7)) : o); }
+    __device__ __forceinline__ int off(int r, int o) const { return r * RS + 16 * (o ^ (r & SWZ)); }
     __device__ __forceinline__ void store(int r, int o, const rat_u4& h, const rat_u4& m, const rat_u4& l) const {
         const int a = off(r, o);
         *reinterpret_cast<rat_u4*>(base + a) = h;

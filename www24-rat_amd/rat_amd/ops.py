@@ -314,7 +314,9 @@ def attn_core_bwd(qkv, o, lse, dout, nseq, L, heads, dim_head, softmax_scale=0.0
     return dqkv
 
 
-def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, lib=None):
+def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, arith="f32", lib=None):
+    if arith != "f32":
+        return ffn_fwd_res(x, x, w1, b1, w2, b2, d, hidden, out=out, arith=arith, lib=lib)
     lib = lib or get_lib()
     _chk(x, name="x")
     y = out if out is not None else torch.empty_like(x)
@@ -322,7 +324,9 @@ def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, lib=None):
     return y
 
 
-def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None, lib=None):
+def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None, arith="f32", lib=None):
+    if arith != "f32":
+        return ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, True, workspace=workspace, arith=arith, lib=lib)
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_ffn_bwd_workspace", d, hidden)
@@ -334,18 +338,19 @@ def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None
     return dx, workspace
 
 
-def ffn_fwd_res(x, res, w1, b1, w2, b2, d, hidden, out=None, lib=None):
+def ffn_fwd_res(x, res, w1, b1, w2, b2, d, hidden, out=None, arith="f32", lib=None):
     """y = FFN(x) + res (res None: no residual) — rat_ffn_fwd_res."""
     lib = lib or get_lib()
     _chk(x, name="x")
     if res is not None:
         _chk(res, name="res")
     y = out if out is not None else torch.empty_like(x)
-    lib.call("rat_ffn_fwd_res", _p(x), _p(res), _p(y), _p(w1), _p(b1), _p(w2), _p(b2), x.numel() // d, d, hidden, _stream(x))
+    lib.call("rat_ffn_fwd_res", _p(x), _p(res), _p(y), _p(w1), _p(b1), _p(w2), _p(b2), x.numel() // d, d, hidden, ARITH[arith],
+             _stream(x))
     return y
 
 
-def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, lib=None):
+def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, arith="f32", lib=None):
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_ffn_bwd_workspace", d, hidden)
@@ -353,7 +358,7 @@ def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, wo
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     lib.call("rat_ffn_bwd_res", _p(x), _p(dy), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2), _p(db2),
-             _p(workspace), workspace.numel() * 4, x.numel() // d, d, hidden, int(bool(add_dy)), _stream(x))
+             _p(workspace), workspace.numel() * 4, x.numel() // d, d, hidden, int(bool(add_dy)), ARITH[arith], _stream(x))
     return dx, workspace
 
 
