@@ -27,6 +27,8 @@ struct dim3 {
 };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 

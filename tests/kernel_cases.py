@@ -245,7 +245,7 @@ def check_ffn(lib, dev, ntok, d, hidden, arith="f32"):
             assert err < 4e-6, ("bf16x3 vs exact fp32", name, err)
 
 
-def check_ffn_res(lib, dev, ntok, d, hidden, with_res):
+def check_ffn_res(lib, dev, ntok, d, hidden, with_res, arith="f32"):
     """y = FFN(x) + res with the residual from a separate tensor (or none): rat_ffn_fwd_res / rat_ffn_bwd_res(add_dy=0)."""
     rs = np.random.RandomState(13)
     x, res = rnd(rs, ntok, d), rnd(rs, ntok, d)
@@ -260,10 +260,10 @@ def check_ffn_res(lib, dev, ntok, d, hidden, with_res):
     ref.backward(dy.double())
     xd, dyd = x.to(dev), dy.to(dev)
     wd = [w.to(dev) for w in ws]
-    y = ops.ffn_fwd_res(xd, res.to(dev) if with_res else None, *wd, d, hidden, lib=lib)
+    y = ops.ffn_fwd_res(xd, res.to(dev) if with_res else None, *wd, d, hidden, arith=arith, lib=lib)
     close(y, ref, 2e-5, 2e-5, "y")
     gs = [torch.zeros_like(w) for w in wd]
-    dx, _ = ops.ffn_bwd_res(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, add_dy=False, lib=lib)
+    dx, _ = ops.ffn_bwd_res(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, add_dy=False, arith=arith, lib=lib)
     scale = max(1.0, ntok ** 0.5 / 4)
     close(dx, xr.grad, 1e-4, 1e-4, "dx")
     for g, w in zip(gs, wr):

@@ -86,6 +86,13 @@ def test_ffn_fwd_bwd(lib, ntok, d, hidden):
     kc.check_ffn(lib, "cuda", ntok, d, hidden)
 
 
+@pytest.mark.parametrize("ntok", [64, 1000, 100000])
+def test_ffn_fwd_bwd_bf16x3(lib, ntok):
+    kc.check_ffn(lib, "cuda", ntok, 64, 128, arith="bf16x3")
+    kc.check_ffn_res(lib, "cuda", ntok, 64, 128, True, arith="bf16x3")
+    kc.check_ffn_res(lib, "cuda", ntok, 64, 128, False, arith="bf16x3")
+
+
 @pytest.mark.parametrize("ntok,d,hidden,with_res", [(70, 8, 16, True), (64, 64, 128, True), (100000, 64, 128, True), (100000, 64, 128, False), (5000, 40, 80, True), (999, 16, 32, True)])
 def test_ffn_separate_residual(lib, ntok, d, hidden, with_res):
     kc.check_ffn_res(lib, "cuda", ntok, d, hidden, with_res)

@@ -48,19 +48,20 @@ def main():
     if any(w.startswith("ffn") for w in args.which):
         w1, b1, w2, b2 = rn(H, d, sc=d ** -0.5), rn(H, sc=0.1), rn(d, H, sc=H ** -0.5), rn(d, sc=0.1)
         y = torch.empty_like(x)
-        if "ffn_fwd" in args.which:
-            ms = timeit(lambda: ops.ffn_fwd(x, w1, b1, w2, b2, d, H, out=y), args.reps)
-            fl = tok * 4 * d * H
-            print("ffn_fwd   %.4f ms  %.1f TFLOP/s  (%.1f %% of %.1f)" % (ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK, PEAK))
-        if "ffn_bwd" in args.which:
-            gs = [torch.zeros_like(t) for t in (w1, b1, w2, b2)]
-            ws = [None]
+        for arith in (["f32", "bf16x3"] if args.arith == "both" else [args.arith]):
+            if "ffn_fwd" in args.which:
+                ms = timeit(lambda: ops.ffn_fwd(x, w1, b1, w2, b2, d, H, out=y, arith=arith), args.reps)
+                fl = tok * 4 * d * H
+                print("ffn_fwd %-6s %.4f ms  %.1f TFLOP/s  (%.1f %% of %.1f)" % (arith, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK, PEAK))
+            if "ffn_bwd" in args.which:
+                gs = [torch.zeros_like(t) for t in (w1, b1, w2, b2)]
+                ws = [None]
 
-            def run():
-                _, ws[0] = ops.ffn_bwd(x, dy, w1, b1, w2, b2, gs[0], gs[1], gs[2], gs[3], d, H, workspace=ws[0])
-            ms = timeit(run, args.reps)
-            fl = 2 * tok * 4 * d * H
-            print("ffn_bwd   %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
+                def run():
+                    _, ws[0] = ops.ffn_bwd(x, dy, w1, b1, w2, b2, gs[0], gs[1], gs[2], gs[3], d, H, workspace=ws[0], arith=arith)
+                ms = timeit(run, args.reps)
+                fl = 2 * tok * 4 * d * H
+                print("ffn_bwd %-6s %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (arith, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
     if any(w.startswith("attn") for w in args.which):
         ln_g, ln_b = 1 + rn(d, sc=0.1), rn(d, sc=0.1)
         w_qkv, w_out, b_out = rn(3 * I, d, sc=d ** -0.5), rn(d, I, sc=I ** -0.5), rn(d, sc=0.1)

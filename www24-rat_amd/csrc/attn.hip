@@ -1090,6 +1090,52 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, 
     }
 }
 
+// The same product with ALL FOUR row tiles on one wave: column tile w (+ 8 i) — every weight fragment is fetched from L2 once per
+// chunk instead of once per row-tile pair (the L2 -> CU path, ~64 B/clk, is otherwise as busy as the MFMA pipe: 184 KB of Q|K|V
+// fragments per chunk), the A fragments are re-read from LDS per column tile (LDS has the bandwidth).  REV: tiles dealt from wave 7 down.
+#ifndef B3_ROWS4
+#define B3_ROWS4 0            // A/B on MI355X (tools/ab_attn.sh): the backward runs 1.45 -> 2.2 ms with this mapping (LDS-bound), kept for reference
+#endif
+template <int KS, bool REV = false, class PA, class Epi>
+__device__ __forceinline__ void b3_gemm_rows4(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
+    const int w = rat_wave();
+    int nt = REV ? 7 - w : w;
+    if (nt >= n_tiles) return;
+    RatB3 b = Bw(nt, 0);
+    for (; nt < n_tiles; nt += 8) {
+        f32x4 acc[4] = {rat_zero4(), rat_zero4(), rat_zero4(), rat_zero4()};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool last = s == KS - 1;
+            const RatB3 bn = Bw(last ? (nt + 8 < n_tiles ? nt + 8 : nt) : nt, last ? 0 : s + 1);
+            const RatB3 a[4] = {A.row_frag(0, s), A.row_frag(1, s), A.row_frag(2, s), A.row_frag(3, s)};
+            rat_mfma3_block<4>(acc, a, b);
+            b = bn;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) epi(i, nt, acc[i]);
+    }
+}
+
+// C[64][64] += A (planes, KS K-steps) x B with the K extent split over the two wave groups (w >> 2): wave = (column tile w & 3, K half),
+// all four row tiles; each weight fragment is fetched once per chunk.  epi receives PARTIAL tiles (the caller adds the two halves).
+template <int KS, class PA, class Epi>
+__device__ __forceinline__ void b3_gemm_rows4_splitk(const PA& A, const RatWPlanes& Bw, const Epi& epi) {
+    const int w = rat_wave(), nt = w & 3, s0 = (w >> 2) * (KS / 2);
+    f32x4 acc[4] = {rat_zero4(), rat_zero4(), rat_zero4(), rat_zero4()};
+    RatB3 b = Bw(nt, s0);
+#pragma unroll
+    for (int i = 0; i < KS / 2; ++i) {
+        const int s = s0 + i;
+        const RatB3 bn = Bw(nt, i + 1 < KS / 2 ? s + 1 : s);
+        const RatB3 a[4] = {A.row_frag(0, s), A.row_frag(1, s), A.row_frag(2, s), A.row_frag(3, s)};
+        rat_mfma3_block<4>(acc, a, b);
+        b = bn;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) epi(i, nt, acc[i]);
+}
+
 template <bool EX>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
@@ -1135,11 +1181,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         __syncthreads();
         RAT_PROF_MARK(0);
         // Q|K|V = LN(x) W_qkv^T
-        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
-            const int col = rat_acc_col(nt);
+        {
+            auto epi = [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
-        });
+                for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
+            };
+            if (B3_ROWS4) b3_gemm_rows4<2>(xp, W.qkv, B3_Q3 / 16, epi);
+            else b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, epi);
+        }
         __syncthreads();
         RAT_PROF_MARK(1);
         // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>
@@ -1321,7 +1371,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
     __syncthreads();
     RAT_PROF_DECL
 #ifndef B3_LOAD_AHEAD
-#define B3_LOAD_AHEAD 1
+#define B3_LOAD_AHEAD 0                              // A/B on MI355X: issuing the next chunk's loads a phase early costs 8-10 % (registers)
 #endif
     // this thread's loads of a chunk (x / dy piece, O items, lse).  vmcnt retires in order, so loads that may miss to HBM must never
     // sit in front of a GEMM phase's operand loads: the NEXT chunk's are issued at the start of P6 (the last phase, LayerNorm
@@ -1379,19 +1429,25 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         __syncthreads();
         RAT_PROF_MARK(0);
         // ---- P1: Q|K|V = LN(x) W_qkv^T   P2: dO = dy W_out   P2b: dW_out^T += O^T dy
-        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
-            const int col = rat_acc_col(nt);
+        {
+            auto epi_q = [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
-        });
-        RAT_SCHED_FENCE();
-        RAT_PROF_MARK(1);
-        b3_gemm_rows<2, B3_P2_REV != 0>(dyp, W.outT, B3_I / 16, [&](int mt, int nt, const f32x4& acc) {
-            const int col = rat_acc_col(nt);
+                for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
+            };
+            auto epi_o = [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * B3_LDT + col] = acc[r];
-        });
-        RAT_SCHED_FENCE();
+                for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * B3_LDT + col] = acc[r];
+            };
+            if (B3_ROWS4) b3_gemm_rows4<2>(xp, W.qkv, B3_Q3 / 16, epi_q);
+            else b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, epi_q);
+            RAT_SCHED_FENCE();
+            RAT_PROF_MARK(1);
+            if (B3_ROWS4) b3_gemm_rows4<2, true>(dyp, W.outT, B3_I / 16, epi_o);       // waves 7..3 (Q|K|V gave waves 0..6 two tiles, wave 7 one)
+            else b3_gemm_rows<2, B3_P2_REV != 0>(dyp, W.outT, B3_I / 16, epi_o);
+            RAT_SCHED_FENCE();
+        }
         RAT_PROF_MARK(2);
         if (rat_wave() < B3_I / 16) {                                        // wave = inner-dimension tile of O^T
             const int mt = rat_wave(), l = rat_lane(), g = l >> 4, col = 16 * mt + (l & 15);
@@ -1510,15 +1566,28 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             // the padded last K step of P4 reads 32 bytes past each plane's last row: for the first two planes that is the next
             // plane's first row (finite), behind the third it is stale fp32 data whose halves may look like bf16 NaNs — clear it
             if (threadIdx.x < 8) reinterpret_cast<float*>(smem + B3_OFF_QKV + (size_t)3 * B3_QP)[threadIdx.x] = 0.f;
+            if (B3_ROWS4)                                        // d(LN out) is accumulated from the two K halves of P4: start from zero
+                for (int e = threadIdx.x; e < ATT_ROWS * B3_LDN / 4; e += ATT_THREADS)
+                    reinterpret_cast<float4*>(dxn)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         RAT_PROF_MARK(6);
         // ---- P4: d(LN out) = dQKV W_qkv   P5: dW_qkv += dQKV^T LN(x)
-        b3_gemm_rows_longk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
-            const int col = rat_acc_col(nt);
+        if (B3_ROWS4) {
+            // two partial tiles per element, added onto the zeroed LDS tile: 0 + a + b == 0 + b + a in fp32, so the order in which
+            // the two wave groups arrive does not matter (bit-reproducible)
+            b3_gemm_rows4_splitk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col] = acc[r];
-        });
+                for (int r = 0; r < 4; ++r) atomicAdd(&dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col], acc[r]);
+            });
+        } else {
+            b3_gemm_rows_longk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
+                const int col = rat_acc_col(nt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col] = acc[r];
+            });
+        }
         RAT_SCHED_FENCE();
         RAT_PROF_MARK(7);
         {

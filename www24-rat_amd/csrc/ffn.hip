@@ -882,6 +882,249 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t_kernel(FfnArgs a) {
     }
 }
 
+// ---- bf16x3 variant of the token-on-lanes backward (D = 64, H = 128): all five GEMMs on v_mfma_f32_16x16x32_bf16.
+//   * weights: A operands of the three chain products, as pre-split fragments from L2 (W1 rows, W2^T rows, W1^T rows with the hidden
+//     index permuted like PlanesW2 above so that stacked dh' accumulator tiles are its B fragment);
+//   * token fragments x^T / dy^T: split once per chunk in registers — the split pieces ARE the plane pieces of the token-major
+//     LDS images that the weight-gradient GEMMs read with transposed block reads (no second split, no fp32 tile);
+//   * gelu(h) and dh': split on the accumulators (4 values per lane and tile), stored as 8-byte half pieces.
+// LDS: [x planes 24576][dy planes 24576][gelu(h) planes 49152][dh' planes 49152][dx exchange 16384] = 160 KiB.
+typedef RatPlanes<128, 7, 64 * 128> PlanesT64;           // [64 tokens][64]
+typedef RatPlanes<256, 7, 64 * 256, 1> PlanesT128;       // [64 tokens][128]
+struct Ffn3W {
+    RatWPlanes w1;       // A[hidden][k = d]            = w1[hidden][k]      N 128, K 64
+    RatWPlanes w2t;      // A[hidden][k = d]            = w2[k][hidden]      N 128, K 64
+    RatWPlanes w1t;      // A[d][k = hidden, permuted]  = w1[k][d]           N 64,  K 128
+};
+constexpr size_t F3_WP = (size_t)8 * 2 * 3 * 1024;     // bytes of each of the three fragment sets
+constexpr size_t f3_bwd_smem() { return (size_t)2 * 3 * 64 * 128 + (size_t)2 * 3 * 64 * 256 + (size_t)64 * 64 * 4; }
+
+struct HalfPieces {                                      // the three planes of 4 consecutive values (one accumulator quad)
+    unsigned h0, h1, m0, m1, l0, l1;
+};
+__device__ __forceinline__ HalfPieces f3_split4(const float4& v) {
+    HalfPieces p;
+    rat_split2(v.x, v.y, p.h0, p.m0, p.l0);
+    rat_split2(v.z, v.w, p.h1, p.m1, p.l1);
+    return p;
+}
+__device__ __forceinline__ RatB3 f3_stack(const HalfPieces& lo, const HalfPieces& hi) {     // k slots 0..3 | 4..7
+    rat_u4 h, m, l;
+    h.x = lo.h0; h.y = lo.h1; h.z = hi.h0; h.w = hi.h1;
+    m.x = lo.m0; m.y = lo.m1; m.z = hi.m0; m.w = hi.m1;
+    l.x = lo.l0; l.y = lo.l1; l.z = hi.l0; l.w = hi.l1;
+    return RatB3{rat_as_bf16x8(h), rat_as_bf16x8(m), rat_as_bf16x8(l)};
+}
+
+__global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W W) {
+    constexpr int D = F3_D, H = F3_H, KD = D / 16, HT = 4, SL = 4;
+    RAT_DYN_SMEM(smem);
+    const PlanesT64 xsp{smem};
+    const PlanesT64 dysp{smem + 3 * 64 * 128};
+    const PlanesT128 gsp{smem + 2 * 3 * 64 * 128};
+    const PlanesT128 dhsp{smem + 2 * 3 * 64 * 128 + 3 * 64 * 256};
+    float* px = reinterpret_cast<float*>(smem + 2 * 3 * 64 * 128 + 2 * 3 * 64 * 256);     // [64][64], 16-byte pieces XOR-swizzled
+
+    const int l = rat_lane(), n = l & 15, g = l >> 4;
+    const int w = rat_wave(), tt = w & 3, half = w >> 2;
+    const int row = 16 * tt + n;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto pxp = [&](int m) { return px + row * D + 4 * ((4 * m + g) ^ (row & 15)); };
+
+    f32x4 acc1[SL], acc2[SL], db1a[HT];
+#pragma unroll
+    for (int i = 0; i < SL; ++i) acc1[i] = acc2[i] = db1a[i] = rat_zero4();
+    float4 db2f[4] = {zero4, zero4, zero4, zero4};                 // column sums of dy in fragment order (half 1 only)
+
+    float4 xN[4], dyN[4];                                          // [2 s + part]: x[token][32 s + 8 g + 4 part .. + 3]
+    int64_t chunk = blockIdx.x;
+    {
+        const int64_t tk = chunk * FB_TOK + row;
+        const bool ok = chunk < a.nchunks && tk < a.ntok;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+            dyN[q] = ok ? ld4(a.dy + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+        }
+    }
+    for (; chunk < a.nchunks; chunk += gridDim.x) {
+        const int64_t tok = chunk * FB_TOK + row;
+        RatB3 xb[2], dyb[2];
+        {
+            float4 xT[4], dyT[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xT[q] = rat_consume4(xN[q]);
+                dyT[q] = rat_consume4(dyN[q]);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                rat_u4 h, m, lo;
+                rat_split8(xT[2 * s], xT[2 * s + 1], h, m, lo);
+                xb[s] = RatB3{rat_as_bf16x8(h), rat_as_bf16x8(m), rat_as_bf16x8(lo)};
+                if (half == 0) xsp.store(row, 4 * s + g, h, m, lo);
+                rat_split8(dyT[2 * s], dyT[2 * s + 1], h, m, lo);
+                dyb[s] = RatB3{rat_as_bf16x8(h), rat_as_bf16x8(m), rat_as_bf16x8(lo)};
+                if (half == 1) dysp.store(row, 4 * s + g, h, m, lo);
+            }
+            if (half == 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    db2f[q].x += dyT[q].x; db2f[q].y += dyT[q].y; db2f[q].z += dyT[q].z; db2f[q].w += dyT[q].w;
+                }
+        }
+        // ---- chain: h^T = W1 x^T (+ b1), dh^T = W2^T dy^T per hidden tile; gelu / gelu' on the accumulators
+        HalfPieces dpp[HT];
+#pragma unroll
+        for (int i = 0; i < HT; ++i) {
+            const int m = HT * half + i;
+            f32x4 c0 = as_v4(ld4(a.b1 + 16 * m + 4 * g)), c1 = rat_zero4();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const RatB3 a0 = W.w1(m, s), a1 = W.w2t(m, s);
+                c0 = RAT_MFMA_BF16(a0.l, xb[s].h, c0);
+                c1 = RAT_MFMA_BF16(a1.l, dyb[s].h, c1);
+                c0 = RAT_MFMA_BF16(a0.h, xb[s].l, c0);
+                c1 = RAT_MFMA_BF16(a1.h, dyb[s].l, c1);
+                c0 = RAT_MFMA_BF16(a0.m, xb[s].m, c0);
+                c1 = RAT_MFMA_BF16(a1.m, dyb[s].m, c1);
+                c0 = RAT_MFMA_BF16(a0.m, xb[s].h, c0);
+                c1 = RAT_MFMA_BF16(a1.m, dyb[s].h, c1);
+                c0 = RAT_MFMA_BF16(a0.h, xb[s].m, c0);
+                c1 = RAT_MFMA_BF16(a1.h, dyb[s].m, c1);
+                c0 = RAT_MFMA_BF16(a0.h, xb[s].h, c0);
+                c1 = RAT_MFMA_BF16(a1.h, dyb[s].h, c1);
+            }
+            float4 gv, dp;
+            float dg;
+            rat_gelu_both(c0[0], gv.x, dg);
+            dp.x = c1[0] * dg;
+            rat_gelu_both(c0[1], gv.y, dg);
+            dp.y = c1[1] * dg;
+            rat_gelu_both(c0[2], gv.z, dg);
+            dp.z = c1[2] * dg;
+            rat_gelu_both(c0[3], gv.w, dg);
+            dp.w = c1[3] * dg;
+            const HalfPieces gp = f3_split4(gv);
+            dpp[i] = f3_split4(dp);
+            gsp.store_half(row, 4 * m + g, gp.h0, gp.h1, gp.m0, gp.m1, gp.l0, gp.l1);
+            dhsp.store_half(row, 4 * m + g, dpp[i].h0, dpp[i].h1, dpp[i].m0, dpp[i].m1, dpp[i].l0, dpp[i].l1);
+            db1a[i][0] += dp.x;
+            db1a[i][1] += dp.y;
+            db1a[i][2] += dp.z;
+            db1a[i][3] += dp.w;
+        }
+        // ---- partial dx^T over this half's hidden tiles: the stacked dh' quads of tiles (2 t, 2 t + 1) are the B fragment
+        f32x4 dxa[KD];
+#pragma unroll
+        for (int m = 0; m < KD; ++m) dxa[m] = rat_zero4();
+#pragma unroll
+        for (int t = 0; t < HT / 2; ++t) {
+            const RatB3 db = f3_stack(dpp[2 * t], dpp[2 * t + 1]);
+#pragma unroll
+            for (int m = 0; m < KD; m += 2) {
+                f32x4 cc[2] = {dxa[m], dxa[m + 1]};
+                const RatB3 aa[2] = {W.w1t(m, 2 * half + t), W.w1t(m + 1, 2 * half + t)};
+                rat_mfma3_block<2>(cc, aa, db);
+                dxa[m] = cc[0];
+                dxa[m + 1] = cc[1];
+            }
+        }
+        // the d tiles of dx are split between the halves: each parks its partial of the OTHER half's tiles in LDS
+        constexpr int KD0 = KD / 2;
+        if (half == 0) {
+#pragma unroll
+            for (int m = KD0; m < KD; ++m) st4(pxp(m), as_f4(dxa[m]));
+        } else {
+#pragma unroll
+            for (int m = 0; m < KD0; ++m) st4(pxp(m), as_f4(dxa[m]));
+        }
+        __syncthreads();
+        auto finish = [&](int m) {
+            const float4 p = ld4(pxp(m));
+            float4 dr = zero4;
+            if (a.add_dy && tok < a.ntok) dr = ld4(a.dy + tok * D + 16 * m + 4 * g);
+            const float4 o = make_float4(dxa[m][0] + p.x + dr.x, dxa[m][1] + p.y + dr.y, dxa[m][2] + p.z + dr.z, dxa[m][3] + p.w + dr.w);
+            if (tok < a.ntok) st4(a.y + tok * D + 16 * m + 4 * g, o);
+        };
+        if (half == 0) {
+#pragma unroll
+            for (int m = 0; m < KD0; ++m) finish(m);
+        } else {
+#pragma unroll
+            for (int m = KD0; m < KD; ++m) finish(m);
+        }
+        {   // next chunk's token fragments: in flight behind the weight-gradient GEMMs
+            const int64_t tk = (chunk + gridDim.x) * FB_TOK + row;
+            const bool ok = chunk + gridDim.x < a.nchunks && tk < a.ntok;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+                dyN[q] = ok ? ld4(a.dy + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+            }
+        }
+        // ---- dW1 += dh'^T x (tiles: hidden (w >> 2) + 2 i  x  d (w & 3)) ; dW2 += dy^T gelu(h) (tiles: d (w & 3)  x  hidden (w >> 2) + 2 i)
+        {
+            const RatB3 xb0 = xsp.col_frag(w & 3, 0), xb1 = xsp.col_frag(w & 3, 1);
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int mt = (w >> 2) + 2 * i;
+                acc1[i] = rat_mfma3(dhsp.col_frag(mt, 0), xb0, acc1[i]);
+                acc1[i] = rat_mfma3(dhsp.col_frag(mt, 1), xb1, acc1[i]);
+            }
+            const RatB3 ya0 = dysp.col_frag(w & 3, 0), ya1 = dysp.col_frag(w & 3, 1);
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int nt = (w >> 2) + 2 * i;
+                acc2[i] = rat_mfma3(ya0, gsp.col_frag(nt, 0), acc2[i]);
+                acc2[i] = rat_mfma3(ya1, gsp.col_frag(nt, 1), acc2[i]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+    float* s_w1 = slab;
+    float* s_w2 = s_w1 + (int64_t)H * D;
+    float* s_b1 = s_w2 + (int64_t)D * H;
+    float* s_b2 = s_b1 + H;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+        const int t2 = (w >> 2) + 2 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s_w1[(int64_t)rat_acc_row(t2, r) * D + rat_acc_col(w & 3)] = acc1[i][r];
+            s_w2[(int64_t)rat_acc_row(w & 3, r) * H + rat_acc_col(t2)] = acc2[i][r];
+        }
+    }
+    {   // bias gradients: per-token-column partials -> LDS [feature][64 token columns] -> fixed-order sums
+        constexpr int LR = FB_TOK + 1;
+        float* red1 = reinterpret_cast<float*>(smem);              // [H][LR]
+        float* red2 = red1 + H * LR;                               // [D][LR]
+#pragma unroll
+        for (int i = 0; i < HT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red1[(16 * (HT * half + i) + 4 * g + r) * LR + row] = db1a[i][r];
+        if (half == 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+                red2[(c0 + 0) * LR + row] = db2f[q].x;
+                red2[(c0 + 1) * LR + row] = db2f[q].y;
+                red2[(c0 + 2) * LR + row] = db2f[q].z;
+                red2[(c0 + 3) * LR + row] = db2f[q].w;
+            }
+        __syncthreads();
+        for (int c = threadIdx.x; c < H + D; c += FB_THREADS) {
+            const float* src = c < H ? red1 + c * LR : red2 + (c - H) * LR;
+            float sacc = 0.f;
+            for (int k = 0; k < FB_TOK; ++k) sacc += src[k];
+            if (c < H) s_b1[c] = sacc; else s_b2[c - H] = sacc;
+        }
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ffn_fast_dim(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
@@ -956,7 +1199,8 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
 
 extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
     const FfnGeom g(d, hidden);
-    return ((size_t)256 * (size_t)g.slab_floats() + 2 * (size_t)d * hidden) * sizeof(float);   // slabs + w1^T + w2^T
+    const size_t fp32 = ((size_t)256 * (size_t)g.slab_floats() + 2 * (size_t)d * hidden) * sizeof(float);   // slabs + w1^T + w2^T
+    return fp32 + ((d == F3_D && hidden == F3_H) ? 3 * F3_WP + 16 : 0);                                      // + bf16x3 weight fragments
 }
 
 extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
@@ -994,6 +1238,18 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const int fast = ffn_fast_dim(a, {x, dy, dx, b1});
+    if (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3) {
+        uintptr_t wsb = reinterpret_cast<uintptr_t>(workspace + (size_t)256 * a.slab_stride + 2 * (size_t)d * hidden);
+        char* ws = reinterpret_cast<char*>((wsb + 15) & ~(uintptr_t)15);
+        if (rat_launch_split_weights(w1, F3_H, F3_D, F3_D, 0, ws, stream) ||                          // A[hidden][d]   = w1[hidden][d]
+            rat_launch_split_weights(w2, F3_H, F3_D, F3_H, 1, ws + F3_WP, stream) ||                  // A[hidden][d]   = w2[d][hidden]
+            rat_launch_split_weights(w1, F3_D, F3_H, F3_D, 1, ws + 2 * F3_WP, stream, 1)) return -1;  // A[d][hidden*] = w1[hidden][d]
+        Ffn3W W{};
+        W.w1 = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
+        W.w2t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + F3_WP), 2};
+        W.w1t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + 2 * F3_WP), 4};
+        RAT_LAUNCH(ffn_bwd_t3_kernel, blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+    } else
     if (fast) {
         float* w1t = workspace + (size_t)256 * a.slab_stride;
         float* w2t = w1t + (size_t)d * hidden;
@@ -1001,7 +1257,9 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
         a.w1t = w1t;
         a.w2t = w2t;
     }
-    if (fast == 64 && hidden == 128) {
+    if (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3) {
+        // launched above
+    } else if (fast == 64 && hidden == 128) {
         RAT_LAUNCH((ffn_bwd_t_kernel<64, 128>), blocks, FB_THREADS, (FfnBTGeom<64, 128>::smem), stream, a);
     } else if (fast == 16 && hidden == 32) {
         RAT_LAUNCH((ffn_bwd_t_kernel<16, 32>), blocks, FB_THREADS, (FfnBTGeom<16, 32>::smem), stream, a);

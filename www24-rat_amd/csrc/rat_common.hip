@@ -106,16 +106,18 @@ int rat_launch_transpose(const float* src, float* dst, int R, int C, void* strea
 }
 
 // weights -> fragment-major bf16x3 planes (rat_device.h RatWPlanes): one thread per (n tile, K step, lane)
-__global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __restrict__ w, int N, int K, int ld, int transpose,
+__global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __restrict__ w, int N, int K, int ld, int transpose, int perm,
                                                                 rat_u4* __restrict__ out, int ntiles, int steps) {
     const int total = ntiles * steps * 64;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int lane = e & 63, fs = e >> 6, nt = fs / steps, s = fs - nt * steps;
-        const int n = 16 * nt + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
+        const int n = 16 * nt + (lane & 15), g = lane >> 4;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
+            // perm: k slot j of lane group g <-> k = 32 s + 4 g + j (j < 4), 32 s + 16 + 4 g + (j - 4) (j >= 4) — the order in which
+            // two stacked 16-row accumulator tiles present their rows as a B fragment (ffn.hip)
+            const int k = 32 * s + (perm ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);
             v[j] = (n < N && k < K) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
         }
         rat_u4 h, m, l;
@@ -126,9 +128,10 @@ __global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __r
         o[128] = l;
     }
 }
-int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream) {
+int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm) {
     const int ntiles = (N + 15) / 16, steps = (K + 31) / 32;
     const int blocks = (ntiles * steps * 64 + 255) / 256;
-    RAT_LAUNCH(rat_split_weights_kernel, (unsigned)blocks, 256, 0, stream, w, N, K, ld, transpose, static_cast<rat_u4*>(out), ntiles, steps);
+    RAT_LAUNCH(rat_split_weights_kernel, (unsigned)blocks, 256, 0, stream, w, N, K, ld, transpose, perm, static_cast<rat_u4*>(out), ntiles,
+               steps);
     return rat_check_launch("rat_split_weights");
 }

@@ -603,10 +603,20 @@ __device__ __forceinline__ void rat_mfma3_block(f32x4 (&acc)[MT], const RatB3 (&
 // of one row); rows are RS bytes apart; SWZ (0, 7 or 15): the piece index is XORed with (row & SWZ), which makes the 16-byte row
 // reads of an MFMA fragment AND the transposed 4-row block reads below bank-conflict free for 128-byte rows (SWZ 7, W = 64) and
 // the row reads for 256-byte rows (SWZ 15, W = 128).
-template <int RS, int SWZ, int PLANE_BYTES>
+// SHIFT: the XOR acts on piece-index bits SHIFT.. (SHIFT 1 keeps the two pieces of a 32-byte column pair adjacent: the transposed
+// reads of 256-byte rows then spread 8 consecutive rows over all 64 banks).
+template <int RS, int SWZ, int PLANE_BYTES, int SHIFT = 0>
 struct RatPlanes {
     char* base;
-    __device__ __forceinline__ int off(int r, int o) const { return r * RS + 16 * (o ^ (r & SWZ)); }
+    __device__ __forceinline__ int off(int r, int o) const { return r * RS + 16 * (o ^ ((r & SWZ) << SHIFT)); }
+    // half a piece: the 4 columns [4 q4, 4 q4 + 4) of row r (8 bytes per plane) — what an accumulator register quad holds
+    __device__ __forceinline__ void store_half(int r, int q4, unsigned h0, unsigned h1, unsigned m0, unsigned m1, unsigned l0,
+                                               unsigned l1) const {
+        const int a = off(r, q4 >> 1) + 8 * (q4 & 1);
+        *reinterpret_cast<uint2*>(base + a) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(base + PLANE_BYTES + a) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(base + 2 * PLANE_BYTES + a) = make_uint2(l0, l1);
+    }
     __device__ __forceinline__ void store(int r, int o, const rat_u4& h, const rat_u4& m, const rat_u4& l) const {
         const int a = off(r, o);
         *reinterpret_cast<rat_u4*>(base + a) = h;
@@ -655,7 +665,7 @@ struct RatWPlanes {
 };
 // B[k][n] = transpose ? w[k * ld + n] : w[n * ld + k] for n < N, k < K (zero beyond); out: rat_wplanes_bytes(N, K) bytes
 inline size_t rat_wplanes_bytes(int N, int K) { return (size_t)((N + 15) / 16) * ((K + 31) / 32) * 3 * 64 * 16; }
-int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream);
+int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm = 0);
 
 // row/col of accumulator register r of a 16x16 tile
 __device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 16 + (rat_lane() >> 4) * 4 + r; }

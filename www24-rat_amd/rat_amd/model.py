@@ -414,7 +414,7 @@ class RAT_m2(BaseModel):
             xa, a1 = self._attn_layer_forward(blk["intra"], x, imap, save, out=x if inplace else None)
             xb, a2 = self._attn_layer_forward(blk["cross"], xa, cmap, save, out=xa if not save else None)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, lib=lib)
+            xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, arith=self.arith, lib=lib)
             if save:
                 saved["blocks"].append((x, a1, xa, a2, xb))
             x = xc
@@ -430,7 +430,7 @@ class RAT_m2(BaseModel):
         for blk, (x_in, a1, xa, a2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             gw = [G(n) for n in blk["ffn"]]
-            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, lib=lib)
+            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith, lib=lib)
             dx = self._attn_layer_backward(blk["cross"], xa, dx, a2, cmap, G)
             dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G)
         return dx
@@ -900,7 +900,7 @@ class RAT_m1(RAT_m2):
             xa, att = self._attn_layer_forward(lay["attn"], x, smap, save)                            # attn(norm(x)) + x
             xn = ops.layernorm_fwd(xa, d, ntok, self._p(lay["ln"][0]), self._p(lay["ln"][1]), d, lib=lib)
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
-            xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, lib=lib)                               # ff(norm(x)) + x
+            xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)             # ff(norm(x)) + x
             if save:
                 rec.append((x, att, xa, xn))
             x = xb
@@ -920,7 +920,8 @@ class RAT_m1(RAT_m2):
         for lay, (x_in, att, xa, xn) in zip(reversed(layers), reversed(rec)):
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
             gw = [G(n) for n in lay["ffn"]]
-            dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn, lib=lib)
+            dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
+                                     arith=self.arith, lib=lib)
             dxa = ops.layernorm_bwd(xa, d, dxn, self._p(lay["ln"][0]), dxn, d, G(lay["ln"][0]), G(lay["ln"][1]), d, add=dx, lib=lib)
             dx = self._attn_layer_backward(lay["attn"], x_in, dxa, att, smap, G)
         return dx
@@ -996,7 +997,7 @@ class RAT_m3(RAT_m2):
             out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, imap, d, h, dh, sc, 0.5, save=save, lib=lib)             # 0.5 * intra(x)
             out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cmap, d, h, dh, sc, 0.5, save=save, out=out, lib=lib)     # += 0.5 * cross(x)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            xn = ops.ffn_fwd_res(out, x, w1, b1, w2, b2, d, H, lib=lib)                                           # mlp(out) + x
+            xn = ops.ffn_fwd_res(out, x, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)                         # mlp(out) + x
             if save:
                 saved["blocks"].append((x, o_s, l_s, o_t, l_t, out))
             x = xn
@@ -1016,7 +1017,8 @@ class RAT_m3(RAT_m2):
         for blk, (x_in, o_s, l_s, o_t, l_t, out) in zip(reversed(self._blocks), reversed(saved["blocks"])):
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             gw = [G(n) for n in blk["ffn"]]
-            dout, _ = ops.ffn_bwd_res(out, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn, lib=lib)
+            dout, _ = ops.ffn_bwd_res(out, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
+                                      arith=self.arith, lib=lib)
             ps = self._m3_params(blk, "intra", blk["w_s"], self._p)
             pt = self._m3_params(blk, "cross", blk["w_t"], self._p)
             gs = self._m3_params(blk, "intra", g_s, G)
