@@ -1026,34 +1026,17 @@ __device__ __forceinline__ void b3_load_piece(const float* src, const int64_t* r
 }
 
 // C[64][16 NT] = A (planes, row operand, KS K-steps) x B (weight fragments).  Wave w owns the row-tile pair {2 (w >> 2), +1} and the
-// column tiles (w & 3) + 4 i: its A fragments are read once; B fragments are requested ahead of their MFMAs — B3_PREFETCH_TILE 1:
-// the whole next column tile (KS fragments in flight), 0: one fragment (12 VGPRs) ahead.
-#ifndef B3_PREFETCH_TILE
-#define B3_PREFETCH_TILE 0
-#endif
-#ifndef B3_LONGK_DEPTH
-#define B3_LONGK_DEPTH 1
-#endif
-#ifndef B3_P5_PREFETCH
-#define B3_P5_PREFETCH 1
-#endif
-#ifndef B3_P2_REV
-#define B3_P2_REV 1
-#endif
-// REV: column tiles are dealt from the other end ((3 - w & 3) + 4 i), so that two back-to-back phases with 4 k + 3 and 4 k + 1 column
-// tiles (Q|K|V: 15, dO: 5) give every wave the same number of tiles in total
+// column tiles (w & 3) + 4 i: its A fragments are read once; the B fragment of the NEXT (column tile, K step) is requested before the
+// MFMAs of the current one.  REV: column tiles are dealt from the other end ((3 - w & 3) + 4 i), so that two back-to-back phases with
+// 4 k + 3 and 4 k + 1 column tiles (Q|K|V: 15, dO: 5) give every wave the same number of tiles in total.
+// Same-box A/B of the alternatives (tools/ab_attn.sh, tools/experiments/): a whole column tile of B in flight: +5 % (registers);
+// all four row tiles on one wave (half the L2 traffic, A re-read per column tile): +50 %; REV: -2 %.
 template <int KS, bool REV = false, class PA, class Epi>
 __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
     const int w = rat_wave(), mt0 = 2 * (w >> 2);
     int nt = REV ? 3 - (w & 3) : (w & 3);
     if (nt >= n_tiles) return;
-#if B3_PREFETCH_TILE
-    RatB3 b[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) b[s] = Bw(nt, s);
-#else
     RatB3 b = Bw(nt, 0);
-#endif
     RatB3 a[2][KS];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1061,17 +1044,6 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, 
         for (int s = 0; s < KS; ++s) a[i][s] = A.row_frag(mt0 + i, s);
     for (; nt < n_tiles; nt += 4) {
         f32x4 acc[2] = {rat_zero4(), rat_zero4()};
-#if B3_PREFETCH_TILE
-        RatB3 bn[KS];
-        const int nn = nt + 4 < n_tiles ? nt + 4 : nt;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) bn[s] = Bw(nn, s);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const RatB3 as[2] = {a[0][s], a[1][s]};
-            rat_mfma3_block<2>(acc, as, b[s]);
-        }
-#else
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const bool last = s == KS - 1;
@@ -1080,60 +1052,9 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, 
             rat_mfma3_block<2>(acc, as, b);
             b = bn;
         }
-#endif
         epi(mt0, nt, acc[0]);
         epi(mt0 + 1, nt, acc[1]);
-#if B3_PREFETCH_TILE
-#pragma unroll
-        for (int s = 0; s < KS; ++s) b[s] = bn[s];
-#endif
     }
-}
-
-// The same product with ALL FOUR row tiles on one wave: column tile w (+ 8 i) — every weight fragment is fetched from L2 once per
-// chunk instead of once per row-tile pair (the L2 -> CU path, ~64 B/clk, is otherwise as busy as the MFMA pipe: 184 KB of Q|K|V
-// fragments per chunk), the A fragments are re-read from LDS per column tile (LDS has the bandwidth).  REV: tiles dealt from wave 7 down.
-#ifndef B3_ROWS4
-#define B3_ROWS4 0            // A/B on MI355X (tools/ab_attn.sh): the backward runs 1.45 -> 2.2 ms with this mapping (LDS-bound), kept for reference
-#endif
-template <int KS, bool REV = false, class PA, class Epi>
-__device__ __forceinline__ void b3_gemm_rows4(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
-    const int w = rat_wave();
-    int nt = REV ? 7 - w : w;
-    if (nt >= n_tiles) return;
-    RatB3 b = Bw(nt, 0);
-    for (; nt < n_tiles; nt += 8) {
-        f32x4 acc[4] = {rat_zero4(), rat_zero4(), rat_zero4(), rat_zero4()};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bool last = s == KS - 1;
-            const RatB3 bn = Bw(last ? (nt + 8 < n_tiles ? nt + 8 : nt) : nt, last ? 0 : s + 1);
-            const RatB3 a[4] = {A.row_frag(0, s), A.row_frag(1, s), A.row_frag(2, s), A.row_frag(3, s)};
-            rat_mfma3_block<4>(acc, a, b);
-            b = bn;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) epi(i, nt, acc[i]);
-    }
-}
-
-// C[64][64] += A (planes, KS K-steps) x B with the K extent split over the two wave groups (w >> 2): wave = (column tile w & 3, K half),
-// all four row tiles; each weight fragment is fetched once per chunk.  epi receives PARTIAL tiles (the caller adds the two halves).
-template <int KS, class PA, class Epi>
-__device__ __forceinline__ void b3_gemm_rows4_splitk(const PA& A, const RatWPlanes& Bw, const Epi& epi) {
-    const int w = rat_wave(), nt = w & 3, s0 = (w >> 2) * (KS / 2);
-    f32x4 acc[4] = {rat_zero4(), rat_zero4(), rat_zero4(), rat_zero4()};
-    RatB3 b = Bw(nt, s0);
-#pragma unroll
-    for (int i = 0; i < KS / 2; ++i) {
-        const int s = s0 + i;
-        const RatB3 bn = Bw(nt, i + 1 < KS / 2 ? s + 1 : s);
-        const RatB3 a[4] = {A.row_frag(0, s), A.row_frag(1, s), A.row_frag(2, s), A.row_frag(3, s)};
-        rat_mfma3_block<4>(acc, a, b);
-        b = bn;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) epi(i, nt, acc[i]);
 }
 
 template <bool EX>
@@ -1181,15 +1102,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         __syncthreads();
         RAT_PROF_MARK(0);
         // Q|K|V = LN(x) W_qkv^T
-        {
-            auto epi = [&](int mt, int nt, const f32x4& acc) {
-                const int col = rat_acc_col(nt);
+        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
-            };
-            if (B3_ROWS4) b3_gemm_rows4<2>(xp, W.qkv, B3_Q3 / 16, epi);
-            else b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, epi);
-        }
+            for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
+        });
         __syncthreads();
         RAT_PROF_MARK(1);
         // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>
@@ -1303,33 +1220,23 @@ constexpr size_t b3_bwd_smem() { return B3_OFF_MISC + (size_t)64 * (2 + 2 * B3_H
 static_assert(B3_OFF_MISC - B3_OFF_QKV >= (size_t)3 * B3_QP + 64, "d(Q|K|V) planes overlay the three fp32 tiles");
 static_assert((size_t)64 * B3_LDN * 4 <= (size_t)3 * B3_XP, "d(LN out) overlays the dy planes");
 
-// C[64][64] = A (planes, row operand, KS K-steps) x B: wave w owns row tiles {2 (w >> 2), +1} x column tile (w & 3); the weight
-// fragment (L2) is requested B3_LONGK_DEPTH steps, the LDS fragments one step ahead of their MFMAs
+// C[64][64] = A (planes, row operand, KS K-steps) x B: wave w owns row tiles {2 (w >> 2), +1} x column tile (w & 3); the operands
+// of step s + 1 (weight fragment from L2, A fragments from LDS) are requested before the MFMAs of step s
 template <int KS, class PA, class Epi>
 __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes& Bw, const Epi& epi) {
     const int w = rat_wave(), mt0 = 2 * (w >> 2), nt = w & 3;
     f32x4 acc[2] = {rat_zero4(), rat_zero4()};
-    RatB3 b0 = Bw(nt, 0);
-#if B3_LONGK_DEPTH > 1
-    RatB3 b1 = Bw(nt, KS > 1 ? 1 : 0);
-#endif
+    RatB3 b = Bw(nt, 0);
     RatB3 a[2] = {A.row_frag(mt0, 0), A.row_frag(mt0 + 1, 0)};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int sn = s + 1 < KS ? s + 1 : s;
-#if B3_LONGK_DEPTH > 1
-        const RatB3 b2 = Bw(nt, s + 2 < KS ? s + 2 : KS - 1);
-#else
-        const RatB3 b1 = Bw(nt, sn);
-#endif
+        const RatB3 bn = Bw(nt, sn);
         const RatB3 an[2] = {A.row_frag(mt0, sn), A.row_frag(mt0 + 1, sn)};
-        rat_mfma3_block<2>(acc, a, b0);
+        rat_mfma3_block<2>(acc, a, b);
         a[0] = an[0];
         a[1] = an[1];
-        b0 = b1;
-#if B3_LONGK_DEPTH > 1
-        b1 = b2;
-#endif
+        b = bn;
     }
     epi(mt0, nt, acc[0]);
     epi(mt0 + 1, nt, acc[1]);
@@ -1370,23 +1277,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
     }
     __syncthreads();
     RAT_PROF_DECL
-#ifndef B3_LOAD_AHEAD
-#define B3_LOAD_AHEAD 0                              // A/B on MI355X: issuing the next chunk's loads a phase early costs 8-10 % (registers)
-#endif
-    // this thread's loads of a chunk (x / dy piece, O items, lse).  vmcnt retires in order, so loads that may miss to HBM must never
-    // sit in front of a GEMM phase's operand loads: the NEXT chunk's are issued at the start of P6 (the last phase, LayerNorm
-    // backward — whose own loads are issued first) and consumed by P0
-    float4 xn0, xn1, dn0, dn1;
-    RowFetch<B3_I> fo;
-    float lsen;
-    auto issue_loads = [&](const int64_t* rt) {
-        b3_load_piece(a.x, rt, xn0, xn1);
-        b3_load_piece(a.dy, rt, dn0, dn1);
-        fo.issue(a.o_save, rt);
-        const int64_t tk = rt[r_own];
-        lsen = tk >= 0 ? a.lse_save[tk * B3_H + sub] : 0.f;
-    };
-    if (B3_LOAD_AHEAD) issue_loads(rowtok0);
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
         const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
@@ -1399,9 +1289,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         }
         const int64_t tok_own = rowtok[r_own];
         // ---- P0: x -> LayerNorm -> planes; dy -> planes (+ db_out partials); O, lse -> fp32 tiles
-        {
-            if (!B3_LOAD_AHEAD) issue_loads(rowtok);
-            float4 x0 = xn0, x1 = xn1, d0 = dn0, d1 = dn1;
+        {   // (the rows were touched into L2 behind the previous chunk's VALU passes.  vmcnt retires in order, so loads that may still
+            //  miss to HBM must not sit in front of a GEMM phase's operand loads: issuing these a phase early cost 8-10 %, A/B)
+            float4 x0, x1, d0, d1;
+            RowFetch<B3_I> fo;
+            b3_load_piece(a.x, rowtok, x0, x1);
+            b3_load_piece(a.dy, rowtok, d0, d1);
+            fo.issue(a.o_save, rowtok);
+            const float lsen = tok_own >= 0 ? a.lse_save[tok_own * B3_H + sub] : 0.f;
             {
                 float gam[8], bet[8];
 #pragma unroll
@@ -1440,12 +1335,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * B3_LDT + col] = acc[r];
             };
-            if (B3_ROWS4) b3_gemm_rows4<2>(xp, W.qkv, B3_Q3 / 16, epi_q);
-            else b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, epi_q);
+            b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, epi_q);                          // 15 column tiles: 4, 4, 4, 3 per column-tile group
             RAT_SCHED_FENCE();
             RAT_PROF_MARK(1);
-            if (B3_ROWS4) b3_gemm_rows4<2, true>(dyp, W.outT, B3_I / 16, epi_o);       // waves 7..3 (Q|K|V gave waves 0..6 two tiles, wave 7 one)
-            else b3_gemm_rows<2, B3_P2_REV != 0>(dyp, W.outT, B3_I / 16, epi_o);
+            b3_gemm_rows<2, true>(dyp, W.outT, B3_I / 16, epi_o);                   //  5 column tiles dealt from the other end: 1, 1, 1, 2
             RAT_SCHED_FENCE();
         }
         RAT_PROF_MARK(2);
@@ -1566,34 +1459,20 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             // the padded last K step of P4 reads 32 bytes past each plane's last row: for the first two planes that is the next
             // plane's first row (finite), behind the third it is stale fp32 data whose halves may look like bf16 NaNs — clear it
             if (threadIdx.x < 8) reinterpret_cast<float*>(smem + B3_OFF_QKV + (size_t)3 * B3_QP)[threadIdx.x] = 0.f;
-            if (B3_ROWS4)                                        // d(LN out) is accumulated from the two K halves of P4: start from zero
-                for (int e = threadIdx.x; e < ATT_ROWS * B3_LDN / 4; e += ATT_THREADS)
-                    reinterpret_cast<float4*>(dxn)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
         RAT_PROF_MARK(6);
         // ---- P4: d(LN out) = dQKV W_qkv   P5: dW_qkv += dQKV^T LN(x)
-        if (B3_ROWS4) {
-            // two partial tiles per element, added onto the zeroed LDS tile: 0 + a + b == 0 + b + a in fp32, so the order in which
-            // the two wave groups arrive does not matter (bit-reproducible)
-            b3_gemm_rows4_splitk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
-                const int col = rat_acc_col(nt);
+        b3_gemm_rows_longk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col], acc[r]);
-            });
-        } else {
-            b3_gemm_rows_longk<8>(dqp, W.qkvT, [&](int mt, int nt, const f32x4& acc) {
-                const int col = rat_acc_col(nt);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col] = acc[r];
-            });
-        }
+            for (int r = 0; r < 4; ++r) dxn[(size_t)rat_acc_row(mt, r) * B3_LDN + col] = acc[r];
+        });
         RAT_SCHED_FENCE();
         RAT_PROF_MARK(7);
         {
             const int w = rat_wave(), nt = w & 3;
             const RatB3 b0 = xp.col_frag(nt, 0), b1 = xp.col_frag(nt, 1);
-#if B3_P5_PREFETCH
             RatB3 a0 = dqp.col_frag(w >> 2, 0), a1 = dqp.col_frag(w >> 2, 1);
 #pragma unroll
             for (int i = 0; i < QSLOTS; ++i) {
@@ -1607,17 +1486,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 a0 = n0;
                 a1 = n1;
             }
-#else
-#pragma unroll
-            for (int i = 0; i < QSLOTS; ++i) {
-                const int mt = (w >> 2) + 2 * i;
-                if (mt < B3_Q3 / 16) {
-                    accq[i] = rat_mfma3(dqp.col_frag(mt, 0), b0, accq[i]);
-                    accq[i] = rat_mfma3(dqp.col_frag(mt, 1), b1, accq[i]);
-                }
-                RAT_SCHED_FENCE();
-            }
-#endif
         }
         __syncthreads();
         RAT_PROF_MARK(8);
@@ -1634,7 +1502,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 if (valid) xv2[k] = *reinterpret_cast<const float4*>(a.x + tok_own * B3_D + 8 * sub + 4 * k);
                 if (valid && addp != nullptr) av2[k] = *reinterpret_cast<const float4*>(addp + tok_own * B3_D + 8 * sub + 4 * k);
             }
-            if (B3_LOAD_AHEAD && chunk + gridDim.x < a.nchunks) issue_loads(rowtok0 + (parity ^ 1) * ATT_ROWS);
 #pragma unroll
             for (int k = 0; k < 8; ++k) gam[k] = lnw[8 * sub + k];
 #pragma unroll
