@@ -124,15 +124,21 @@ int rat_attn_bwd(const float* x, const float* dy, const float* o_save, const flo
  *                     rounding; measured against fp64 in tools/probes/bf16x3_probe.hip) at 2.4x the fp32-MFMA rate.  Compiled for
  *                     the north-star geometry (embedding_dim 64, 8 heads x 10); any other shape runs RAT_ARITH_F32 regardless.
  * The forward needs rat_attn_fwd_workspace() bytes of workspace for the pre-split weight fragments under RAT_ARITH_BF16X3
- * (NULL / too small: exact fp32); the backward's rat_attn_bwd_workspace() already covers its own. */
+ * (NULL / too small: exact fp32); the backward's rat_attn_bwd_workspace() already covers its own.
+ *
+ * dropout_p > 0: the nn.Dropout behind the output projection (Attention.to_out = Sequential(Linear, Dropout), RAT_m2.py:186-189):
+ *   y = out_scale * Dropout(to_out(...)) + res, mask(token, column) = a counter-based function of (dropout_seed, token * d + column)
+ *   — the generator of rat_dropout — so the backward call re-derives it from the same (p, seed) instead of reading a stored mask
+ *   (torch's Philox stream cannot be matched bit for bit; parity for p > 0 is statistical).  Ignored without a projection. */
 size_t rat_attn_fwd_workspace(int d, int heads, int dim_head);
 int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
-                    float ln_eps, int arith, float* workspace, size_t workspace_bytes, void* stream);
+                    float ln_eps, float dropout_p, uint64_t dropout_seed, int arith, float* workspace, size_t workspace_bytes,
+                    void* stream);
 int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save, float* dx,
                     const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace, size_t workspace_bytes,
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
-                    float ln_eps, int arith, void* stream);
+                    float ln_eps, float dropout_p, uint64_t dropout_seed, int arith, void* stream);
 
 /* ---- K2d: the attention core alone, for sequences longer than the fused kernel's 64-row tile — RAT_m0 attends jointly over all
  * T*S tokens of a sample (RAT_m0.py:123-127; 231 at the north-star shape).  That variant runs LayerNorm as K2c and the two

@@ -128,6 +128,36 @@ def check_attn(lib, dev, case, mode, seed=2, arith="f32"):
             assert err < 4e-6, ("bf16x3 vs exact fp32", name, err)
 
 
+def check_attn_dropout(lib, dev, case, mode, p=0.25, seed=123456789, arith="f32"):
+    """Dropout behind the output projection (RAT_m2.py:186-189): y = Dropout(to_out(...)) + x.  The mask is a pure function of
+    (seed, element index) — the generator of rat_dropout — so the reference uses the mask that rat_dropout produces on ones."""
+    B, T, S, d, heads, dh, proj = case
+    assert proj
+    rs = np.random.RandomState(31)
+    x = rnd(rs, B, T, S, d)
+    ws = attn_weights(rs, d, heads, dh, proj)
+    dy = rnd(rs, B, T, S, d)
+    mask = ops.dropout(torch.ones_like(x).to(dev), p, seed, lib=lib).cpu().double()
+    kept = float((mask > 0).double().mean())
+    assert abs(kept - (1 - p)) < 0.1 and set(np.unique(mask.numpy()).round(6)) <= {0.0, round(1 / (1 - p), 6)}
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    ref = mask * (attn_reference(xr, *wr, heads, dh, mode) - xr) + xr
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    wd = [w.to(dev) for w in ws]
+    params = ops.attn_params(*wd)
+    smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
+    y, o_save, lse = ops.attn_fwd(xd, params, smap, d, heads, dh, save=True, arith=arith, dropout=(p, seed), lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    gs = [torch.zeros_like(w) for w in wd]
+    dx, _ = ops.attn_bwd(xd, dyd, o_save, lse, params, ops.attn_params(*gs), smap, d, heads, dh, arith=arith, dropout=(p, seed), lib=lib)
+    scale = max(1.0, (B * T * S) ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    for name, g, w in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, wr):
+        close(g, w.grad, 1e-4, 1e-4 * scale, name)
+
+
 def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed=5):
     """rat_attn_fwd_ex / rat_attn_bwd_ex: y = out_scale * attention(LN(x)) + res with res in {none, a second tensor, the output
     itself}, an explicit softmax scale; backward with the matching `add` term."""

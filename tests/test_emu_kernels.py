@@ -65,6 +65,13 @@ def test_attn_fwd_bwd_bf16x3(emu, mode, two_blocks):
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,arith", [((2, 3, 4, 8, 2, 4, True), "f32"), ((1, 2, 5, 64, 8, 10, True), "f32"), ((1, 3, 5, 64, 8, 10, True), "bf16x3")],
+                         ids=["generic", "fast_f32", "bf16x3"])
+def test_attention_output_dropout(emu, case, arith):
+    kc.check_attn_dropout(emu, "cpu", case, "intra", arith=arith)
+    kc.check_attn_dropout(emu, "cpu", case, "cross", arith=arith)
+
+
 def test_persistent_kernels_loop_over_several_chunks(emu, two_blocks):
     """exact-fp32 fast kernels and the FFN with every work-group looping over several chunks (RAT_MAX_BLOCKS=2)"""
     kc.check_attn(emu, "cpu", (2, 5, 9, 64, 8, 10, True), "intra")

@@ -86,6 +86,13 @@ def test_ffn_fwd_bwd(lib, ntok, d, hidden):
     kc.check_ffn(lib, "cuda", ntok, d, hidden)
 
 
+@pytest.mark.parametrize("case,arith", [((2, 3, 4, 8, 2, 4, True), "f32"), ((5, 6, 14, 40, 8, 10, True), "f32"), ((40, 11, 21, 64, 8, 10, True), "f32"),
+                                        ((40, 11, 21, 64, 8, 10, True), "bf16x3")], ids=str)
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attention_output_dropout(lib, case, arith, mode):
+    kc.check_attn_dropout(lib, "cuda", case, mode, arith=arith)
+
+
 @pytest.mark.parametrize("ntok", [64, 1000, 100000])
 def test_ffn_fwd_bwd_bf16x3(lib, ntok):
     kc.check_ffn(lib, "cuda", ntok, 64, 128, arith="bf16x3")

@@ -63,6 +63,7 @@ struct AttnArgs {
     int d, heads, dh;
     float eps, scale;
     int vec_x, vec_wqkv, vec_wout;
+    RatDrop drop;        // Dropout behind the output projection (RAT_m2.py:186-189); the EX instantiations only
     unsigned long long* prof;
 };
 
@@ -108,7 +109,15 @@ __device__ __forceinline__ void map_rows(const AttnArgs& a, int64_t chunk, int64
 
 // load `width` floats per row from a token-indexed global array into an LDS tile (padding rows -> 0)
 __device__ __forceinline__ void load_rows(float* tile, int ld, const float* src, const int64_t* rowtok, int width,
-                                          bool vec, float mul = 1.0f) {
+                                          bool vec, float mul = 1.0f, const RatDrop* drop = nullptr) {
+    if (drop != nullptr && drop->threshold != 0) {           // dy through the projection's Dropout: element-wise mask, scalar path
+        for (int e = threadIdx.x; e < ATT_ROWS * width; e += ATT_THREADS) {
+            const int r = e / width, c = e - r * width;
+            const int64_t tok = rowtok[r];
+            tile[(size_t)r * ld + c] = tok >= 0 ? drop->apply(src[tok * width + c], tok * width + c) * mul : 0.f;
+        }
+        return;
+    }
     if (vec) {
         const int w4 = width >> 2;
         for (int e = threadIdx.x; e < ATT_ROWS * w4; e += ATT_THREADS) {
@@ -240,7 +249,17 @@ __device__ __forceinline__ void layer_norm_rows(float* xs, int ld, int D, int ro
 // tile[rows][0:width] (+ residual rows of `res`, token-indexed) -> dst rows, 16-byte coalesced when vec
 // dst = mul * tile + res (res may be nullptr, or dst itself: every element is read and written by the same thread)
 __device__ __forceinline__ void store_rows_residual(float* dst, const float* tile, int ld, const float* res,
-                                                    const int64_t* rowtok, int rows, int width, bool vec, float mul) {
+                                                    const int64_t* rowtok, int rows, int width, bool vec, float mul,
+                                                    const RatDrop* drop = nullptr) {
+    if (drop != nullptr && drop->threshold != 0) {           // y = mul * Dropout(tile) + res, element-wise mask
+        for (int e = threadIdx.x; e < rows * width; e += ATT_THREADS) {
+            const int r = e / width, c = e - r * width;
+            const int64_t tok = rowtok[r];
+            const float v = drop->apply(tile[(size_t)r * ld + c], tok * width + c) * mul;
+            dst[tok * width + c] = res != nullptr ? v + res[tok * width + c] : v;
+        }
+        return;
+    }
     if (vec) {
         const int w4 = width >> 2;
         for (int e = threadIdx.x; e < rows * w4; e += ATT_THREADS) {
@@ -499,7 +518,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
                 }
             });
             __syncthreads();
-            store_rows_residual(a.y, xs, ldx, EX ? a.res : a.x, rowtok, rows, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f);
+            store_rows_residual(a.y, xs, ldx, EX ? a.res : a.x, rowtok, rows, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f,
+                                EX ? &a.drop : nullptr);
         } else {
             store_rows_residual(a.y, qkv, ldq, EX ? a.res : a.x, rowtok, rows, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f);
         }
@@ -590,9 +610,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
             fx.stash(xs, ldx);
             fdy.stash(dys, ldx, EX ? a.out_scale : 1.0f);
             fo.stash(ob, ldt);
+            if (EX && a.drop.threshold != 0) {                   // rare: re-stage dy through the Dropout mask (after the plain stash)
+                __syncthreads();
+                load_rows(dys, ldx, a.dy, rowtok, D, false, a.out_scale, &a.drop);
+            }
         } else {
             load_rows(xs, ldx, a.x, rowtok, D, a.vec_x != 0);
-            load_rows(dys, ldx, a.dy, rowtok, D, a.vec_x != 0, EX ? a.out_scale : 1.0f);
+            load_rows(dys, ldx, a.dy, rowtok, D, a.vec_x != 0, EX ? a.out_scale : 1.0f, EX ? &a.drop : nullptr);
             load_rows(ob, ldt, a.o_save, rowtok, I, (I % 4) == 0 && a.vec_x != 0);
         }
         for (int e = threadIdx.x; e < ATT_ROWS * H; e += ATT_THREADS) {
@@ -1189,7 +1213,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         __syncthreads();
         RAT_PROF_MARK(4);
         if (EX) {
-            store_rows_residual(a.y, ys, LDY, a.res, rowtok, rows, B3_D, true, a.out_scale);
+            store_rows_residual(a.y, ys, LDY, a.res, rowtok, rows, B3_D, true, a.out_scale, &a.drop);
         } else {                                                 // y = tile + x, the x piece still in registers: no global re-read
             const int r = threadIdx.x >> 3, sb = threadIdx.x & 7;
             const int64_t tok = rowtok[r];
@@ -1305,6 +1329,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                     bet[k] = lnw[B3_D + 8 * sub + k];
                 }
                 b3_layer_norm_to_planes(tok_own >= 0, x0, x1, a.eps, xp, gam, bet, mu, rs);
+            }
+            if (EX && a.drop.threshold != 0 && tok_own >= 0) {               // dy through the projection's Dropout
+                const int64_t i0 = tok_own * B3_D + 8 * sub;
+                d0.x = a.drop.apply(d0.x, i0); d0.y = a.drop.apply(d0.y, i0 + 1); d0.z = a.drop.apply(d0.z, i0 + 2); d0.w = a.drop.apply(d0.w, i0 + 3);
+                d1.x = a.drop.apply(d1.x, i0 + 4); d1.y = a.drop.apply(d1.y, i0 + 5); d1.z = a.drop.apply(d1.z, i0 + 6); d1.w = a.drop.apply(d1.w, i0 + 7);
             }
             if (EX && a.out_scale != 1.0f) {
                 const float m_ = a.out_scale;
@@ -1643,8 +1672,8 @@ int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
 
 extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_save, const RatAttnParams* w_host,
                             const RatSeqMap* map_host, int d, int heads, int dim_head, float ln_eps, void* stream) {
-    return rat_attn_fwd_ex(x, x, y, o_save, lse_save, w_host, map_host, d, heads, dim_head, 0.f, 1.f, ln_eps, RAT_ARITH_F32, nullptr, 0,
-                           stream);
+    return rat_attn_fwd_ex(x, x, y, o_save, lse_save, w_host, map_host, d, heads, dim_head, 0.f, 1.f, ln_eps, 0.f, 0, RAT_ARITH_F32,
+                           nullptr, 0, stream);
 }
 
 // bf16x3 kernels exist for the north-star geometry only; every other shape runs the exact-fp32 kernels whatever `arith` says
@@ -1658,8 +1687,8 @@ extern "C" size_t rat_attn_fwd_workspace(int d, int heads, int dim_head) {
 
 extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save,
                                const RatAttnParams* w_host, const RatSeqMap* map_host, int d, int heads, int dim_head,
-                               float softmax_scale, float out_scale, float ln_eps, int arith, float* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               float softmax_scale, float out_scale, float ln_eps, float dropout_p, uint64_t dropout_seed,
+                               int arith, float* workspace, size_t workspace_bytes, void* stream) {
     if (check_dims(map_host, d, heads, dim_head, false)) return -1;
     RAT_REQUIRE(x && y && w_host && w_host->ln_g && w_host->ln_b && w_host->w_qkv, "null pointer");
     RAT_REQUIRE(w_host->w_out != nullptr || heads * dim_head == d, "missing w_out");
@@ -1677,8 +1706,11 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     const size_t smem = g.fwd_smem();
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
     const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() * per_cu ? a.nchunks : rat_max_blocks() * per_cu);
+    RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
+    if (dropout_p > 0.f && w_host->w_out != nullptr)              // Attention.to_out is Identity without a projection: no Dropout there
+        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p)};
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
-    const bool plain = res == x && out_scale == 1.0f;
+    const bool plain = res == x && out_scale == 1.0f && a.drop.threshold == 0;
     if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && workspace != nullptr &&
         workspace_bytes >= B3_W_QKV + B3_W_OUT && aligned16(workspace)) {
         char* ws = reinterpret_cast<char*>(workspace);
@@ -1726,13 +1758,14 @@ extern "C" int rat_attn_bwd(const float* x, const float* dy, const float* o_save
                             size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
                             float ln_eps, void* stream) {
     return rat_attn_bwd_ex(x, dy, dy, o_save, lse_save, dx, w_host, grads_host, workspace, workspace_bytes, map_host, d, heads,
-                           dim_head, 0.f, 1.f, ln_eps, RAT_ARITH_F32, stream);
+                           dim_head, 0.f, 1.f, ln_eps, 0.f, 0, RAT_ARITH_F32, stream);
 }
 
 extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save,
                                float* dx, const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace,
                                size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head,
-                               float softmax_scale, float out_scale, float ln_eps, int arith, void* stream) {
+                               float softmax_scale, float out_scale, float ln_eps, float dropout_p, uint64_t dropout_seed, int arith,
+                               void* stream) {
     if (check_dims(map_host, d, heads, dim_head, true)) return -1;
     RAT_REQUIRE(x && dy && o_save && lse_save && dx && w_host && grads_host && workspace, "null pointer");
     RAT_REQUIRE(w_host->w_out != nullptr || heads * dim_head == d, "missing w_out");
@@ -1742,7 +1775,10 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     if (softmax_scale > 0.f) a.scale = softmax_scale;
     a.out_scale = out_scale;
     a.add = add;
-    a.add_lds = (add == dy && out_scale == 1.0f) ? 1 : 0;
+    RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
+    if (dropout_p > 0.f && w_host->w_out != nullptr)
+        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p)};
+    a.add_lds = (add == dy && out_scale == 1.0f && a.drop.threshold == 0) ? 1 : 0;
     a.x = x;
     a.dy = dy;
     a.y = dx;
@@ -1765,7 +1801,7 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.outT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 2};
         W.qkvT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV + B3_W_OUTT), 8};
-        if (add == dy && out_scale == 1.0f) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
     } else
     if (fast == 64 && dim_head == 10 && a.add_lds) RAT_LAUNCH((attn_bwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);

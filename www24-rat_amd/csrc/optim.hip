@@ -105,13 +105,6 @@ extern "C" int rat_clip_adam(float* w, const float* g, float* m, float* v, int64
 // y[i] = keep(seed, i) ? x[i] / (1 - p) : 0.  torch's Philox stream cannot be matched bit for bit; parity for p > 0 is
 // statistical (SURVEY.md §7 hard part 5).
 namespace {
-__device__ __forceinline__ uint32_t rat_hash32(uint64_t seed, uint64_t i) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);          // splitmix64 finaliser
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
-}
 
 __global__ void __launch_bounds__(OPT_THREADS)
 dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint32_t threshold, float scale, uint64_t seed) {

@@ -107,6 +107,24 @@ __device__ __forceinline__ float4 rat_consume4(const float4& src) {
 #endif
 }
 
+// counter-based dropout generator shared by rat_dropout (optim.hip) and the attention output-projection dropout (attn.hip):
+// element i of a tensor is kept iff rat_hash32(seed, i) >= p * 2^32 — a pure function of (seed, i), so backward re-derives the mask
+__device__ __forceinline__ uint32_t rat_hash32(uint64_t seed, uint64_t i) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);          // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+struct RatDrop {                     // threshold == 0: no dropout
+    uint64_t seed;
+    uint32_t threshold;
+    float scale;                     // 1 / (1 - p)
+    __device__ __forceinline__ float apply(float v, int64_t idx) const {
+        return threshold == 0 ? v : (rat_hash32(seed, (uint64_t)idx) >= threshold ? v * scale : 0.f);
+    }
+};
+
 __device__ __forceinline__ f32x4 rat_zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     return z;

@@ -45,9 +45,9 @@ _SIGNATURES = {
     "rat_ffn_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "rat_attn_fwd_workspace": (c_size_t, [c_int, c_int, c_int]),
     "rat_attn_fwd_ex": (c_int, [_P, _P, _P, _P, _P, POINTER(RatAttnParams), POINTER(RatSeqMap), c_int, c_int, c_int, c_float, c_float,
-                                c_float, c_int, _P, c_size_t, _P]),
+                                c_float, c_float, ctypes.c_uint64, c_int, _P, c_size_t, _P]),
     "rat_attn_bwd_ex": (c_int, [_P, _P, _P, _P, _P, _P, POINTER(RatAttnParams), POINTER(RatAttnParams), _P, c_size_t,
-                                POINTER(RatSeqMap), c_int, c_int, c_int, c_float, c_float, c_float, c_int, _P]),
+                                POINTER(RatSeqMap), c_int, c_int, c_int, c_float, c_float, c_float, c_float, ctypes.c_uint64, c_int, _P]),
     "rat_attn_core_fwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int, c_float, _P]),
     "rat_attn_core_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, c_float, _P]),
     "rat_attn_core_fwd_map": (c_int, [_P, _P, _P, POINTER(RatSeqMap), c_int, c_int, c_float, _P]),

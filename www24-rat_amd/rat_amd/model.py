@@ -194,11 +194,10 @@ class RAT_m2(BaseModel):
                  pool="cls", dim_head=10, dropout=0., emb_dropout=0., scale_dim=4, **kwargs):
         super().__init__(feature_map, model_id=model_id, gpu=gpu, embedding_regularizer=embedding_regularizer,
                          net_regularizer=net_regularizer, **kwargs)
-        if dropout and dropout > 0:
-            raise NotImplementedError("attention dropout > 0 is not implemented (every shipped config uses 0)")
         d, nf = embedding_dim, feature_map.num_fields
         self._cfg = dict(d=d, heads=num_heads, dh=dim_head, depth=depth, hidden=d * scale_dim, nf=nf,
                          batch_norm=bool(batch_norm), use_wide=bool(use_wide), emb_dropout=float(emb_dropout),
+                         attn_dropout=float(dropout or 0.0),
                          net_dropout=net_dropout, lam_emb=parse_regularizer(embedding_regularizer),
                          lam_net=parse_regularizer(net_regularizer))
         self._fields = field_infos(feature_map)
@@ -229,6 +228,7 @@ class RAT_m2(BaseModel):
         if self._embedding_grad not in ("auto", "atomic", "sorted", "sparse"):
             raise ValueError("embedding_grad=%r" % self._embedding_grad)
         self._sparse = None
+        self._pending_reduce = None      # (work handle, gradient buffer) of the dense-net all-reduce started inside backward
         self._validate_ids = bool(kwargs.get("validate_ids", True))
         self._id_errors = None
         self._ws = {}
@@ -322,18 +322,24 @@ class RAT_m2(BaseModel):
         c, lib = self._cfg, self._lib
         d, heads, dh = c["d"], c["heads"], c["dh"]
         mode, per = self._attn_mode(smap)
+        # Dropout behind the output projection (RAT_m2.py:186-189), training only; the seed comes from torch's CPU generator (so
+        # seed_everything governs it) and is kept for the backward, which re-derives the mask
+        drop = (c["attn_dropout"], int(torch.randint(0, 2 ** 62, (1,)))) if (self.training and c["attn_dropout"] > 0) else (0.0, 0)
         if mode == "fused":
-            y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, arith=self.arith, lib=lib)
-            return y, (o, l)
+            y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, arith=self.arith, dropout=drop, lib=lib)
+            return y, (o, l, drop)
         if mode == "grouped":
             if desc[0][3] is None:
                 raise NotImplementedError("grouped attention needs an output projection")
             y, kept = None, []
             for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(desc[0], per)):
+                # Dropout(sum of the groups' partial projections + bias) = sum of the equally masked partials: same seed in every launch
                 y, o, l = ops.attn_fwd_ex(x, x if g == 0 else y, params_g, smap, d, per, dh, 0.0, 1.0, save=save, out=y,
-                                          arith=self.arith, lib=lib)
-                kept.append((w_g, wo_g, params_g, zb, o, l))
+                                          arith=self.arith, dropout=drop, lib=lib)
+                kept.append((w_g, wo_g, params_g, zb, o, l, drop))
             return y, (kept if save else None)
+        if drop[0] > 0:
+            raise NotImplementedError("attention dropout > 0 on the composed path (sequences above 64 tokens) is not implemented")
         inner, ntok = heads * dh, x.numel() // d
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in desc[0]]
         if w_out is None:
@@ -355,7 +361,8 @@ class RAT_m2(BaseModel):
         if mode == "fused":
             ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
             grads = ops.attn_params(*[G(n) if n else None for n in names])
-            dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, arith=self.arith, lib=lib)
+            dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, arith=self.arith,
+                                 dropout=att[2], lib=lib)
             return dx
         if mode == "grouped":
             groups, ig = heads // per, per * dh
@@ -366,11 +373,11 @@ class RAT_m2(BaseModel):
             t_w = torch.empty((3 * ig, d), dtype=torch.float32, device=dy.device)
             t_wo = torch.empty((d, ig), dtype=torch.float32, device=dy.device)
             dx = None
-            for g, (w_g, wo_g, params_g, zb, o, l) in enumerate(att):
+            for g, (w_g, wo_g, params_g, zb, o, l, drop) in enumerate(att):
                 first = g == 0
                 grads_g = ops.attn_params(g_lng if first else t_lng, g_lnb if first else t_lnb, t_w, t_wo, g_bout if first else t_b)
                 dx, _ = ops.attn_bwd_ex(x_in, dy, dy if first else dx, o, l, params_g, grads_g, smap, d, per, dh, 0.0, 1.0,
-                                        workspace=ws, out=dx, arith=self.arith, lib=lib)  # dx = dy + sum over groups, in place
+                                        workspace=ws, out=dx, arith=self.arith, dropout=drop, lib=lib)   # dx = dy + sum over groups, in place
                 gq[:, g].copy_(t_w.view(3, ig, d))
                 go[:, g].copy_(t_wo)
                 if not first:                                                              # LayerNorm sees every group's gradient
@@ -580,8 +587,20 @@ class RAT_m2(BaseModel):
         import torch.distributed as dist
         if self._world_size() > 1:
             g = self._gather_flat_grad()
+            pending, self._pending_reduce = self._pending_reduce, None
             if g is not None:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                if pending is not None and pending[1] is g:          # the dense-net part is already on its way (started in backward)
+                    n0 = self._n_emb - self._n_sparse
+                    if n0 > 0:
+                        dist.all_reduce(g[:n0], op=dist.ReduceOp.SUM)
+                    pending[0].wait()
+                else:
+                    if pending is not None:
+                        pending[0].wait()
+                        raise RuntimeError("gradient buffers were replaced between backward and the exchange: the in-flight all-reduce "
+                                           "of the dense-net gradients would be summed twice (gradient accumulation under data "
+                                           "parallelism is not supported on this path)")
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
                 if g is not self._last_gflat:
                     for n in self._dense_names():
                         self._params[n].grad = self._gflat_view(g, n)
@@ -808,6 +827,15 @@ class RAT_m2(BaseModel):
             dflat = da                                                                             # [B, F*d]
         # ---- encoder, reversed
         dx = self._encoder_backward(saved, dx, G)
+        # every dense-net gradient (encoder, DNN, fc) is final now: add its regulariser term and, under data parallelism, start
+        # its all-reduce — it travels over xGMI while the embedding-table gradients below are still being produced
+        n_dense0 = self._n_emb - self._n_sparse
+        if g_reg is not None and c["lam_net"] > 0:
+            g_reg_dev = g_reg.reshape(1).to(torch.float32).contiguous()
+            ops.l2_reg(self._flat[self._n_emb:], gflat[n_dense0:], c["lam_net"], None, lam_scale_dev=g_reg_dev, lib=lib)
+        if self._world_size() > 1 and n_dense0 < gflat.numel():
+            import torch.distributed as dist
+            self._pending_reduce = (dist.all_reduce(gflat[n_dense0:], op=dist.ReduceOp.SUM, async_op=True), gflat)
         if saved["seeds"] is not None and c["emb_dropout"] > 0:
             dx = ops.dropout(dx, c["emb_dropout"], saved["seeds"][0], out=dx, lib=lib)
         # ---- embedding tables
@@ -822,8 +850,6 @@ class RAT_m2(BaseModel):
             g_reg = g_reg.reshape(1).to(torch.float32).contiguous()
             if c["lam_emb"] > 0 and self._n_emb > 0:
                 ops.l2_reg(self._flat[:self._n_emb], gflat[:self._n_emb], c["lam_emb"], None, lam_scale_dev=g_reg, lib=lib)
-            if c["lam_net"] > 0:
-                ops.l2_reg(self._flat[self._n_emb:], gflat[self._n_emb:], c["lam_net"], None, lam_scale_dev=g_reg, lib=lib)
         self._last_gflat = gflat
         return [self._gflat_view(gflat, n) if self._offsets[n] >= self._n_sparse else None for n in self._order]
 
@@ -955,6 +981,8 @@ class RAT_m3(RAT_m2):
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
         if num_heads < 2:
             raise ValueError("RAT_m3 splits the projections into num_heads/2 heads (RAT_m3.py:181): num_heads must be >= 2")
+        if dropout and dropout > 0:
+            raise NotImplementedError("attention dropout > 0 is wired for RAT_m2 / m1 / m0 only (every shipped config uses 0)")
         self.encoder = _EncoderM3(d, num_heads, dim_head, dropout, depth, hidden)
 
     def _build_encoder_descriptors(self):

@@ -187,10 +187,11 @@ def label_grad(dgrid, label_ids, dlabel, nbt, S, d, lib=None):
 ARITH = {"f32": 0, "bf16x3": 1}       # RAT_ARITH_* of include/rat_hip.h
 
 
-def attn_fwd(x, params, seqmap, d, heads, dim_head, save=False, eps=1e-5, out=None, arith="f32", lib=None):
-    """PreNorm(Attention)(x) + x.  arith "f32": rat_attn_fwd (exact fp32 MFMA); "bf16x3": the split-operand bf16 MFMA kernels."""
-    if arith != "f32":
-        return attn_fwd_ex(x, x, params, seqmap, d, heads, dim_head, save=save, eps=eps, out=out, arith=arith, lib=lib)
+def attn_fwd(x, params, seqmap, d, heads, dim_head, save=False, eps=1e-5, out=None, arith="f32", dropout=(0.0, 0), lib=None):
+    """PreNorm(Attention)(x) + x.  arith "f32": rat_attn_fwd (exact fp32 MFMA); "bf16x3": the split-operand bf16 MFMA kernels.
+    dropout = (p, seed) of the Dropout behind the output projection (training only)."""
+    if arith != "f32" or dropout[0] > 0:
+        return attn_fwd_ex(x, x, params, seqmap, d, heads, dim_head, save=save, eps=eps, out=out, arith=arith, dropout=dropout, lib=lib)
     lib = lib or get_lib()
     _chk(x, name="x")
     y = out if out is not None else torch.empty_like(x)
@@ -204,10 +205,11 @@ def attn_fwd(x, params, seqmap, d, heads, dim_head, save=False, eps=1e-5, out=No
     return y, o_save, lse
 
 
-def attn_bwd(x, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=1e-5, workspace=None, arith="f32", lib=None):
-    if arith != "f32":
+def attn_bwd(x, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=1e-5, workspace=None, arith="f32", dropout=(0.0, 0),
+             lib=None):
+    if arith != "f32" or dropout[0] > 0:
         return attn_bwd_ex(x, dy, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=eps, workspace=workspace,
-                           arith=arith, lib=lib)
+                           arith=arith, dropout=dropout, lib=lib)
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_attn_bwd_workspace", d, heads, dim_head)
@@ -236,7 +238,7 @@ def _attn_fwd_workspace(lib, d, heads, dim_head, device):
 
 
 def attn_fwd_ex(x, res, params, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, save=False, eps=1e-5, out=None,
-                arith="f32", lib=None):
+                arith="f32", dropout=(0.0, 0), lib=None):
     """y = out_scale * attention(LayerNorm(x)) + res (res: a tensor laid out like x, the output itself, or None)."""
     lib = lib or get_lib()
     _chk(x, name="x")
@@ -248,13 +250,13 @@ def attn_fwd_ex(x, res, params, seqmap, d, heads, dim_head, softmax_scale=0.0, o
         lse = torch.empty((ntok, heads), dtype=torch.float32, device=x.device)
     ws = _attn_fwd_workspace(lib, d, heads, dim_head, x.device) if arith != "f32" else None
     lib.call("rat_attn_fwd_ex", _p(x), _p(res), _p(y), _p(o_save), _p(lse), ctypes.byref(params), ctypes.byref(seqmap), d, heads,
-             dim_head, float(softmax_scale), float(out_scale), eps, ARITH[arith], _p(ws), ws.numel() * 4 if ws is not None else 0,
-             _stream(x))
+             dim_head, float(softmax_scale), float(out_scale), eps, float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF, ARITH[arith],
+             _p(ws), ws.numel() * 4 if ws is not None else 0, _stream(x))
     return y, o_save, lse
 
 
 def attn_bwd_ex(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, eps=1e-5,
-                workspace=None, out=None, arith="f32", lib=None):
+                workspace=None, out=None, arith="f32", dropout=(0.0, 0), lib=None):
     """dx = add + LayerNorm-backward(... out_scale * dy ...) (add: tensor laid out like x, or None)."""
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
@@ -264,7 +266,7 @@ def attn_bwd_ex(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_he
     dx = out if out is not None else torch.empty_like(x)
     lib.call("rat_attn_bwd_ex", _p(x), _p(dy), _p(add), _p(o_save), _p(lse), _p(dx), ctypes.byref(params), ctypes.byref(grads),
              _p(workspace), workspace.numel() * 4, ctypes.byref(seqmap), d, heads, dim_head, float(softmax_scale),
-             float(out_scale), eps, ARITH[arith], _stream(x))
+             float(out_scale), eps, float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF, ARITH[arith], _stream(x))
     return dx, workspace
 
 
