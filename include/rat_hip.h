@@ -194,7 +194,7 @@ int rat_layernorm_bwd(const float* x, int64_t x_stride, const float* dy, const f
                       int64_t nrows, int d, float eps, void* stream);
 
 /* ---- K6: BM25-style top-K retrieval pre-compute — the scoring / top-k / merge core of BM25_topk_retrieval_v4
- * (fuxictr/datasets/data_utils.py:774-1064) on the `exact_match_cols: []` path of the shipped dataset configs:
+ * (fuxictr/datasets/data_utils.py:774-1064); without exact-match columns (the shipped dataset configs):
  *   score[b][n] = sum_f (qry_ids[b][f] == db[n][f]) * qry_idf[b][f]   (float64, f ascending)
  *   out_values[b][0:K] = the K largest scores, descending; zero scores are dropped: out_indices = -1, out_values = 0;
  *   out_lens[b] = number of entries kept (data_utils.py:786-818 padded_topk + sort_results).
@@ -204,6 +204,14 @@ int rat_layernorm_bwd(const float* x, int64_t x_stride, const float* dy, const f
  * n_fields <= 32, topk <= 32. */
 int rat_bm25_topk(const int32_t* db_ids_field_major, const int32_t* qry_ids, const double* qry_idf, double* out_values,
                   int64_t* out_indices, int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk, void* stream);
+
+/* The same with exact-match columns (`exact_match_col_indices`, data_utils.py:851-866, 932-938): db_groups [n_db] / qry_groups
+ * [n_qry] int32 number the distinct values of the exact-match columns (every query group >= 0 — queries whose key the pool
+ * does not hold are filtered by the caller, as at data_utils.py:923-924); the id columns passed are the REMAINING ones.
+ *   score[b][n] = db_groups[n] == qry_groups[b] ? (BM25 score as above) + 1 : 0 */
+int rat_bm25_topk_grouped(const int32_t* db_ids_field_major, const int32_t* db_groups, const int32_t* qry_ids,
+                          const double* qry_idf, const int32_t* qry_groups, double* out_values, int64_t* out_indices,
+                          int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk, void* stream);
 
 /* ---- K3: prediction head -----------------------------------------------------------------------------
  * Plain fp32 GEMM on MFMA for MLP_Layer's nn.Linear (deep.py:126-141) forward / dgrad / wgrad:

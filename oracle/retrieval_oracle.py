@@ -100,19 +100,24 @@ def precompute(data, cfg, pool=None):
     to its score for query b per label half (NaN where the row is not a candidate) — used to compare indices up to ties."""
     import re
     cols, k, qb, lw = cfg["used_col_indices"], cfg["topK"], cfg.get("qry_batch_size"), bool(cfg.get("label_wise"))
+    exm = cfg.get("exact_match_col_indices")
 
     def one(db, db_labels, qry, index_map, n_global):
         halves = [np.nonzero(db_labels)[0], np.nonzero(1 - db_labels)[0]] if lw else [np.arange(len(db))]
         idx_parts, val_parts, len_parts, score_parts = [], [], [], []
         for sel in halves:
-            v, i, ln = topk(db[sel], qry, k, qb)
+            if exm:
+                v, i, ln, sub_scores = topk_exact(db[sel], qry, exm, k, qb)
+            else:
+                v, i, ln = topk(db[sel], qry, k, qb)
+                sub_scores = scores(db[sel], qry, qb)
             g = sel[i]                                            # -1 -> sel[-1], as in the reference
             g = g if index_map is None else index_map[g]
             if not lw and index_map is None:
                 g = i                                             # data_generator.py:210: the raw result, -1 kept
             sc = np.full((len(qry), n_global), np.nan)
             cand = sel if index_map is None else index_map[sel]
-            sc[:, cand] = scores(db[sel], qry, qb)
+            sc[:, cand] = sub_scores
             idx_parts.append(g), val_parts.append(v), len_parts.append(ln), score_parts.append(sc)
         if lw:
             return np.concatenate(idx_parts, -1), np.concatenate(val_parts, -1), np.stack(len_parts, -1), score_parts
@@ -154,3 +159,80 @@ def assert_driver_equivalent(got, want, score_halves, k, atol=1e-12):
                         assert abs(sc[b, idx] - val) <= atol, (h, b, idx, val, sc[b, idx])
             pad = gv[b, sl] == 0
             np.testing.assert_array_equal(gi[b, sl][pad], wi[b, sl][pad])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# exact_match_col_indices (data_utils.py:851-866, 895-911, 921-938, 1038-1048): candidates of a query are the pool rows that
+# agree with it on ALL exact-match columns; BM25 runs over the remaining columns only.
+#
+# Parity status: PINNED against the reference's function run in the build container (tests/golden/make_golden_retrieval.py),
+# with ONE stand-in: the reference pads the group member lists with tensorflow.keras `pad_sequences` (data_utils.py:34, :903);
+# tensorflow is absent from the image (and unpinned by the reference — it ships no requirements file), so the generator
+# restates its published behaviour (padding='post', truncating='pre' by default: a list longer than maxlen keeps its LAST
+# maxlen entries) — see `pad_post` below, which is that restatement on this side.
+def exact_match_groups(db, qry, exm_cols):
+    """(group id per pool row, group id per query or -1 when no pool row carries the query's key) —
+    `db_df.groupby(cols).groups` / `get_indexer` (data_utils.py:852-859).  Groups are numbered in ascending key order."""
+    keys, db_grp = np.unique(db[:, exm_cols], axis=0, return_inverse=True)
+    lut = {tuple(k.tolist()): g for g, k in enumerate(keys)}
+    qry_grp = np.array([lut.get(tuple(r.tolist()), -1) for r in qry[:, exm_cols]], dtype=np.int64).reshape(-1)
+    return db_grp.reshape(-1).astype(np.int64), qry_grp
+
+
+def pad_post(seqs, maxlen, value=-1):
+    """keras pad_sequences(padding='post', truncating='pre', maxlen=maxlen or the longest)"""
+    width = max(len(s) for s in seqs) if maxlen is None else maxlen
+    out = np.full((len(seqs), width), value, dtype=np.int64)
+    for i, s in enumerate(seqs):
+        t = np.asarray(s)[-width:] if len(s) else np.asarray(s)
+        out[i, :len(t)] = t
+    return out
+
+
+def topk_exact(db, qry, exm_cols, k, qry_batch_size=None):
+    """-> (values, indices, lens, score_matrix [Q, N]).  Per query batch (the batching IS part of the result):
+      * queries whose key has no pool row keep (0, -1, len 0)                                         (data_utils.py:1047-1050)
+      * if no group of the batch is larger than K: every member in ascending pool order, value 1.0       (:911-917, 1038-1044)
+        (with no remaining column the groups are first cut to their LAST K members, pad_sequences maxlen=K, :903-905)
+      * otherwise score = (BM25 over the remaining columns + 1) for group members, top-K of that          (:918-1037)
+    score_matrix holds the value each (query, pool row) pair would be returned with (0 = not a candidate)."""
+    exm_cols = list(exm_cols)
+    rest = [c for c in range(db.shape[1]) if c not in exm_cols]
+    db_grp, qry_grp = exact_match_groups(db, qry, exm_cols)
+    members = [np.nonzero(db_grp == g)[0] for g in range(db_grp.max() + 1 if len(db_grp) else 0)]
+    db_r, qry_r = db[:, rest], qry[:, rest]
+    tables = idf_tables(db_r)
+    q, n = len(qry), len(db)
+    values = np.zeros((q, k), dtype=np.float64)
+    indices = np.full((q, k), -1, dtype=np.int64)
+    lens = np.zeros(q, dtype=np.int64)
+    score = np.zeros((q, n), dtype=np.float64)
+    step = q if qry_batch_size is None else qry_batch_size
+    for q0 in range(0, q, step):
+        rows = np.arange(q0, min(q0 + step, q))
+        rows = rows[qry_grp[rows] != -1]
+        if len(rows) == 0:
+            continue
+        padded = pad_post([members[qry_grp[b]] for b in rows], k if not rest else None)
+        if padded.shape[1] <= k:
+            for j, b in enumerate(rows):
+                m = padded[j][padded[j] != -1]
+                lens[b] = len(m)
+                indices[b, :len(m)] = m
+                values[b, :len(m)] = 1.0
+                score[b, m] = 1.0
+            continue
+        w = map_idf(qry_r[rows], tables)
+        for j, b in enumerate(rows):
+            m = members[qry_grp[b]]
+            s = np.ones(len(m), dtype=np.float64)
+            bm = np.zeros(len(m), dtype=np.float64)
+            for f in range(len(rest)):
+                bm += (qry_r[b, f] == db_r[m, f]) * w[j, f]
+            s = (bm + 1.0) * s
+            score[b, m] = s
+            order = np.lexsort((m, -s))[:k]
+            lens[b] = len(order)
+            indices[b, :len(order)] = m[order]
+            values[b, :len(order)] = s[order]
+    return values, indices, lens, score

@@ -30,12 +30,37 @@ def run_variants(case):
             "rechunked": dict(qry_batch_size=8, db_chunk_size=64, enable_clean=True)}
 
 
+# ---- exact_match_col_indices (data_utils.py:851-866): candidates = pool rows equal to the query on the exact-match columns
+EXM_CASES = {
+    # one exact-match column, groups larger than topK: BM25 + 1 over the other columns inside the group
+    "one_col": dict(n_db=300, n_qry=29, vocab=[6, 17, 9, 4], exm=[0], topk=5, seed=31, unseen=True),
+    # two exact-match columns (not adjacent), small groups mixed with large ones
+    "two_cols": dict(n_db=500, n_qry=33, vocab=[5, 40, 6, 7], exm=[0, 2], topk=6, seed=32, unseen=True),
+    # every group fits in topK: members in pool order with value 1.0, no scoring at all
+    "groups_fit": dict(n_db=90, n_qry=17, vocab=[30, 5, 4], exm=[0], topk=12, seed=33, unseen=True),
+    # all columns exact-match: nothing left to score, groups cut to their LAST topK members
+    "all_cols": dict(n_db=200, n_qry=25, vocab=[4, 3], exm=[0, 1], topk=7, seed=34, unseen=False),
+}
+
+
+def make_exm_case(case):
+    return make_case(case)
+
+
+def run_exm_variants(case):
+    """the query batching decides, batch by batch, between the "every group fits" shortcut and scoring"""
+    return {"whole": dict(), "chunked": dict(qry_batch_size=8, db_chunk_size=50), "small_batches": dict(qry_batch_size=3)}
+
+
 # ---- the DataGenerator-level driver (fuxictr/pytorch/data_generator.py:106-215): fold / separate-pool / label-wise retrieval
 DRIVER_CASES = {
     "fold3_self": dict(n=50, n_pool=None, vocab=[9, 7, 5], topk=4, split_type="3-fold", label_wise=False, seed=21, qry_batch_size=16),
     "fold4_self_labelwise": dict(n=61, n_pool=None, vocab=[6, 5, 4], topk=3, split_type="4-fold", label_wise=True, seed=22, qry_batch_size=None),
     "separate_pool": dict(n=23, n_pool=40, vocab=[8, 6], topk=5, split_type="random", label_wise=False, seed=23, qry_batch_size=10),
     "separate_pool_labelwise": dict(n=19, n_pool=35, vocab=[5, 4, 3], topk=2, split_type="sequential", label_wise=True, seed=24, qry_batch_size=None),
+    "fold3_self_exact": dict(n=80, n_pool=None, vocab=[4, 7, 5], topk=3, split_type="3-fold", label_wise=False, seed=25, qry_batch_size=16, exm=[0]),
+    "separate_pool_labelwise_exact": dict(n=21, n_pool=70, vocab=[3, 4, 5], topk=2, split_type="random", label_wise=True, seed=26, qry_batch_size=None,
+                                          exm=[0]),
 }
 
 
@@ -49,6 +74,6 @@ def make_driver_case(case):
     data = table(case["n"])
     pool = None if case["n_pool"] is None else table(case["n_pool"])
     cfg = dict(pre_retrieval=True, split_type=case["split_type"], label_wise=case["label_wise"], topK=case["topk"],
-               used_col_indices=list(range(len(case["vocab"]))), exact_match_col_indices=None,
+               used_col_indices=list(range(len(case["vocab"]))), exact_match_col_indices=case.get("exm"),
                qry_batch_size=case["qry_batch_size"], db_chunk_size=17, device="cpu", enable_clean=False)
     return data, pool, cfg

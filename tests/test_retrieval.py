@@ -61,10 +61,115 @@ def test_kernel_emulated(name):
     check_product(name, "cpu", L.RatLib(build_emu.build()))
 
 
-def test_exact_match_columns_are_rejected():
+def check_same_lane_ties(device, lib):
+    """Rows 0, 256 and 512 are scanned by the SAME lane (256 lanes, row = lane + 256 j): two equal scores arrive first, then a
+    better one.  The displaced entries must keep their arrival order in the lane's private list, or the merge sees row 256 before
+    row 0 (and with a short topK loses row 0 altogether)."""
     from rat_amd import retrieval
-    with pytest.raises(NotImplementedError):
-        retrieval.BM25_topk_retrieval_v4(np.zeros((3, 2), dtype=np.int64), np.zeros((2, 2), dtype=np.int64), exact_match_col_indices=[0])
+    for topk in (2, 3, 9):                                  # 9 > 8: the one-query-per-work-group instantiation
+        db = np.full((1024, 2), 7, dtype=np.int64)
+        db[:, 0] = np.arange(1024) % 5 + 10                 # column 0: five values; column 1: everything 7 except the marked rows
+        for r in (0, 256, 300, 512, 700):
+            db[r, 1] = 3
+        db[512, 0], db[700, 0] = 99, 98                     # rare ids: rows 512 / 700 match the queries on BOTH columns
+        db[[0, 256, 300], 0] = 50
+        qry = np.array([[99, 3], [98, 3]], dtype=np.int64)
+        want = ro.topk(db, qry, topk)
+        assert want[1][0][:2].tolist() == [512, 0] and (topk < 3 or want[1][0][2] == 256)
+        got = retrieval.BM25_topk_retrieval_v4(db, qry, device=device, topK=topk, lib=lib)
+        np.testing.assert_array_equal(got.indices, want[1])
+        np.testing.assert_allclose(got.values, want[0], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(got.lens, want[2])
+
+
+def test_same_lane_ties_keep_pool_order_emulated():
+    import build_emu
+    import rat_amd._lib as L
+    check_same_lane_ties("cpu", L.RatLib(build_emu.build()))
+
+
+@pytest.mark.gpu
+def test_same_lane_ties_keep_pool_order_gpu():
+    import rat_amd._lib as L
+    check_same_lane_ties("cuda:0", L.get_lib())
+
+
+# ---- exact_match_col_indices: group filter + (BM25 + 1) inside the group (data_utils.py:851-866, 895-938, 1038-1050)
+def gold_exm(name, tag):
+    return gold_of("exm/" + name, tag)
+
+
+@pytest.mark.parametrize("name", list(rc.EXM_CASES))
+def test_exact_match_oracle_matches_reference(name):
+    case = rc.EXM_CASES[name]
+    db, qry = rc.make_exm_case(case)
+    took_shortcut, scored = False, False
+    for tag, kw in rc.run_exm_variants(case).items():
+        v, i, ln, sc = ro.topk_exact(db, qry, case["exm"], case["topk"], kw.get("qry_batch_size"))
+        ro.assert_topk_equivalent(sc, (v, i, ln), gold_exm(name, tag))
+        took_shortcut |= bool(((v == 1.0) | (v == 0.0)).all())
+        scored |= bool((v > 1.0).any())
+    assert scored == (name in ("one_col", "two_cols")) and (took_shortcut or scored)
+
+
+def check_exact_match_product(name, device, lib):
+    from rat_amd import retrieval
+    case = rc.EXM_CASES[name]
+    db, qry = rc.make_exm_case(case)
+    for tag, kw in rc.run_exm_variants(case).items():
+        wv, wi, wl, sc = ro.topk_exact(db, qry, case["exm"], case["topk"], kw.get("qry_batch_size"))
+        got = retrieval.BM25_topk_retrieval_v4(db_np_data=db, qry_np_data=qry, exact_match_col_indices=list(case["exm"]), device=device,
+                                               topK=case["topk"], lib=lib, **kw)
+        np.testing.assert_array_equal(got.indices, wi)                         # same deterministic tie order as the oracle
+        np.testing.assert_allclose(got.values, wv, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(got.lens, wl)
+        ro.assert_topk_equivalent(sc, got, gold_exm(name, tag))                # and equivalent to the reference's own output
+
+
+@pytest.mark.parametrize("name", ["one_col", "all_cols"])
+def test_exact_match_emulated(name):
+    import build_emu
+    import rat_amd._lib as L
+    check_exact_match_product(name, "cpu", L.RatLib(build_emu.build()))
+
+
+def test_exact_match_col_indices_follow_h5_generator():
+    from rat_amd import retrieval
+    cfg = {"used_cols": ["user_id", "item_id", "tag_id"], "exact_match_cols": ["tag_id", "user_id"]}
+    assert retrieval.exact_match_col_indices(cfg) == [2, 0]                    # positions inside used_cols, in exact_match_cols order
+    assert retrieval.exact_match_col_indices({"used_cols": ["a"], "exact_match_cols": []}) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(rc.EXM_CASES))
+def test_exact_match_gpu(name):
+    import rat_amd._lib as L
+    check_exact_match_product(name, "cuda:0", L.get_lib())
+
+
+@pytest.mark.gpu
+def test_exact_match_large_pool_properties_gpu():
+    """150k-row pool, 2 exact-match columns of 5 used, 400 queries: results of a query sample against the oracle, and for every
+    query: all returned rows belong to its group, values sorted, len = min(group size, K)."""
+    import rat_amd._lib as L
+    from rat_amd import retrieval
+    rs = np.random.RandomState(12)
+    vocab = [40, 3000, 25, 200, 50]
+    exm, topk = [0, 2], 10
+    db = np.stack([rs.randint(0, v, size=150_000) for v in vocab], axis=1).astype(np.int64)
+    qry = np.stack([rs.randint(0, v, size=400) for v in vocab], axis=1).astype(np.int64)
+    qry[5, 0] = 99                                                              # a key the pool does not hold
+    got = retrieval.BM25_topk_retrieval_v4(db, qry, exact_match_col_indices=exm, device="cuda:0", topK=topk, qry_batch_size=128,
+                                           lib=L.get_lib())
+    assert (np.diff(got.values, axis=1) <= 0).all() and got.lens[5] == 0 and (got.indices[5] == -1).all()
+    for b in range(len(qry)):
+        idx = got.indices[b][got.indices[b] >= 0]
+        assert (db[idx][:, exm] == qry[b, exm]).all()
+        assert got.lens[b] == min(topk, int((db[:, exm] == qry[b, exm]).all(axis=1).sum())) == len(idx)
+    wv, wi, wl, _ = ro.topk_exact(db, qry, exm, topk, 128)
+    np.testing.assert_array_equal(got.indices, wi)
+    np.testing.assert_allclose(got.values, wv, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(got.lens, wl)
 
 
 @pytest.mark.gpu

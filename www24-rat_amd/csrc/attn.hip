@@ -1659,6 +1659,9 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
     a.prof = rat_prof_buffer();
 }
 
+// the compile-time dim_head instantiations move per-head vectors 8 bytes at a time, o_save rows included
+bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
 // which compiled fast shape (if any) serves these dimensions
 int fast_dim(const AttnArgs& a, std::initializer_list<const void*> ptrs) {
     if (!((a.dh == 10 || a.dh == 20) && a.heads == fast_heads(a.dh)) || a.w_out == nullptr) return 0;
@@ -1724,7 +1727,10 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         return rat_check_launch("rat_attn_fwd (bf16x3)");
     }
-    if (fast == 64 && dim_head == 10 && plain) RAT_LAUNCH((attn_fwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
+    const bool head_vec = aligned8(o_save);            // else the run-time dim_head kernel (4-byte accesses), which stops at DH_MAX
+    RAT_REQUIRE(head_vec || dim_head <= DH_MAX, "o_save must be 8-byte aligned for dim_head 20");
+    if (!head_vec) RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
+    else if (fast == 64 && dim_head == 10 && plain) RAT_LAUNCH((attn_fwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
@@ -1803,8 +1809,10 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
         W.qkvT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV + B3_W_OUTT), 8};
         if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-    } else
-    if (fast == 64 && dim_head == 10 && a.add_lds) RAT_LAUNCH((attn_bwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
+    } else if (!aligned8(o_save)) {                    // run-time dim_head kernel: 4-byte accesses, dim_head <= DH_MAX
+        RAT_REQUIRE(dim_head <= DH_MAX, "o_save must be 8-byte aligned for dim_head 20");
+        RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
+    } else if (fast == 64 && dim_head == 10 && a.add_lds) RAT_LAUNCH((attn_bwd_kernel<64, 10, false>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<64, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);

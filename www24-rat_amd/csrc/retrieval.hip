@@ -1,8 +1,10 @@
 // retrieval.hip — K6: BM25-style top-K retrieval pre-compute.
 //
-// Replaces the scoring / top-k / merge core of BM25_topk_retrieval_v4 (fuxictr/datasets/data_utils.py:774-1064) on the path
-// the shipped dataset configs take (`exact_match_cols: []`, configs/datasets/movielenslatest_x1.yaml:58-75):
+// Replaces the scoring / top-k / merge core of BM25_topk_retrieval_v4 (fuxictr/datasets/data_utils.py:774-1064):
 //     score[b, n] = sum_f (qry[b, f] == db[n, f]) * idf[b, f]          (data_utils.py:1003, float64)
+//   with exact-match columns (rat_bm25_topk_grouped; data_utils.py:851-866, 932-938): only the pool rows of the query's GROUP (equal
+//   on every exact-match column; the host numbers the groups) are candidates and a candidate scores (BM25 + 1):
+//     score[b, n] = (grp_db[n] == grp_qry[b]) ? score[b, n] + 1 : 0
 //     per query: the K largest scores, sorted descending, zero scores dropped (index -1), lens = number kept
 //                                                                         (padded_topk + sort_results, data_utils.py:786-818)
 // The reference materialises [qry_batch x db_chunk x F] tensors chunk by chunk, takes torch.topk per chunk and merges; here
@@ -27,6 +29,8 @@ struct RetrArgs {
     const int32_t* db_t;     // [F][N]
     const int32_t* qry;      // [Q][F]
     const double* idf;       // [Q][F]
+    const int32_t* db_grp;   // [N] exact-match group of every pool row, or null (no exact-match columns)
+    const int32_t* qry_grp;  // [Q] group of every query (>= 0)
     double* out_val;         // [Q][K]
     int64_t* out_idx;        // [Q][K]
     int64_t* out_len;        // [Q]
@@ -81,6 +85,20 @@ __global__ void __launch_bounds__(RT_THREADS) bm25_topk_kernel(RetrArgs a) {
                     for (int u = 0; u < RU; ++u) s[u][t] += (qid == id[u] && n0 + (int64_t)u * RT_THREADS < a.N) ? w : 0.0;
                 }
             }
+            if (a.db_grp) {                                                               // exact-match gate: (BM25 + 1) inside the group, 0 outside
+                int32_t g[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int64_t n = n0 + (int64_t)u * RT_THREADS;
+                    g[u] = n < a.N ? a.db_grp[n] : -1;
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const int32_t qg = a.qry_grp[q0 + t < a.Q ? q0 + t : a.Q - 1];
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) s[u][t] = g[u] == qg ? s[u][t] + 1.0 : 0.0;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < RU; ++u) {                                                // rows in increasing order
                 const int64_t n = n0 + (int64_t)u * RT_THREADS;
@@ -89,9 +107,12 @@ __global__ void __launch_bounds__(RT_THREADS) bm25_topk_kernel(RetrArgs a) {
                     if (s[u][t] > kth[t]) {                                               // positive AND strictly better than the K-th
                         double cs = s[u][t];
                         int64_t ci = n;
+                        bool placed = false;          // once the newcomer sits the rest only shifts down: a displaced entry is OLDER
+                                                      // (lower index) than the equal scores below it and must stay in front of them
 #pragma unroll
-                        for (int k = 0; k < KMAX; ++k) {                                  // bubble the newcomer into place
-                            if (k < a.K && cs > val[t][k]) {
+                        for (int k = 0; k < KMAX; ++k) {
+                            if (k < a.K && (placed || cs > val[t][k])) {
+                                placed = true;
                                 const double ts = val[t][k];
                                 const int64_t ti = idx[t][k];
                                 val[t][k] = cs;
@@ -149,9 +170,9 @@ __global__ void __launch_bounds__(RT_THREADS) bm25_topk_kernel(RetrArgs a) {
 
 }  // namespace
 
-extern "C" int rat_bm25_topk(const int32_t* db_ids_field_major, const int32_t* qry_ids, const double* qry_idf, double* out_values,
-                             int64_t* out_indices, int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk,
-                             void* stream) {
+static int bm25_topk_launch(const char* what, const int32_t* db_ids_field_major, const int32_t* db_groups, const int32_t* qry_ids,
+                            const double* qry_idf, const int32_t* qry_groups, double* out_values, int64_t* out_indices,
+                            int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk, void* stream) {
     RAT_REQUIRE(db_ids_field_major && qry_ids && qry_idf && out_values && out_indices && out_lens, "null pointer");
     RAT_REQUIRE(n_db > 0 && n_qry > 0 && n_fields > 0 && topk > 0, "bad dims");
     RAT_REQUIRE(n_fields <= RT_FMAX, "more than 32 retrieval columns are not supported");
@@ -160,6 +181,8 @@ extern "C" int rat_bm25_topk(const int32_t* db_ids_field_major, const int32_t* q
     a.db_t = db_ids_field_major;
     a.qry = qry_ids;
     a.idf = qry_idf;
+    a.db_grp = db_groups;
+    a.qry_grp = qry_groups;
     a.out_val = out_values;
     a.out_idx = out_indices;
     a.out_len = out_lens;
@@ -173,5 +196,20 @@ extern "C" int rat_bm25_topk(const int32_t* db_ids_field_major, const int32_t* q
     } else {
         RAT_LAUNCH((bm25_topk_kernel<32, 1, 4>), (unsigned)(n_qry < 65536 ? n_qry : 65536), RT_THREADS, 0, stream, a);
     }
-    return rat_check_launch("rat_bm25_topk");
+    return rat_check_launch(what);
+}
+
+extern "C" int rat_bm25_topk(const int32_t* db_ids_field_major, const int32_t* qry_ids, const double* qry_idf, double* out_values,
+                             int64_t* out_indices, int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk,
+                             void* stream) {
+    return bm25_topk_launch("rat_bm25_topk", db_ids_field_major, nullptr, qry_ids, qry_idf, nullptr, out_values, out_indices, out_lens,
+                            n_db, n_qry, n_fields, topk, stream);
+}
+
+extern "C" int rat_bm25_topk_grouped(const int32_t* db_ids_field_major, const int32_t* db_groups, const int32_t* qry_ids,
+                                     const double* qry_idf, const int32_t* qry_groups, double* out_values, int64_t* out_indices,
+                                     int64_t* out_lens, int64_t n_db, int64_t n_qry, int n_fields, int topk, void* stream) {
+    RAT_REQUIRE(db_groups && qry_groups, "null group pointer");
+    return bm25_topk_launch("rat_bm25_topk_grouped", db_ids_field_major, db_groups, qry_ids, qry_idf, qry_groups, out_values,
+                            out_indices, out_lens, n_db, n_qry, n_fields, topk, stream);
 }

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "rat_attn_fused_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "rat_colsum_workspace": (c_size_t, [c_int, c_int]),
     "rat_bm25_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
+    "rat_bm25_topk_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_ffn_fwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
     "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, c_int, c_int, _P]),
     "rat_layernorm_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P]),
