@@ -1040,6 +1040,60 @@ __device__ __forceinline__ void b3_layer_norm_to_planes(bool valid, const float4
     }
 }
 // this thread's piece of a token-indexed [.][64] tensor for the chunk whose row map is `rowtok` (zeros for padding rows)
+// Token-indexed global accesses of the bf16x3 kernels: UNIFORM base (the kernel argument, in SGPRs) + 32-bit byte offset per lane.
+// The 64-bit form (base + lane offset hoisted out of the chunk loop as a VGPR pair per array) got spilled, and every reload is a
+// scratch load that waits for vmcnt(0): the loads of a phase went out one HBM round trip at a time.  The host only launches these
+// kernels when every byte offset fits 32 bits (b3_off32_ok).  Loads are unconditional (padding rows read token 0 and are zeroed
+// afterwards), so that nothing waits before the last load of the phase has been issued.
+__device__ __forceinline__ float4 b3_ld4(const float* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ float b3_ld1(const float* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void b3_st4(float* base, uint32_t byte_off, const float4& v) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__device__ __forceinline__ void b3_zero_unless(bool valid, float4& v) {
+    v.x = valid ? v.x : 0.f; v.y = valid ? v.y : 0.f; v.z = valid ? v.z : 0.f; v.w = valid ? v.w : 0.f;
+}
+// this thread's 8-column piece of its row: byte offset of the piece in a [tokens][64] array
+__device__ __forceinline__ uint32_t b3_piece_off(int64_t tok) {
+    return (uint32_t)(tok >= 0 ? tok : 0) * (uint32_t)(B3_D * 4) + 32u * (threadIdx.x & 7);
+}
+// the [64][80] O tile: 1280 float4 over 512 threads; element e -> row e / 20, float4 e % 20
+struct B3RowFetchO {
+    static constexpr int W4 = B3_I / 4;
+    static constexpr int NIT = (ATT_ROWS * W4 + ATT_THREADS - 1) / ATT_THREADS;
+    float4 v[NIT];
+    unsigned valid;
+    __device__ __forceinline__ void issue(const float* src, const int64_t* rowtok) {
+        uint32_t off[NIT];
+        valid = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            const int r = e < ATT_ROWS * W4 ? e / W4 : 0;
+            const int64_t tok = rowtok[r];
+            const bool ok = e < ATT_ROWS * W4 && tok >= 0;
+            valid |= ok ? 1u << it : 0u;
+            off[it] = (uint32_t)(ok ? tok : 0) * (uint32_t)(B3_I * 4) + 16u * (uint32_t)(e % W4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) v[it] = b3_ld4(src, off[it]);
+    }
+    __device__ __forceinline__ void stash(float* tile, int ld) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            if (e < ATT_ROWS * W4) {
+                b3_zero_unless((valid >> it) & 1u, v[it]);
+                *reinterpret_cast<float4*>(tile + (size_t)(e / W4) * ld + 4 * (e % W4)) = v[it];
+            }
+        }
+    }
+};
+
 __device__ __forceinline__ void b3_load_piece(const float* src, const int64_t* rowtok, float4& v0, float4& v1) {
     const int64_t tok = rowtok[threadIdx.x >> 3];
     v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1135,7 +1189,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         RAT_PROF_MARK(1);
         // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>
         float pf = 0.f;
-        if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)
+        if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)   // (no prefetch: +2-3 %, same-box A/B)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
         typedef HeadVec<B3_DH> HV;
         const int ntasks = nsq * B3_H * L;
@@ -1313,14 +1367,22 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         }
         const int64_t tok_own = rowtok[r_own];
         // ---- P0: x -> LayerNorm -> planes; dy -> planes (+ db_out partials); O, lse -> fp32 tiles
-        {   // (the rows were touched into L2 behind the previous chunk's VALU passes.  vmcnt retires in order, so loads that may still
-            //  miss to HBM must not sit in front of a GEMM phase's operand loads: issuing these a phase early cost 8-10 %, A/B)
-            float4 x0, x1, d0, d1;
-            RowFetch<B3_I> fo;
-            b3_load_piece(a.x, rowtok, x0, x1);
-            b3_load_piece(a.dy, rowtok, d0, d1);
+        {   // Same-box A/B of the alternatives (tools/ab_attn.sh): touching the next chunk's lines into L2 behind the VALU passes +5 %;
+            // requesting the next chunk's rows a phase or two early (P4, P5, P6) +8-10 % — the registers that carry them across the
+            // GEMM phases come back as spills, and a spill reload is a scratch load that waits for vmcnt(0).
+            const bool valid = tok_own >= 0;
+            const uint32_t po = b3_piece_off(tok_own);
+            B3RowFetchO fo;
+            float4 x0 = b3_ld4(a.x, po), x1 = b3_ld4(a.x, po + 16u);
+            float4 d0 = b3_ld4(a.dy, po), d1 = b3_ld4(a.dy, po + 16u);
             fo.issue(a.o_save, rowtok);
-            const float lsen = tok_own >= 0 ? a.lse_save[tok_own * B3_H + sub] : 0.f;
+            float lsen = b3_ld1(a.lse_save, (uint32_t)(valid ? tok_own : 0) * (uint32_t)(B3_H * 4) + 4u * sub);
+            RAT_SCHED_FENCE();                                               // every request is out before anything is consumed
+            b3_zero_unless(valid, x0);
+            b3_zero_unless(valid, x1);
+            b3_zero_unless(valid, d0);
+            b3_zero_unless(valid, d1);
+            lsen = valid ? lsen : 0.f;
             {
                 float gam[8], bet[8];
 #pragma unroll
@@ -1388,21 +1450,12 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         }
         __syncthreads();
         RAT_PROF_MARK(3);
-        // ---- P3: attention backward on the VALU — the two passes of attn_bwd_kernel<64, 10>
+        // ---- P3: attention backward on the VALU — the two passes of attn_bwd_kernel<64, 10>.  Same-box A/B of the loop shapes
+        // (tools/ab_attn.sh): 2 / 3 / 4 keys per trip with all their rows requested up front +7 / +14 / +20 % (spills), the
+        // software-pipelined form (rows of key j + 1 requested before the arithmetic of key j, ping-pong registers) +4 %.
         typedef HeadVec<B3_DH> HV;
         const int ntasks = nsq * B3_H * L;
         const float sl2 = a.scale * RAT_LOG2E;
-        float pf = 0.f;
-        {   // the next chunk's lines travel HBM -> L2 behind the two passes; the loads proper are issued at P4
-            int t = threadIdx.x;
-            if (chunk + gridDim.x < a.nchunks) {
-                const int64_t* nrt = (rowtok0 + (parity ^ 1) * ATT_ROWS);
-                if (t < ATT_ROWS * 2) pf = prefetch_lines_map(nrt, t, 2, a.x, B3_D);
-                else if ((t -= ATT_ROWS * 2) < ATT_ROWS * 2) pf = prefetch_lines_map(nrt, t, 2, a.dy, B3_D);
-                else if ((t -= ATT_ROWS * 2) < ATT_ROWS * 3) pf = prefetch_lines_map(nrt, t, 3, a.o_save, B3_I);
-                else if ((t -= ATT_ROWS * 3) < ATT_ROWS) pf = prefetch_lines_map(nrt, t, 1, a.lse_save, B3_H);
-            }
-        }
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % B3_H;
@@ -1525,11 +1578,18 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             const float* addp = EX ? a.add : a.dy;
             float xh[8], gg[8], ad[8], out[8], gam[8];
             float4 xv2[2], av2[2];
+            const uint32_t po = b3_piece_off(tok_own);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                xv2[k] = av2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) xv2[k] = *reinterpret_cast<const float4*>(a.x + tok_own * B3_D + 8 * sub + 4 * k);
-                if (valid && addp != nullptr) av2[k] = *reinterpret_cast<const float4*>(addp + tok_own * B3_D + 8 * sub + 4 * k);
+                xv2[k] = b3_ld4(a.x, po + 16u * k);
+                av2[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (addp != nullptr) av2[k] = b3_ld4(addp, po + 16u * k);    // uniform branch
+            }
+            RAT_SCHED_FENCE();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                b3_zero_unless(valid, xv2[k]);
+                b3_zero_unless(valid, av2[k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) gam[k] = lnw[8 * sub + k];
@@ -1560,14 +1620,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 dbet[k] += gg[k];
             }
             if (valid) {
-                *reinterpret_cast<float4*>(a.y + tok_own * B3_D + 8 * sub) = make_float4(out[0], out[1], out[2], out[3]);
-                *reinterpret_cast<float4*>(a.y + tok_own * B3_D + 8 * sub + 4) = make_float4(out[4], out[5], out[6], out[7]);
+                b3_st4(a.y, po, make_float4(out[0], out[1], out[2], out[3]));
+                b3_st4(a.y, po + 16u, make_float4(out[4], out[5], out[6], out[7]));
             }
         }
         __syncthreads();
-#ifndef RAT_EMU
-        asm volatile("" ::"v"(pf));
-#endif
         RAT_PROF_MARK(9);
     }
     RAT_PROF_FLUSH(a.prof, 60);
@@ -1683,6 +1740,13 @@ extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_
 static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
     return d == B3_D && heads == B3_H && dim_head == B3_DH && w->w_out != nullptr;
 }
+// ... and only while every token's byte offset in the widest array (o_save: 320 B per token) fits 32 bits (b3_ld4)
+static bool b3_off32_ok(const RatSeqMap* m) {
+    if (m->hi_stride < 0 || m->lo_stride < 0 || m->pos_stride < 0) return false;
+    const int64_t qd = m->q_div, hi = (m->nseq - 1) / qd, lo = m->nseq - 1 < qd - 1 ? m->nseq - 1 : qd - 1;
+    const double max_tok = (double)hi * (double)m->hi_stride + (double)lo * (double)m->lo_stride + (double)(m->L - 1) * (double)m->pos_stride;
+    return (max_tok + 1.0) * (double)(B3_I * 4) < 4294967296.0;
+}
 
 extern "C" size_t rat_attn_fwd_workspace(int d, int heads, int dim_head) {
     return (d == B3_D && heads == B3_H && dim_head == B3_DH) ? B3_W_QKV + B3_W_OUT : 0;
@@ -1714,7 +1778,7 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p)};
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
     const bool plain = res == x && out_scale == 1.0f && a.drop.threshold == 0;
-    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && workspace != nullptr &&
+    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) && workspace != nullptr &&
         workspace_bytes >= B3_W_QKV + B3_W_OUT && aligned16(workspace)) {
         char* ws = reinterpret_cast<char*>(workspace);
         if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
@@ -1797,7 +1861,7 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const size_t smem = g.bwd_smem(heads);
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
-    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && aligned16(workspace) &&
+    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) && aligned16(workspace) &&
         (a.slab_stride * 256 * 4) % 16 == 0) {
         char* ws = reinterpret_cast<char*>(workspace) + (size_t)256 * a.slab_stride * sizeof(float);
         if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
