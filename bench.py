@@ -167,7 +167,7 @@ class KernelTimer:
         if name in ("rat_attn_core_fwd_map", "rat_attn_core_bwd_map"):
             return "L%d" % args[3 if name == "rat_attn_core_fwd_map" else 5]._obj.L
         if name in ("rat_ffn_fwd_res", "rat_ffn_bwd_res"):               # RAT_m1 runs the block MLP at two token counts
-            return "n%d" % int(args[7 if name == "rat_ffn_fwd_res" else 13])
+            return "n%d" % int(args[7 if name == "rat_ffn_fwd_res" else 14])
         return ""
 
     def summary(self, steps):

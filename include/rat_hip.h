@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 2
+#define RAT_ABI_VERSION 3
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -96,7 +96,28 @@ typedef struct RatAttnParams {      /* HOST struct of device pointers; state_dic
     float* w_qkv; /* [3*h*dh][d]  ...fn.to_qkv.weight (no bias)                                          */
     float* w_out; /* [d][h*dh]    ...fn.to_out.0.weight, NULL when heads==1 && dim_head==d (Identity)    */
     float* b_out; /* [d]          ...fn.to_out.0.bias                                                    */
+    void* planes; /* optional, RAT_ARITH_BF16X3 only: the bf16x3 fragment planes of w_qkv / w_out (rat_attn_planes_bytes bytes,
+                   * 16-byte aligned) as written by rat_split_weights_batch from the jobs of rat_attn_split_jobs — valid until
+                   * the weights change.  NULL: rat_attn_fwd_ex / rat_attn_bwd_ex derive them themselves (2 - 3 small launches
+                   * per call).  Ignored in the struct that receives gradients. */
 } RatAttnParams;
+
+/* ---- bf16x3 weight planes, once per optimizer step instead of once per call ------------------------------------------------
+ * The bf16x3 kernels read every weight matrix as pre-split fragment-major planes.  The planes depend on the
+ * weights only, so a training step needs them once: collect the jobs of every layer (rat_attn_split_jobs / rat_ffn_split_jobs
+ * fill in what to split where inside that layer's `planes` buffer), run them all in ONE launch (rat_split_weights_batch) and
+ * hand the buffers to the forward and backward entry points (RatAttnParams.planes, the `planes` argument of rat_ffn_bwd_res).
+ * rat_*_planes_bytes return 0 and rat_*_split_jobs return 0 jobs when no bf16x3 kernel serves the shape. */
+typedef struct RatSplitJob {
+    const float* w; /* source matrix, row-major with leading dimension ld                                   */
+    void* out;      /* fragment planes of B[k][n] = transpose ? w[k*ld + n] : w[n*ld + k], n < N, k < K       */
+    int32_t N, K, ld, transpose, perm, reserved;
+} RatSplitJob;
+size_t rat_attn_planes_bytes(int d, int heads, int dim_head);
+int rat_attn_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes, RatSplitJob* jobs_out /* [4] */);
+size_t rat_ffn_planes_bytes(int d, int hidden);
+int rat_ffn_split_jobs(const float* w1, const float* w2, int d, int hidden, void* planes, RatSplitJob* jobs_out /* [3] */);
+int rat_split_weights_batch(const RatSplitJob* jobs_host, int njobs, void* stream);
 
 /* o_save [ntok][h*dh] (attention output before to_out) and lse_save [ntok][h] (log2-domain log-sum-exp of the
  * scaled scores), token-indexed like x, are written when non-NULL (training) and consumed by rat_attn_bwd. */
@@ -178,7 +199,8 @@ int rat_ffn_fwd_res(const float* x, const float* res, float* y, const float* w1,
                     const float* b2, int64_t ntok, int d, int hidden, int arith, void* stream);
 int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                     const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
-                    size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, int arith, void* stream);
+                    size_t workspace_bytes, const void* planes /* of rat_ffn_split_jobs, or NULL */, int64_t ntok, int d,
+                    int hidden, int add_dy, int arith, void* stream);
 
 /* ---- K2c: stand-alone nn.LayerNorm(d) (biased variance, affine) over selected token rows — RAT_m1's PreNorm in front of
  * FeedForward and the final `self.norm` of each Transformer (RAT_m1.py:137-141,198,209), of which only token 0 of every

@@ -126,6 +126,21 @@ def check_attn(lib, dev, case, mode, seed=2, arith="f32"):
                 [(n, ga, gb) for n, ga, gb in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, g0) if ga is not None]:
             err = float((a_ - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
             assert err < 4e-6, ("bf16x3 vs exact fp32", name, err)
+        # weight planes split ONCE by the caller (RatAttnParams.planes + rat_split_weights_batch): bit-identical to the per-call split
+        nbytes = ops.attn_planes_bytes(d, heads, dh, lib=lib)
+        if nbytes:
+            planes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            p2 = ops.attn_params(*wd, planes=planes)
+            jobs = ops.attn_split_jobs(p2, d, heads, dh, planes, lib=lib)
+            assert len(jobs) == 4
+            arr, n = ops.split_job_array(jobs)
+            ops.split_weights_batch(arr, n, xd, lib=lib)
+            y2, o2, l2 = ops.attn_fwd(xd, p2, smap, d, heads, dh, save=True, arith=arith, lib=lib)
+            g2 = [torch.zeros_like(w) if w is not None else None for w in wd]
+            dx2, _ = ops.attn_bwd(xd, dyd, o2, l2, p2, ops.attn_params(*g2), smap, d, heads, dh, arith=arith, lib=lib)
+            for name, a_, b_ in [("y", y, y2), ("o_save", o_save, o2), ("lse", lse, l2), ("dx", dx, dx2)] + \
+                    [(n_, ga, gb) for n_, ga, gb in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, g2) if ga is not None]:
+                assert torch.equal(a_, b_), ("planes split by the caller", name)
 
 
 def check_attn_dropout(lib, dev, case, mode, p=0.25, seed=123456789, arith="f32"):
@@ -273,6 +288,17 @@ def check_ffn(lib, dev, ntok, d, hidden, arith="f32"):
         for name, a_, b_ in [("y", y, y0), ("dx", dx, dx0)] + [("g%d" % i, ga, gb) for i, (ga, gb) in enumerate(zip(gs, g0))]:
             err = float((a_ - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
             assert err < 4e-6, ("bf16x3 vs exact fp32", name, err)
+        nbytes = ops.ffn_planes_bytes(d, hidden, lib=lib)       # weight planes split once by the caller: bit-identical
+        if nbytes:
+            planes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            jobs = ops.ffn_split_jobs(wd[0], wd[2], d, hidden, planes, lib=lib)
+            assert len(jobs) == 3
+            arr, n = ops.split_job_array(jobs)
+            ops.split_weights_batch(arr, n, xd, lib=lib)
+            g2 = [torch.zeros_like(w) for w in wd]
+            dx2, _ = ops.ffn_bwd(xd, dyd, *wd, g2[0], g2[1], g2[2], g2[3], d, hidden, arith=arith, planes=planes, lib=lib)
+            for name, a_, b_ in [("dx", dx, dx2)] + [("g%d" % i, ga, gb) for i, (ga, gb) in enumerate(zip(gs, g2))]:
+                assert torch.equal(a_, b_), ("planes split by the caller", name)
 
 
 def check_ffn_res(lib, dev, ntok, d, hidden, with_res, arith="f32"):

@@ -1752,6 +1752,22 @@ extern "C" size_t rat_attn_fwd_workspace(int d, int heads, int dim_head) {
     return (d == B3_D && heads == B3_H && dim_head == B3_DH) ? B3_W_QKV + B3_W_OUT : 0;
 }
 
+// RatAttnParams.planes: [W_qkv | W_out^T | W_qkv^T | W_out] fragment planes (the backward's three first, the forward's second one last)
+extern "C" size_t rat_attn_planes_bytes(int d, int heads, int dim_head) {
+    return (d == B3_D && heads == B3_H && dim_head == B3_DH) ? B3_W_BYTES : 0;
+}
+extern "C" int rat_attn_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes, RatSplitJob* jobs_out) {
+    RAT_REQUIRE(w_host && jobs_out, "null pointer");
+    if (!b3_shape(d, heads, dim_head, w_host) || planes == nullptr) return 0;
+    RAT_REQUIRE(aligned16(planes) && w_host->w_qkv, "planes must be 16-byte aligned");
+    char* ws = static_cast<char*>(planes);
+    jobs_out[0] = RatSplitJob{w_host->w_qkv, ws, B3_Q3, B3_D, B3_D, 0, 0, 0};                                        // forward + backward
+    jobs_out[1] = RatSplitJob{w_host->w_out, ws + B3_W_QKV, B3_I, B3_D, B3_I, 1, 0, 0};                               // backward: dO
+    jobs_out[2] = RatSplitJob{w_host->w_qkv, ws + B3_W_QKV + B3_W_OUTT, B3_D, B3_Q3, B3_D, 1, 0, 0};                  // backward: d(LN out)
+    jobs_out[3] = RatSplitJob{w_host->w_out, ws + B3_W_QKV + B3_W_OUTT + B3_W_QKVT, B3_D, B3_I, B3_I, 0, 0, 0};       // forward: out-proj
+    return 4;
+}
+
 extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float* o_save, float* lse_save,
                                const RatAttnParams* w_host, const RatSeqMap* map_host, int d, int heads, int dim_head,
                                float softmax_scale, float out_scale, float ln_eps, float dropout_p, uint64_t dropout_seed,
@@ -1778,14 +1794,24 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p)};
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
     const bool plain = res == x && out_scale == 1.0f && a.drop.threshold == 0;
-    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) && workspace != nullptr &&
-        workspace_bytes >= B3_W_QKV + B3_W_OUT && aligned16(workspace)) {
-        char* ws = reinterpret_cast<char*>(workspace);
-        if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
-            rat_launch_split_weights(w_host->w_out, B3_D, B3_I, B3_I, 0, ws + B3_W_QKV, stream)) return -1;
+    const bool have_planes = w_host->planes != nullptr && aligned16(w_host->planes);
+    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) &&
+        (have_planes || (workspace != nullptr && workspace_bytes >= B3_W_QKV + B3_W_OUT && aligned16(workspace)))) {
+        const char* p_qkv;
+        const char* p_out;
+        if (have_planes) {                                       // split once per step by the caller (rat_split_weights_batch)
+            p_qkv = static_cast<const char*>(w_host->planes);
+            p_out = p_qkv + B3_W_QKV + B3_W_OUTT + B3_W_QKVT;
+        } else {
+            char* ws = reinterpret_cast<char*>(workspace);
+            if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
+                rat_launch_split_weights(w_host->w_out, B3_D, B3_I, B3_I, 0, ws + B3_W_QKV, stream)) return -1;
+            p_qkv = ws;
+            p_out = ws + B3_W_QKV;
+        }
         Attn3W W{};
-        W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
-        W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 3};
+        W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(p_qkv), 2};
+        W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(p_out), 3};
         const unsigned b3_blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
         if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
@@ -1863,10 +1889,16 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
     if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) && aligned16(workspace) &&
         (a.slab_stride * 256 * 4) % 16 == 0) {
-        char* ws = reinterpret_cast<char*>(workspace) + (size_t)256 * a.slab_stride * sizeof(float);
-        if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
-            rat_launch_split_weights(w_host->w_out, B3_I, B3_D, B3_I, 1, ws + B3_W_QKV, stream) ||
-            rat_launch_split_weights(w_host->w_qkv, B3_D, B3_Q3, B3_D, 1, ws + B3_W_QKV + B3_W_OUTT, stream)) return -1;
+        const char* ws;
+        if (w_host->planes != nullptr && aligned16(w_host->planes)) {     // split once per step by the caller (rat_split_weights_batch)
+            ws = static_cast<const char*>(w_host->planes);
+        } else {
+            char* wsw = reinterpret_cast<char*>(workspace) + (size_t)256 * a.slab_stride * sizeof(float);
+            if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, wsw, stream) ||
+                rat_launch_split_weights(w_host->w_out, B3_I, B3_D, B3_I, 1, wsw + B3_W_QKV, stream) ||
+                rat_launch_split_weights(w_host->w_qkv, B3_D, B3_Q3, B3_D, 1, wsw + B3_W_QKV + B3_W_OUTT, stream)) return -1;
+            ws = wsw;
+        }
         Attn3W W{};
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.outT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 2};

@@ -1203,16 +1203,30 @@ extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
     return fp32 + ((d == F3_D && hidden == F3_H) ? 3 * F3_WP + 16 : 0);                                      // + bf16x3 weight fragments
 }
 
+// `planes` of rat_ffn_bwd_res: [W1 | W2^T | W1^T (hidden index permuted)] fragment planes
+extern "C" size_t rat_ffn_planes_bytes(int d, int hidden) { return (d == F3_D && hidden == F3_H) ? 3 * F3_WP : 0; }
+extern "C" int rat_ffn_split_jobs(const float* w1, const float* w2, int d, int hidden, void* planes, RatSplitJob* jobs_out) {
+    RAT_REQUIRE(w1 && w2 && jobs_out, "null pointer");
+    if (!(d == F3_D && hidden == F3_H) || planes == nullptr) return 0;
+    RAT_REQUIRE(aligned16(planes), "planes must be 16-byte aligned");
+    char* ws = static_cast<char*>(planes);
+    jobs_out[0] = RatSplitJob{w1, ws, F3_H, F3_D, F3_D, 0, 0, 0};                    // A[hidden][d]   = w1[hidden][d]
+    jobs_out[1] = RatSplitJob{w2, ws + F3_WP, F3_H, F3_D, F3_H, 1, 0, 0};            // A[hidden][d]   = w2[d][hidden]
+    jobs_out[2] = RatSplitJob{w1, ws + 2 * F3_WP, F3_D, F3_H, F3_D, 1, 1, 0};        // A[d][hidden*] = w1[hidden][d]
+    return 3;
+}
+
 extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                            const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                            size_t workspace_bytes, int64_t ntok, int d, int hidden, void* stream) {
-    return rat_ffn_bwd_res(x, dy, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, ntok, d, hidden, 1, RAT_ARITH_F32,
+    return rat_ffn_bwd_res(x, dy, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, nullptr, ntok, d, hidden, 1, RAT_ARITH_F32,
                            stream);
 }
 
 extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                                const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
-                               size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, int arith, void* stream) {
+                               size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
+                               void* stream) {
     if (ffn_check(ntok, d, hidden, true)) return -1;
     RAT_REQUIRE(x && dy && dx && w1 && b1 && w2 && b2 && dw1 && db1 && dw2 && db2 && workspace, "null pointer");
     RAT_REQUIRE(workspace_bytes >= rat_ffn_bwd_workspace(d, hidden), "workspace too small");
@@ -1239,11 +1253,17 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const int fast = ffn_fast_dim(a, {x, dy, dx, b1});
     if (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3) {
-        uintptr_t wsb = reinterpret_cast<uintptr_t>(workspace + (size_t)256 * a.slab_stride + 2 * (size_t)d * hidden);
-        char* ws = reinterpret_cast<char*>((wsb + 15) & ~(uintptr_t)15);
-        if (rat_launch_split_weights(w1, F3_H, F3_D, F3_D, 0, ws, stream) ||                          // A[hidden][d]   = w1[hidden][d]
-            rat_launch_split_weights(w2, F3_H, F3_D, F3_H, 1, ws + F3_WP, stream) ||                  // A[hidden][d]   = w2[d][hidden]
-            rat_launch_split_weights(w1, F3_D, F3_H, F3_D, 1, ws + 2 * F3_WP, stream, 1)) return -1;  // A[d][hidden*] = w1[hidden][d]
+        const char* ws;
+        if (planes != nullptr && aligned16(planes)) {            // split once per step by the caller (rat_split_weights_batch)
+            ws = static_cast<const char*>(planes);
+        } else {
+            uintptr_t wsb = reinterpret_cast<uintptr_t>(workspace + (size_t)256 * a.slab_stride + 2 * (size_t)d * hidden);
+            char* wsw = reinterpret_cast<char*>((wsb + 15) & ~(uintptr_t)15);
+            if (rat_launch_split_weights(w1, F3_H, F3_D, F3_D, 0, wsw, stream) ||                          // A[hidden][d]   = w1[hidden][d]
+                rat_launch_split_weights(w2, F3_H, F3_D, F3_H, 1, wsw + F3_WP, stream) ||                  // A[hidden][d]   = w2[d][hidden]
+                rat_launch_split_weights(w1, F3_D, F3_H, F3_D, 1, wsw + 2 * F3_WP, stream, 1)) return -1;  // A[d][hidden*] = w1[hidden][d]
+            ws = wsw;
+        }
         Ffn3W W{};
         W.w1 = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.w2t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + F3_WP), 2};

@@ -128,6 +128,55 @@ __global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __r
         o[128] = l;
     }
 }
+// every job of a step in one launch: `per_job` consecutive work-groups per job (kernel-argument table), striding over its fragments
+constexpr int RAT_SPLIT_BATCH = 48;
+struct RatSplitTable {
+    RatSplitJob job[RAT_SPLIT_BATCH];
+};
+__global__ void __launch_bounds__(256) rat_split_weights_batch_kernel(RatSplitTable t, int per_job) {
+    const int bx = blockIdx.x % per_job;
+    const RatSplitJob& jb = t.job[blockIdx.x / per_job];
+    const float* __restrict__ w = jb.w;
+    rat_u4* __restrict__ out = static_cast<rat_u4*>(jb.out);
+    const int N = jb.N, K = jb.K, ld = jb.ld, transpose = jb.transpose, perm = jb.perm;
+    const int ntiles = (N + 15) / 16, steps = (K + 31) / 32, total = ntiles * steps * 64;
+    for (int e = bx * 256 + threadIdx.x; e < total; e += per_job * 256) {
+        const int lane = e & 63, fs = e >> 6, nt = fs / steps, s = fs - nt * steps;
+        const int n = 16 * nt + (lane & 15), g = lane >> 4;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 32 * s + (perm ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);      // as rat_split_weights_kernel
+            v[j] = (n < N && k < K) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
+        }
+        rat_u4 h, m, l;
+        rat_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
+        rat_u4* o = out + ((size_t)fs * 3) * 64 + lane;
+        o[0] = h;
+        o[64] = m;
+        o[128] = l;
+    }
+}
+extern "C" int rat_split_weights_batch(const RatSplitJob* jobs_host, int njobs, void* stream) {
+    RAT_REQUIRE(njobs >= 0 && (njobs == 0 || jobs_host != nullptr), "bad job list");
+    for (int j0 = 0; j0 < njobs; j0 += RAT_SPLIT_BATCH) {
+        const int nb = njobs - j0 < RAT_SPLIT_BATCH ? njobs - j0 : RAT_SPLIT_BATCH;
+        RatSplitTable t{};
+        int most = 1;
+        for (int j = 0; j < nb; ++j) {
+            const RatSplitJob& jb = jobs_host[j0 + j];
+            RAT_REQUIRE(jb.w && jb.out && jb.N > 0 && jb.K > 0 && jb.ld > 0, "bad split job");
+            RAT_REQUIRE((reinterpret_cast<uintptr_t>(jb.out) & 15) == 0, "split job output must be 16-byte aligned");
+            t.job[j] = jb;
+            const int frag = ((jb.N + 15) / 16) * ((jb.K + 31) / 32) * 64;
+            most = most > (frag + 255) / 256 ? most : (frag + 255) / 256;
+        }
+        RAT_LAUNCH(rat_split_weights_batch_kernel, (unsigned)(most * nb), 256, 0, stream, t, most);
+        if (rat_check_launch("rat_split_weights_batch")) return -1;
+    }
+    return 0;
+}
+
 int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm) {
     const int ntiles = (N + 15) / 16, steps = (K + 31) / 32;
     const int blocks = (ntiles * steps * 64 + 255) / 256;

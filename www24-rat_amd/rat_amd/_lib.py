@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RatField(Structure):
@@ -24,7 +24,13 @@ class RatSeqMap(Structure):
 
 
 class RatAttnParams(Structure):
-    _fields_ = [("ln_g", c_void_p), ("ln_b", c_void_p), ("w_qkv", c_void_p), ("w_out", c_void_p), ("b_out", c_void_p)]
+    _fields_ = [("ln_g", c_void_p), ("ln_b", c_void_p), ("w_qkv", c_void_p), ("w_out", c_void_p), ("b_out", c_void_p),
+                ("planes", c_void_p)]
+
+
+class RatSplitJob(Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("N", c_int32), ("K", c_int32), ("ld", c_int32), ("transpose", c_int32),
+                ("perm", c_int32), ("reserved", c_int32)]
 
 
 class RatError(RuntimeError):
@@ -57,7 +63,12 @@ _SIGNATURES = {
     "rat_bm25_topk": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_bm25_topk_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_ffn_fwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
-    "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "rat_attn_planes_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rat_attn_split_jobs": (c_int, [POINTER(RatAttnParams), c_int, c_int, c_int, _P, POINTER(RatSplitJob)]),
+    "rat_ffn_planes_bytes": (c_size_t, [c_int, c_int]),
+    "rat_ffn_split_jobs": (c_int, [_P, _P, c_int, c_int, _P, POINTER(RatSplitJob)]),
+    "rat_split_weights_batch": (c_int, [POINTER(RatSplitJob), c_int, _P]),
     "rat_layernorm_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int, c_float, _P]),
     "rat_layernorm_bwd_workspace": (c_size_t, [c_int64, c_int]),
     "rat_layernorm_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, c_size_t, c_int64, c_int, c_float, _P]),

@@ -407,7 +407,52 @@ class RAT_m2(BaseModel):
                 blk[which] = self._attn_descriptor("encoder.encoder.%d.%s_attention." % (i, which))
             p = "encoder.encoder.%d.mlp.net." % i
             blk["ffn"] = [p + "0.weight", p + "0.bias", p + "3.weight", p + "3.bias"]
+            blk["ffn_planes"] = None
             self._blocks.append(blk)
+        self._build_weight_planes()
+
+    def _build_weight_planes(self):
+        """bf16x3 fragment planes of every encoder weight matrix, refreshed by ONE launch per forward (`_refresh_weight_planes`)
+        instead of 2 - 3 split launches inside every attention / FFN call (52 per north-star step).  One uint8 buffer, a 16-byte
+        aligned slot per layer; the job list holds raw pointers into the flat parameter buffer and into that buffer, both of
+        which live as long as these descriptors."""
+        c, lib = self._cfg, self._lib
+        d, heads, dh, H = c["d"], c["heads"], c["dh"], c["hidden"]
+        self._split_jobs = (None, 0)
+        a_bytes = ops.attn_planes_bytes(d, heads, dh, lib=lib)
+        f_bytes = ops.ffn_planes_bytes(d, H, lib=lib)
+        slots = []
+        for blk in self._blocks:
+            for which in ("intra", "cross"):
+                if a_bytes and blk[which][0][3] is not None:
+                    slots.append((blk, which, a_bytes))
+            if f_bytes:
+                slots.append((blk, "ffn", f_bytes))
+        if not slots:
+            return
+        total = sum((b + 15) // 16 * 16 for _, _, b in slots)
+        self._planes = torch.empty(total, dtype=torch.uint8, device=self.device)
+        jobs, off = [], 0
+        for blk, which, nbytes in slots:
+            view = self._planes[off:off + nbytes]
+            off += (nbytes + 15) // 16 * 16
+            if which == "ffn":
+                w1, _, w2, _ = [self._p(n) for n in blk["ffn"]]
+                got = ops.ffn_split_jobs(w1, w2, d, H, view, lib=lib)
+                if got:
+                    blk["ffn_planes"] = view
+            else:
+                got = ops.attn_split_jobs(blk[which][1], d, heads, dh, view, lib=lib)
+                if got:
+                    blk[which][1].planes = view.data_ptr()
+            jobs += got
+        self._split_jobs = ops.split_job_array(jobs)
+
+    def _refresh_weight_planes(self):
+        """the weights may have changed since the last forward (optimizer step, load_state_dict): split them again — one launch"""
+        arr, n = getattr(self, "_split_jobs", (None, 0))
+        if n and self.arith == "bf16x3":
+            ops.split_weights_batch(arr, n, self._flat, lib=self._lib)
 
     def _encoder_forward(self, x, x0, dims, save, saved):
         """depth x (intra attention, cross attention, FFN), each with its residual (RAT_m2.py:219-236).
@@ -416,6 +461,7 @@ class RAT_m2(BaseModel):
         B, T, L, S = dims
         d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
+        self._refresh_weight_planes()
         for bi, blk in enumerate(self._blocks):
             inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
             xa, a1 = self._attn_layer_forward(blk["intra"], x, imap, save, out=x if inplace else None)
@@ -437,7 +483,8 @@ class RAT_m2(BaseModel):
         for blk, (x_in, a1, xa, a2, xb) in zip(reversed(self._blocks), reversed(saved["blocks"])):
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             gw = [G(n) for n in blk["ffn"]]
-            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith, lib=lib)
+            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
+                                planes=blk["ffn_planes"], lib=lib)
             dx = self._attn_layer_backward(blk["cross"], xa, dx, a2, cmap, G)
             dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G)
         return dx

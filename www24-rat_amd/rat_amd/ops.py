@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import RatAttnParams, RatSeqMap, get_lib
+from ._lib import RatAttnParams, RatSeqMap, RatSplitJob, get_lib
 
 FIELD_DTYPE = np.dtype([("table", "<u8"), ("col", "<i4"), ("ncols", "<i4"), ("vocab", "<i4"), ("padding_idx", "<i4")])
 assert FIELD_DTYPE.itemsize == 24
@@ -51,12 +51,57 @@ def cross_map(B, T, S):
     return RatSeqMap(nseq=B * S, L=T, q_div=S, hi_stride=T * S, lo_stride=1, pos_stride=S)
 
 
-def attn_params(ln_g, ln_b, w_qkv, w_out, b_out):
+def attn_params(ln_g, ln_b, w_qkv, w_out, b_out, planes=None):
+    """planes: optional uint8 tensor of ``attn_planes_bytes`` bytes holding the bf16x3 fragment planes of these weights (filled by
+    ``split_weights_batch`` from ``attn_split_jobs``); without it the bf16x3 entry points split the weights on every call."""
     for t in (ln_g, ln_b, w_qkv, w_out, b_out):
         _chk(t, name="attention parameter")
     return RatAttnParams(ln_g.data_ptr(), ln_b.data_ptr(), w_qkv.data_ptr(),
                          w_out.data_ptr() if w_out is not None else None,
-                         b_out.data_ptr() if b_out is not None else None)
+                         b_out.data_ptr() if b_out is not None else None,
+                         planes.data_ptr() if planes is not None else None)
+
+
+# ----------------------------------------------------------------------------- bf16x3 weight planes, once per step
+def attn_planes_bytes(d, heads, dim_head, lib=None):
+    return (lib or get_lib()).size("rat_attn_planes_bytes", d, heads, dim_head)
+
+
+def ffn_planes_bytes(d, hidden, lib=None):
+    return (lib or get_lib()).size("rat_ffn_planes_bytes", d, hidden)
+
+
+def attn_split_jobs(params, d, heads, dim_head, planes, lib=None):
+    """-> list of RatSplitJob that fill ``planes`` (uint8 tensor, 16-byte aligned) from the weights of ``params``"""
+    lib = lib or get_lib()
+    jobs = (RatSplitJob * 4)()
+    n = lib.cdll.rat_attn_split_jobs(ctypes.byref(params), d, heads, dim_head, _p(planes), jobs)
+    if n < 0:
+        raise RuntimeError("rat_attn_split_jobs: " + lib.last_error())
+    return [jobs[i] for i in range(n)]
+
+
+def ffn_split_jobs(w1, w2, d, hidden, planes, lib=None):
+    lib = lib or get_lib()
+    jobs = (RatSplitJob * 3)()
+    n = lib.cdll.rat_ffn_split_jobs(_p(w1), _p(w2), d, hidden, _p(planes), jobs)
+    if n < 0:
+        raise RuntimeError("rat_ffn_split_jobs: " + lib.last_error())
+    return [jobs[i] for i in range(n)]
+
+
+def split_job_array(jobs):
+    """a ctypes array that can be kept and replayed every step (the pointers inside must stay valid)"""
+    arr = (RatSplitJob * max(len(jobs), 1))()
+    for i, j in enumerate(jobs):
+        arr[i] = j
+    return arr, len(jobs)
+
+
+def split_weights_batch(job_array, njobs, like, lib=None):
+    """ONE launch for every job; `like`: any tensor on the target device (stream selection)"""
+    if njobs:
+        (lib or get_lib()).call("rat_split_weights_batch", job_array, njobs, _stream(like))
 
 
 # ----------------------------------------------------------------------------- K0
@@ -326,9 +371,10 @@ def ffn_fwd(x, w1, b1, w2, b2, d, hidden, out=None, arith="f32", lib=None):
     return y
 
 
-def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None, arith="f32", lib=None):
+def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None, arith="f32", planes=None, lib=None):
     if arith != "f32":
-        return ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, True, workspace=workspace, arith=arith, lib=lib)
+        return ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, True, workspace=workspace, arith=arith, planes=planes,
+                           lib=lib)
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_ffn_bwd_workspace", d, hidden)
@@ -352,7 +398,7 @@ def ffn_fwd_res(x, res, w1, b1, w2, b2, d, hidden, out=None, arith="f32", lib=No
     return y
 
 
-def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, arith="f32", lib=None):
+def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, arith="f32", planes=None, lib=None):
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_ffn_bwd_workspace", d, hidden)
@@ -360,7 +406,7 @@ def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, wo
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
     lib.call("rat_ffn_bwd_res", _p(x), _p(dy), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2), _p(db2),
-             _p(workspace), workspace.numel() * 4, x.numel() // d, d, hidden, int(bool(add_dy)), ARITH[arith], _stream(x))
+             _p(workspace), workspace.numel() * 4, _p(planes), x.numel() // d, d, hidden, int(bool(add_dy)), ARITH[arith], _stream(x))
     return dx, workspace
 
 
