@@ -1367,7 +1367,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         }
         const int64_t tok_own = rowtok[r_own];
         // ---- P0: x -> LayerNorm -> planes; dy -> planes (+ db_out partials); O, lse -> fp32 tiles
-        {   // Same-box A/B of the alternatives (tools/ab_attn.sh): touching the next chunk's lines into L2 behind the VALU passes +5 %;
+        {   // Same-box A/B of the alternatives (tools/ab_attn.sh): touching the next chunk's lines into L2 behind the VALU passes +4-5 %
+            // (also with the touched value waited for right after pass 1 instead of at the end of the iteration);
             // requesting the next chunk's rows a phase or two early (P4, P5, P6) +8-10 % — the registers that carry them across the
             // GEMM phases come back as spills, and a spill reload is a scratch load that waits for vmcnt(0).
             const bool valid = tok_own >= 0;

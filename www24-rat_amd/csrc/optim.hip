@@ -40,7 +40,26 @@ sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    int64_t head = 0;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {                 // 16-byte requests, two in flight per thread (HBM-bound sweep)
+        const int64_t n4 = n >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float a0 = 0.f, a1 = 0.f;
+        int64_t i = tid;
+        for (; i + nthr < n4; i += 2 * nthr) {
+            const float4 u = g4[i], w = g4[i + nthr];
+            a0 = fmaf(u.x, u.x, a0); a0 = fmaf(u.y, u.y, a0); a0 = fmaf(u.z, u.z, a0); a0 = fmaf(u.w, u.w, a0);
+            a1 = fmaf(w.x, w.x, a1); a1 = fmaf(w.y, w.y, a1); a1 = fmaf(w.z, w.z, a1); a1 = fmaf(w.w, w.w, a1);
+        }
+        if (i < n4) {
+            const float4 u = g4[i];
+            a0 = fmaf(u.x, u.x, a0); a0 = fmaf(u.y, u.y, a0); a0 = fmaf(u.z, u.z, a0); a0 = fmaf(u.w, u.w, a0);
+        }
+        acc = a0 + a1;
+        head = n4 << 2;
+    }
+    for (int64_t i = head + tid; i < n; i += nthr) {
         const float v = g[i];
         acc = fmaf(v, v, acc);
     }
