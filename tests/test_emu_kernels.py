@@ -19,7 +19,7 @@ def emu():
     return RatLib(build_emu.build())
 
 
-@pytest.mark.parametrize("d", [8, 10])
+@pytest.mark.parametrize("d", [8, 10, 64])           # 64: the wave-per-row scatter kernel (sequence field with 3 ids included)
 def test_gather_fwd_bwd(emu, d):
     kc.check_gather(emu, "cpu", d)
 

@@ -10,6 +10,12 @@
 namespace {
 
 constexpr int GATHER_THREADS = 256;
+#ifndef GATHER_BWD_ROWS
+#define GATHER_BWD_ROWS 8                 // rows per wave of the d = 64 scatter (grid = rows / this, capped)
+#endif
+#ifndef GB_TRIP
+#define GB_TRIP 2                         // rows requested before the first atomic of a trip
+#endif
 constexpr int GATHER_ITEMS = 4;       // independent rows in flight per thread
 
 // vectorised path: d % 4 == 0, one item = one 16-byte piece of one grid row
@@ -128,6 +134,56 @@ gather_bwd_fields_kernel(const float* __restrict__ dgrid, const float* __restric
             id = id < 0 ? 0 : (id >= f.vocab ? f.vocab - 1 : id);
             if (id != f.padding_idx) atomicAdd(f.table + (int64_t)id * d + c, g);
         }
+    }
+}
+
+// The same for d = 64 (a wave = one 256-byte row): the row index is wave-uniform, so its decomposition into (sample row, field)
+// and the id / field-descriptor fetches run on the scalar unit — the element-wise form above spends most of its time in three
+// 64-bit integer divisions per element.  GB_TRIP rows per trip: their gradient rows are requested before the atomics of the first.
+__global__ void __launch_bounds__(GATHER_THREADS)
+gather_bwd_fields64_kernel(const float* __restrict__ dgrid, const float* __restrict__ dflat, const int32_t* __restrict__ idx,
+                           const RatField* __restrict__ gfields, int nrows, int T, int S, int L) {
+    constexpr int d = 64;
+    const int lane = threadIdx.x & 63;
+#ifdef RAT_EMU
+    const int wave0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+#else
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+#endif
+    const int nwaves = (int)(gridDim.x * blockDim.x) >> 6;
+    const int F = S - 1;
+    auto fetch = [&](int r, int& bt, int& fi) {
+        bt = r / F;
+        fi = r - bt * F;
+        float g = dgrid[((int64_t)bt * S + 1 + fi) * d + lane];
+        if (dflat != nullptr) {
+            const int b = bt / T;
+            if (bt - b * T == 0) g += dflat[((int64_t)b * F + fi) * d + lane];
+        }
+        return g;
+    };
+    auto scatter = [&](int bt, int fi, float g) {
+        const RatField f = gfields[fi];
+        const int32_t* ids = idx + (int64_t)bt * L + f.col;
+        for (int j = 0; j < f.ncols; ++j) {
+            int id = ids[j];
+            id = id < 0 ? 0 : (id >= f.vocab ? f.vocab - 1 : id);
+            if (id != f.padding_idx) atomicAdd(f.table + (int64_t)id * d + lane, g);
+        }
+    };
+    int r = wave0;
+    for (; r + (GB_TRIP - 1) * nwaves < nrows; r += GB_TRIP * nwaves) {
+        int bt[GB_TRIP], fi[GB_TRIP];
+        float g[GB_TRIP];
+#pragma unroll
+        for (int u = 0; u < GB_TRIP; ++u) g[u] = fetch(r + u * nwaves, bt[u], fi[u]);
+#pragma unroll
+        for (int u = 0; u < GB_TRIP; ++u) scatter(bt[u], fi[u], g[u]);
+    }
+    for (; r < nrows; r += nwaves) {
+        int bt0, fi0;
+        const float g0 = fetch(r, bt0, fi0);
+        scatter(bt0, fi0, g0);
     }
 }
 
@@ -254,8 +310,12 @@ extern "C" int rat_gather_bwd(const float* dgrid, const float* dflat, const int3
     const int64_t nbt = (int64_t)B * T;
     if (nfields > 0) {
         RAT_REQUIRE(grad_fields_dev, "null grad field table");
-        RAT_LAUNCH(gather_bwd_fields_kernel, pick_blocks(nbt * nfields * d, 4), GATHER_THREADS, 0, stream, dgrid, dflat,
-                   idx, grad_fields_dev, nbt, T, S, L, d);
+        if (d == 64 && nbt * nfields < (int64_t)0x7fffffff)
+            RAT_LAUNCH(gather_bwd_fields64_kernel, pick_blocks(nbt * nfields * d, GATHER_BWD_ROWS), GATHER_THREADS, 0, stream, dgrid, dflat,
+                       idx, grad_fields_dev, (int)(nbt * nfields), T, S, L);
+        else
+            RAT_LAUNCH(gather_bwd_fields_kernel, pick_blocks(nbt * nfields * d, 4), GATHER_THREADS, 0, stream, dgrid, dflat,
+                       idx, grad_fields_dev, nbt, T, S, L, d);
     }
     if (dlabel_table) {
         int blocks = pick_blocks(nbt * d, 16);
