@@ -82,6 +82,55 @@ gather_fwd_vec_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict
     }
 }
 
+// d = 64 and fewer than 2^31 grid rows: 32-bit index arithmetic (the path above spends two 64-bit divisions per 16-byte piece) and
+// branch-free fetches — the label row and the field rows go through the same unconditional id load and row load, so that all
+// GATHER_ITEMS rows of a lane are in flight together (a load inside a divergent branch is waited for inside the branch).
+__global__ void __launch_bounds__(GATHER_THREADS)
+gather_fwd_rows64_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ label_ids,
+                         const RatField* __restrict__ fields, const float* __restrict__ label_table,
+                         float* __restrict__ grid, unsigned nrows, unsigned S, int L) {
+    constexpr int d = 64;
+    const unsigned piece = threadIdx.x & 15;                                    // 16 lanes per 256-byte row
+    const unsigned slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, nslots = (gridDim.x * blockDim.x) >> 4;
+    for (unsigned r0 = slot; r0 < nrows; r0 += GATHER_ITEMS * nslots) {
+        const float* tab[GATHER_ITEMS];
+        const int32_t* idp[GATHER_ITEMS];
+        int vocab[GATHER_ITEMS], extra[GATHER_ITEMS], id[GATHER_ITEMS];
+        bool ok[GATHER_ITEMS];
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) {
+            const unsigned row = r0 + u * nslots;
+            ok[u] = row < nrows;
+            const unsigned rr = ok[u] ? row : 0u;
+            const unsigned bt = rr / S, s = rr - bt * S;
+            const RatField f = fields[s > 0 ? s - 1 : 0];
+            const bool lab = s == 0;
+            tab[u] = lab ? label_table : f.table;
+            vocab[u] = lab ? 3 : f.vocab;
+            extra[u] = lab ? 0 : f.ncols - 1;
+            idp[u] = lab ? label_ids + bt : idx + (int64_t)bt * L + f.col;
+        }
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) id[u] = *idp[u];
+        float4 v[GATHER_ITEMS];
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) {
+            const int i = id[u] < 0 ? 0 : (id[u] >= vocab[u] ? vocab[u] - 1 : id[u]);   // memory safety only: rat_check_ids REPORTS
+            v[u] = *(reinterpret_cast<const float4*>(tab[u] + (int64_t)i * d) + piece);
+        }
+#pragma unroll
+        for (int u = 0; u < GATHER_ITEMS; ++u) {
+            for (int j = 1; j <= extra[u]; ++j) {                                // MaskedSumPooling bag (padding row is all-zero)
+                int i = idp[u][j];
+                i = i < 0 ? 0 : (i >= vocab[u] ? vocab[u] - 1 : i);
+                const float4 w = *(reinterpret_cast<const float4*>(tab[u] + (int64_t)i * d) + piece);
+                v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
+            }
+            if (ok[u]) reinterpret_cast<float4*>(grid)[(size_t)(r0 + u * nslots) * 16 + piece] = v[u];
+        }
+    }
+}
+
 // generic path: any d, one item = one float
 __global__ void __launch_bounds__(GATHER_THREADS)
 gather_fwd_scalar_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ label_ids,
@@ -292,8 +341,12 @@ extern "C" int rat_gather_fwd(const int32_t* idx, const int32_t* label_ids, cons
     const int64_t nrows = (int64_t)B * T * S;
     const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(grid) | reinterpret_cast<uintptr_t>(label_table)) % 16 == 0);
     if (vec) {
-        RAT_LAUNCH(gather_fwd_vec_kernel, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
-                   label_ids, fields_dev, label_table, grid, nrows, S, L, d);
+        if (d == 64 && nrows < (int64_t)0x7fffffff)
+            RAT_LAUNCH(gather_fwd_rows64_kernel, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
+                       label_ids, fields_dev, label_table, grid, (unsigned)nrows, (unsigned)S, L);
+        else
+            RAT_LAUNCH(gather_fwd_vec_kernel, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
+                       label_ids, fields_dev, label_table, grid, nrows, S, L, d);
     } else {
         RAT_LAUNCH(gather_fwd_scalar_kernel, pick_blocks(nrows * d, 4), GATHER_THREADS, 0, stream, idx, label_ids,
                    fields_dev, label_table, grid, nrows, S, L, d);
