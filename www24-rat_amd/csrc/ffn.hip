@@ -1043,19 +1043,32 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             for (int m = 0; m < KD0; ++m) st4(pxp(m), as_f4(dxa[m]));
         }
         __syncthreads();
-        auto finish = [&](int m) {
+        // the residual pieces of dy are requested unconditionally (rows past the end read token 0) and all of them before the first is
+        // used: a load inside a divergent branch is waited for inside the branch, i.e. one exposed L2 round trip per tile
+        const bool live = tok < a.ntok;
+        const float* pr = a.dy + (live ? tok : 0) * D + 4 * g;
+        auto finish = [&](int m, const float4& dr) {
             const float4 p = ld4(pxp(m));
-            float4 dr = zero4;
-            if (a.add_dy && tok < a.ntok) dr = ld4(a.dy + tok * D + 16 * m + 4 * g);
             const float4 o = make_float4(dxa[m][0] + p.x + dr.x, dxa[m][1] + p.y + dr.y, dxa[m][2] + p.z + dr.z, dxa[m][3] + p.w + dr.w);
-            if (tok < a.ntok) st4(a.y + tok * D + 16 * m + 4 * g, o);
+            if (live) st4(a.y + tok * D + 16 * m + 4 * g, o);
         };
+        static_assert(KD0 == 2, "two dx tiles per half");
         if (half == 0) {
-#pragma unroll
-            for (int m = 0; m < KD0; ++m) finish(m);
+            float4 r0 = zero4, r1 = zero4;
+            if (a.add_dy) {                                         // uniform
+                r0 = ld4(pr);
+                r1 = ld4(pr + 16);
+            }
+            finish(0, r0);
+            finish(1, r1);
         } else {
-#pragma unroll
-            for (int m = KD0; m < KD; ++m) finish(m);
+            float4 r0 = zero4, r1 = zero4;
+            if (a.add_dy) {
+                r0 = ld4(pr + 32);
+                r1 = ld4(pr + 48);
+            }
+            finish(2, r0);
+            finish(3, r1);
         }
         {   // next chunk's token fragments: in flight behind the weight-gradient GEMMs
             const int64_t tk = (chunk + gridDim.x) * FB_TOK + row;
