@@ -1454,6 +1454,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         // ---- P3: attention backward on the VALU — the two passes of attn_bwd_kernel<64, 10>.  Same-box A/B of the loop shapes
         // (tools/ab_attn.sh): 2 / 3 / 4 keys per trip with all their rows requested up front +7 / +14 / +20 % (spills), the
         // software-pipelined form (rows of key j + 1 requested before the arithmetic of key j, ping-pong registers) +4 %.
+        // A ONE-pass form was built and measured too (every (sequence, head) group inside one wave; lane = query owner AND key owner of
+        // row pos; step t: key (pos + t) mod L, (p, dS) handed to the key's owner by a lane shuffle, so nothing is recomputed: 25
+        // instead of 35 packed FMAs per pair): correct, but +29 % at L = 21 and +16 % at L = 11 — its K / V / q / dO reads are a
+        // different row per lane, while in both passes below all lanes of a group read the SAME row (an LDS broadcast).
         typedef HeadVec<B3_DH> HV;
         const int ntasks = nsq * B3_H * L;
         const float sl2 = a.scale * RAT_LOG2E;
