@@ -1358,12 +1358,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
         const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
-        int nsq, rows;
+        int nsq;
         {
             const int64_t q0 = chunk * a.nsq_chunk;
             const int64_t left = a.nseq - q0;
             nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
-            rows = nsq * a.L;
         }
         const int64_t tok_own = rowtok[r_own];
         // ---- P0: x -> LayerNorm -> planes; dy -> planes (+ db_out partials); O, lse -> fp32 tiles

@@ -587,7 +587,7 @@ __device__ __forceinline__ RatB3 rat_split8_frag(const float4& a, const float4& 
 // value of element e (0..7) of a 16-byte piece triple: h + m + l is exact, in this order
 __device__ __forceinline__ float rat_join(unsigned h, unsigned m, unsigned l, int hi) {
     const unsigned sh = hi ? 0u : 16u, mk = hi ? 0xffff0000u : 0xffffffffu;
-    return (rat_bitsf((h << sh) & mk | 0u) + rat_bitsf((m << sh) & mk)) + rat_bitsf((l << sh) & mk);
+    return (rat_bitsf((h << sh) & mk) + rat_bitsf((m << sh) & mk)) + rat_bitsf((l << sh) & mk);
 }
 
 // c += a * b, six cross products, small terms first
