@@ -182,7 +182,7 @@ def check_model_sparse_training(case_name, gpu, steps=3):
             assert model._grad_mode == "sparse" and model._n_sparse == model._n_tab > 0
             assert all(p.grad is None for n, p in model.named_parameters() if n.startswith(("embedding_layer.", "lr_layer.")))
     (la, wa), (ls, ws) = out["atomic"], out["sparse"]
-    np.testing.assert_allclose(ls, la, rtol=0, atol=3e-6)
+    np.testing.assert_allclose(ls, la, rtol=0, atol=1e-5)          # atomics: arrival-order sums in the dense path
     noise = mc.noise_tensors(model)
     for k in wa:
         if k.startswith("query_proj") or k in noise or k.endswith("num_batches_tracked"):

@@ -74,7 +74,8 @@ def test_sparse_equals_dense_at_the_config3_rank_shape(lib):
     sparse, ls = _run(name, "sparse", 3, 1024)
     assert sparse._grad_mode == "sparse"
     flat_s = sparse._flat.detach().cpu()
-    np.testing.assert_allclose(ls, ld, rtol=0, atol=3e-6)
+    # (the dense path sums with fp32 atomics in arrival order: over repeated runs the step-3 losses differed by 1.7e-6 .. 3.4e-6)
+    np.testing.assert_allclose(ls, ld, rtol=0, atol=1e-5)
     noise = sc.mc.noise_tensors(sparse)
     keep = torch.ones_like(flat_s, dtype=torch.bool)
     for n in noise:
