@@ -1189,7 +1189,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         RAT_PROF_MARK(1);
         // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>.  (A two-stage form for L <= 24 — the row of scores
         //  kept in registers, max first, then ONE exponential and a plain packed axpy per key instead of the online rescaling: 110
-        //  instead of 180 VALU cycles per pair — measured 4-10 % SLOWER, one key or three keys per trip alike: tools/ab_attn.sh.)
+        //  instead of 180 VALU cycles per pair — measured 4-10 % SLOWER, one key or three keys per trip alike; 5 / 6 / 7 keys per trip
+        //  instead of 3: no change; three queries per lane on a third of the keys (a third of the LDS bytes per pair, partial softmax
+        //  states merged by lane shuffles): 9-17 % slower.  tools/ab_attn.sh.)
         float pf = 0.f;
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)   // (no prefetch: +2-3 %, same-box A/B)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
