@@ -201,6 +201,29 @@ def test_large_pool_properties_gpu(topk):
     ro.assert_topk_equivalent(s, (got.values[sample], got.indices[sample], got.lens[sample]), want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("topk", [5, 20])
+def test_heavy_ties_keep_pool_order_gpu(topk):
+    """tiny vocabularies over a 60k-row pool: almost every score is shared by thousands of rows, so the result is decided by the tie
+    order alone (lower pool index first) — in every lane's private list and in the merge"""
+    import rat_amd._lib as L
+    from rat_amd import retrieval
+    rs = np.random.RandomState(17)
+    vocab = [3, 4, 2, 5]
+    db = np.stack([rs.randint(0, v, size=60_000) for v in vocab], axis=1).astype(np.int64)
+    qry = np.stack([rs.randint(0, v, size=64) for v in vocab], axis=1).astype(np.int64)
+    got = retrieval.BM25_topk_retrieval_v4(db, qry, device="cuda:0", topK=topk, lib=L.get_lib())
+    want = ro.topk(db, qry, topk)
+    np.testing.assert_array_equal(got.indices, want[1])
+    np.testing.assert_allclose(got.values, want[0], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(got.lens, want[2])
+    got = retrieval.BM25_topk_retrieval_v4(db, qry, exact_match_col_indices=[1], device="cuda:0", topK=topk, lib=L.get_lib())
+    wv, wi, wl, _ = ro.topk_exact(db, qry, [1], topk)
+    np.testing.assert_array_equal(got.indices, wi)
+    np.testing.assert_allclose(got.values, wv, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(got.lens, wl)
+
+
 # ---- the driver: fold / separate-pool / label-wise pre-retrieval as DataGenerator runs it (data_generator.py:106-215)
 def gold_driver(name):
     g = np.load(GOLD)
