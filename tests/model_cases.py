@@ -105,3 +105,35 @@ def check_training(name, gpu):
     with torch.no_grad():
         yp = model.forward(batch)["y_pred"].cpu().numpy()
     np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=2e-3 if case["batch_norm"] else 3e-6)
+
+
+CHECKPOINT_CASES = ["tiny_seq_bn", "m0_tiny_seq", "m1_tiny_seq", "m3_tiny_seq"]
+
+
+def check_checkpoint(name, gpu, tmpdir):
+    """On-disk format of `.model` files (base_model.py:275-284): tests/golden/ckpt_<case>.model was written by the REFERENCE class's
+    own save_weights after two training steps (tests/golden/make_golden_checkpoints.py).  load_weights must take it as is and the
+    eval predictions must be the reference's under those weights (`eval_after/y_pred`, 2e-6 — no training on our side, so BatchNorm's
+    running statistics are the file's); save_weights must write a file with the same keys, shapes, dtypes and bits."""
+    case = gc.case_by_name(name)
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    path = os.path.join(GOLD, "ckpt_%s.model" % name)
+    model = build_model(case, gpu=gpu, seed=99)
+    model.load_weights(path)
+    model.eval()
+    with torch.no_grad():
+        yp = model.forward(batch_of(case))["y_pred"].cpu().numpy()
+    np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=2e-6)
+    ref = torch.load(path, map_location="cpu")
+    out = os.path.join(str(tmpdir), "roundtrip.model")
+    model.save_weights(out)
+    mine = torch.load(out, map_location="cpu")
+    assert list(mine.keys()) == list(ref.keys()), "state_dict keys / order differ from the reference's file"
+    for k in ref:
+        assert mine[k].dtype == ref[k].dtype and mine[k].shape == ref[k].shape, k
+        assert torch.equal(mine[k], ref[k]), k
+    # and the reference-side reader: torch.load + load_state_dict(strict) into a fresh model of ours round-trips the weights
+    again = build_model(case, gpu=gpu, seed=5)
+    again.load_weights(out)
+    for k, v in again.state_dict().items():
+        assert torch.equal(v.cpu(), ref[k]), k

@@ -25,13 +25,13 @@ def check_sorted_reduce(lib, dev, d, B=5, T=4, dup_vocab=3):
     tables = [flat[offs[i]:offs[i + 1]].view(f.vocab, d) for i, f in enumerate(fields)]
     cols_hi = [fields[0].vocab, 6, 6, 6, 9]
     idx = torch.stack([torch.from_numpy(rs.randint(0, cols_hi[c], size=(B, T))) for c in range(L)], -1).int().contiguous()
-    idx[0, 1, 0] = 99                                    # outside the vocabulary: takes no part (rat_check_ids reports it)
+    idx[0, 1, 0] = 99                                    # outside the vocabulary: clamped to the last row like the forward gather
+    #                                                      and the atomic scatter (rat_check_ids reports it)
     dgrid = rnd(rs, B, T, 4, d)
     dflat = rnd(rs, B, 3 * d)
-    # reference: CPU autograd of the lookups (out-of-range id masked out)
+    # reference: CPU autograd of the lookups (out-of-range id clamped)
     tl = [torch.zeros(f.vocab, d, requires_grad=True) for f in fields]
-    ok = (idx[..., 0] < fields[0].vocab).float().unsqueeze(-1)
-    e0 = tl[0][idx[..., 0].clamp(max=fields[0].vocab - 1).long()] * ok
+    e0 = tl[0][idx[..., 0].clamp(max=fields[0].vocab - 1).long()]
     e1 = torch.nn.functional.embedding(idx[..., 1:4].long(), tl[1], padding_idx=5).sum(-2)
     e2 = torch.nn.functional.embedding(idx[..., 4].long(), tl[2], padding_idx=8)
     ref = torch.stack([e0, e1, e2], dim=2)
@@ -150,15 +150,28 @@ def _model(case_name, gpu, mode, **over):
     return case, model, mc.batch_of(case)
 
 
-def check_model_sorted_equals_atomic(case_name, gpu):
+def check_model_sorted_equals_atomic(case_name, gpu, bad_ids=False):
+    """bad_ids: one out-of-vocabulary and one negative id in the batch — every path clamps them the same way (the forward reads the
+    clamped row, both gradient paths update it), so the modes still agree; check_id_errors() reports them."""
     grads = {}
     for mode in ("atomic", "sorted", "sorted"):
         case, model, batch = _model(case_name, gpu, mode)
+        if bad_ids:
+            X = batch[0].clone()
+            X[0, 1, 0] = 10 ** 6
+            X[1, 0, 0] = -3
+            batch = (X,) + tuple(batch[1:])
         model.train()
         model.optimizer.zero_grad()
         model.get_total_loss(batch).backward()
         g = {k: p.grad.detach().clone().cpu() for k, p in model.named_parameters() if p.grad is not None}
         grads.setdefault(mode, []).append(g)
+        if bad_ids:
+            try:
+                model.check_id_errors()
+                raise AssertionError("the out-of-vocabulary ids were not reported")
+            except IndexError:
+                pass
     a, (s1, s2) = grads["atomic"][0], grads["sorted"]
     assert set(a) == set(s1)
     noise = mc.noise_tensors(model)

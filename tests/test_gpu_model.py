@@ -30,6 +30,12 @@ def test_two_training_steps(name):
     mc.check_training(name, gpu=0)
 
 
+@pytest.mark.parametrize("name", mc.CHECKPOINT_CASES)
+def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):
+    """`.model` files written by the reference's own RAT_m2 / m0 / m1 / m3 classes (tests/golden/make_golden_checkpoints.py)"""
+    mc.check_checkpoint(name, gpu=0, tmpdir=tmp_path)
+
+
 @pytest.mark.parametrize("name", ["tiny_seq_bn", "northstar_shape", "kkbox_shape"])
 def test_composed_attention_path(name, monkeypatch):
     """fused-kernel threshold lowered: every attention layer runs LayerNorm -> GEMM -> attention core (strided sequences in the

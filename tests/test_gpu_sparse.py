@@ -38,6 +38,10 @@ def test_sorted_mode_equals_atomic_mode_and_is_reproducible(lib, name):
     sc.check_model_sorted_equals_atomic(name, gpu=0)
 
 
+def test_out_of_vocabulary_ids_are_treated_alike_by_every_gradient_path(lib):
+    sc.check_model_sorted_equals_atomic("tiny_seq_bn", gpu=0, bad_ids=True)
+
+
 @pytest.mark.parametrize("name", ["tiny_seq_bn", "northstar_shape"])
 def test_sparse_training_equals_dense_training(lib, name):
     sc.check_model_sparse_training(name, gpu=0, steps=3)

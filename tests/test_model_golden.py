@@ -35,6 +35,12 @@ def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
 
+# `.model` files written by the reference classes themselves: one on the emulator, all four on the GPU
+@pytest.mark.parametrize("name", ["tiny_seq_bn"])
+def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):
+    mc.check_checkpoint(name, gpu=-1, tmpdir=tmp_path)
+
+
 # (RAT_m0 shares RAT_m1's transformer-stack code; its long-sequence composed path is exercised by
 # test_m2_composed_attention_path here and by the m0_northstar_shape golden case on the GPU)
 # one case per variant on the emulator (35-40 s each); the GPU suite runs every case of golden_cases.CASES

@@ -49,6 +49,10 @@ def test_sorted_mode_equals_atomic_mode_and_is_reproducible(emu_default):
     sc.check_model_sorted_equals_atomic("tiny_seq_bn", gpu=-1)
 
 
+def test_out_of_vocabulary_ids_are_treated_alike_by_every_gradient_path(emu_default):
+    sc.check_model_sorted_equals_atomic("tiny_seq_bn", gpu=-1, bad_ids=True)
+
+
 def test_sparse_training_equals_dense_training(emu_default):
     sc.check_model_sparse_training("tiny_seq_bn", gpu=-1, steps=2)
 

@@ -91,8 +91,11 @@ keys_from_ids_kernel(const int32_t* __restrict__ idx, const RatField* __restrict
         uint32_t key = invalid;
         if (fi >= 0) {
             const RatField f = fields[fi];
-            const int id = idx[bt * L + c];
-            if (id >= 0 && id < f.vocab && id != f.padding_idx)
+            // out-of-vocabulary ids: ONE policy on every path (forward gather, atomic scatter, this plan) — clamped into the table
+            // for memory safety and REPORTED by rat_check_ids; the gradient goes to the row the forward read
+            int id = idx[bt * L + c];
+            id = id < 0 ? 0 : (id >= f.vocab ? f.vocab - 1 : id);
+            if (id != f.padding_idx)
                 key = (uint32_t)((f.table - flat_base) / width + id);
         }
         keys[e] = key;

@@ -228,6 +228,7 @@ class RAT_m2(BaseModel):
         if self._embedding_grad not in ("auto", "atomic", "sorted", "sparse"):
             raise ValueError("embedding_grad=%r" % self._embedding_grad)
         self._sparse = None
+        self._sparse_is_global = False   # the row lists in _sparse were already merged over the ranks
         self._pending_reduce = None      # (work handle, gradient buffer) of the dense-net all-reduce started inside backward
         self._validate_ids = bool(kwargs.get("validate_ids", True))
         self._id_errors = None
@@ -583,6 +584,7 @@ class RAT_m2(BaseModel):
         dev = self._flat.device
         emb_prefix = "embedding_layer.embedding_layer.embedding_layer."
         lr_prefix = "lr_layer.embedding_layer.embedding_layer.embedding_layer."
+        self._settle_pending_reduce()        # RCCL may still be reducing the buffer that is about to be zeroed / replaced
 
         def tables(g):
             view = lambda n: self._gflat_view(g, n)           # noqa: E731
@@ -601,6 +603,13 @@ class RAT_m2(BaseModel):
         if not held:
             self._gbuf = (g, gft, lft)
         return g, gft, lft
+
+    def _settle_pending_reduce(self):
+        """A backward that was NOT followed by _exchange_gradients (a custom loop, a second backward) leaves the dense-net
+        all-reduce it started in flight: wait for it before its buffer is zeroed, replaced or accumulated into."""
+        pending, self._pending_reduce = self._pending_reduce, None
+        if pending is not None:
+            pending[0].wait()
 
     def _gflat_view(self, gflat, name):
         """view of parameter `name`'s gradient inside the flat gradient buffer (which, in sparse mode, starts BEHIND the tables)"""
@@ -652,8 +661,9 @@ class RAT_m2(BaseModel):
                     for n in self._dense_names():
                         self._params[n].grad = self._gflat_view(g, n)
                     self._last_gflat = g
-            if self._sparse is not None:
+            if self._sparse is not None and not self._sparse_is_global:      # (a second call must not merge global lists again)
                 self._sparse = [self._merge_sparse(part) for part in self._sparse]
+                self._sparse_is_global = True
 
     def _merge_sparse(self, part):
         """all-gather one family's (rows, grads, count) at capacity and reduce the union: -> the same record, global"""
@@ -687,9 +697,15 @@ class RAT_m2(BaseModel):
         """nn.Embedding raises IndexError on an out-of-vocabulary id (embedding.py:158-178); the kernels clamp for memory safety
         and rat_check_ids counts the offenders on the device.  This reads the counters (ONE host synchronisation — called where
         the training loop synchronises anyway: end of an epoch / of an evaluation) and raises like the reference would."""
+        world = self._world_size()
         if self._id_errors is None:
-            return
-        bad_ids, bad_labels = [int(v) for v in self._id_errors.tolist()]
+            if world == 1:
+                return
+            self._id_errors = torch.zeros(2, dtype=torch.int32, device=self.device)
+        counts = self._id_errors
+        if world > 1:            # every rank raises together (a rank that raised alone would leave the others in the next collective)
+            counts = self._all_reduce_sum(counts.clone())
+        bad_ids, bad_labels = [int(v) for v in counts.tolist()]
         if bad_ids or bad_labels:
             self._id_errors.zero_()
             raise IndexError("index out of range in self: %d feature id(s) outside their embedding table and %d label id(s) "
@@ -880,7 +896,9 @@ class RAT_m2(BaseModel):
         if g_reg is not None and c["lam_net"] > 0:
             g_reg_dev = g_reg.reshape(1).to(torch.float32).contiguous()
             ops.l2_reg(self._flat[self._n_emb:], gflat[n_dense0:], c["lam_net"], None, lam_scale_dev=g_reg_dev, lib=lib)
-        if self._world_size() > 1 and n_dense0 < gflat.numel():
+        if self._world_size() > 1 and n_dense0 < gflat.numel() and self._gbuf is not None and gflat is self._gbuf[0]:
+            # (a fresh buffer means some p.grad was still held — gradient accumulation: autograd will ADD this buffer into p.grad,
+            # so nothing is reduced early; _exchange_gradients falls back to one all-reduce of the accumulated gradients)
             import torch.distributed as dist
             self._pending_reduce = (dist.all_reduce(gflat[n_dense0:], op=dist.ReduceOp.SUM, async_op=True), gflat)
         if saved["seeds"] is not None and c["emb_dropout"] > 0:
@@ -936,6 +954,7 @@ class RAT_m2(BaseModel):
                 ops.sparse_reduce_scalar(plan_lr, dlogit, B, L, out_rows=rows, out_vals=vals, lib=lib)
                 sparse.append((rows, vals, plan_lr.count.clone(), 1, rows_lr, self._n_feat))
         self._sparse = sparse if mode == "sparse" else None
+        self._sparse_is_global = False
 
 
 class RAT_m1(RAT_m2):
@@ -948,7 +967,18 @@ class RAT_m1(RAT_m2):
     def __init__(self, feature_map, model_id="RAT_m1", **kwargs):
         super().__init__(feature_map, model_id=model_id, **kwargs)
 
+    @staticmethod
+    def _no_ffn_dropout(dropout, which):
+        """The reference's RAT_m1 / RAT_m0 hand `dropout` to FeedForward as well (two nn.Dropout per layer: RAT_m1.py:157,159,202;
+        RAT_m0.py:156,158,201); only the Dropout behind the attention output projection exists on the HIP path, so a positive rate
+        would silently train with a different regularisation — refuse it (every shipped config uses 0)."""
+        if dropout and dropout > 0:
+            raise NotImplementedError("%s with dropout > 0: the reference also applies it inside FeedForward (after GELU and after the "
+                                      "second Linear); the HIP feed-forward kernels carry no dropout mask — only RAT_m2's attention-"
+                                      "output Dropout is implemented" % which)
+
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
+        self._no_ffn_dropout(dropout, "RAT_m1")
         self.intra_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:71
         self.cross_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:72
 
@@ -1121,6 +1151,7 @@ class RAT_m0(RAT_m1):
         super().__init__(feature_map, model_id=model_id, **kwargs)
 
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
+        self._no_ffn_dropout(dropout, "RAT_m0")
         self.encoder = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)               # RAT_m0.py:70
 
     def _build_encoder_descriptors(self):

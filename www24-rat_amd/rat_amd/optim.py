@@ -53,7 +53,13 @@ class FusedClipAdam(torch.optim.Optimizer):
         for rows, g, count, width, _total, base in sparse:   # lazy Adam on the touched table rows (rat_adam_rows)
             ops.adam_rows(model._flat[base:], m[base:], v[base:], rows, g, count, rows.numel(), width, norm_sq, max_norm or 0.0,
                           lr, b1, b2, eps, self._step, lib=model._lib)
+        model._sparse = None                             # consumed: a second step without a new backward must not re-apply them
         return norm_sq
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+        if hasattr(self._model, "_sparse"):
+            self._model._sparse = None
 
     def step(self, closure=None):
         loss = closure() if closure is not None else None
