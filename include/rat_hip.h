@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 3
+#define RAT_ABI_VERSION 4
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -346,6 +346,34 @@ int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, const float* l
 int rat_sumsq(const float* g, int64_t n, float* norm_sq_out, void* stream);
 int rat_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* norm_sq,
                   float max_norm, float lr, float beta1, float beta2, float eps, int step, void* stream);
+
+/* ---- ABI v4: the optimizer half of one training iteration in two sweeps, capturable in a hipGraph --------------------
+ * base_model.py:79-94 (add_regularization), :221 (clip_grad_norm_), :224 (Adam.step), :220 (zero_grad) — the four dense passes
+ * of rat_l2_reg + rat_sumsq + rat_clip_adam + the next step's zero-fill become:
+ * rat_sumsq_reg      : *norm_sq_out += sum_i (g[i] + lam(i) w[i])^2, lam(i) = lam_a for i < n_split ("embedding_layer" tensors,
+ *                      base_model.py:86) else lam_b (net_regularizer), both multiplied by *lam_scale_dev when given;
+ *                      *reg_out (nullable) += sum_i (lam(i)/2) w[i]^2 — the regulariser's VALUE with the unscaled lambdas.
+ *                      g is NOT modified: the regulariser gradient only ever exists in registers.
+ * rat_clip_adam_fused: coef as rat_clip_adam; g' = (g + lam w) coef; Adam with step size hyper_dev[0] = lr/(1-beta1^t) and
+ *                      hyper_dev[1] = 1/sqrt(1-beta2^t); zero_g: g[i] = 0 afterwards (optimizer.zero_grad() of the next step).
+ * rat_adam_tick      : the optimizer's clock on the device: *step_dev += 1, hyper_out[0..2] = {lr/(1-beta1^t), 1/sqrt(1-beta2^t),
+ *                      lr} from *lr_dev (double arithmetic like torch.optim.Adam's host code) — a replayed graph needs no new
+ *                      kernel arguments.
+ * rat_adam_rows_dev  : rat_adam_rows with the two step scalars read from hyper_dev. */
+int rat_adam_tick(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_out, void* stream);
+int rat_sumsq_reg(const float* g, const float* w, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                  const float* lam_scale_dev, float* norm_sq_out, float* reg_out, void* stream);
+int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                        const float* lam_scale_dev, const float* norm_sq, float max_norm, const float* hyper_dev,
+                        float beta1, float beta2, float eps, int zero_g, void* stream);
+/* rat_scatter_rows: dense_base[rows[s]*d + c] = grads[s*d + c] for s < *count_dev — the merged (unique rows, gradient rows)
+ * lists of all ranks written into the (zeroed) dense gradient block, so that the dense-semantics optimizer (regulariser on every
+ * row, base_model.py:79-94) runs unchanged after a row-list exchange. */
+int rat_scatter_rows(float* dense_base, const int32_t* rows, const float* grads, const int32_t* count_dev, int64_t max_rows,
+                     int d, void* stream);
+int rat_adam_rows_dev(float* w_base, float* m_base, float* v_base, const int32_t* rows, const float* grads,
+                      const int32_t* count_dev, int64_t max_rows, int d, const float* norm_sq, float max_norm,
+                      const float* hyper_dev, float beta1, float beta2, float eps, void* stream);
 
 /* Inverted dropout (nn.Dropout; RAT_m2.py:83,135 emb_dropout, deep.py:133-134 net_dropout): y = keep(seed,i) ? x/(1-p) : 0
  * with a counter-based mask, so the backward pass calls the same function on the gradient with the same seed.

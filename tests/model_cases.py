@@ -137,3 +137,49 @@ def check_checkpoint(name, gpu, tmpdir):
     again.load_weights(out)
     for k, v in again.state_dict().items():
         assert torch.equal(v.cpu(), ref[k]), k
+
+
+def check_train_step_api(name, gpu, steps=2, **model_kw):
+    """BaseModel.train_step — the fused iteration (no autograd node, regulariser folded into the two-sweep optimizer, on a GPU
+    replayed as a hipGraph from the third call of a batch shape on) — against the reference's golden training run: the loss of
+    every step and the weights after it (`train<k>/post/*` = after the reference's zero_grad / backward / clip / Adam.step).
+    steps > 2: the extra steps are compared with the literal sequence (train_step_reference_order) on a second model."""
+    case = gc.case_by_name(name)
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    model = build_model(case, gpu=gpu, seed=1, **model_kw)
+    load_weights(model, case)
+    batch = batch_of(case)
+    model.train()
+    noise = noise_tensors(model)
+    twin = None
+    if steps > 2:
+        twin = build_model(case, gpu=gpu, seed=1, **model_kw)
+        load_weights(twin, case)
+        twin.train()
+        twin.fused_step = False
+    for step in range(1, steps + 1):
+        before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        loss = float(model.train_step(batch))
+        if twin is not None:
+            ref_loss = float(twin.train_step(batch))
+        if step <= 2:
+            assert abs(loss - float(gold["train%d/loss" % step])) < 2e-6, (step, loss, float(gold["train%d/loss" % step]))
+        else:
+            assert abs(loss - ref_loss) < 5e-6, (step, loss, ref_loss)
+        for k, v in model.state_dict().items():
+            if k.startswith("query_proj"):
+                assert torch.equal(v, before[k])
+                continue
+            if k in noise:
+                assert float((v - before[k]).abs().max()) <= 1.0001e-3
+                continue
+            atol = 3e-6 if not k.endswith("running_mean") else 3e-6 + step * 0.1 * 1e-3 * 1.01
+            if step <= 2:
+                gc.check_summary(gold, "train%d/post/%s" % (step, k), v.detach().cpu().numpy(), rtol=3e-4, atol=atol)
+            else:
+                # Adam steps of rounding-level gradients are sign-like: bound the outliers instead of loosening everything
+                a, r = v.detach().cpu().double(), twin.state_dict()[k].detach().cpu().double()
+                bad = (a - r).abs() > atol * step + 3e-4 * r.abs()
+                assert float(bad.double().mean()) < 1e-3 and float((a - r).abs().max()) <= 2.1e-3 * step, (k, step)
+    assert all(p.grad is None for p in model.parameters()), "the fused step leaves no p.grad behind (zero_grad semantics)"
+    return model

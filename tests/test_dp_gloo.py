@@ -2,7 +2,9 @@
 half of a batch, must reproduce the single-process full-batch training step — with BatchNorm OFF (no cross-sample coupling
 at all) and with BatchNorm ON, where the SyncBN exchange (rat_bn_local_stats -> all-gather -> rat_bn_relu_fwd_sync, and the
 matching backward) makes the replicas normalise with the GLOBAL batch statistics, i.e. what the reference's single-device
-BatchNorm1d sees (deep.py:128-132)."""
+BatchNorm1d sees (deep.py:128-132).  The case has embedding_regularizer = 0.01: the table gradients travel as
+all-gathered (row ids, gradient rows) lists, the replica-identical lambda*W term is applied locally by the fused optimizer
+(base_model.py:79-94)."""
 import os
 import sys
 import tempfile
@@ -43,10 +45,18 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False):
     per = batch[0].shape[0] // world
     shard = tuple(t[rank * per:(rank + 1) * per] for t in batch)
     model.train()
+    merges, inner = [0], model._merge_sparse
+
+    def counting_merge(part):
+        merges[0] += 1
+        return inner(part)
+    model._merge_sparse = counting_merge
+    assert model._cfg["lam_emb"] > 0 and model._grad_mode == "atomic"
     for _ in range(2):
         loss = model.train_step(shard)
     buffers = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}
-    torch.save({"flat": model._flat.clone(), "loss": loss, "buffers": buffers}, os.path.join(out_dir, "rank%d.pt" % rank))
+    torch.save({"flat": model._flat.clone(), "loss": loss, "buffers": buffers, "merges": merges[0]},
+               os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,6 +92,9 @@ def test_two_rank_step_equals_full_batch_step(batch_norm):
         r0 = torch.load(os.path.join(out_dir, "rank0.pt"))
         r1 = torch.load(os.path.join(out_dir, "rank1.pt"))
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    # embedding_regularizer = 0.01 > 0 (dense semantics: lambda*W on every row) and yet the table gradients travelled as row lists
+    # (SURVEY.md §8e C2): 2 steps x 2 table families (feature tables, LR tables) merged on every rank, no dense table all-reduce
+    assert r0["merges"] == r1["merges"] == 4
     np.testing.assert_allclose(r0["flat"][keep].numpy(), ref[keep].numpy(), rtol=2e-4, atol=2e-6)
     assert bool(ref_buffers) == batch_norm
     for k, v in ref_buffers.items():                 # running statistics: the global batch's, identical on both ranks

@@ -101,23 +101,56 @@ def test_auc_and_logloss_match_the_oracle_within_1e4(fwd_setup):
     assert abs(mine["AUC"] - want["AUC"]) < 1e-4 and abs(mine["logloss"] - want["logloss"]) < 1e-4, (mine, want)
 
 
+def _relu_margins(orc, w, X, y, cfg):
+    """Per sample: the smallest |pre-activation| over every ReLU input of the DNN head, evaluated in float64 on the target sample's
+    field embeddings; with BatchNorm the ReLU input is the NORMALISED value under the training-mode statistics of exactly these
+    rows (deep.py:126-141)."""
+    w64 = {k: v.double() for k, v in w.items() if k.startswith(("dnn.", "embedding_layer.", "label_embedding_layer."))}
+    _, target_fields = orc.build_grid(X, y, w64, cfg)
+    a = target_fields.reshape(target_fields.shape[0], -1)
+    layers, out_pos = orc.dnn_layout(cfg)
+    margin = torch.full((a.shape[0],), float("inf"), dtype=torch.float64)
+    for lin, bn in layers:
+        z = a @ w64["dnn.dnn.%d.weight" % lin].t() + w64["dnn.dnn.%d.bias" % lin]
+        if bn is not None:
+            mu = z.mean(dim=0)
+            var = ((z - mu) ** 2).mean(dim=0)
+            z = (z - mu) / torch.sqrt(var + cfg.bn_eps) * w64["dnn.dnn.%d.weight" % bn] + w64["dnn.dnn.%d.bias" % bn]
+        margin = torch.minimum(margin, z.abs().min(dim=1).values)
+        a = torch.relu(z)
+    return margin
+
+
 def _relu_safe_rows(orc, w, X, y, cfg, margin=1e-5):
     """Rows whose DNN pre-activations all stay `margin` away from 0 (float64 evaluation of the head on the target sample's field
     embeddings).  A hidden unit within rounding distance of 0 lands on either side of the ReLU depending on the GEMM's summation
     order; ONE such flip changes that sample's whole DNN-branch gradient (every row of the first weight matrix, its table rows) by
     far more than any tolerance — an artefact of the comparison, not of either implementation (the reference itself is not
     reproducible there), so those few samples are left out of the slice."""
-    w64 = {k: v.double() for k, v in w.items() if k.startswith(("dnn.", "embedding_layer.", "label_embedding_layer."))}
-    _, target_fields = orc.build_grid(X, y, w64, cfg)
-    a = target_fields.reshape(target_fields.shape[0], -1)
-    layers, out_pos = orc.dnn_layout(cfg)
-    ok = torch.ones(a.shape[0], dtype=torch.bool)
-    for lin, bn in layers:
-        assert bn is None
-        z = a @ w64["dnn.dnn.%d.weight" % lin].t() + w64["dnn.dnn.%d.bias" % lin]
-        ok &= z.abs().min(dim=1).values > margin
-        a = torch.relu(z)
-    return ok
+    assert not cfg.batch_norm
+    return _relu_margins(orc, w, X, y, cfg) > margin
+
+
+def _relu_safe_slice_with_batchnorm(orc, w, X, y, cfg, nslice, margin=3e-6, tries=60):
+    """BatchNorm couples the rows of a slice (the ReLU inputs are normalised with the slice's own statistics), so dropping an unsafe
+    row moves every other row's pre-activations by O(1/n) — far more than the margin: "drop and re-check" is a fresh draw every
+    time, not a converging iteration.  This therefore SEARCHES: start with rows [0, nslice), and while some row has a normalised
+    pre-activation within `margin` of 0 (the fp32 GEMM + statistics error is ~1e-6 there) replace those rows by the next unused
+    ones.  About one row in 400 is replaced per round and a round succeeds with probability ~1/3.  -> (row indices, rounds, rows
+    replaced in total)"""
+    n_all = X.shape[0]
+    rows = torch.arange(nslice)
+    nxt, replaced = nslice, 0
+    for it in range(tries):
+        bad = (_relu_margins(orc, w, X[rows], y[rows], cfg) <= margin).nonzero().reshape(-1)
+        if bad.numel() == 0:
+            return rows, it, replaced
+        for b in bad.tolist():
+            assert nxt < n_all, "ran out of replacement rows"
+            rows[b] = nxt
+            nxt += 1
+            replaced += 1
+    raise AssertionError("no ReLU-safe slice found in %d rounds" % tries)
 
 
 def _chunks_per_group(n, T, S):
@@ -135,7 +168,10 @@ def test_gradients_of_a_full_size_slice_match_the_oracle(name, nslice):
     cfg = _oracle_cfg(orc, spec, fm, batch_norm=False, embedding_regularizer=0.0)
     w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     take = min(spec["batch"], nslice + nslice // 4)                          # head-room for the rows dropped below
-    keep = _relu_safe_rows(orc, w, batch[0][:take], batch[1][:take], cfg).nonzero().reshape(-1)[:nslice]
+    safe = _relu_safe_rows(orc, w, batch[0][:take], batch[1][:take], cfg)
+    keep = safe.nonzero().reshape(-1)[:nslice]
+    print("%s: %d of the first %d samples are ReLU-unsafe and left out; slice = %d samples"
+          % (name, int((~safe).sum()), take, keep.numel()))
     assert keep.numel() >= min(nslice, spec["batch"]) * 0.7, keep.numel()
     if nslice < spec["batch"]:
         intra, cross = _chunks_per_group(int(keep.numel()), T, S)
@@ -161,3 +197,52 @@ def test_gradients_of_a_full_size_slice_match_the_oracle(name, nslice):
     bad = {k: v for k, v in worst.items() if not v[0] < GRAD_RTOL}
     assert not bad, "gradients outside %g of their tensor's largest element: %s" % (GRAD_RTOL, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
     assert len(worst) >= 20
+
+
+@pytest.mark.parametrize("name,nslice", [("synthetic_F20_V1M_K10_d64_B4096", 384), ("tmall_like_F8_K30_d64_h32_B4096", 384)],
+                         ids=["synthetic_F20_V1M_K10_d64_B4096", "tmall_like_F8_K30_d64_h32_B4096"])
+def test_gradients_of_a_full_size_slice_match_the_oracle_with_batchnorm(name, nslice):
+    """The same comparison with `batch_norm=True` — the shipped setting (deep.py:128-132): training-mode statistics of the slice,
+    BatchNorm backward through 400-wide (Tmall: 200 / 80) layers, dgamma / dbeta, and the running-statistics update.  Every
+    parameter gradient is compared except the biases in front of a BatchNorm (true gradient 0, rounding noise on both sides)."""
+    from oracle import rat_m2_oracle as orc
+    import model_cases as mc
+    spec, fm, model, batch = _build(name, batch_norm=True)
+    T, S = spec["K"] + 1, spec["F"] + 1
+    cfg = _oracle_cfg(orc, spec, fm, batch_norm=True, embedding_regularizer=0.0)
+    w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    keep, rounds, replaced = _relu_safe_slice_with_batchnorm(orc, w, batch[0], batch[1], cfg, nslice)
+    print("%s (BatchNorm on): ReLU-safe slice of %d samples after %d round(s), %d sample(s) replaced" % (name, keep.numel(), rounds, replaced))
+    intra, cross = _chunks_per_group(int(keep.numel()), T, S)
+    assert intra >= 4 and cross >= 4
+    sub = tuple(t[keep] for t in batch)
+    model.train()
+    model.optimizer.zero_grad()
+    loss = model.get_total_loss(sub)
+    loss.backward()
+    torch.cuda.synchronize()
+    model.check_id_errors()
+    ref_loss, _ref_pred, ref_grads, bn_state = orc.loss_and_grads(w, sub[0], sub[1], cfg, training=True)
+    assert abs(float(loss) - float(ref_loss)) < 2e-6, (float(loss), float(ref_loss))
+    noise = mc.noise_tensors(model)
+    assert len(noise) == len(spec["dnn_hidden_units"])
+    worst = {}
+    for k, p in model.named_parameters():
+        if k.startswith("query_proj"):
+            assert p.grad is None
+            continue
+        if k in noise:
+            continue
+        got, ref = p.grad.detach().cpu().double(), ref_grads[k].double()
+        scale = float(ref.abs().max())
+        assert scale > 0, k
+        worst[k] = (float((got - ref).abs().max()) / scale, scale)
+    bad = {k: v for k, v in worst.items() if not v[0] < GRAD_RTOL}
+    assert not bad, "gradients outside %g of their tensor's largest element: %s" % (GRAD_RTOL, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
+    assert sum(1 for k in worst if k.startswith("dnn.")) >= 2 * len(spec["dnn_hidden_units"]) + 2      # W, gamma, beta per layer + out
+    sd = model.state_dict()
+    for k, v in bn_state.items():                                   # running statistics after this one training forward
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v)
+        else:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v.numpy(), rtol=3e-5, atol=3e-6, err_msg=k)

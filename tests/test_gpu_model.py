@@ -30,6 +30,37 @@ def test_two_training_steps(name):
     mc.check_training(name, gpu=0)
 
 
+@pytest.mark.parametrize("name", [c["name"] for c in gc.CASES])
+def test_train_step_api_matches_the_reference_run(name):
+    """train_step(): fused iteration; steps 1-2 eager against the golden run, steps 3-5 are hipGraph REPLAYS (captured at the third
+    call of the batch shape) against the literal zero_grad / backward / clip / step sequence on a twin model"""
+    model = mc.check_train_step_api(name, gpu=0, steps=5)
+    graphs = [e[1] for e in model._step_graphs.values() if e[1] is not None]
+    assert len(graphs) == 1 and model.optimizer._step == 5
+
+
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "northstar_shape"])
+@pytest.mark.parametrize("mode", ["sorted", "sparse"])
+def test_train_step_graph_with_sorted_and_sparse_table_gradients(name, mode):
+    """the rocPRIM sort / scan of the plan and the row optimizer inside the captured step"""
+    kw = dict(embedding_grad=mode)
+    if mode == "sparse":
+        kw["embedding_regularizer"] = 0.0
+    case = gc.case_by_name(name)
+    a = mc.build_model(case, gpu=0, seed=1, **kw)
+    b = mc.build_model(case, gpu=0, seed=1, **kw)
+    mc.load_weights(a, case), mc.load_weights(b, case)
+    b.use_graph = False
+    batch = mc.batch_of(case)
+    a.train(), b.train()
+    for step in range(5):
+        la, lb = float(a.train_step(batch)), float(b.train_step(batch))
+        assert abs(la - lb) < 1e-6, (step, la, lb)
+    assert any(e[1] is not None for e in a._step_graphs.values())
+    for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(va, vb), k            # same kernels, same order, deterministic table gradients: bit-identical
+
+
 @pytest.mark.parametrize("name", mc.CHECKPOINT_CASES)
 def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):
     """`.model` files written by the reference's own RAT_m2 / m0 / m1 / m3 classes (tests/golden/make_golden_checkpoints.py)"""

@@ -35,6 +35,12 @@ def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
 
+# BaseModel.train_step = the fused iteration (two-sweep optimizer with the regulariser folded in, no autograd node)
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "m1_tiny_seq"])
+def test_train_step_api_matches_the_reference_run(name):
+    mc.check_train_step_api(name, gpu=-1)
+
+
 # `.model` files written by the reference classes themselves: one on the emulator, all four on the GPU
 @pytest.mark.parametrize("name", ["tiny_seq_bn"])
 def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):

@@ -4,6 +4,7 @@
 // HBM-bound streaming kernels: 16-byte accesses, grid-stride, <= 2048 blocks.
 #include "rat_device.h"
 #include "../../include/rat_hip.h"
+#include <initializer_list>
 
 namespace {
 
@@ -87,6 +88,115 @@ clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __re
     }
 }
 
+// ---- one-sweep forms (ABI v4).  The regulariser gradient lambda*W is never written into g: the norm pass evaluates
+// sum (g + lambda w)^2 (and the regulariser's VALUE) from g and w, the Adam pass forms g + lambda w in registers and leaves
+// g = 0 behind for the next backward — 2 sweeps (g, w | g, w, m, v -> w, m, v, g) where l2_reg + sumsq + clip_adam + the
+// next step's zero-fill made 4 (w, g -> g | g | g, w, m, v -> w, m, v | -> g).  Elements [0, n_split) carry lam_a (the
+// "embedding_layer" tensors, base_model.py:86), the rest lam_b (net_regularizer).
+__device__ __forceinline__ float4 opt_ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ void opt_st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+
+__global__ void __launch_bounds__(OPT_THREADS)
+sumsq_reg_kernel(const float* __restrict__ g, const float* __restrict__ w, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                 const float* lam_scale_dev, float* norm_sq_out, float* reg_out, int vec) {
+    RAT_DYN_SMEM(smem);
+    float* scratch = reinterpret_cast<float*>(smem);
+    const float sc = lam_scale_dev != nullptr ? *lam_scale_dev : 1.0f;
+    const float la = lam_a * sc, lb = lam_b * sc;
+    float acc = 0.f, wa = 0.f, wb = 0.f;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    int64_t head = 0;
+    if (vec) {
+        const int64_t n4 = n >> 2, s4 = n_split >> 2;
+        for (int64_t i = tid; i < n4; i += nthr) {
+            const float4 gv = opt_ld4(g, i), wv = opt_ld4(w, i);
+            const bool a = i < s4;
+            const float l = a ? la : lb;
+            float t;
+            t = fmaf(l, wv.x, gv.x); acc = fmaf(t, t, acc);
+            t = fmaf(l, wv.y, gv.y); acc = fmaf(t, t, acc);
+            t = fmaf(l, wv.z, gv.z); acc = fmaf(t, t, acc);
+            t = fmaf(l, wv.w, gv.w); acc = fmaf(t, t, acc);
+            float q = wv.x * wv.x;
+            q = fmaf(wv.y, wv.y, q); q = fmaf(wv.z, wv.z, q); q = fmaf(wv.w, wv.w, q);
+            if (a) wa += q; else wb += q;
+        }
+        head = n4 << 2;
+    }
+    for (int64_t i = head + tid; i < n; i += nthr) {
+        const bool a = i < n_split;
+        const float wv = w[i], t = fmaf(a ? la : lb, wv, g[i]);
+        acc = fmaf(t, t, acc);
+        if (a) wa = fmaf(wv, wv, wa); else wb = fmaf(wv, wv, wb);
+    }
+    const float s = opt_block_sum(acc, scratch);
+    if (threadIdx.x == 0) atomicAdd(norm_sq_out, s);
+    if (reg_out != nullptr) {                                       // (lambda/2) ||W||^2 with the UNSCALED lambdas: the loss term
+        const float r = opt_block_sum(0.5f * lam_a * wa + 0.5f * lam_b * wb, scratch);
+        if (threadIdx.x == 0) atomicAdd(reg_out, r);
+    }
+}
+
+__device__ __forceinline__ float opt_adam1(float& w, float g, float& m, float& v, float lam, float coef, float step_size, float beta1,
+                                           float beta2, float eps, float inv_sqrt_bc2) {
+    const float gv = fmaf(lam, w, g) * coef;
+    m = beta1 * m + (1.0f - beta1) * gv;
+    v = beta2 * v + (1.0f - beta2) * gv * gv;
+    w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+    return 0.f;
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                       int64_t n_split, float lam_a, float lam_b, const float* lam_scale_dev, const float* norm_sq, float max_norm,
+                       const float* __restrict__ hyper, float beta1, float beta2, float eps, int zero_g, int vec) {
+    float coef = 1.0f;
+    if (norm_sq != nullptr) {
+        coef = max_norm / (sqrtf(*norm_sq) + 1e-6f);
+        coef = coef < 1.0f ? coef : 1.0f;
+    }
+    const float sc = lam_scale_dev != nullptr ? *lam_scale_dev : 1.0f;
+    const float la = lam_a * sc, lb = lam_b * sc;
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    int64_t head = 0;
+    if (vec) {
+        const int64_t n4 = n >> 2, s4 = n_split >> 2;
+        for (int64_t i = tid; i < n4; i += nthr) {
+            float4 wv = opt_ld4(w, i), mv = opt_ld4(m, i), vv = opt_ld4(v, i);
+            const float4 gv = opt_ld4(g, i);
+            const float l = i < s4 ? la : lb;
+            opt_adam1(wv.x, gv.x, mv.x, vv.x, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+            opt_adam1(wv.y, gv.y, mv.y, vv.y, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+            opt_adam1(wv.z, gv.z, mv.z, vv.z, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+            opt_adam1(wv.w, gv.w, mv.w, vv.w, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+            opt_st4(w, i, wv); opt_st4(m, i, mv); opt_st4(v, i, vv);
+            if (zero_g) opt_st4(g, i, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        head = n4 << 2;
+    }
+    for (int64_t i = head + tid; i < n; i += nthr) {
+        float wv = w[i], mv = m[i], vv = v[i];
+        opt_adam1(wv, g[i], mv, vv, i < n_split ? la : lb, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
+        w[i] = wv; m[i] = mv; v[i] = vv;
+        if (zero_g) g[i] = 0.f;
+    }
+}
+
+// the optimizer's clock on the device (so that a captured step — a hipGraph replay — needs no new kernel arguments):
+// *step += 1; hyper[0] = lr / (1 - beta1^step), hyper[1] = 1 / sqrt(1 - beta2^step), hyper[2] = lr   (torch.optim.Adam's
+// bias corrections, evaluated in double like the host does)
+__global__ void adam_tick_kernel(int32_t* step, const float* lr, float beta1, float beta2, float* hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int s = *step + 1;
+    *step = s;
+    const double bc1 = 1.0 - pow((double)beta1, (double)s);
+    const double bc2 = 1.0 - pow((double)beta2, (double)s);
+    hyper[0] = (float)((double)*lr / bc1);
+    hyper[1] = (float)(1.0 / sqrt(bc2));
+    hyper[2] = *lr;
+}
+
 int opt_blocks(int64_t n) {
     int64_t b = (n + OPT_THREADS * 4 - 1) / (OPT_THREADS * 4);
     if (b < 1) b = 1;
@@ -117,6 +227,37 @@ extern "C" int rat_clip_adam(float* w, const float* g, float* m, float* v, int64
     RAT_LAUNCH(clip_adam_kernel, opt_blocks(n), OPT_THREADS, 0, stream, w, g, m, v, n, norm_sq, max_norm,
                (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
     return rat_check_launch("rat_clip_adam");
+}
+
+static bool opt_vec_ok(std::initializer_list<const void*> ps, int64_t n_split) {
+    for (const void* p : ps)
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    return (n_split & 3) == 0;
+}
+
+extern "C" int rat_adam_tick(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_out, void* stream) {
+    RAT_REQUIRE(step_dev && lr_dev && hyper_out, "bad args");
+    RAT_LAUNCH(adam_tick_kernel, 1, 64, 0, stream, step_dev, lr_dev, beta1, beta2, hyper_out);
+    return rat_check_launch("rat_adam_tick");
+}
+
+extern "C" int rat_sumsq_reg(const float* g, const float* w, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                             const float* lam_scale_dev, float* norm_sq_out, float* reg_out, void* stream) {
+    RAT_REQUIRE(n > 0 && g && w && norm_sq_out && n_split >= 0 && n_split <= n, "bad args");
+    const int vec = opt_vec_ok({g, w}, n_split) ? 1 : 0;
+    RAT_LAUNCH(sumsq_reg_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, g, w, n, n_split, lam_a, lam_b, lam_scale_dev,
+               norm_sq_out, reg_out, vec);
+    return rat_check_launch("rat_sumsq_reg");
+}
+
+extern "C" int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                                   const float* lam_scale_dev, const float* norm_sq, float max_norm, const float* hyper_dev,
+                                   float beta1, float beta2, float eps, int zero_g, void* stream) {
+    RAT_REQUIRE(n > 0 && w && g && m && v && hyper_dev && n_split >= 0 && n_split <= n, "bad args");
+    const int vec = opt_vec_ok({w, g, m, v}, n_split) ? 1 : 0;
+    RAT_LAUNCH(clip_adam_fused_kernel, opt_blocks(n), OPT_THREADS, 0, stream, w, g, m, v, n, n_split, lam_a, lam_b, lam_scale_dev,
+               norm_sq, max_norm, hyper_dev, beta1, beta2, eps, zero_g, vec);
+    return rat_check_launch("rat_clip_adam_fused");
 }
 
 // ---- inverted dropout with a counter-based generator (nn.Dropout of RAT_m2.py:83,135 `emb_dropout` and deep.py:133-134

@@ -334,6 +334,41 @@ adam_rows_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict
     }
 }
 
+// the same with the step size and bias correction read from the device (rat_adam_tick's hyper[0..1]: capturable in a hipGraph)
+__global__ void __launch_bounds__(SP_THREADS)
+adam_rows_dev_kernel(float* __restrict__ w, float* __restrict__ m, float* __restrict__ v, const int32_t* __restrict__ rows,
+                     const float* __restrict__ g, const int32_t* __restrict__ count, int d, const float* norm_sq, float max_norm,
+                     const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    float coef = 1.0f;
+    if (norm_sq != nullptr) {
+        coef = max_norm / (sqrtf(*norm_sq) + 1e-6f);
+        coef = coef < 1.0f ? coef : 1.0f;
+    }
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1];
+    const int64_t n = (int64_t)(*count) * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / d;
+        const int64_t o = (int64_t)rows[s] * d + (i - s * d);
+        const float gv = g[i] * coef;
+        const float mv = beta1 * m[o] + (1.0f - beta1) * gv;
+        const float vv = beta2 * v[o] + (1.0f - beta2) * gv * gv;
+        m[o] = mv;
+        v[o] = vv;
+        w[o] -= step_size * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+    }
+}
+
+// (unique rows, gradient rows) -> the dense gradient block: plain stores (rows are unique; the block holds the caller's zeros)
+__global__ void __launch_bounds__(SP_THREADS)
+scatter_rows_kernel(float* __restrict__ dense, const int32_t* __restrict__ rows, const float* __restrict__ g,
+                    const int32_t* __restrict__ count, int d) {
+    const int64_t n = (int64_t)(*count) * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / d;
+        dense[(int64_t)rows[s] * d + (i - s * d)] = g[i];
+    }
+}
+
 }  // namespace
 
 extern "C" size_t rat_sparse_workspace(int64_t n) {
@@ -427,4 +462,24 @@ extern "C" int rat_adam_rows(float* w_base, float* m_base, float* v_base, const 
     RAT_LAUNCH(adam_rows_kernel, (unsigned)blocks, SP_THREADS, 0, stream, w_base, m_base, v_base, rows, grads, count_dev, d, norm_sq,
                max_norm, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
     return rat_check_launch("rat_adam_rows");
+}
+
+extern "C" int rat_adam_rows_dev(float* w_base, float* m_base, float* v_base, const int32_t* rows, const float* grads,
+                                 const int32_t* count_dev, int64_t max_rows, int d, const float* norm_sq, float max_norm,
+                                 const float* hyper_dev, float beta1, float beta2, float eps, void* stream) {
+    RAT_REQUIRE(w_base && m_base && v_base && rows && grads && count_dev && hyper_dev && d > 0 && max_rows > 0, "bad args");
+    int64_t blocks = (max_rows * d + SP_THREADS * 4 - 1) / (SP_THREADS * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    RAT_LAUNCH(adam_rows_dev_kernel, (unsigned)blocks, SP_THREADS, 0, stream, w_base, m_base, v_base, rows, grads, count_dev, d, norm_sq,
+               max_norm, hyper_dev, beta1, beta2, eps);
+    return rat_check_launch("rat_adam_rows_dev");
+}
+
+extern "C" int rat_scatter_rows(float* dense_base, const int32_t* rows, const float* grads, const int32_t* count_dev, int64_t max_rows,
+                                int d, void* stream) {
+    RAT_REQUIRE(dense_base && rows && grads && count_dev && d > 0 && max_rows > 0, "bad args");
+    int64_t blocks = (max_rows * d + SP_THREADS * 4 - 1) / (SP_THREADS * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    RAT_LAUNCH(scatter_rows_kernel, (unsigned)blocks, SP_THREADS, 0, stream, dense_base, rows, grads, count_dev, d);
+    return rat_check_launch("rat_scatter_rows");
 }

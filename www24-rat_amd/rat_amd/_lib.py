@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RatField(Structure):
@@ -103,6 +103,12 @@ _SIGNATURES = {
     "rat_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "rat_dropout": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P]),
     "rat_clip_adam": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    "rat_adam_tick": (c_int, [_P, _P, c_float, c_float, _P, _P]),
+    "rat_sumsq_reg": (c_int, [_P, _P, c_int64, c_int64, c_float, c_float, _P, _P, _P, _P]),
+    "rat_clip_adam_fused": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, c_float, _P, _P, c_float, _P, c_float, c_float, c_float,
+                                    c_int, _P]),
+    "rat_scatter_rows": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "rat_adam_rows_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, _P, c_float, c_float, c_float, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

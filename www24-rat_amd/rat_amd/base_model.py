@@ -251,7 +251,17 @@ class BaseModel(nn.Module):
 
     def train_step(self, batch_data):
         """One iteration of base_model.py:220-226: zero_grad -> loss -> backward -> clip(10.) -> Adam.
-        Returns the (device) loss tensor; no host synchronisation."""
+        Returns the (device) loss tensor; no host synchronisation.  The concrete model may run the whole iteration as one fused
+        pass over its flat buffers (RAT_m2._fused_train_step: no autograd node, regulariser folded into a two-sweep optimizer,
+        optionally replayed as a captured hipGraph); `train_step_reference_order` is the literal sequence."""
+        fused = getattr(self, "_fused_train_step", None)
+        if fused is not None and self.fused_step:
+            return fused(batch_data)
+        return self.train_step_reference_order(batch_data)
+
+    fused_step = True          # set False to make train_step run the literal zero_grad / backward / clip / step sequence
+
+    def train_step_reference_order(self, batch_data):
         self.optimizer.zero_grad()
         loss = self.get_total_loss(batch_data)
         loss.backward()

@@ -217,6 +217,8 @@ class RAT_m2(BaseModel):
         self._lib = None
         self._last_gflat = None
         self._gbuf = None              # persistent flat gradient buffer + the gradient field tables that point into it
+        self._gbuf_clean = False       # True: the buffer is known to hold zeros (left so by the two-sweep optimizer)
+        self._tape = None              # a StepGraph that is recording this model's training step (graph.py)
         self._sync_bn = bool(kwargs.get("sync_batch_norm", True))     # under data parallelism: BatchNorm over the GLOBAL batch
         # how the embedding-table gradients are produced:
         #   "atomic" fp32 atomics into dense tables (fastest, not run-to-run reproducible); "sorted" the same dense tables from a
@@ -229,6 +231,7 @@ class RAT_m2(BaseModel):
             raise ValueError("embedding_grad=%r" % self._embedding_grad)
         self._sparse = None
         self._sparse_is_global = False   # the row lists in _sparse were already merged over the ranks
+        self._table_lists = None         # dense modes under data parallelism: this backward's table gradients as row lists
         self._pending_reduce = None      # (work handle, gradient buffer) of the dense-net all-reduce started inside backward
         self._validate_ids = bool(kwargs.get("validate_ids", True))
         self._id_errors = None
@@ -537,6 +540,7 @@ class RAT_m2(BaseModel):
             raise NotImplementedError("embedding_grad='sparse' touches only the rows of the batch: the reference's dense L2 term "
                                       "(lambda*W on EVERY row, base_model.py:79-94) cannot be carried — use embedding_regularizer=0")
         self._grad_mode = mode
+        self._lists_possible = row_aligned      # (sort + segmented reduction needs table rows on 16-byte boundaries)
         self._n_sparse = self._n_tab if mode == "sparse" else 0
         self._gbuf = None
         self._build_descriptors()
@@ -596,12 +600,15 @@ class RAT_m2(BaseModel):
         size = self._flat.numel() - self._n_sparse
         if self._gbuf is not None and not held and self._gbuf[0].numel() == size and self._gbuf[0].device == dev:
             g, gft, lft = self._gbuf
-            g.zero_()
+            if not self._gbuf_clean:           # (the two-sweep optimizer leaves g = 0 behind: rat_clip_adam_fused, zero_g)
+                g.zero_()
+            self._gbuf_clean = False
             return g, gft, lft
         g = torch.zeros(size, dtype=torch.float32, device=dev)
         gft, lft = tables(g) if self._n_sparse == 0 else (None, None)
         if not held:
             self._gbuf = (g, gft, lft)
+            self._gbuf_clean = False
         return g, gft, lft
 
     def _settle_pending_reduce(self):
@@ -609,7 +616,7 @@ class RAT_m2(BaseModel):
         all-reduce it started in flight: wait for it before its buffer is zeroed, replaced or accumulated into."""
         pending, self._pending_reduce = self._pending_reduce, None
         if pending is not None:
-            pending[0].wait()
+            pending[0][0].wait()
 
     def _gflat_view(self, gflat, name):
         """view of parameter `name`'s gradient inside the flat gradient buffer (which, in sparse mode, starts BEHIND the tables)"""
@@ -636,34 +643,47 @@ class RAT_m2(BaseModel):
                 self._gflat_view(g, n).copy_(self._params[n].grad)
         return g
 
-    def _exchange_gradients(self):
-        """Data parallelism: ONE all-reduce (RCCL over xGMI) of the flat gradient bucket; in sparse mode the bucket holds only the
-        dense net (+ label table) and the table gradients travel as all-gathered (row ids, gradient rows) lists that every rank
-        merges with the same deterministic plan + segmented reduction."""
-        import torch.distributed as dist
-        if self._world_size() > 1:
+    def _exchange_gradients(self, g=None):
+        """Data parallelism.  C1: all-reduce (RCCL over xGMI) of the dense-net slice of the flat gradient bucket —
+        started inside backward, only waited for here.  Tables: in sparse mode, and in the dense modes whenever the fused training
+        step asked backward for row lists (`_table_lists`), C2: all-gather of (row ids, gradient rows, count) + the same
+        deterministic plan + segmented reduction on every rank (28.8 MB per rank at the north-star strong-scaling shape instead of
+        a 257 MB all-reduce; the regulariser's lambda*W is replica-identical and never travels); otherwise one dense all-reduce.
+        `g`: the flat gradient buffer when the caller holds it (the fused step; p.grad is not populated there)."""
+        if self._world_size() == 1:
+            return
+        explicit = g is not None
+        if g is None:
             g = self._gather_flat_grad()
-            pending, self._pending_reduce = self._pending_reduce, None
-            if g is not None:
-                if pending is not None and pending[1] is g:          # the dense-net part is already on its way (started in backward)
-                    n0 = self._n_emb - self._n_sparse
-                    if n0 > 0:
-                        dist.all_reduce(g[:n0], op=dist.ReduceOp.SUM)
-                    pending[0].wait()
-                else:
-                    if pending is not None:
-                        pending[0].wait()
-                        raise RuntimeError("gradient buffers were replaced between backward and the exchange: the in-flight all-reduce "
-                                           "of the dense-net gradients would be summed twice (gradient accumulation under data "
-                                           "parallelism is not supported on this path)")
-                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
-                if g is not self._last_gflat:
-                    for n in self._dense_names():
-                        self._params[n].grad = self._gflat_view(g, n)
-                    self._last_gflat = g
-            if self._sparse is not None and not self._sparse_is_global:      # (a second call must not merge global lists again)
-                self._sparse = [self._merge_sparse(part) for part in self._sparse]
-                self._sparse_is_global = True
+        pending, self._pending_reduce = self._pending_reduce, None
+        lists, self._table_lists = self._table_lists, None
+        if g is not None:
+            n0 = self._n_emb - self._n_sparse                      # [0, n0): "embedding_layer" tensors with a dense gradient
+            if pending is not None and pending[1] is g:            # the dense-net part is already on its way
+                if lists is not None:
+                    for part in lists:
+                        rows, grads, count, width, _total, base = self._merge_sparse(part)
+                        ops.scatter_rows(g[base:], rows, grads, count, width, lib=self._lib)     # into the zeroed table block
+                    if n0 > self._n_tab:
+                        self._all_reduce_sum(g[self._n_tab:n0])    # the label table (3 x d floats)
+                elif n0 > 0:
+                    self._all_reduce_sum(g[:n0])
+                self._collective(lambda: pending[0][0].wait())
+            else:
+                if pending is not None:
+                    pending[0][0].wait()
+                    raise RuntimeError("gradient buffers were replaced between backward and the exchange: the in-flight all-reduce "
+                                       "of the dense-net gradients would be summed twice (gradient accumulation under data "
+                                       "parallelism is not supported on this path)")
+                assert lists is None
+                self._all_reduce_sum(g)
+            if not explicit and g is not self._last_gflat:
+                for n in self._dense_names():
+                    self._params[n].grad = self._gflat_view(g, n)
+                self._last_gflat = g
+        if self._sparse is not None and not self._sparse_is_global:      # (a second call must not merge global lists again)
+            self._sparse = [self._merge_sparse(part) for part in self._sparse]
+            self._sparse_is_global = True
 
     def _merge_sparse(self, part):
         """all-gather one family's (rows, grads, count) at capacity and reduce the union: -> the same record, global"""
@@ -681,16 +701,26 @@ class RAT_m2(BaseModel):
         ops.sparse_reduce_rows(plan, all_grads, cap, world, width, out_rows, out_grads, lib=lib)
         return (out_rows, out_grads, plan.count.clone(), width, total_rows, base_off)
 
+    def _collective(self, fn):
+        """Every communication call of the step goes through here as a closure over tensors that already exist.  Normally it just
+        runs; while the step is being captured into hipGraphs (graph.StepGraph) the capture is suspended around it and the closure is
+        kept, to be run again between the graph segments of every replay."""
+        return self._tape.between_segments(fn) if self._tape is not None else fn()
+
     def _all_gather_flat(self, t):
         """[n] -> [world * n], ranks in order (RCCL all-gather on the GPU, gloo in the CPU tests)."""
         import torch.distributed as dist
-        out = torch.empty(self._world_size() * t.numel(), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t) if t.is_cuda else dist.all_gather(list(out.view(self._world_size(), -1).unbind(0)), t)
+        world = self._world_size()
+        out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+        if t.is_cuda:
+            self._collective(lambda: dist.all_gather_into_tensor(out, t))
+        else:
+            self._collective(lambda: dist.all_gather(list(out.view(world, -1).unbind(0)), t))
         return out
 
     def _all_reduce_sum(self, t):
         import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        self._collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
         return t
 
     def check_id_errors(self):
@@ -740,6 +770,74 @@ class RAT_m2(BaseModel):
         else:
             y_pred, _, _, _ = self._run_forward(batch, save=False, with_reg=False)
         return {"y_true": batch[2].unsqueeze(-1), "y_pred": y_pred}
+
+    # ------------------------------------------------------------------------------ the fused training iteration
+    def _fused_train_step(self, inputs):
+        """BaseModel.train_one_epoch's iteration (base_model.py:220-226) as ONE pass over the flat buffers, no autograd node:
+        forward -> BCE -> backward (gradients WITHOUT the regulariser term) -> [exchange] -> rat_sumsq_reg (clip norm of g + lambda W
+        and the regulariser's value in one sweep) -> rat_clip_adam_fused (Adam on g + lambda W, leaves g = 0: the next zero_grad).
+        Same arithmetic per element as the reference's sequence; p.grad is not populated (it would be None after zero_grad anyway).
+        On a GPU the iteration is captured into a hipGraph after `graph_warmup` eager steps of the same batch shape and replayed
+        from then on (graph.StepGraph; `use_graph = False` or a positive dropout rate keep it eager)."""
+        batch = self._prepare_batch(inputs)
+        self.batch_size = batch[0].shape[0]
+        if not self.training:
+            raise RuntimeError("train_step() on a model in eval mode")
+        if any(p.grad is not None for p in self._params.values()):       # optimizer.zero_grad() of the reference's iteration
+            self.optimizer.zero_grad()
+            self._gbuf_clean = False
+        self._settle_pending_reduce()
+        graph = self._step_graph_for(batch)
+        if graph is not None:
+            return graph.run(batch)
+        with torch.no_grad():
+            self.optimizer.prepare_step()
+            return self._fused_iteration(batch, count=True)
+
+    def _fused_iteration(self, batch, count):
+        """the launches of one fused iteration on `batch` = (idx, label ids, y_true) device tensors -> total loss (device scalar)"""
+        world = self._world_size()
+        inv = self._inv_world()
+        _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
+        self._run_backward(saved, inv, None, table_lists=world > 1)
+        g = self._last_gflat
+        self._exchange_gradients(g)
+        reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count)
+        self._gbuf_clean = self._gbuf is not None and g is self._gbuf[0]
+        return (loss + reg[0]) * inv[0]
+
+    def _inv_world(self):
+        world = self._world_size()
+        t = getattr(self, "_inv_world_t", None)
+        if t is None or t.device != self._flat.device or self._inv_world_n != world:
+            t = torch.full((1,), 1.0 / world, dtype=torch.float32, device=self._flat.device)
+            self._inv_world_t, self._inv_world_n = t, world
+        return t
+
+    use_graph = True           # capture the fused iteration into a hipGraph (CUDA devices only)
+    graph_warmup = 2           # eager fused steps of a batch shape before it is captured
+    graph_shapes = 2           # at most this many batch shapes get a graph (the full batch and an epoch's tail batch)
+
+    def _step_graph_for(self, batch):
+        if not (self.use_graph and batch[0].is_cuda):
+            return None
+        c = self._cfg
+        if c["attn_dropout"] > 0 or c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers):
+            return None                                    # dropout seeds are drawn on the host per step: not replayable
+        graphs = self.__dict__.setdefault("_step_graphs", {})
+        key = (tuple(batch[0].shape), self.arith, self._world_size())
+        entry = graphs.get(key)
+        if entry is None:
+            if len(graphs) >= self.graph_shapes:
+                return None
+            entry = graphs[key] = [0, None]
+        if entry[1] is None:
+            entry[0] += 1
+            if entry[0] <= self.graph_warmup:
+                return None                                # eager: fills every lazily built cache (workspaces, plans, tables)
+            from .graph import StepGraph
+            entry[1] = StepGraph(self, batch)
+        return entry[1]
 
     def _loss_terms(self, inputs, with_reg):
         batch = self._prepare_batch(inputs)
@@ -835,9 +933,12 @@ class RAT_m2(BaseModel):
             self._ws[key] = ws
         return ws
 
-    def _run_backward(self, saved, g_loss, g_reg):
+    def _run_backward(self, saved, g_loss, g_reg, table_lists=False):
         """g_loss / g_reg: DEVICE scalars (autograd's incoming gradients of the loss / regulariser outputs; g_reg None = no
-        regulariser term) — multiplied in by rat_logit_bwd / rat_l2_reg, never read on the host."""
+        regulariser term) — multiplied in by rat_logit_bwd / rat_l2_reg, never read on the host.
+        table_lists (dense modes only): leave the table block of the gradient buffer untouched (zero) and keep this backward's
+        table gradients as (unique rows, gradient rows, count) lists in `_table_lists` — what _exchange_gradients ships under data
+        parallelism instead of the dense table block."""
         c, lib = self._cfg, self._lib
         idx, labels, y_true = saved["batch"]
         B, T, L, S = saved["dims"]
@@ -845,6 +946,9 @@ class RAT_m2(BaseModel):
         dev = self._flat.device
         gflat, gftab, lr_gftab = self._grad_buffer()
         mode = self._grad_mode
+        as_lists = bool(table_lists) and mode != "sparse" and self._lists_possible
+        if as_lists:
+            mode = "lists"
         if mode != "atomic":
             lr_gftab = None                                     # the LR rows come from the sorted reduction below, not from atomics
             if self._col2field is None or self._col2field.numel() != L:
@@ -900,7 +1004,12 @@ class RAT_m2(BaseModel):
             # (a fresh buffer means some p.grad was still held — gradient accumulation: autograd will ADD this buffer into p.grad,
             # so nothing is reduced early; _exchange_gradients falls back to one all-reduce of the accumulated gradients)
             import torch.distributed as dist
-            self._pending_reduce = (dist.all_reduce(gflat[n_dense0:], op=dist.ReduceOp.SUM, async_op=True), gflat)
+            handle, part = [None], gflat[n_dense0:]
+
+            def start():
+                handle[0] = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True)
+            self._collective(start)
+            self._pending_reduce = (handle, gflat)
         if saved["seeds"] is not None and c["emb_dropout"] > 0:
             dx = ops.dropout(dx, c["emb_dropout"], saved["seeds"][0], out=dx, lib=lib)
         # ---- embedding tables
@@ -910,6 +1019,8 @@ class RAT_m2(BaseModel):
         else:
             self._table_gradients_sorted(dx, dflat, dlogit, idx, labels, gflat, (B, T, L, S), mode)
             ops.label_grad(dx, labels, G("label_embedding_layer.weight"), B * T, S, d, lib=lib)
+            if as_lists:
+                self._table_lists, self._sparse = self._sparse, None
         # ---- L2 regulariser gradient (base_model.py:79-94): lambda * W on the "embedding_layer" tensors
         if g_reg is not None:
             g_reg = g_reg.reshape(1).to(torch.float32).contiguous()
@@ -953,7 +1064,7 @@ class RAT_m2(BaseModel):
                 vals = torch.empty((cap, 1), dtype=torch.float32, device=dev)
                 ops.sparse_reduce_scalar(plan_lr, dlogit, B, L, out_rows=rows, out_vals=vals, lib=lib)
                 sparse.append((rows, vals, plan_lr.count.clone(), 1, rows_lr, self._n_feat))
-        self._sparse = sparse if mode == "sparse" else None
+        self._sparse = sparse if mode in ("sparse", "lists") else None
         self._sparse_is_global = False
 
 

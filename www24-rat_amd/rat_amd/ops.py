@@ -554,3 +554,38 @@ def dropout(x, p, seed, out=None, lib=None):
     y = out if out is not None else torch.empty_like(x)
     lib.call("rat_dropout", _p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(x))
     return y
+
+
+# ----------------------------------------------------------------------------- ABI v4: two-sweep optimizer, device-side clock
+def adam_tick(step_dev, lr_dev, beta1, beta2, hyper, lib=None):
+    """*step_dev += 1; hyper[0..2] = lr/(1-beta1^t), 1/sqrt(1-beta2^t), lr"""
+    lib = lib or get_lib()
+    _chk(step_dev, torch.int32, "step_dev"), _chk(lr_dev, name="lr_dev"), _chk(hyper, name="hyper")
+    lib.call("rat_adam_tick", _p(step_dev), _p(lr_dev), float(beta1), float(beta2), _p(hyper), _stream(hyper))
+
+
+def sumsq_reg(g, w, n_split, lam_a, lam_b, norm_sq_out, reg_out=None, lam_scale_dev=None, lib=None):
+    lib = lib or get_lib()
+    assert g.numel() == w.numel()
+    lib.call("rat_sumsq_reg", _p(g), _p(w), g.numel(), int(n_split), float(lam_a), float(lam_b), _p(lam_scale_dev), _p(norm_sq_out),
+             _p(reg_out), _stream(g))
+
+
+def clip_adam_fused(w, g, m, v, n_split, lam_a, lam_b, norm_sq, max_norm, hyper, beta1, beta2, eps, zero_g=True, lam_scale_dev=None,
+                    lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_clip_adam_fused", _p(w), _p(g), _p(m), _p(v), w.numel(), int(n_split), float(lam_a), float(lam_b), _p(lam_scale_dev),
+             _p(norm_sq), float(max_norm), _p(hyper), float(beta1), float(beta2), float(eps), 1 if zero_g else 0, _stream(w))
+
+
+def adam_rows_dev(w_base, m_base, v_base, rows, grads, count, max_rows, d, norm_sq, max_norm, hyper, beta1, beta2, eps, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_adam_rows_dev", _p(w_base), _p(m_base), _p(v_base), _p(rows), _p(grads), _p(count), int(max_rows), d, _p(norm_sq),
+             float(max_norm), _p(hyper), float(beta1), float(beta2), float(eps), _stream(grads))
+
+
+def scatter_rows(dense_base, rows, grads, count, d, lib=None):
+    """merged (unique rows, gradient rows) lists -> the zeroed dense gradient block"""
+    lib = lib or get_lib()
+    _chk(rows, torch.int32, "rows"), _chk(count, torch.int32, "count")
+    lib.call("rat_scatter_rows", _p(dense_base), _p(rows), _p(grads), _p(count), rows.numel(), int(d), _stream(grads))

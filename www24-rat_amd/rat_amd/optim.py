@@ -39,6 +39,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
         self._step += 1
+        self._clock_step = None
         ns = getattr(model, "_n_sparse", 0)
         norm_sq = None
         if max_norm is not None:                         # ONE global norm over dense gradients and sparse row lists alike
@@ -61,6 +62,66 @@ class FusedClipAdam(torch.optim.Optimizer):
         if hasattr(self._model, "_sparse"):
             self._model._sparse = None
 
+    # ---- the two-sweep form used by BaseModel.train_step (ABI v4) -------------------------------------------------------------
+    def _clock(self):
+        """device-side step counter, learning rate and the derived Adam scalars (rat_adam_tick): what lets a captured step be
+        replayed without new kernel arguments.  Host mirrors: self._step, param_groups[0]["lr"]."""
+        flat = self._model._flat
+        if getattr(self, "_step_dev", None) is None or self._step_dev.device != flat.device:
+            self._step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
+            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=flat.device)
+            self._reg_value = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._clock_step, self._clock_lr = None, None
+        return self._step_dev, self._lr_dev, self._hyper
+
+    def prepare_step(self):
+        """host -> device synchronisation of the clock; cheap, and a no-op unless the learning rate changed (lr_decay) or the step
+        count was set from outside (load_state_dict).  Never called while a graph is being captured."""
+        step_dev, lr_dev, _ = self._clock()
+        self._buffers()
+        lr = float(self.param_groups[0]["lr"])
+        if self._clock_lr != lr:
+            lr_dev.fill_(lr)
+            self._clock_lr = lr
+        if self._clock_step != self._step:
+            step_dev.fill_(self._step)
+            self._clock_step = self._step
+
+    @torch.no_grad()
+    def fused_step(self, grad, max_norm, count=True):
+        """clip_grad_norm_(max_norm) + Adam + zero_grad over the flat buffers with the regulariser folded in (rat_sumsq_reg,
+        rat_clip_adam_fused): `grad` is the flat gradient WITHOUT the lambda*W terms; afterwards it holds zeros.  Returns the
+        regulariser's value (device scalar, (lambda/2)||W||^2 over the tensors the reference regularises).  Call prepare_step()
+        first.  count=False: the launches are being recorded, not executed (graph capture) — the host step mirror stays."""
+        model = self._model
+        c = model._cfg
+        sparse = getattr(model, "_sparse", None) or []
+        m, v = self._buffers()
+        step_dev, lr_dev, hyper = self._clock()
+        group = self.param_groups[0]
+        (b1, b2), eps = group["betas"], group["eps"]
+        ns = getattr(model, "_n_sparse", 0)
+        n_split = model._n_emb - ns
+        lib = model._lib
+        ops.adam_tick(step_dev, lr_dev, b1, b2, hyper, lib=lib)
+        if count:
+            self._step += 1
+            self._clock_step = self._step
+        self._norm_sq.zero_()
+        self._reg_value.zero_()
+        ops.sumsq_reg(grad, model._flat[ns:], n_split, c["lam_emb"], c["lam_net"], self._norm_sq, reg_out=self._reg_value, lib=lib)
+        for rows, g, cnt, width, _total, _base in sparse:
+            ops.sumsq_rows(g, cnt, rows.numel(), width, self._norm_sq, lib=lib)
+        norm_sq = self._norm_sq if max_norm is not None else None
+        ops.clip_adam_fused(model._flat[ns:], grad, m[ns:], v[ns:], n_split, c["lam_emb"], c["lam_net"], norm_sq, max_norm or 0.0,
+                            hyper, b1, b2, eps, zero_g=True, lib=lib)
+        for rows, g, cnt, width, _total, base in sparse:
+            ops.adam_rows_dev(model._flat[base:], m[base:], v[base:], rows, g, cnt, rows.numel(), width, norm_sq, max_norm or 0.0,
+                              hyper, b1, b2, eps, lib=lib)
+        model._sparse = None
+        return self._reg_value
+
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self.clip_and_step(None)
@@ -79,6 +140,7 @@ class FusedClipAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         state_dict = dict(state_dict)
         self._step = state_dict.pop("rat_step", 0)
+        self._clock_step = None                          # the device clock is re-synchronised by the next prepare_step()
         m, v = state_dict.pop("rat_m", None), state_dict.pop("rat_v", None)
         super().load_state_dict(state_dict)
         if m is not None:
