@@ -72,6 +72,9 @@ def parse(argv=None):
                     help="how table gradients are produced (default: the workload's / the model's `auto` rule)")
     ap.add_argument("--step-times", action="store_true", help="print the host-side issue time of every timed step to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager fused step instead of hipGraph replays")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements of the default N = 1 line (exact-fp32 run, per-rank B/8 shape, 100 M-row gather)")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline (default 0 = the workload's own batch)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline (after 1 warm-up step)")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -283,6 +286,46 @@ def cpu_baseline(spec, fm, batch_size, seed, model="RAT_m2", timed_steps=3, thre
                        % (timed_steps, batch_size, spec["F"], spec["K"], spec["d"], spec["total_vocab"], ncpu))
 
 
+def big_table_gather(lib, device, ev_over, rows_per_field=2_500_000, F=40, d=64, K=10, B=1024, reps=12):
+    """rat_gather_fwd at BASELINE.json configs[3]'s per-rank shape on its REAL table: F = 40 fields x 2.5 M rows x 64 floats = 25.6 GB
+    in HBM (uniform random ids: no cache can hold it), B = 1024, T = 11 -> 450 560 row reads of 256 B per launch.  The table is
+    allocated and filled on the device for this measurement only and freed afterwards."""
+    import torch
+    from rat_amd import ops
+    from types import SimpleNamespace
+    T, S = K + 1, F + 1
+    table = torch.empty((F * rows_per_field, d), dtype=torch.float32, device=device)
+    table.normal_(0.0, 1e-2)
+    fields = [SimpleNamespace(col=i, ncols=1, vocab=rows_per_field, padding_idx=None) for i in range(F)]
+    tabs = [table[i * rows_per_field:(i + 1) * rows_per_field] for i in range(F)]
+    ftab = ops.field_table(fields, tabs, device)
+    label_tab = torch.randn(3, d, device=device)
+    g = torch.Generator().manual_seed(11)
+    idxs = [torch.randint(0, rows_per_field, (B, T, F), generator=g).to(torch.int32).to(device) for _ in range(4)]
+    labels = torch.randint(0, 2, (B, T), generator=g).to(torch.int32).to(device)
+    for i in range(3):
+        ops.gather_fwd(idxs[i % 4], labels, ftab, F, label_tab, B, T, F, d, lib=lib)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s_, e_ in evs:
+        s_.record(), e_.record()
+    torch.cuda.synchronize()
+    for i, (s_, e_) in enumerate(evs):
+        s_.record()
+        ops.gather_fwd(idxs[i % 4], labels, ftab, F, label_tab, B, T, F, d, lib=lib)
+        e_.record()
+    torch.cuda.synchronize()
+    raw = sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps
+    ms = max(raw - ev_over, 1e-6)
+    nbytes = B * (T * F * d * 4 + T * S * d * 4 + T * F * 4)
+    del table, tabs
+    torch.cuda.empty_cache()
+    return dict(bound="hbm", what="rat_gather_fwd alone at configs[3]'s per-rank shape (F=40, B=1024, K=10, d=64) on a 25.6 GB table "
+                "(100 M rows), uniform ids, %d launches over 4 id sets" % reps, avg_launch_ms=round(ms, 4),
+                avg_launch_ms_event_pair=round(raw, 4), event_pair_overhead_ms=round(ev_over, 4), algorithmic_bytes=nbytes,
+                achieved_GBps=round(nbytes / (ms * 1e-3) / 1e9, 1), frac_of_8TBps=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                frac_of_8TBps_event_pair=round(nbytes / (raw * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+
+
 # ------------------------------------------------------------------------------------------------- the worker
 def worker(args):
     import torch
@@ -334,22 +377,39 @@ def worker(args):
         b = synthetic.make_batch(spec, fm, seed=seed, device=dev, as_float64=False)
         return b if lo is None else tuple(t[lo:hi].contiguous() for t in b)
 
-    def timed_region(batches, steps, warmup, label):
+    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph
+    model.use_graph = graph_mode
+    model.graph_shapes = 8                       # weak / strong / per-rank shapes and both arithmetics each get their own graph
+    region_info = {}
+
+    def timed_region(batches, steps, warmup, label, kernel_pass=True):
         """W untimed warm-up steps, then K steps between barrier + synchronize.  The one-off host work (creating the timing
         events, gc.freeze() — what fit_generator does before its first batch) happens BEFORE the last warm-up step, so that the
-        timed region starts on a busy device instead of one that idled (and clocked down) through ~100 ms of host-only set-up."""
+        timed region starts on a busy device instead of one that idled (and clocked down) through ~100 ms of host-only set-up.
+
+        train_step() replays a captured hipGraph from its (graph_warmup + 1)-th call of a batch shape on.  The capture has to be over
+        before the LAST warm-up step; when W is too small for that, extra untimed steps are run first (`graph_prepare_steps`).  A
+        replay cannot host per-launch HIP events, so in graph mode the per-kernel numbers come from `kernel_pass`: the SAME K steps
+        once more, eagerly (same kernels, same arguments, same stream), with HIP events around every timed launch — after the
+        timed region, never inside it."""
         timer.enabled = False
         timer.reset()
         nb = len(batches)
+        prep = 0
+        if graph_mode:
+            prep = max(0, model.graph_warmup + 1 - max(warmup - 1, 0))
+            for i in range(prep):
+                model.train_step(batches[i % nb])
         for i in range(max(warmup - 1, 0)):
             model.train_step(batches[i % nb])
         sync()
-        timer.prepare(steps, max(warmup - 1, 1))
+        if not graph_mode:
+            timer.prepare(steps, max(warmup - 1, 1))
         model.freeze_host_heap()
         if warmup > 0:
             model.train_step(batches[(warmup - 1) % nb])
         sync()
-        timer.enabled = True
+        timer.enabled = not graph_mode
         t0 = time.perf_counter()
         stamps = []
         for i in range(steps):
@@ -367,8 +427,47 @@ def worker(args):
             t = torch.tensor([elapsed], dtype=torch.float64, device=model.device if not dry else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t[0])
+        info = dict(graph=graph_mode, graph_prepare_steps=prep)
+        if graph_mode and kernel_pass:
+            model.use_graph = False
+            timer.calls_seen = 0
+            model.train_step(batches[0])
+            sync()
+            timer.prepare(steps, 1)
+            model.train_step(batches[1 % nb])
+            sync()
+            timer.enabled = True
+            t1 = time.perf_counter()
+            for i in range(steps):
+                model.train_step(batches[i % nb])
+            sync()
+            info["eager_instrumented_ms_per_step"] = round((time.perf_counter() - t1) / steps * 1e3, 3)
+            timer.enabled = False
+            model.use_graph = True
         model.check_id_errors()
-        return elapsed, timer.summary(steps)
+        region_info[label] = info
+        return elapsed, (timer.summary(steps) if (kernel_pass or not graph_mode) else {})
+
+    def event_overhead_ms(n=60):
+        """what a HIP-event pair adds to a launch it brackets: the bracketed time of the smallest launch the C ABI offers (rat_sumsq
+        of ONE element: a one-block kernel of ~2 us whose own run time is part of the figure).  Subtracted from the bracketed
+        times of the ~0.1 ms gather kernels in `targets` (raw values are printed beside); irrelevant for the ms-scale kernels."""
+        if dry:
+            return 0.0
+        from rat_amd import ops
+        x = torch.ones(1, dtype=torch.float32, device=model.device)
+        out = torch.zeros(1, dtype=torch.float32, device=model.device)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for s_, e_ in evs:
+            s_.record(), e_.record()
+        torch.cuda.synchronize()
+        for s_, e_ in evs:
+            s_.record()
+            ops.sumsq(x, out, lib=model._lib)
+            e_.record()
+        torch.cuda.synchronize()
+        ts = sorted(s_.elapsed_time(e_) for s_, e_ in evs)
+        return ts[len(ts) // 2]
 
     want_weak = world == 1 or args.scaling in ("both", "weak")
     want_strong = world > 1 and args.scaling in ("both", "strong")
@@ -385,7 +484,7 @@ def worker(args):
 
     # exact-fp32 arithmetic timed beside the default one in the SAME invocation; N = 1 only
     alt = None
-    if world == 1 and args.arith is None and hasattr(model, "arith_modes") and len(model.arith_modes()) > 1:
+    if world == 1 and args.arith is None and not args.no_extras and hasattr(model, "arith_modes") and len(model.arith_modes()) > 1:
         default_arith = model.arith
         other = [m for m in model.arith_modes() if m != default_arith][0]
         model.set_arith(other)
@@ -395,6 +494,26 @@ def worker(args):
                    kernels={k[0] + (":" + k[1] if k[1] else ""): round(v["avg_ms"], 4) for k, v in ks.items()})
         model.set_arith(default_arith)
         del batches
+
+    extras = world == 1 and not args.no_extras and not dry
+    if alt is not None and args.no_extras:
+        alt = None
+    # §8e's strong-scaling partitioning on ONE GPU: the per-rank shape of an 8-GPU run of the global batch (B/8 samples per step)
+    per_rank = None
+    if extras and B % 8 == 0 and B // 8 >= 8:
+        pb = B // 8
+        batches = [make(3000 + i, 0, pb) for i in range(NBATCH)]
+        el, _ = timed_region(batches, args.steps * 4, 3, "per_rank_shape", kernel_pass=False)
+        per_rank = dict(batch=pb, value=round(pb * args.steps * 4 / el, 1), unit="samples/s", ms_per_step=round(el / (args.steps * 4) * 1e3, 3),
+                        steps=args.steps * 4, what="the same training step at the batch ONE rank gets when 8 GPUs split the global batch of "
+                        "%d (SURVEY 8e partitioning), measured on this single GPU: value / the headline value = what the fixed per-step "
+                        "costs leave of linear strong scaling before any communication" % B)
+        del batches
+    ev_over = event_overhead_ms() if rank == 0 else 0.0
+    # the embedding gather on a table that cannot sit in any cache: BASELINE.json configs[3]'s 100 M rows x 64 floats = 25.6 GB
+    gather_big = None
+    if extras and args.workload == "synthetic_F20_V1M_K10_d64_B4096" and args.model == "RAT_m2":
+        gather_big = big_table_gather(model._lib, model.device, ev_over)
 
     if rank == 0:
         primary, per_rank_batch, scaling = (weak, B, "weak") if weak is not None else (strong, B // world, "strong")
@@ -449,9 +568,15 @@ def worker(args):
         for nm in ("rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted"):
             p = pooled.get(nm)
             if p and p["n"] > 0 and p["bound"] == "hbm":
-                gbs = p["amount"] / p["n"] / (p["ms"] / p["n"] * 1e-3) / 1e9
-                targets[nm] = dict(bound="hbm", avg_launch_ms=round(p["ms"] / p["n"], 4), algorithmic_bytes=round(p["amount"] / p["n"]),
-                                   achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4))
+                raw_ms = p["ms"] / p["n"]
+                ms = max(raw_ms - ev_over, 1e-6)             # the HIP-event pair's own cost taken out (event_overhead_ms)
+                gbs = p["amount"] / p["n"] / (ms * 1e-3) / 1e9
+                targets[nm] = dict(bound="hbm", avg_launch_ms=round(ms, 4), avg_launch_ms_event_pair=round(raw_ms, 4),
+                                   event_pair_overhead_ms=round(ev_over, 4), algorithmic_bytes=round(p["amount"] / p["n"]),
+                                   achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4),
+                                   frac_of_8TBps_event_pair=round(p["amount"] / p["n"] / (raw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+        if gather_big is not None:
+            targets["rat_gather_fwd_V100M"] = gather_big
         T = spec["K"] + 1
         cross_ms = cross_fl = 0.0
         for key, st in ksum.items():
@@ -483,6 +608,14 @@ def worker(args):
             result["strong_scaling"] = dict(value=round(B * args.steps / el, 1), unit="samples/s", ms_per_step=round(el / args.steps * 1e3, 3),
                                             global_batch=B, batch_per_gpu=B // world,
                                             partitioning="one global batch of %d samples, rank r trains on rows [r*%d, (r+1)*%d)" % (B, B // world, B // world))
+        result["step_mode"] = dict(region_info.get(scaling, {}),
+                                   what="train_step(): fused iteration (forward, BCE, backward, [exchange], two-sweep clip+Adam with the "
+                                        "regulariser folded in)" + (", replayed as a captured hipGraph; `kernels` / `roofline` / `targets` "
+                                        "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
+                                        else ", eager launches"))
+        if per_rank is not None:
+            per_rank["ratio_to_headline"] = round(per_rank["value"] / result["value"], 4)
+            result["per_rank_shape"] = per_rank
         if alt is not None:
             result["exact_f32" if alt["arith"] == "f32" else "alt_arith"] = alt
         if args.model != "RAT_m2":

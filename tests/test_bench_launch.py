@@ -26,5 +26,7 @@ def test_bench_gpus2_self_launch_dry_run():
                 "targets", "kernels"):
         assert key in out, key
     assert out["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    assert {"rat_gather_fwd", "rat_gather_bwd", "cross_attention"} <= set(out["targets"])
+    # (no rat_gather_bwd under data parallelism: the table gradients are produced as row lists for the exchange)
+    assert {"rat_gather_fwd", "cross_attention"} <= set(out["targets"])
+    assert out["step_mode"]["graph"] is False             # hipGraph capture needs a GPU
     assert "cpu_baseline" not in out                      # N = 1 only (and never in a dry run)
