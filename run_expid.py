@@ -36,7 +36,17 @@ def _find(data_dir, stem):
     return None
 
 
-def build_sources(params, feature_map, synthetic_rows):
+def distributed_env():
+    """(rank, local_rank, world) from a torch.distributed launcher's environment (torchrun / `python -m torch.distributed.run`);
+    (0, 0, 1) when there is none — the reference's single-device entry (run_expid.py:27-40, torch_utils.py:34-39)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
+
+
+def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
+    """train / valid / test batch sources.  Under data parallelism (`shard` = (rank, world)) only the TRAINING source is sharded —
+    `batch_size` is the global batch, each rank takes its equal slice of every batch; validation and test run unsharded on
+    every rank (identical metrics everywhere, rank 0's decide: BaseModel._agreed_value)."""
     topk = params["retrieval_configs"]["topK"]
     bs = params["batch_size"]
     if synthetic_rows:
@@ -45,7 +55,7 @@ def build_sources(params, feature_map, synthetic_rows):
                                ("test", max(synthetic_rows // 8, bs), 3)):
             data, idx, val, lens = rat_data.synthetic_split(feature_map, n, topk, seed)
             out[split] = rat_data.RetrievalBatches(data, data, idx, val, lens, bs, shuffle=(split == "train") and params.get("shuffle", True),
-                                                   seed=params.get("seed", 0))
+                                                   seed=params.get("seed", 0), shard=shard if split == "train" else (0, 1))
         return out["train"], out["valid"], out["test"]
     data_dir = os.path.join(params["data_root"], params["dataset_id"])
     rcfg = params["retrieval_configs"]
@@ -66,9 +76,13 @@ def build_sources(params, feature_map, synthetic_rows):
             pool = _find(data_dir, "retrieval_pool")
         if rpath is None:
             rpath = os.path.join(data_dir, "retrieval_%d_%s.npz" % (topk, split))
-            precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
+            if shard[0] == 0:                                   # one rank computes and writes the file, the others wait for it
+                precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
+            if shard[1] > 1:
+                import torch.distributed as dist
+                dist.barrier()
         out.append(rat_data.batches_from_files(dpath, rpath, bs, pool_path=pool, shuffle=(split == "train") and params.get("shuffle", True),
-                                               seed=params.get("seed", 0)))
+                                               seed=params.get("seed", 0), shard=shard if split == "train" else (0, 1)))
     return out
 
 
@@ -105,7 +119,24 @@ def main(argv=None):
     params["gpu"], params["version"] = args["gpu"], args["version"]
     if args["epochs"] is not None:
         params["epochs"] = args["epochs"]
-    set_logger(params)
+    # data parallelism: under a torch.distributed launcher every process is one rank — one GPU each (LOCAL_RANK
+    # replaces --gpu), RCCL process group over 127.0.0.1 / xGMI (gloo when --gpu -1: the CPU tests), the SAME seed on every rank
+    # (identical initial replicas), the training batches sharded by rank, rank 0 alone logs, checkpoints and writes the result line
+    rank, local_rank, world = distributed_env()
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args["gpu"] >= 0:
+            params["gpu"] = local_rank
+            torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl" if args["gpu"] >= 0 else "gloo", rank=rank, world_size=world)
+    if rank == 0:
+        set_logger(params)
+    else:                                    # the other ranks keep their own (quiet) log next to rank 0's
+        set_logger(params, log_file=os.path.join(params["model_root"], params["dataset_id"], "%s.rank%d.log" % (params["model_id"], rank)))
+        logging.getLogger().setLevel(logging.WARNING)
     logging.info(print_to_json(params))
     seed_everything(seed=params["seed"])
 
@@ -119,7 +150,7 @@ def main(argv=None):
         feature_map = synthetic.feature_map_for(params["dataset_id"], spec)
     else:
         raise RuntimeError("feature_map not exist!")
-    train_gen, valid_gen, test_gen = build_sources(params, feature_map, args["synthetic"])
+    train_gen, valid_gen, test_gen = build_sources(params, feature_map, args["synthetic"], shard=(rank, world))
 
     model_class = getattr(models, params["model"])
     model = model_class(feature_map, **params)
@@ -138,11 +169,15 @@ def main(argv=None):
     logging.info("******** Test evaluation ********")
     test_result = model.evaluate_generator(test_gen) if test_gen else {}
 
-    result_file = os.path.join(params["model_root"], params["dataset_id"], params["model_id"] + ".csv")
-    with open(result_file, "a+") as fw:
-        fw.write(" {},[command] python {},[exp_id] {},[dataset_id] {},[train] {},[val] {},[test] {}\n".format(
-            datetime.datetime.now().strftime("%Y%m%d-%H%M%S"), " ".join(sys.argv), args["expid"], params["dataset_id"],
-            "N.A.", print_to_list(valid_result), print_to_list(test_result)))
+    if rank == 0:
+        result_file = os.path.join(params["model_root"], params["dataset_id"], params["model_id"] + ".csv")
+        with open(result_file, "a+") as fw:
+            fw.write(" {},[command] python {},[exp_id] {},[dataset_id] {},[train] {},[val] {},[test] {}\n".format(
+                datetime.datetime.now().strftime("%Y%m%d-%H%M%S"), " ".join(sys.argv), args["expid"], params["dataset_id"],
+                "N.A.", print_to_list(valid_result), print_to_list(test_result)))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
     return valid_result, test_result
 
 

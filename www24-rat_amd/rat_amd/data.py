@@ -30,7 +30,12 @@ class RetrievalBatches:
     """Iterable over batches of (X [B,1+K,L], y [B,1+K], retrieved_values [B,K], retrieved_lens [B])."""
 
     def __init__(self, data, pool, retr_indices, retr_values, retr_lens, batch_size, shuffle=False, seed=0,
-                 drop_last=False):
+                 drop_last=False, shard=(0, 1)):
+        """shard = (rank, world): data parallelism over the batch dimension — `batch_size` stays the GLOBAL batch,
+        every rank walks the same permutation (same seed) and takes rows [rank*per, (rank+1)*per) of each global batch,
+        per = len(batch) // world (a tail batch's len % world left-over samples are dropped so that all ranks hold equal shards and
+        the mean-of-means of the loss stays the global mean)."""
+        self.shard = (int(shard[0]), int(shard[1]))
         data, pool = np.asarray(data), np.asarray(pool)
         self.ids = np.ascontiguousarray(data[:, :-1].astype(np.int32))
         self.labels = np.ascontiguousarray(data[:, -1].astype(np.float32))
@@ -56,6 +61,7 @@ class RetrievalBatches:
         src = DeviceRetrievalBatches.__new__(DeviceRetrievalBatches)
         src._init_from_arrays(self.ids, self.labels, self.pool_ids, self.pool_labels, self.retr_indices, self.batch_size, device,
                               self.shuffle, self.drop_last, lib)
+        src.shard = self.shard
         src._rng = np.random.RandomState()
         src._rng.set_state(self._rng.get_state())
         return src
@@ -64,12 +70,23 @@ class RetrievalBatches:
         n = len(self.ids)
         order = self._rng.permutation(n) if self.shuffle else np.arange(n)
         for b in range(len(self)):
-            rows = order[b * self.batch_size:(b + 1) * self.batch_size]
+            rows = shard_rows(order[b * self.batch_size:(b + 1) * self.batch_size], self.shard)
+            if len(rows) == 0:
+                continue
             ridx = self.retr_indices[rows]                                              # [B, K]
             X = np.concatenate([self.ids[rows][:, None, :], self.pool_ids[ridx]], axis=1)
             y = np.concatenate([self.labels[rows][:, None], self.pool_labels[ridx]], axis=1)
             yield (torch.from_numpy(X), torch.from_numpy(y), torch.from_numpy(self.retr_values[rows]),
                    torch.from_numpy(self.retr_lens[rows]))
+
+
+def shard_rows(rows, shard):
+    """rows of one GLOBAL batch -> this rank's equal share (see RetrievalBatches.__init__)"""
+    rank, world = shard
+    if world == 1:
+        return rows
+    per = len(rows) // world
+    return rows[rank * per:(rank + 1) * per]
 
 
 class DeviceBatch:
@@ -93,7 +110,8 @@ class DeviceRetrievalBatches:
     permutation per epoch when ``shuffle``), so both sources produce identical batches for the same seed."""
 
     def __init__(self, data, pool, retr_indices, batch_size, device, shuffle=False, seed=0, drop_last=False, lib=None,
-                 retr_lens=None):
+                 retr_lens=None, shard=(0, 1)):
+        self.shard = (int(shard[0]), int(shard[1]))         # (rank, world): see RetrievalBatches
         if retr_lens is not None:                       # same rejection of label-wise retrieval files as the host path
             assert np.asarray(retr_lens).ndim == 1, "RIM does not support label-wise retrieval-enhanced training"
         data, pool_arr = np.asarray(data), np.asarray(pool)
@@ -130,7 +148,10 @@ class DeviceRetrievalBatches:
         order = self._rng.permutation(self.n) if self.shuffle else np.arange(self.n)
         order_dev = torch.from_numpy(order.astype(np.int64)).to(self.device)      # one small upload per epoch
         for b in range(len(self)):
-            yield self.assemble(order_dev[b * self.batch_size:(b + 1) * self.batch_size])
+            rows = shard_rows(order_dev[b * self.batch_size:(b + 1) * self.batch_size], getattr(self, "shard", (0, 1)))
+            if len(rows) == 0:
+                continue
+            yield self.assemble(rows)
 
 
 def batches_from_files(data_path, retrieval_path, batch_size, pool_path=None, **kw):
