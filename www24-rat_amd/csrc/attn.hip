@@ -25,6 +25,7 @@
 #include "rat_device.h"
 #include "../../include/rat_hip.h"
 
+#include <cstdlib>
 #include <initializer_list>
 
 namespace {
@@ -1291,6 +1292,265 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
     RAT_PROF_FLUSH(a.prof, 48);
 }
 
+// ---- forward, bf16x3, attention core on the MATRIX pipe as well (round 3) ------------------------------------------------------
+// softmax(Q K^T * scale) V per (sequence, head) as 16 x 16 x 32 bf16 MFMAs with 3-way split operands — the same fp32-class
+// arithmetic as the projections (every bf16 x bf16 product exact, fp32 accumulation) instead of one VALU lane per (sequence,
+// head, query) walking all keys (41.6 % of attn_fwd3_kernel's time, r2_phase_shares.txt).  What makes the tiny per-head
+// products (L x 10 x L, L = 11 / 21) fit the 16 x 16 x 32 instruction without wasting its K dimension:
+//   * S^T = K Q^T: the contraction is over dim_head = 10.  Every (row, head) of Q and of K is stored as ONE 64-byte vector
+//     [h(10) | m(10) | l(10) | 0 0] of bf16 chunks, and the 32 k-slots of ONE instruction are that whole vector: A = K rows,
+//     B = Q rows gives the three "diagonal" products  kh qh + km qm + kl ql; the same B against A read ROTATED by 10 and by 20
+//     slots ([m l h], [l h m]: 4-byte reads of the same storage, slot s <- element (s + 10 r) mod 30) gives the six cross
+//     products — 3 instructions, all nine products of the split (the bf16x3 GEMMs keep six), 94 % of the K dimension used.
+//     Slots 30, 31 of B are zero, so whatever A holds there does not matter.
+//   * the accumulator of S^T (lane = query column, registers = 4 consecutive keys) IS the B operand layout of the next product
+//     O^T = V^T P^T (contraction over keys: k-slot 8 g + t <-> key 4 g + (t & 3), plane pair t >> 2), so the probabilities never
+//     leave their registers: scale, mask, online softmax over key blocks, split into three bf16 chunks, three MFMAs against
+//     A = V^T read from per-(sequence, head) TRANSPOSED planes [c][key] (8-byte reads).  Six products: ph vh, ph vm, pm vh, pm vm,
+//     ph vl, pl vh.
+//   * the Q|K|V projection's epilogue writes those layouts directly (2-byte stores of the upper halves of x, x - h, x - h - m:
+//     4 VALU operations per value), there is no fp32 Q|K|V tile any more.
+// One wave owns a (sequence, head) pair at a time: 40 pairs (L = 11) / 24 pairs (L = 21) per 64-row chunk = 5 / 3 per wave.
+// O goes to an fp32 LDS tile (over the dead LayerNorm planes), from which the unchanged tail takes over (O -> planes, output
+// projection); o_save now leaves as whole 320-byte rows from that tile.
+// LDS map (bytes): [0, 24576) LN planes -> fp32 O tile [64][84] -> fp32 y tile [64][68] | Q vectors 33792 -> O planes |
+// K vectors 33792 | V^T planes <= 61440 | row maps.  Rows of the Q / K regions are 528 bytes (8 heads x 64 + 16) apart: the 16
+// rows of a fragment read then fall on distinct banks.
+constexpr int B3M_ROW = B3_H * 64 + 16;                 // bytes per token row of the Q / K vector regions
+constexpr int B3M_QK = 64 * B3M_ROW;                    // 33792
+constexpr int B3M_V = 61440;                            // V^T planes: nsq_chunk * 8 heads * 3 planes * 10 * KP * 2 bytes (KP = 16 ceil(L / 16))
+constexpr int B3M_LDO = B3_I + 4;                       // fp32 O tile row (floats)
+constexpr size_t B3M_OFF_Q = (size_t)3 * B3_XP, B3M_OFF_K = B3M_OFF_Q + B3M_QK, B3M_OFF_V = B3M_OFF_K + B3M_QK,
+                 B3M_OFF_MAP = B3M_OFF_V + B3M_V;
+constexpr size_t b3m_fwd_smem() { return B3M_OFF_MAP + 2 * 64 * 8 + 64 * 4; }
+static_assert((size_t)64 * B3M_LDO * 4 <= (size_t)3 * B3_XP, "the fp32 O tile overlays the LayerNorm planes");
+static_assert((size_t)3 * B3_OP <= (size_t)B3M_QK, "the O planes overlay the Q vectors");
+static_assert(b3m_fwd_smem() <= 160 * 1024, "LDS budget");
+// does the V^T region hold a chunk's sequences at this length?
+static bool b3m_fits(int L, int nsq_chunk) { return L >= 1 && L <= 64 && (size_t)nsq_chunk * B3_H * 60 * (16 * ((L + 15) / 16)) <= (size_t)B3M_V; }
+
+// upper 16 bits of the three chunks of x (x = h + m + l exactly, rat_split2's truncation split)
+__device__ __forceinline__ void b3m_split1(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const unsigned xb = rat_fbits(x);
+    const float r1 = x - rat_bitsf(xb & 0xffff0000u);
+    const unsigned rb = rat_fbits(r1);
+    const float r2 = r1 - rat_bitsf(rb & 0xffff0000u);
+    h = (unsigned short)(xb >> 16);
+    m = (unsigned short)(rb >> 16);
+    l = (unsigned short)(rat_fbits(r2) >> 16);
+}
+__device__ __forceinline__ unsigned b3m_pack(unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); }
+
+template <bool EX>
+__global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Attn3W W) {
+    RAT_DYN_SMEM(smem);
+    const PlanesX xp{smem};                                                 // LayerNorm(x) planes
+    float* const os = reinterpret_cast<float*>(smem);                       // fp32 O tile [64][84] (after the projection)
+    float* const ys = reinterpret_cast<float*>(smem);                       // fp32 y tile [64][68] (after O -> planes)
+    char* const qv = smem + B3M_OFF_Q;
+    char* const kv = smem + B3M_OFF_K;
+    char* const vt = smem + B3M_OFF_V;
+    const PlanesO op{smem + B3M_OFF_Q};                                     // O planes over the (then dead) Q vectors
+    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(smem + B3M_OFF_MAP);
+    int* const rowmap = reinterpret_cast<int*>(smem + B3M_OFF_MAP + 2 * 64 * 8);    // row -> (sequence slot << 8) | position
+    constexpr int LDY = B3_D + 4;
+    const int L = a.L;
+    const int KB = (L + 15) >> 4, KP = 16 * KB;                            // key blocks / padded keys per sequence
+    const int VPL = 10 * KP * 2, VB = 3 * VPL;                             // bytes of one V^T plane / of one (sequence, head) block
+
+    // every byte the MFMAs may read must hold a finite bf16 (pads and not-yet-written rows included): zero the operand regions once
+    for (int e = threadIdx.x; e < (int)((B3M_OFF_MAP - B3M_OFF_Q) / 16); e += ATT_THREADS)
+        reinterpret_cast<float4*>(smem + B3M_OFF_Q)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x < 64) rowmap[threadIdx.x] = ((threadIdx.x / L) << 8) | (threadIdx.x % L);
+    float gam[8], bet[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        gam[k] = a.ln_g[8 * (threadIdx.x & 7) + k];
+        bet[k] = a.ln_b[8 * (threadIdx.x & 7) + k];
+    }
+    {
+        int nsq0, rows0;
+        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
+    }
+    __syncthreads();
+    RAT_PROF_DECL
+    const int lane = rat_lane(), g = lane >> 4, n16 = lane & 15;
+    const float sl2 = a.scale * RAT_LOG2E;
+    int parity = 0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
+        const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
+        int nsq, rows;
+        {
+            const int64_t q0 = chunk * a.nsq_chunk;
+            const int64_t left = a.nseq - q0;
+            nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+            rows = nsq * a.L;
+        }
+        float4 x0, x1;                                           // kept: the residual of the plain PreNorm(Attention)(x) + x layer
+        b3_load_piece(a.x, rowtok, x0, x1);
+        b3_layer_norm_to_planes(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr);
+        if (chunk + gridDim.x < a.nchunks) {
+            int nsq1, rows1;
+            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
+        }
+        __syncthreads();
+        RAT_PROF_MARK(0);
+        // Q|K|V = LN(x) W_qkv^T, written straight into the core's operand layouts
+        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int which = nt / 5;                            // 0 Q, 1 K, 2 V: uniform per column tile (80 = 5 x 16)
+            const int cc = 16 * nt + n16 - 80 * which, head = cc / 10, c = cc - 10 * head;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int R = rat_acc_row(mt, r);
+                unsigned short h, m, l;
+                b3m_split1(acc[r], h, m, l);
+                if (which < 2) {
+                    char* p = (which ? kv : qv) + R * B3M_ROW + head * 64 + 2 * c;
+                    *reinterpret_cast<unsigned short*>(p) = h;
+                    *reinterpret_cast<unsigned short*>(p + 20) = m;
+                    *reinterpret_cast<unsigned short*>(p + 40) = l;
+                } else if (R < rows) {
+                    const int rm = rowmap[R];
+                    char* p = vt + ((rm >> 8) * B3_H + head) * VB + (c * KP + (rm & 255)) * 2;
+                    *reinterpret_cast<unsigned short*>(p) = h;
+                    *reinterpret_cast<unsigned short*>(p + VPL) = m;
+                    *reinterpret_cast<unsigned short*>(p + 2 * VPL) = l;
+                }
+            }
+        });
+        __syncthreads();
+        RAT_PROF_MARK(1);
+        float pf = 0.f;
+        if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)
+            pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
+        // ---- the core: one (sequence, head) pair per wave at a time
+        for (int task = rat_wave(); task < nsq * B3_H; task += ATT_WAVES) {
+            const int sq = task >> 3, hd = task & 7;
+            const char* vblk = vt + (sq * B3_H + hd) * VB + ((n16 < 10 ? n16 : 9) * KP + 4 * g) * 2;   // this lane's c row of V^T
+            for (int qt = 0; qt < KB; ++qt) {
+                const int qi = 16 * qt + n16;                    // this lane's query (column of S^T / O^T)
+                const int qrow = sq * L + (qi < L ? qi : L - 1);
+                const bf16x8 qf = rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(qv + qrow * B3M_ROW + hd * 64 + 16 * g));
+                float m_run = -INFINITY, l_run = 0.f;
+                f32x4 ot = rat_zero4();
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int kj = 16 * kb + n16;
+                    const char* kr = kv + (sq * L + (kj < L ? kj : L - 1)) * B3M_ROW + hd * 64;
+                    // S^T block [16 keys][16 queries]: K against Q, and K rotated by one / two planes against the same Q
+                    const bf16x8 k0 = rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(kr + 16 * g));
+                    rat_u4 k1, k2;
+                    {
+                        const unsigned* kd = reinterpret_cast<const unsigned*>(kr);
+                        const int b1 = 4 * g + 5, b2 = 4 * g + 10;      // first storage dword of the fragment, rotations 1 and 2 (mod 15)
+                        k1.x = kd[(b1) % 15];     k1.y = kd[(b1 + 1) % 15]; k1.z = kd[(b1 + 2) % 15]; k1.w = g == 3 ? 0u : kd[(b1 + 3) % 15];
+                        k2.x = kd[(b2) % 15];     k2.y = kd[(b2 + 1) % 15]; k2.z = kd[(b2 + 2) % 15]; k2.w = g == 3 ? 0u : kd[(b2 + 3) % 15];
+                    }
+                    f32x4 st = RAT_MFMA_BF16(rat_as_bf16x8(k2), qf, rat_zero4());
+                    st = RAT_MFMA_BF16(rat_as_bf16x8(k1), qf, st);
+                    st = RAT_MFMA_BF16(k0, qf, st);
+                    // scale, mask the keys beyond L, online softmax over the key blocks (log2 domain)
+                    float sc[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[r] = (16 * kb + 4 * g + r) < L ? st[r] * sl2 : -INFINITY;
+                    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float mn = fmaxf(m_run, mx);
+                    const float corr = rat_exp2(m_run - mn);
+                    m_run = mn;
+                    float pr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pr[r] = rat_exp2(sc[r] - mn);
+                    l_run = l_run * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));      // this lane group's keys; groups are added at the end
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[r] *= corr;
+                    unsigned short ph[4], pm[4], pl[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b3m_split1(pr[r], ph[r], pm[r], pl[r]);
+                    const unsigned h01 = b3m_pack(ph[0], ph[1]), h23 = b3m_pack(ph[2], ph[3]);
+                    const unsigned m01 = b3m_pack(pm[0], pm[1]), m23 = b3m_pack(pm[2], pm[3]);
+                    const unsigned l01 = b3m_pack(pl[0], pl[1]), l23 = b3m_pack(pl[2], pl[3]);
+                    // V^T fragments: keys 16 kb + 4 g .. + 3 of row c in each plane
+                    const uint2 vh = *reinterpret_cast<const uint2*>(vblk + 32 * kb);
+                    const uint2 vm = *reinterpret_cast<const uint2*>(vblk + 32 * kb + VPL);
+                    const uint2 vl = *reinterpret_cast<const uint2*>(vblk + 32 * kb + 2 * VPL);
+                    rat_u4 a_hm, a_lh, b_hh, b_mm, b_hl;
+                    a_hm.x = vh.x; a_hm.y = vh.y; a_hm.z = vm.x; a_hm.w = vm.y;
+                    a_lh.x = vl.x; a_lh.y = vl.y; a_lh.z = vh.x; a_lh.w = vh.y;
+                    b_hh.x = h01; b_hh.y = h23; b_hh.z = h01; b_hh.w = h23;
+                    b_mm.x = m01; b_mm.y = m23; b_mm.z = m01; b_mm.w = m23;
+                    b_hl.x = h01; b_hl.y = h23; b_hl.z = l01; b_hl.w = l23;
+                    ot = RAT_MFMA_BF16(rat_as_bf16x8(a_lh), rat_as_bf16x8(b_hl), ot);      // vl ph + vh pl
+                    ot = RAT_MFMA_BF16(rat_as_bf16x8(a_hm), rat_as_bf16x8(b_mm), ot);      // vh pm + vm pm
+                    ot = RAT_MFMA_BF16(rat_as_bf16x8(a_hm), rat_as_bf16x8(b_hh), ot);      // vh ph + vm ph
+                }
+                float lt = l_run + __shfl_xor(l_run, 16, 64);
+                lt += __shfl_xor(lt, 32, 64);
+                const float inv = 1.0f / lt;
+                if (qi < L) {                                    // O^T rows 4 g + r = dim_head index c (10 of 16 used), column = query
+                    const int R = sq * L + qi;
+                    float* dst = os + (size_t)R * B3M_LDO + hd * B3_DH + 4 * g;
+                    if (g < 2) {
+                        *reinterpret_cast<float2*>(dst) = make_float2(ot[0] * inv, ot[1] * inv);
+                        *reinterpret_cast<float2*>(dst + 2) = make_float2(ot[2] * inv, ot[3] * inv);
+                    } else if (g == 2) {
+                        *reinterpret_cast<float2*>(dst) = make_float2(ot[0] * inv, ot[1] * inv);
+                    } else if (a.lse_save != nullptr) {          // (the otherwise idle lane group stores the log-sum-exp)
+                        a.lse_save[rowtok[R] * B3_H + hd] = m_run + rat_log2(lt);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        RAT_PROF_MARK(2);
+        // O tile -> planes (row operand of the output projection; padding rows are exact zeros) and, as whole rows, -> o_save
+        for (int e = threadIdx.x; e < ATT_ROWS * (B3_I / 8); e += ATT_THREADS) {
+            const int r = e / (B3_I / 8), o8 = e - r * (B3_I / 8);
+            const float* src = os + (size_t)r * B3M_LDO + 8 * o8;
+            float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            const int64_t tok = rowtok[r];
+            b3_zero_unless(tok >= 0, v0);
+            b3_zero_unless(tok >= 0, v1);
+            if (tok >= 0 && a.o_save != nullptr) {
+                *reinterpret_cast<float4*>(a.o_save + tok * B3_I + 8 * o8) = v0;
+                *reinterpret_cast<float4*>(a.o_save + tok * B3_I + 8 * o8 + 4) = v1;
+            }
+            rat_u4 h, m, l;
+            rat_split8(v0, v1, h, m, l);
+            op.store(r, o8, h, m, l);
+        }
+        __syncthreads();
+        RAT_PROF_MARK(3);
+        // y = O W_out^T + b_out (+ residual), staged through LDS for whole-row stores
+        b3_gemm_rows<3>(op, W.out, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
+            const int col = rat_acc_col(nt);
+            const float bias = a.b_out[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ys[(size_t)rat_acc_row(mt, r) * LDY + col] = acc[r] + bias;
+        });
+        __syncthreads();
+        RAT_PROF_MARK(4);
+        if (EX) {
+            store_rows_residual(a.y, ys, LDY, a.res, rowtok, rows, B3_D, true, a.out_scale, &a.drop);
+        } else {                                                 // y = tile + x, the x piece still in registers: no global re-read
+            const int r = threadIdx.x >> 3, sb = threadIdx.x & 7;
+            const int64_t tok = rowtok[r];
+            if (tok >= 0) {
+                const float4 t0 = *reinterpret_cast<const float4*>(ys + (size_t)r * LDY + 8 * sb);
+                const float4 t1 = *reinterpret_cast<const float4*>(ys + (size_t)r * LDY + 8 * sb + 4);
+                *reinterpret_cast<float4*>(a.y + tok * B3_D + 8 * sb) = make_float4(t0.x + x0.x, t0.y + x0.y, t0.z + x0.z, t0.w + x0.w);
+                *reinterpret_cast<float4*>(a.y + tok * B3_D + 8 * sb + 4) = make_float4(t1.x + x1.x, t1.y + x1.y, t1.z + x1.z, t1.w + x1.w);
+            }
+        }
+        __syncthreads();
+#ifndef RAT_EMU
+        asm volatile("" ::"v"(pf));
+#endif
+        RAT_PROF_MARK(5);
+    }
+    RAT_PROF_FLUSH(a.prof, 48);
+}
+
 // ---- backward, bf16x3.  LDS map (bytes): [x planes 24576][dy planes 24576][Q|K|V fp32 62464][O fp32 21504][dO fp32 21504][misc];
 // the three fp32 tiles are contiguous: once the attention core is done, d(Q|K|V) is re-written over them as planes (3 x 30720),
 // and the dy planes (dead after dO / dW_out) become the fp32 tile of d(LayerNorm out).
@@ -1821,7 +2081,11 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(p_qkv), 2};
         W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(p_out), 3};
         const unsigned b3_blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-        if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        static const bool valu_core = getenv("RAT_ATTN_FWD_CORE") != nullptr && std::string(getenv("RAT_ATTN_FWD_CORE")) == "valu";
+        if (!valu_core && b3m_fits(a.L, a.nsq_chunk)) {          // the attention core on the matrix pipe (attn_fwd3m_kernel)
+            if (plain) RAT_LAUNCH((attn_fwd3m_kernel<false>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
+            else RAT_LAUNCH((attn_fwd3m_kernel<true>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
+        } else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         return rat_check_launch("rat_attn_fwd (bf16x3)");
     }
