@@ -67,10 +67,16 @@ def test_attn_fwd_bwd_bf16x3(emu, mode, two_blocks):
 
 @pytest.mark.parametrize("case,mode", [((1, 11, 4, 64, 8, 10, True), "cross"), ((1, 2, 33, 64, 8, 10, True), "intra"),
                                        ((3, 16, 2, 64, 8, 10, True), "cross")], ids=["L11", "L33", "L16"])
-def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks):
-    """attn_fwd3m_kernel (QK^T and PV on the bf16 MFMA as well): one key block with masked keys (L = 11), exactly one block (16), three
-    blocks with one sequence per chunk (33); the north-star intra length 21 is the case above"""
+def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, monkeypatch):
+    """attn_fwd3m_kernel (QK^T and PV on the bf16 MFMA as well; opt-in: measured slower than the VALU core): one key
+    block with masked keys (L = 11), exactly one block (16), three blocks with one sequence per chunk (33)"""
+    monkeypatch.setenv("RAT_ATTN_FWD_CORE", "mfma")
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
+
+
+def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blocks, monkeypatch):
+    monkeypatch.setenv("RAT_ATTN_FWD_CORE", "mfma")
+    kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), "intra", arith="bf16x3")
 
 
 @pytest.mark.parametrize("case,arith", [((2, 3, 4, 8, 2, 4, True), "f32"), ((1, 2, 5, 64, 8, 10, True), "f32"), ((1, 3, 5, 64, 8, 10, True), "bf16x3")],

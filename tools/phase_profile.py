@@ -24,7 +24,7 @@ PHASES = {
                       "pass2 (dK,dV) + copy", "dXn gemm (wave 0)", "dWqkv + barrier", "LN bwd + store"]),
     24: ("ffn_fwd", ["load", "W1 gemm + gelu", "W2 gemm + store"]),
     36: ("ffn_bwd", ["load", "W1 gemm + gelu", "dW2", "dh gemm", "dx gemm + dW1"]),
-    48: ("attn_fwd bf16x3", ["LN -> planes", "QKV gemm", "softmax(QK)V valu", "O -> planes", "out-proj", "store"]),
+    48: ("attn_fwd bf16x3", ["LN -> planes", "QKV gemm (+ operand layouts)", "softmax(QK)V core", "O -> planes", "out-proj", "store"]),
     72: ("ffn_bwd_t (wave 0)", ["consume + stage", "h / dh chain + gelu", "dx partial", "barrier 1", "dx store + prefetch issue", "dW1, dW2", "barrier 2"]),
     60: ("attn_bwd bf16x3", ["loads, LN, planes", "QKV gemm (wave 0)", "dO gemm (wave 0)", "dW_out + barrier", "pass1 (dQ)", "pass2 (dK,dV)",
                              "dQKV -> planes", "dXn gemm (wave 0)", "dW_qkv + barrier", "LN bwd + store"]),
@@ -39,6 +39,7 @@ def main():
     model = RAT_m2(fm, **synthetic.model_kwargs(spec, gpu=0))
     batch = synthetic.make_batch(spec, fm, seed=1, device=model.device)
     model.train()
+    model.use_graph = False                    # eager launches: the stamps are read from a buffer the graph would not know about
     model.train_step(batch)
     buf = torch.zeros(96, dtype=torch.int64, device=model.device)
     model._lib.cdll.rat_debug_set_prof(ctypes.c_void_p(buf.data_ptr()))

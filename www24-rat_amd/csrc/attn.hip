@@ -1297,37 +1297,42 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
 // arithmetic as the projections (every bf16 x bf16 product exact, fp32 accumulation) instead of one VALU lane per (sequence,
 // head, query) walking all keys (41.6 % of attn_fwd3_kernel's time, r2_phase_shares.txt).  What makes the tiny per-head
 // products (L x 10 x L, L = 11 / 21) fit the 16 x 16 x 32 instruction without wasting its K dimension:
-//   * S^T = K Q^T: the contraction is over dim_head = 10.  Every (row, head) of Q and of K is stored as ONE 64-byte vector
-//     [h(10) | m(10) | l(10) | 0 0] of bf16 chunks, and the 32 k-slots of ONE instruction are that whole vector: A = K rows,
-//     B = Q rows gives the three "diagonal" products  kh qh + km qm + kl ql; the same B against A read ROTATED by 10 and by 20
-//     slots ([m l h], [l h m]: 4-byte reads of the same storage, slot s <- element (s + 10 r) mod 30) gives the six cross
-//     products — 3 instructions, all nine products of the split (the bf16x3 GEMMs keep six), 94 % of the K dimension used.
-//     Slots 30, 31 of B are zero, so whatever A holds there does not matter.
+//   * S^T = K Q^T: the contraction is over dim_head = 10.  The 32 k-slots of ONE instruction hold all three bf16 chunks of a
+//     (row, head) vector: lane group g < 3 carries chunk g of elements 0..7 (a 16-byte PIECE), lane group 3 the piece
+//     [h8 h9 m8 m9 l8 l9 0 0].  A = K rows, B = Q rows gives the "diagonal" products kh qh + km qm + kl ql; reading A with its
+//     chunks ROTATED by one and by two (lane group g takes piece (g + r) mod 3; the fourth piece is stored in its three
+//     rotations) gives the six cross products — 3 instructions for all nine products of the split (the bf16x3 GEMMs keep six),
+//     94 % of the K dimension used, every operand fetch a 16-byte LDS read.
 //   * the accumulator of S^T (lane = query column, registers = 4 consecutive keys) IS the B operand layout of the next product
-//     O^T = V^T P^T (contraction over keys: k-slot 8 g + t <-> key 4 g + (t & 3), plane pair t >> 2), so the probabilities never
-//     leave their registers: scale, mask, online softmax over key blocks, split into three bf16 chunks, three MFMAs against
-//     A = V^T read from per-(sequence, head) TRANSPOSED planes [c][key] (8-byte reads).  Six products: ph vh, ph vm, pm vh, pm vm,
-//     ph vl, pl vh.
-//   * the Q|K|V projection's epilogue writes those layouts directly (2-byte stores of the upper halves of x, x - h, x - h - m:
-//     4 VALU operations per value), there is no fp32 Q|K|V tile any more.
-// One wave owns a (sequence, head) pair at a time: 40 pairs (L = 11) / 24 pairs (L = 21) per 64-row chunk = 5 / 3 per wave.
+//     O^T = V^T P^T (contraction over keys: k-slot 8 g + t <-> key 4 g + (t & 3), chunk pair t >> 2), so the probabilities never
+//     leave their registers: scale, mask, softmax, split into three bf16 chunks, three MFMAs against A = V^T read from
+//     per-(sequence, head) TRANSPOSED planes [c][key] (8-byte reads).  Six products: ph vh, ph vm, pm vh, pm vm, ph vl, pl vh.
+//   * the Q|K|V projection runs TRANSPOSED (weights as the A operand, tokens on the lanes: the fragment registers are the same,
+//     only the roles in the instruction swap), so that a lane's accumulator quad is 4 consecutive Q|K|V columns of ONE token: Q and K
+//     leave as 32-bit stores of element pairs straight into the piece layout, V as 2-byte stores into the transposed planes
+//     (consecutive lanes = consecutive keys: conflict-free).  There is no fp32 Q|K|V tile any more.
+// A wave works on (sequence, head, query tile) units: 40 pairs (L = 11) / 24 pairs x 2 query tiles (L = 21) per 64-row chunk.
 // O goes to an fp32 LDS tile (over the dead LayerNorm planes), from which the unchanged tail takes over (O -> planes, output
-// projection); o_save now leaves as whole 320-byte rows from that tile.
-// LDS map (bytes): [0, 24576) LN planes -> fp32 O tile [64][84] -> fp32 y tile [64][68] | Q vectors 33792 -> O planes |
-// K vectors 33792 | V^T planes <= 61440 | row maps.  Rows of the Q / K regions are 528 bytes (8 heads x 64 + 16) apart: the 16
-// rows of a fragment read then fall on distinct banks.
-constexpr int B3M_ROW = B3_H * 64 + 16;                 // bytes per token row of the Q / K vector regions
-constexpr int B3M_QK = 64 * B3M_ROW;                    // 33792
-constexpr int B3M_V = 61440;                            // V^T planes: nsq_chunk * 8 heads * 3 planes * 10 * KP * 2 bytes (KP = 16 ceil(L / 16))
+// projection); o_save leaves as whole 320-byte rows from that tile.
+// LDS map (bytes): [0, 24576) LN planes -> fp32 O tile [64][84] -> fp32 y tile [64][68] | Q pieces 33792 -> O planes |
+// K pieces 50176 | V^T planes <= 51840 | row maps.  Q rows are 528 bytes (8 heads x 64 + 16), K rows 784 (8 x 96 + 16) apart:
+// the 16 rows of a fragment read fall on distinct banks; V^T rows are 2 KP + 8 bytes apart.
+constexpr int B3M_QROW = B3_H * 64 + 16;                // bytes per token row of the Q region
+constexpr int B3M_KROW = B3_H * 96 + 16;                // ... of the K region (the fourth piece in its three rotations)
+constexpr int B3M_Q = 64 * B3M_QROW;                    // 33792
+constexpr int B3M_K = 64 * B3M_KROW;                    // 50176
+constexpr int B3M_V = 51840;                            // V^T planes: nsq_chunk * 8 heads * 3 planes * 10 rows of (2 KP + 8) bytes, KP = 16 ceil(L / 16)
 constexpr int B3M_LDO = B3_I + 4;                       // fp32 O tile row (floats)
-constexpr size_t B3M_OFF_Q = (size_t)3 * B3_XP, B3M_OFF_K = B3M_OFF_Q + B3M_QK, B3M_OFF_V = B3M_OFF_K + B3M_QK,
+constexpr size_t B3M_OFF_Q = (size_t)3 * B3_XP, B3M_OFF_K = B3M_OFF_Q + B3M_Q, B3M_OFF_V = B3M_OFF_K + B3M_K,
                  B3M_OFF_MAP = B3M_OFF_V + B3M_V;
 constexpr size_t b3m_fwd_smem() { return B3M_OFF_MAP + 2 * 64 * 8 + 64 * 4; }
 static_assert((size_t)64 * B3M_LDO * 4 <= (size_t)3 * B3_XP, "the fp32 O tile overlays the LayerNorm planes");
-static_assert((size_t)3 * B3_OP <= (size_t)B3M_QK, "the O planes overlay the Q vectors");
+static_assert((size_t)3 * B3_OP <= (size_t)B3M_Q, "the O planes overlay the Q pieces");
 static_assert(b3m_fwd_smem() <= 160 * 1024, "LDS budget");
 // does the V^T region hold a chunk's sequences at this length?
-static bool b3m_fits(int L, int nsq_chunk) { return L >= 1 && L <= 64 && (size_t)nsq_chunk * B3_H * 60 * (16 * ((L + 15) / 16)) <= (size_t)B3M_V; }
+static bool b3m_fits(int L, int nsq_chunk) {
+    return L >= 1 && L <= 64 && (size_t)nsq_chunk * B3_H * 30 * (2 * 16 * ((L + 15) / 16) + 8) <= (size_t)B3M_V;
+}
 
 // upper 16 bits of the three chunks of x (x = h + m + l exactly, rat_split2's truncation split)
 __device__ __forceinline__ void b3m_split1(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -1341,6 +1346,213 @@ __device__ __forceinline__ void b3m_split1(float x, unsigned short& h, unsigned 
 }
 __device__ __forceinline__ unsigned b3m_pack(unsigned short lo, unsigned short hi) { return (unsigned)lo | ((unsigned)hi << 16); }
 
+// max / sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the lane groups of one accumulator column).  gfx950: two row-swap
+// instructions (v_permlane16_swap: row 1 <-> row 0 and row 3 <-> row 2 of the two operands; v_permlane32_swap: upper half <->
+// lower half) instead of two trips through the LDS crossbar (ds_bpermute); same pairing order as the shuffle form.
+__device__ __forceinline__ float b3m_rows_max(float v) {
+#ifdef RAT_EMU
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+#else
+    auto r = __builtin_amdgcn_permlane16_swap(rat_fbits(v), rat_fbits(v), false, false);
+    v = fmaxf(rat_bitsf(r[0]), rat_bitsf(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(rat_fbits(v), rat_fbits(v), false, false);
+    return fmaxf(rat_bitsf(r[0]), rat_bitsf(r[1]));
+#endif
+}
+__device__ __forceinline__ float b3m_rows_sum(float v) {
+#ifdef RAT_EMU
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+#else
+    auto r = __builtin_amdgcn_permlane16_swap(rat_fbits(v), rat_fbits(v), false, false);
+    v = rat_bitsf(r[0]) + rat_bitsf(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(rat_fbits(v), rat_fbits(v), false, false);
+    return rat_bitsf(r[0]) + rat_bitsf(r[1]);
+#endif
+}
+
+struct B3mCore {
+    const char* qv;
+    const char* kv;
+    const char* vt;
+    float* os;
+    float* lse_save;
+    const int64_t* rowtok;
+    int L, VROW, VPL, VB;        // V^T: bytes per c row / per plane / per (sequence, head) block
+    float sl2;
+    int nsq;
+};
+
+// NU independent units = (sequence, head, query tile) at once, all KB key blocks of a unit in registers.  Phases, each over all units:
+// every operand fetch of S^T (16-byte reads) -> every S^T block (3 MFMAs each, independent chains) -> ONE softmax over a unit's keys (no
+// online rescaling) with the V^T fetches in flight -> the 3 KB MFMAs of O^T -> stores.  The units share nothing, so within a phase the
+// hardware has NU * KB independent chains to interleave (a single unit is one long dependent chain: LDS read -> 3 MFMAs -> cross-lane
+// max -> exp2 -> split -> 3 MFMAs).
+template <int KB, int NU>
+__device__ __forceinline__ void b3m_units(const B3mCore& c, int u0) {
+    const int lane = rat_lane(), g = lane >> 4, n16 = lane & 15, L = c.L;
+    int sq[NU], hd[NU], qi[NU];
+    rat_u4 qf[NU], kf[NU][KB][3];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+        const int u = u0 + n, task = rat_wave() + ATT_WAVES * (u / KB), qt = u % KB;
+        sq[n] = task >> 3;
+        hd[n] = task & 7;
+        qi[n] = 16 * qt + n16;
+        const int qrow = sq[n] * L + (qi[n] < L ? qi[n] : L - 1);
+        qf[n] = *reinterpret_cast<const rat_u4*>(c.qv + qrow * B3M_QROW + hd[n] * 64 + 16 * g);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int kj = 16 * kb + n16;
+            const char* kr = c.kv + (sq[n] * L + (kj < L ? kj : L - 1)) * B3M_KROW + hd[n] * 96;
+            // rotation r: lane group g < 3 reads piece (g + r) mod 3, lane group 3 the r-th rotation of the fourth piece
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                kf[n][kb][r] = *reinterpret_cast<const rat_u4*>(kr + (g == 3 ? 48 + 16 * r : 16 * ((g + r) % 3)));
+        }
+    }
+    RAT_SCHED_FENCE();
+    f32x4 st[NU][KB];
+#pragma unroll
+    for (int n = 0; n < NU; ++n)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            f32x4 t = RAT_MFMA_BF16(rat_as_bf16x8(kf[n][kb][2]), rat_as_bf16x8(qf[n]), rat_zero4());
+            t = RAT_MFMA_BF16(rat_as_bf16x8(kf[n][kb][1]), rat_as_bf16x8(qf[n]), t);
+            st[n][kb] = RAT_MFMA_BF16(rat_as_bf16x8(kf[n][kb][0]), rat_as_bf16x8(qf[n]), t);
+        }
+    // V^T fragments (keys 16 kb + 4 g .. + 3 of row c in each plane): requested now, consumed after the softmax
+    uint2 vf[NU][KB][3];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+        const char* vblk = c.vt + (sq[n] * B3_H + hd[n]) * c.VB + (n16 < 10 ? n16 : 9) * c.VROW + 8 * g;     // this lane's c row of V^T
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) vf[n][kb][p] = *reinterpret_cast<const uint2*>(vblk + 32 * kb + p * c.VPL);
+    }
+    float pr[NU][KB][4], lt[NU], mx[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[n][kb][r] = (16 * kb + 4 * g + r) < L ? st[n][kb][r] * c.sl2 : -INFINITY;
+                m = fmaxf(m, pr[n][kb][r]);
+            }
+        mx[n] = b3m_rows_max(m);
+    }
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[n][kb][r] = rat_exp2(pr[n][kb][r] - mx[n]);
+                sum += pr[n][kb][r];
+            }
+        lt[n] = b3m_rows_sum(sum);
+    }
+    f32x4 ot[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+        ot[n] = rat_zero4();
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            unsigned short ph[4], pm[4], pl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b3m_split1(pr[n][kb][r], ph[r], pm[r], pl[r]);
+            const unsigned h01 = b3m_pack(ph[0], ph[1]), h23 = b3m_pack(ph[2], ph[3]);
+            const unsigned m01 = b3m_pack(pm[0], pm[1]), m23 = b3m_pack(pm[2], pm[3]);
+            const unsigned l01 = b3m_pack(pl[0], pl[1]), l23 = b3m_pack(pl[2], pl[3]);
+            const uint2 vh = vf[n][kb][0], vm = vf[n][kb][1], vl = vf[n][kb][2];
+            rat_u4 a_hm, a_lh, b_hh, b_mm, b_hl;
+            a_hm.x = vh.x; a_hm.y = vh.y; a_hm.z = vm.x; a_hm.w = vm.y;
+            a_lh.x = vl.x; a_lh.y = vl.y; a_lh.z = vh.x; a_lh.w = vh.y;
+            b_hh.x = h01; b_hh.y = h23; b_hh.z = h01; b_hh.w = h23;
+            b_mm.x = m01; b_mm.y = m23; b_mm.z = m01; b_mm.w = m23;
+            b_hl.x = h01; b_hl.y = h23; b_hl.z = l01; b_hl.w = l23;
+            ot[n] = RAT_MFMA_BF16(rat_as_bf16x8(a_lh), rat_as_bf16x8(b_hl), ot[n]);      // vl ph + vh pl
+            ot[n] = RAT_MFMA_BF16(rat_as_bf16x8(a_hm), rat_as_bf16x8(b_mm), ot[n]);      // vh pm + vm pm
+            ot[n] = RAT_MFMA_BF16(rat_as_bf16x8(a_hm), rat_as_bf16x8(b_hh), ot[n]);      // vh ph + vm ph
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+        const float inv = 1.0f / lt[n];
+        if (qi[n] < L) {                                         // O^T rows 4 g + r = dim_head index c (10 of 16 used), column = query
+            const int R = sq[n] * L + qi[n];
+            float* dst = c.os + (size_t)R * B3M_LDO + hd[n] * B3_DH + 4 * g;
+            if (g < 2) {
+                *reinterpret_cast<float2*>(dst) = make_float2(ot[n][0] * inv, ot[n][1] * inv);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(ot[n][2] * inv, ot[n][3] * inv);
+            } else if (g == 2) {
+                *reinterpret_cast<float2*>(dst) = make_float2(ot[n][0] * inv, ot[n][1] * inv);
+            } else if (c.lse_save != nullptr) {                  // (the otherwise idle lane group stores the log-sum-exp)
+                c.lse_save[c.rowtok[R] * B3_H + hd[n]] = mx[n] + rat_log2(lt[n]);
+            }
+        }
+    }
+}
+
+template <int KB>
+__device__ __forceinline__ void b3m_core(const B3mCore& c) {
+    constexpr int NU = KB == 1 ? 3 : 2;
+    const int w = rat_wave();
+    const int ntask = c.nsq * B3_H > w ? (c.nsq * B3_H - w + ATT_WAVES - 1) / ATT_WAVES : 0;       // this wave's (sequence, head) pairs
+    const int nu = ntask * KB;
+    int u = 0;
+    for (; u + NU <= nu; u += NU) b3m_units<KB, NU>(c, u);
+    if (NU > 2 && u + 2 <= nu) {
+        b3m_units<KB, 2>(c, u);
+        u += 2;
+    }
+    for (; u < nu; ++u) b3m_units<KB, 1>(c, u);
+}
+
+// b3_gemm_rows with the operand roles swapped: C^T[16 NT columns][64 rows] — the weight fragment is the A operand, the activation
+// fragment the B operand (the registers are the same: lane l holds k-slots 8 (l >> 4).. of row / column l & 15 either way).  The
+// epilogue gets acc[r] = C[row 16 mt + (lane & 15)][column 16 nt + 4 (lane >> 4) + r]: four consecutive columns of one token per lane.
+template <int KS, class PA, class Epi>
+__device__ __forceinline__ void b3_gemm_rows_t(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
+    const int w = rat_wave(), mt0 = 2 * (w >> 2);
+    int nt = w & 3;
+    if (nt >= n_tiles) return;
+    RatB3 b = Bw(nt, 0);
+    RatB3 a[2][KS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[i][s] = A.row_frag(mt0 + i, s);
+    for (; nt < n_tiles; nt += 4) {
+        f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bool last = s == KS - 1;
+            const RatB3 bn = Bw(last ? (nt + 4 < n_tiles ? nt + 4 : nt) : nt, last ? 0 : s + 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = RAT_MFMA_BF16(b.l, a[i][s].h, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = RAT_MFMA_BF16(b.h, a[i][s].l, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = RAT_MFMA_BF16(b.m, a[i][s].m, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = RAT_MFMA_BF16(b.m, a[i][s].h, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = RAT_MFMA_BF16(b.h, a[i][s].m, acc[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = RAT_MFMA_BF16(b.h, a[i][s].h, acc[i]);
+            b = bn;
+        }
+        epi(mt0, nt, acc[0]);
+        epi(mt0 + 1, nt, acc[1]);
+    }
+}
+
 template <bool EX>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
@@ -1350,13 +1562,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Att
     char* const qv = smem + B3M_OFF_Q;
     char* const kv = smem + B3M_OFF_K;
     char* const vt = smem + B3M_OFF_V;
-    const PlanesO op{smem + B3M_OFF_Q};                                     // O planes over the (then dead) Q vectors
+    const PlanesO op{smem + B3M_OFF_Q};                                     // O planes over the (then dead) Q pieces
     int64_t* const rowtok0 = reinterpret_cast<int64_t*>(smem + B3M_OFF_MAP);
     int* const rowmap = reinterpret_cast<int*>(smem + B3M_OFF_MAP + 2 * 64 * 8);    // row -> (sequence slot << 8) | position
     constexpr int LDY = B3_D + 4;
     const int L = a.L;
-    const int KB = (L + 15) >> 4, KP = 16 * KB;                            // key blocks / padded keys per sequence
-    const int VPL = 10 * KP * 2, VB = 3 * VPL;                             // bytes of one V^T plane / of one (sequence, head) block
+    const int KB = (L + 15) >> 4;                                          // key blocks per sequence
+    const int VROW = 2 * 16 * KB + 8, VPL = 10 * VROW, VB = 3 * VPL;       // V^T: bytes per c row / plane / (sequence, head) block
 
     // every byte the MFMAs may read must hold a finite bf16 (pads and not-yet-written rows included): zero the operand regions once
     for (int e = threadIdx.x; e < (int)((B3M_OFF_MAP - B3M_OFF_Q) / 16); e += ATT_THREADS)
@@ -1395,26 +1607,46 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Att
         }
         __syncthreads();
         RAT_PROF_MARK(0);
-        // Q|K|V = LN(x) W_qkv^T, written straight into the core's operand layouts
-        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
+        // (Q|K|V)^T = W_qkv LN(x)^T: tokens on the lanes, written straight into the core's operand layouts
+        b3_gemm_rows_t<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
             const int which = nt / 5;                            // 0 Q, 1 K, 2 V: uniform per column tile (80 = 5 x 16)
-            const int cc = 16 * nt + n16 - 80 * which, head = cc / 10, c = cc - 10 * head;
+            const int R = 16 * mt + n16;                         // this lane's token row
+            const int c0 = 16 * nt + 4 * g - 80 * which;         // first of its four columns inside Q / K / V (even)
+            unsigned short h[4], m[4], l[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int R = rat_acc_row(mt, r);
-                unsigned short h, m, l;
-                b3m_split1(acc[r], h, m, l);
-                if (which < 2) {
-                    char* p = (which ? kv : qv) + R * B3M_ROW + head * 64 + 2 * c;
-                    *reinterpret_cast<unsigned short*>(p) = h;
-                    *reinterpret_cast<unsigned short*>(p + 20) = m;
-                    *reinterpret_cast<unsigned short*>(p + 40) = l;
-                } else if (R < rows) {
-                    const int rm = rowmap[R];
-                    char* p = vt + ((rm >> 8) * B3_H + head) * VB + (c * KP + (rm & 255)) * 2;
-                    *reinterpret_cast<unsigned short*>(p) = h;
-                    *reinterpret_cast<unsigned short*>(p + VPL) = m;
-                    *reinterpret_cast<unsigned short*>(p + 2 * VPL) = l;
+            for (int r = 0; r < 4; ++r) b3m_split1(acc[r], h[r], m[r], l[r]);
+            if (which < 2) {
+#pragma unroll
+                for (int pr2 = 0; pr2 < 2; ++pr2) {              // element pairs (c, c + 1), c even: never across a head
+                    const int cc = c0 + 2 * pr2, head = cc / 10, c = cc - 10 * head;
+                    const unsigned dh = b3m_pack(h[2 * pr2], h[2 * pr2 + 1]), dm = b3m_pack(m[2 * pr2], m[2 * pr2 + 1]),
+                                   dl = b3m_pack(l[2 * pr2], l[2 * pr2 + 1]);
+                    const bool tail = c == 8;                    // the fourth piece [h8 h9 m8 m9 l8 l9 0 0]
+                    char* p = (which ? kv + R * B3M_KROW + head * 96 : qv + R * B3M_QROW + head * 64);
+                    const int step = tail ? 4 : 16;
+                    char* q = p + (tail ? 48 : 2 * c);
+                    *reinterpret_cast<unsigned*>(q) = dh;
+                    *reinterpret_cast<unsigned*>(q + step) = dm;
+                    *reinterpret_cast<unsigned*>(q + 2 * step) = dl;
+                    if (which == 1 && tail) {                    // K: the fourth piece rotated by one ([m l h]) and by two ([l h m])
+                        *reinterpret_cast<unsigned*>(p + 64) = dm;
+                        *reinterpret_cast<unsigned*>(p + 68) = dl;
+                        *reinterpret_cast<unsigned*>(p + 72) = dh;
+                        *reinterpret_cast<unsigned*>(p + 80) = dl;
+                        *reinterpret_cast<unsigned*>(p + 84) = dh;
+                        *reinterpret_cast<unsigned*>(p + 88) = dm;
+                    }
+                }
+            } else if (R < rows) {
+                const int rm = rowmap[R];
+                char* vb = vt + (rm >> 8) * B3_H * VB + (rm & 255) * 2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cc = c0 + r, head = cc / 10, c = cc - 10 * head;
+                    char* p = vb + head * VB + c * VROW;
+                    *reinterpret_cast<unsigned short*>(p) = h[r];
+                    *reinterpret_cast<unsigned short*>(p + VPL) = m[r];
+                    *reinterpret_cast<unsigned short*>(p + 2 * VPL) = l[r];
                 }
             }
         });
@@ -1423,82 +1655,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Att
         float pf = 0.f;
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
-        // ---- the core: one (sequence, head) pair per wave at a time
-        for (int task = rat_wave(); task < nsq * B3_H; task += ATT_WAVES) {
-            const int sq = task >> 3, hd = task & 7;
-            const char* vblk = vt + (sq * B3_H + hd) * VB + ((n16 < 10 ? n16 : 9) * KP + 4 * g) * 2;   // this lane's c row of V^T
-            for (int qt = 0; qt < KB; ++qt) {
-                const int qi = 16 * qt + n16;                    // this lane's query (column of S^T / O^T)
-                const int qrow = sq * L + (qi < L ? qi : L - 1);
-                const bf16x8 qf = rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(qv + qrow * B3M_ROW + hd * 64 + 16 * g));
-                float m_run = -INFINITY, l_run = 0.f;
-                f32x4 ot = rat_zero4();
-                for (int kb = 0; kb < KB; ++kb) {
-                    const int kj = 16 * kb + n16;
-                    const char* kr = kv + (sq * L + (kj < L ? kj : L - 1)) * B3M_ROW + hd * 64;
-                    // S^T block [16 keys][16 queries]: K against Q, and K rotated by one / two planes against the same Q
-                    const bf16x8 k0 = rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(kr + 16 * g));
-                    rat_u4 k1, k2;
-                    {
-                        const unsigned* kd = reinterpret_cast<const unsigned*>(kr);
-                        const int b1 = 4 * g + 5, b2 = 4 * g + 10;      // first storage dword of the fragment, rotations 1 and 2 (mod 15)
-                        k1.x = kd[(b1) % 15];     k1.y = kd[(b1 + 1) % 15]; k1.z = kd[(b1 + 2) % 15]; k1.w = g == 3 ? 0u : kd[(b1 + 3) % 15];
-                        k2.x = kd[(b2) % 15];     k2.y = kd[(b2 + 1) % 15]; k2.z = kd[(b2 + 2) % 15]; k2.w = g == 3 ? 0u : kd[(b2 + 3) % 15];
-                    }
-                    f32x4 st = RAT_MFMA_BF16(rat_as_bf16x8(k2), qf, rat_zero4());
-                    st = RAT_MFMA_BF16(rat_as_bf16x8(k1), qf, st);
-                    st = RAT_MFMA_BF16(k0, qf, st);
-                    // scale, mask the keys beyond L, online softmax over the key blocks (log2 domain)
-                    float sc[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sc[r] = (16 * kb + 4 * g + r) < L ? st[r] * sl2 : -INFINITY;
-                    float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    const float mn = fmaxf(m_run, mx);
-                    const float corr = rat_exp2(m_run - mn);
-                    m_run = mn;
-                    float pr[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pr[r] = rat_exp2(sc[r] - mn);
-                    l_run = l_run * corr + ((pr[0] + pr[1]) + (pr[2] + pr[3]));      // this lane group's keys; groups are added at the end
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ot[r] *= corr;
-                    unsigned short ph[4], pm[4], pl[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b3m_split1(pr[r], ph[r], pm[r], pl[r]);
-                    const unsigned h01 = b3m_pack(ph[0], ph[1]), h23 = b3m_pack(ph[2], ph[3]);
-                    const unsigned m01 = b3m_pack(pm[0], pm[1]), m23 = b3m_pack(pm[2], pm[3]);
-                    const unsigned l01 = b3m_pack(pl[0], pl[1]), l23 = b3m_pack(pl[2], pl[3]);
-                    // V^T fragments: keys 16 kb + 4 g .. + 3 of row c in each plane
-                    const uint2 vh = *reinterpret_cast<const uint2*>(vblk + 32 * kb);
-                    const uint2 vm = *reinterpret_cast<const uint2*>(vblk + 32 * kb + VPL);
-                    const uint2 vl = *reinterpret_cast<const uint2*>(vblk + 32 * kb + 2 * VPL);
-                    rat_u4 a_hm, a_lh, b_hh, b_mm, b_hl;
-                    a_hm.x = vh.x; a_hm.y = vh.y; a_hm.z = vm.x; a_hm.w = vm.y;
-                    a_lh.x = vl.x; a_lh.y = vl.y; a_lh.z = vh.x; a_lh.w = vh.y;
-                    b_hh.x = h01; b_hh.y = h23; b_hh.z = h01; b_hh.w = h23;
-                    b_mm.x = m01; b_mm.y = m23; b_mm.z = m01; b_mm.w = m23;
-                    b_hl.x = h01; b_hl.y = h23; b_hl.z = l01; b_hl.w = l23;
-                    ot = RAT_MFMA_BF16(rat_as_bf16x8(a_lh), rat_as_bf16x8(b_hl), ot);      // vl ph + vh pl
-                    ot = RAT_MFMA_BF16(rat_as_bf16x8(a_hm), rat_as_bf16x8(b_mm), ot);      // vh pm + vm pm
-                    ot = RAT_MFMA_BF16(rat_as_bf16x8(a_hm), rat_as_bf16x8(b_hh), ot);      // vh ph + vm ph
-                }
-                float lt = l_run + __shfl_xor(l_run, 16, 64);
-                lt += __shfl_xor(lt, 32, 64);
-                const float inv = 1.0f / lt;
-                if (qi < L) {                                    // O^T rows 4 g + r = dim_head index c (10 of 16 used), column = query
-                    const int R = sq * L + qi;
-                    float* dst = os + (size_t)R * B3M_LDO + hd * B3_DH + 4 * g;
-                    if (g < 2) {
-                        *reinterpret_cast<float2*>(dst) = make_float2(ot[0] * inv, ot[1] * inv);
-                        *reinterpret_cast<float2*>(dst + 2) = make_float2(ot[2] * inv, ot[3] * inv);
-                    } else if (g == 2) {
-                        *reinterpret_cast<float2*>(dst) = make_float2(ot[0] * inv, ot[1] * inv);
-                    } else if (a.lse_save != nullptr) {          // (the otherwise idle lane group stores the log-sum-exp)
-                        a.lse_save[rowtok[R] * B3_H + hd] = m_run + rat_log2(lt);
-                    }
-                }
+        // ---- the core: (sequence, head) pairs dealt to the waves; a wave works on NU independent (pair, query tile) units at a time
+        {
+            const B3mCore cc{qv, kv, vt, os, a.lse_save, rowtok, L, VROW, VPL, VB, sl2, nsq};
+            switch (KB) {
+                case 1: b3m_core<1>(cc); break;
+                case 2: b3m_core<2>(cc); break;
+                case 3: b3m_core<3>(cc); break;
+                default: b3m_core<4>(cc); break;
             }
         }
         __syncthreads();
@@ -2081,8 +2245,13 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(p_qkv), 2};
         W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(p_out), 3};
         const unsigned b3_blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-        static const bool valu_core = getenv("RAT_ATTN_FWD_CORE") != nullptr && std::string(getenv("RAT_ATTN_FWD_CORE")) == "valu";
-        if (!valu_core && b3m_fits(a.L, a.nsq_chunk)) {          // the attention core on the matrix pipe (attn_fwd3m_kernel)
+        // RAT_ATTN_FWD_CORE=mfma selects attn_fwd3m_kernel (the attention core on the matrix pipe as well).  It is correct (same
+        // parity gates) but MEASURED SLOWER than the VALU core at this geometry — 0.80 / 0.69 ms against 0.64 / 0.52 ms per launch at
+        // L = 21 / 11 (profiles/round3/r3_attn_fwd_core_ab.txt): 16 x 16 score tiles are 43-47 % full at L = 21 / 11, and what the
+        // matrix pipe saves is spent on the VALU again, splitting Q|K|V and P into bf16 chunks and laying them out — so it is opt-in.
+        const char* core_env = getenv("RAT_ATTN_FWD_CORE");
+        const bool mfma_core = core_env != nullptr && std::string(core_env) == "mfma";
+        if (mfma_core && b3m_fits(a.L, a.nsq_chunk)) {
             if (plain) RAT_LAUNCH((attn_fwd3m_kernel<false>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_fwd3m_kernel<true>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
         } else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);

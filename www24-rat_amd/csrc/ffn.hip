@@ -975,7 +975,10 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
         }
         // ---- chain: h^T = W1 x^T (+ b1), dh^T = W2^T dy^T per hidden tile; gelu / gelu' on the accumulators
         RatB3 dbs[HT / 2];                                       // stacked dh' quads of tiles (2 t, 2 t + 1): the dx phase's B fragments
-        HalfPieces dpe;       // (six plain scalars instead of the struct: 15 spills; the stack built at the dx phase: +3.5 %, A/B)
+        // the even tile's dh' pieces are needed again when the odd tile's exist (f3_stack): carried in registers they were kept in
+        // SCRATCH by the compiler at 256 VGPRs (a 24-byte stack object: scratch_store x4 + x2 and two overlapping scratch_load x4 per
+        // tile pair, 44 bytes per lane of scratch, +155 MB of HBM writes per launch — r2_traffic_pmc.json) — they are re-read from the
+        // dh' planes instead, where this same thread has just stored them (3 ds_read_b64)
 #pragma unroll
         for (int i = 0; i < HT; ++i) {
             const int m = HT * half + i;
@@ -1010,8 +1013,15 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             const HalfPieces dq = f3_split4(dp);
             gsp.store_half(row, 4 * m + g, gp.h0, gp.h1, gp.m0, gp.m1, gp.l0, gp.l1);
             dhsp.store_half(row, 4 * m + g, dq.h0, dq.h1, dq.m0, dq.m1, dq.l0, dq.l1);
-            if (i % 2 == 0) dpe = dq;
-            else dbs[i / 2] = f3_stack(dpe, dq);
+            if (i % 2 == 1) {
+                unsigned eh0, eh1, em0, em1, el0, el1;                    // (plain scalars: a struct here is kept in scratch too)
+                dhsp.load_half(row, 4 * (m - 1) + g, eh0, eh1, em0, em1, el0, el1);
+                rat_u4 sh, sm, sl;
+                sh.x = eh0; sh.y = eh1; sh.z = dq.h0; sh.w = dq.h1;
+                sm.x = em0; sm.y = em1; sm.z = dq.m0; sm.w = dq.m1;
+                sl.x = el0; sl.y = el1; sl.z = dq.l0; sl.w = dq.l1;
+                dbs[i / 2] = RatB3{rat_as_bf16x8(sh), rat_as_bf16x8(sm), rat_as_bf16x8(sl)};
+            }
             db1a[i][0] += dp.x;
             db1a[i][1] += dp.y;
             db1a[i][2] += dp.z;

@@ -635,6 +635,16 @@ struct RatPlanes {
         *reinterpret_cast<uint2*>(base + PLANE_BYTES + a) = make_uint2(m0, m1);
         *reinterpret_cast<uint2*>(base + 2 * PLANE_BYTES + a) = make_uint2(l0, l1);
     }
+    // ... and the same 8 bytes per plane read back (by the thread that wrote them: no barrier needed, LDS operations of a wave
+    // stay in order)
+    __device__ __forceinline__ void load_half(int r, int q4, unsigned& h0, unsigned& h1, unsigned& m0, unsigned& m1, unsigned& l0,
+                                              unsigned& l1) const {
+        const int a = off(r, q4 >> 1) + 8 * (q4 & 1);
+        const uint2 h = *reinterpret_cast<const uint2*>(base + a);
+        const uint2 m = *reinterpret_cast<const uint2*>(base + PLANE_BYTES + a);
+        const uint2 l = *reinterpret_cast<const uint2*>(base + 2 * PLANE_BYTES + a);
+        h0 = h.x; h1 = h.y; m0 = m.x; m1 = m.y; l0 = l.x; l1 = l.y;
+    }
     __device__ __forceinline__ void store(int r, int o, const rat_u4& h, const rat_u4& m, const rat_u4& l) const {
         const int a = off(r, o);
         *reinterpret_cast<rat_u4*>(base + a) = h;
