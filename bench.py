@@ -73,6 +73,7 @@ def parse(argv=None):
     ap.add_argument("--step-times", action="store_true", help="print the host-side issue time of every timed step to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager fused step instead of hipGraph replays")
+    ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the default N = 1 line (exact-fp32 run, per-rank B/8 shape, 100 M-row gather)")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline (default 0 = the workload's own batch)")
@@ -377,6 +378,8 @@ def worker(args):
         dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)
 
     spec = synthetic.WORKLOADS[args.workload]
+    if args.batch:
+        spec = dict(spec, batch=args.batch)
     fm = synthetic.feature_map_for(args.workload, spec)
     seed_everything(2021)
     gpu = -1 if dry else local_rank

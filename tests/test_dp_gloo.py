@@ -35,7 +35,7 @@ def _make(case_name, batch_norm=False):
     return case, model, mc.batch_of(case)
 
 
-def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False):
+def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, row_lists=True):
     _setup_paths()
     import rat_amd._lib as L
     L._default = L.RatLib(emu_path)
@@ -51,6 +51,7 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False):
         merges[0] += 1
         return inner(part)
     model._merge_sparse = counting_merge
+    model.row_list_exchange = row_lists       # (the traffic rule would pick the dense all-reduce for this toy vocabulary)
     assert model._cfg["lam_emb"] > 0 and model._grad_mode == "atomic"
     for _ in range(2):
         loss = model.train_step(shard)
@@ -61,8 +62,8 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch_norm", [False, True], ids=["bn_off", "sync_bn"])
-def test_two_rank_step_equals_full_batch_step(batch_norm):
+@pytest.mark.parametrize("batch_norm,row_lists", [(False, True), (True, True), (True, False)], ids=["bn_off", "sync_bn", "sync_bn_dense_tables"])
+def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists):
     _setup_paths()
     import build_emu
     import rat_amd._lib as L
@@ -88,13 +89,14 @@ def test_two_rank_step_equals_full_batch_step(batch_norm):
         L._default = old
     port = 29500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, port, "tiny_seq_bn", emu_path, out_dir, batch_norm), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, "tiny_seq_bn", emu_path, out_dir, batch_norm, row_lists), nprocs=2, join=True)
         r0 = torch.load(os.path.join(out_dir, "rank0.pt"))
         r1 = torch.load(os.path.join(out_dir, "rank1.pt"))
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
     # embedding_regularizer = 0.01 > 0 (dense semantics: lambda*W on every row) and yet the table gradients travelled as row lists
     # (SURVEY.md §8e C2): 2 steps x 2 table families (feature tables, LR tables) merged on every rank, no dense table all-reduce
-    assert r0["merges"] == r1["merges"] == 4
+    # — or, with row_lists off, as one dense all-reduce of the table block (what the traffic rule picks when every rank brings a full batch)
+    assert r0["merges"] == r1["merges"] == (4 if row_lists else 0)
     np.testing.assert_allclose(r0["flat"][keep].numpy(), ref[keep].numpy(), rtol=2e-4, atol=2e-6)
     assert bool(ref_buffers) == batch_norm
     for k, v in ref_buffers.items():                 # running statistics: the global batch's, identical on both ranks

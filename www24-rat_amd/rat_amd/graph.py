@@ -36,7 +36,8 @@ class StepGraph:
     # ---- recording ------------------------------------------------------------------------------------------------------
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        self._ctx = torch.cuda.graph(g, pool=self._pool, stream=self._stream)
+        # thread_local: RCCL's watchdog / proxy threads keep making HIP calls of their own while this thread records
+        self._ctx = torch.cuda.graph(g, pool=self._pool, stream=self._stream, capture_error_mode="thread_local")
         self._ctx.__enter__()
         self._open = g
 

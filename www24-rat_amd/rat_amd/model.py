@@ -799,12 +799,31 @@ class RAT_m2(BaseModel):
         world = self._world_size()
         inv = self._inv_world()
         _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
-        self._run_backward(saved, inv, None, table_lists=world > 1)
+        if self._graph_test_splits:
+            self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
+        self._run_backward(saved, inv, None, table_lists=world > 1 and self._row_lists_travel_lighter(batch[0].shape, world))
+        if self._graph_test_splits:
+            self._collective(lambda: None)
         g = self._last_gflat
         self._exchange_gradients(g)
         reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count)
         self._gbuf_clean = self._gbuf is not None and g is self._gbuf[0]
         return (loss + reg[0]) * inv[0]
+
+    def _row_lists_travel_lighter(self, idx_shape, world):
+        """Table gradients under data parallelism in the dense modes: all-gather of (row ids, gradient rows) lists at capacity (every
+        rank receives world x min(pairs, rows) x (4 d + 4) bytes, then sorts and merges them) or one dense all-reduce of the table block
+        (a ring moves ~2 x its size per rank)?  Lists win at the strong-scaling rank shape (north star, 8 ranks of 512 samples: 8 x 28.8 MB
+        against 2 x 257 MB) and lose when every rank brings a full batch (weak scaling at B = 4096: 8 x 230 MB): pick by bytes, with
+        a margin for the merge."""
+        if self.row_list_exchange is not None:
+            return bool(self.row_list_exchange)
+        B, T, L = [int(v) for v in idx_shape]
+        d = self._cfg["d"]
+        rows_feat, rows_lr = self._n_feat // d, self._n_tab - self._n_feat
+        lists = world * (min(B * T * L, rows_feat) * (4 * d + 4) + min(B * L, rows_lr) * 8)
+        dense = 2 * 4 * self._n_tab
+        return lists < 0.6 * dense
 
     def _inv_world(self):
         world = self._world_size()
@@ -814,6 +833,8 @@ class RAT_m2(BaseModel):
             self._inv_world_t, self._inv_world_n = t, world
         return t
 
+    row_list_exchange = None    # None: decide by traffic (_row_lists_travel_lighter); True / False: force (tests, experiments)
+    _graph_test_splits = False  # tests: cut the captured step into segments the way collectives do under data parallelism
     use_graph = True           # capture the fused iteration into a hipGraph (CUDA devices only)
     graph_warmup = 2           # eager fused steps of a batch shape before it is captured
     graph_shapes = 2           # at most this many batch shapes get a graph (the full batch and an epoch's tail batch)
@@ -836,8 +857,19 @@ class RAT_m2(BaseModel):
             if entry[0] <= self.graph_warmup:
                 return None                                # eager: fills every lazily built cache (workspaces, plans, tables)
             from .graph import StepGraph
-            entry[1] = StepGraph(self, batch)
-        return entry[1]
+            try:
+                entry[1] = StepGraph(self, batch)
+            except Exception as exc:                       # capture refused (driver / runtime / collective inside a segment ...):
+                import logging                             # this shape stays on the eager fused step
+                logging.warning("hipGraph capture of the training step failed (%s: %s); continuing with eager launches",
+                                type(exc).__name__, exc)
+                self._tape = None
+                self._sparse = self._table_lists = self._pending_reduce = None
+                if self._gbuf is not None:
+                    self._gbuf[0].zero_()
+                    self._gbuf_clean = True
+                entry[1] = False
+        return entry[1] or None
 
     def _loss_terms(self, inputs, with_reg):
         batch = self._prepare_batch(inputs)
