@@ -59,9 +59,12 @@ def test_train_step_graph_with_sorted_and_sparse_table_gradients(name, mode):
     assert any(e[1] for e in a._step_graphs.values())
     # same kernels in the same order; not bit-identical run to run (the loss / fc gradients are fp32 atomic sums), and Adam turns
     # rounding-level gradient differences into +-lr steps: bound the outliers like check_train_step_api does
+    noise = mc.noise_tensors(a)              # biases in front of BatchNorm: true gradient 0, Adam steps on rounding noise
     for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
         if k.endswith("num_batches_tracked"):
             assert int(va) == int(vb) == 5, k
+            continue
+        if k in noise or k.endswith("running_mean"):
             continue
         x, y = va.detach().cpu().double(), vb.detach().cpu().double()
         bad = (x - y).abs() > 1.5e-5 + 3e-4 * y.abs()
@@ -85,8 +88,9 @@ def test_train_step_graph_in_segments_with_eager_closures_between():
     ga = [e[1] for e in a._step_graphs.values() if e[1]][0]
     gb = [e[1] for e in b._step_graphs.values() if e[1]][0]
     assert sum(isinstance(i, torch.cuda.CUDAGraph) for i in ga.items) == 3 and len(ga.items) == 5 and len(gb.items) == 1
+    noise = mc.noise_tensors(a)
     for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
-        if k.endswith("num_batches_tracked"):
+        if k.endswith("num_batches_tracked") or k in noise or k.endswith("running_mean"):
             continue
         x, y = va.detach().cpu().double(), vb.detach().cpu().double()
         bad = (x - y).abs() > 1.5e-5 + 3e-4 * y.abs()
