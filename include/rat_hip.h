@@ -246,6 +246,11 @@ int rat_sgemm(int trans_a, int trans_b, int M, int N, int K, const float* A, int
 size_t rat_sgemm_workspace(int M, int N, int K);
 int rat_sgemm_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                  float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes, void* stream);
+/* ABI v4: the same with the arithmetic selectable — RAT_ARITH_BF16X3 runs the product on v_mfma_f32_16x16x32_bf16 with 3-way split
+ * operands (fp32-class accuracy, see rat_attn_fwd_ex) when both operands allow 16-byte fetches and K >= 64; otherwise exact fp32. */
+int rat_sgemm_arith(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes,
+                    int arith, void* stream);
 
 /* BatchNorm1d (train: batch stats, biased var; running stats momentum update with unbiased var; eval:
  * running stats) followed by ReLU — deep.py:128-132.  use_bn=0 -> ReLU only.  z,a [M][N].

@@ -74,7 +74,9 @@ def check_gather(lib, dev, d, B=3, T=4):
         close(g, t.grad, 1e-4, 2e-6 * float(t.grad.abs().max()) + 1e-6)
 
 
-def check_sgemm(lib, dev, ta, tb, M=70, N=37, K=29):
+def check_sgemm(lib, dev, ta, tb, M=70, N=37, K=29, arith="f32"):
+    """arith "bf16x3": sgemm3_kernel (operands split into bf16 planes, k-major tiles through transposed block reads) — same
+    tolerance as the exact-fp32 kernel; it needs lda, ldb % 4 == 0 and K >= 64, other shapes silently run exact fp32."""
     rs = np.random.RandomState(1)
     A = rnd(rs, *((K, M) if ta else (M, K)))
     Bm = rnd(rs, *((N, K) if tb else (K, N)))
@@ -82,7 +84,7 @@ def check_sgemm(lib, dev, ta, tb, M=70, N=37, K=29):
     C = rnd(rs, M, N)
     ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double() + 0.5 * C.double()
     Cd = C.to(dev)
-    ops.sgemm(ta, tb, M, N, K, A.to(dev), A.shape[1], Bm.to(dev), Bm.shape[1], Cd, N, bias=bias.to(dev), beta=0.5, lib=lib)
+    ops.sgemm(ta, tb, M, N, K, A.to(dev), A.shape[1], Bm.to(dev), Bm.shape[1], Cd, N, bias=bias.to(dev), beta=0.5, arith=arith, lib=lib)
     close(Cd, ref, 1e-5, 1e-5 * max(1.0, K ** 0.5))       # fp32 accumulation over K terms of O(1) products
 
 

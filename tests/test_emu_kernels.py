@@ -29,6 +29,11 @@ def test_sgemm(emu, ta, tb):
     kc.check_sgemm(emu, "cpu", ta, tb)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_sgemm_bf16x3(emu, ta, tb):
+    kc.check_sgemm(emu, "cpu", ta, tb, M=72, N=40, K=100, arith="bf16x3")      # ragged last k tile, partial n tile
+
+
 def test_sgemm_split_k(emu):
     """few output tiles, long K: the k range is split across work-groups and reduced in slice order"""
     assert emu.size("rat_sgemm_workspace", 40, 33, 700) > 0

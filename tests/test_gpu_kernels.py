@@ -26,6 +26,12 @@ def test_sgemm(lib, ta, tb, shape):
     kc.check_sgemm(lib, "cuda", ta, tb, *shape)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("shape", [(72, 40, 100), (512, 400, 1280), (400, 1280, 512), (400, 400, 4096), (4096, 400, 400), (100, 240, 64)])
+def test_sgemm_bf16x3(lib, ta, tb, shape):
+    kc.check_sgemm(lib, "cuda", ta, tb, *shape, arith="bf16x3")
+
+
 ATTN_CASES = [  # B, T, S, d, heads, dh, project_out
     (2, 3, 4, 8, 2, 4, True),
     (1, 4, 5, 10, 2, 10, True),

@@ -45,6 +45,35 @@ def main():
     x = torch.randn(B, T, S, d, generator=g).to(dev)
     dy = torch.randn(B, T, S, d, generator=g).to(dev)
     rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    if "gather" in args.which:
+        from types import SimpleNamespace
+        F, vocab = 20, 50_000
+        table = torch.randn(F * vocab, d, generator=g).to(dev) * 0.01
+        fields = [SimpleNamespace(col=i, ncols=1, vocab=vocab, padding_idx=None) for i in range(F)]
+        tabs = [table[i * vocab:(i + 1) * vocab] for i in range(F)]
+        gtable = torch.zeros_like(table)
+        ftab = ops.field_table(fields, tabs, dev)
+        gftab = ops.field_table(fields, [gtable[i * vocab:(i + 1) * vocab] for i in range(F)], dev)
+        label_tab = rn(3, d)
+        idxs = [torch.randint(0, vocab, (B, T, F), generator=g).to(torch.int32).to(dev) for _ in range(4)]
+        labels = torch.randint(0, 2, (B, T), generator=g).to(torch.int32).to(dev)
+        it = [0]
+
+        def fwd():
+            it[0] += 1
+            ops.gather_fwd(idxs[it[0] % 4], labels, ftab, F, label_tab, B, T, F, d)
+        ms = timeit(fwd, args.reps)
+        nb = B * (T * F * d * 4 + T * S * d * 4 + T * F * 4)
+        print("gather_fwd %.4f ms  %.0f GB/s  (%.1f %% of 8 TB/s)" % (ms, nb / ms / 1e6, 100 * nb / ms / 1e6 / 8000))
+        dlab = torch.zeros(3, d, device=dev)
+        dflat = rn(B, F * d)
+
+        def bwd():
+            it[0] += 1
+            ops.gather_bwd(dy, dflat, idxs[it[0] % 4], labels, gftab, F, dlab, B, T, F, d)
+        ms = timeit(bwd, args.reps)
+        nb = B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4)
+        print("gather_bwd %.4f ms  %.0f GB/s  (%.1f %% of 8 TB/s)" % (ms, nb / ms / 1e6, 100 * nb / ms / 1e6 / 8000))
     if any(w.startswith("ffn") for w in args.which):
         w1, b1, w2, b2 = rn(H, d, sc=d ** -0.5), rn(H, sc=0.1), rn(d, H, sc=H ** -0.5), rn(d, sc=0.1)
         y = torch.empty_like(x)

@@ -16,7 +16,10 @@ constexpr int GATHER_THREADS = 256;
 #ifndef GB_TRIP
 #define GB_TRIP 2                         // rows requested before the first atomic of a trip
 #endif
-constexpr int GATHER_ITEMS = 4;       // independent rows in flight per thread
+#ifndef RAT_GATHER_ITEMS
+#define RAT_GATHER_ITEMS 4
+#endif
+constexpr int GATHER_ITEMS = RAT_GATHER_ITEMS;       // independent rows in flight per thread
 
 // vectorised path: d % 4 == 0, one item = one 16-byte piece of one grid row
 __global__ void __launch_bounds__(GATHER_THREADS)
@@ -126,7 +129,14 @@ gather_fwd_rows64_kernel(const int32_t* __restrict__ idx, const int32_t* __restr
                 const float4 w = *(reinterpret_cast<const float4*>(tab[u] + (int64_t)i * d) + piece);
                 v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
             }
+#if defined(RAT_GATHER_NT) && !defined(RAT_EMU)
+            if (ok[u]) {
+                f32x4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
+                __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(grid) + (size_t)(r0 + u * nslots) * 16 + piece);
+            }
+#else
             if (ok[u]) reinterpret_cast<float4*>(grid)[(size_t)(r0 + u * nslots) * 16 + piece] = v[u];
+#endif
         }
     }
 }

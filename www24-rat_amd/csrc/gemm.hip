@@ -84,6 +84,37 @@ struct TileLoader {
     }
 };
 
+__device__ __forceinline__ void sgemm_epilogue(const GemmArgs& g, const f32x4 (&acc)[2][2], int m0, int n0, int wm, int wn, int slice) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + rat_acc_col(wn + j);
+            if (g.slices > 1) {                            // raw partial tile; bias / beta are applied by the reduction
+                if (col < g.N)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + rat_acc_row(wm + i, r);
+                        if (row < g.M) g.partial[((size_t)slice * g.M + row) * g.N + col] = acc[i][j][r];
+                    }
+                continue;
+            }
+            if (col < g.N) {
+                const float b = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + rat_acc_row(wm + i, r);
+                    if (row < g.M) {
+                        float v = acc[i][j][r] + b;
+                        float* c = g.C + (size_t)row * g.ldc + col;
+                        if (g.beta != 0.f) v += g.beta * (*c);
+                        *c = v;
+                    }
+                }
+            }
+        }
+}
+
 __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
     RAT_DYN_SMEM(smem);
     float* As = reinterpret_cast<float*>(smem);           // [64][GM_LD]  As[m][k] = op(A)[m0+m][k0+k]
@@ -116,34 +147,7 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm_kernel(GemmArgs g) {
         rat_wave_gemm<2, 2>(acc, Af, Bf, wm, wn, 2, 2, GM_K / 16);
         __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + rat_acc_col(wn + j);
-            if (g.slices > 1) {                            // raw partial tile; bias / beta are applied by the reduction
-                if (col < g.N)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = m0 + rat_acc_row(wm + i, r);
-                        if (row < g.M) g.partial[((size_t)slice * g.M + row) * g.N + col] = acc[i][j][r];
-                    }
-                continue;
-            }
-            if (col < g.N) {
-                const float b = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + rat_acc_row(wm + i, r);
-                    if (row < g.M) {
-                        float v = acc[i][j][r] + b;
-                        float* c = g.C + (size_t)row * g.ldc + col;
-                        if (g.beta != 0.f) v += g.beta * (*c);
-                        *c = v;
-                    }
-                }
-            }
-        }
+    sgemm_epilogue(g, acc, m0, n0, wm, wn, slice);
 }
 
 // C[m][n] = sum_s partial[s][m][n] (+ bias[n]) (+ beta * C[m][n]), slices summed in index order (deterministic)
@@ -158,6 +162,100 @@ __global__ void __launch_bounds__(256) sgemm_reduce_kernel(GemmArgs g) {
         if (g.beta != 0.f) v += g.beta * (*c);
         *c = v;
     }
+}
+
+// ---- bf16x3 variant (round 3): the same 64 x 64 x 32 tiling on v_mfma_f32_16x16x32_bf16 with 3-way split operands (rat_device.h
+// "bf16x3": six exact bf16 products per fp32 product, fp32 accumulation — the arithmetic of the encoder kernels).  Operand tiles are
+// split ONCE, by the thread that fetched them, into LDS plane images:
+//   * k contiguous in memory ([R][K]):  RatPlanes<80, 0>  [64 r][32 k] (+16 pad bytes per row: the 16 rows of a fragment read fall
+//     on distinct banks), k stored in the slot order of col_frag so that both kinds of operand agree;   fragment = row_frag
+//   * r contiguous in memory ([K][R]):  RatPlanes<128, 7> [32 k][64 r] in its natural orientation;      fragment = col_frag (two
+//     transposed 4 x 16 block reads per plane, ds_read_b64_tr_b16) — no transposing scalar stores as in sgemm_kernel.
+// One K = 32 step per tile pair: 4 x 6 MFMAs of 16 cycles per wave against 4 x 8 x 32 cycles on v_mfma_f32_16x16x4_f32.
+typedef RatPlanes<80, 0, 64 * 80> GmPlanesR;           // [64 r][32 k]
+typedef RatPlanes<128, 7, 32 * 128> GmPlanesK;         // [32 k][64 r]
+constexpr int GM3_OPERAND = 3 * 64 * 80;               // bytes per operand (the larger of the two images)
+
+template <bool KMAJOR>
+struct Tile3 {
+    char* base;
+    // the thread's two float4 of TileLoader::fetch -> planes
+    __device__ __forceinline__ void stash(const float4 (&v)[GM_VEC]) const {
+        if (KMAJOR) {                                      // element e -> k = e / 16, r = 4 (e % 16): two fetches = rows k, k + 16
+            const GmPlanesK pl{base};
+#pragma unroll
+            for (int u = 0; u < GM_VEC; ++u) {
+                const int e = threadIdx.x + GM_THREADS * u;
+                const int k = e / (GM_TILE / 4), q4 = e % (GM_TILE / 4);
+                unsigned h0, h1, m0, m1, l0, l1;
+                rat_split2(v[u].x, v[u].y, h0, m0, l0);
+                rat_split2(v[u].z, v[u].w, h1, m1, l1);
+                pl.store_half(k, q4, h0, h1, m0, m1, l0, l1);
+            }
+        } else {                                           // element e -> r = e / 8, k = 4 (e % 8): slot order of col_frag
+            const GmPlanesR pl{base};
+#pragma unroll
+            for (int u = 0; u < GM_VEC; ++u) {
+                const int e = threadIdx.x + GM_THREADS * u;
+                const int r = e / (GM_K / 4), k = (e % (GM_K / 4)) * 4;
+                unsigned h0, h1, m0, m1, l0, l1;
+                rat_split2(v[u].x, v[u].y, h0, m0, l0);
+                rat_split2(v[u].z, v[u].w, h1, m1, l1);
+                pl.store_half(r, 2 * ((k & 15) >> 2) + (k >> 4), h0, h1, m0, m1, l0, l1);     // piece g = (k % 16) / 4, half = k >= 16
+            }
+        }
+    }
+    __device__ __forceinline__ RatB3 frag(int t) const {   // rows / columns 16 t .. 16 t + 15 of the tile, all 32 k
+        if (KMAJOR) return GmPlanesK{base}.col_frag(t, 0);
+        return GmPlanesR{base}.row_frag(t, 0);
+    }
+};
+
+template <bool KA, bool KB>
+__global__ void __launch_bounds__(GM_THREADS) sgemm3_kernel(GemmArgs g) {
+    RAT_DYN_SMEM(smem);
+    const Tile3<KA> At{smem};
+    const Tile3<KB> Bt{smem + GM3_OPERAND};
+    const int tiles_n = (g.N + GM_TILE - 1) / GM_TILE;
+    const int tile = blockIdx.x / g.slices, slice = blockIdx.x - tile * g.slices;
+    const int m0 = (tile / tiles_n) * GM_TILE;
+    const int n0 = (tile % tiles_n) * GM_TILE;
+    const int kbeg = slice * g.kper, kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
+    const int wave = rat_wave();
+    const int wm = (wave >> 1) * 2, wn = (wave & 1) * 2;
+    const TileLoader la{g.A, g.M, g.K, g.lda, m0, KA, g.veca != 0};
+    const TileLoader lb{g.B, g.N, g.K, g.ldb, n0, KB, g.vecb != 0};
+    f32x4 acc[2][2];
+    acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = rat_zero4();
+    float4 ra[GM_VEC], rb[GM_VEC];
+    la.fetch(kbeg, ra);
+    lb.fetch(kbeg, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GM_K) {
+        At.stash(ra);
+        Bt.stash(rb);
+        __syncthreads();
+        if (k0 + GM_K < kend) {                            // next tile's loads fly while this one is multiplied
+            la.fetch(k0 + GM_K, ra);
+            lb.fetch(k0 + GM_K, rb);
+        }
+        const RatB3 a0 = At.frag(wm), a1 = At.frag(wm + 1), b0 = Bt.frag(wn), b1 = Bt.frag(wn + 1);
+        {
+            f32x4 c[2] = {acc[0][0], acc[1][0]};
+            const RatB3 aa[2] = {a0, a1};
+            rat_mfma3_block<2>(c, aa, b0);
+            acc[0][0] = c[0];
+            acc[1][0] = c[1];
+        }
+        {
+            f32x4 c[2] = {acc[0][1], acc[1][1]};
+            const RatB3 aa[2] = {a0, a1};
+            rat_mfma3_block<2>(c, aa, b1);
+            acc[0][1] = c[0];
+            acc[1][1] = c[1];
+        }
+        __syncthreads();
+    }
+    sgemm_epilogue(g, acc, m0, n0, wm, wn, slice);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -186,7 +284,8 @@ extern "C" size_t rat_sgemm_workspace(int M, int N, int K) {
 }
 
 static int sgemm_launch(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                        float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes, void* stream) {
+                        float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes, void* stream,
+                        int arith = RAT_ARITH_F32) {
     RAT_REQUIRE(M > 0 && N > 0 && K > 0, "bad dims");
     RAT_REQUIRE(A && B && C, "null pointer");
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, 0, 0, beta, 1, 0, nullptr};
@@ -199,7 +298,17 @@ static int sgemm_launch(int trans_a, int trans_b, int M, int N, int K, const flo
     }
     g.partial = workspace;
     const int tiles = ((M + GM_TILE - 1) / GM_TILE) * ((N + GM_TILE - 1) / GM_TILE);
-    RAT_LAUNCH(sgemm_kernel, tiles * g.slices, GM_THREADS, (size_t)2 * GM_TILE * GM_LD * sizeof(float), stream, g);
+    // bf16x3: 16-byte fetches on both operands and a contraction long enough to matter; everything else runs exact fp32
+    if (arith == RAT_ARITH_BF16X3 && g.veca && g.vecb && K >= 2 * GM_K && M >= 16 && N >= 16) {
+        const size_t smem3 = (size_t)2 * GM3_OPERAND;
+        const bool ka = g.ta != 0, kb = g.tb == 0;
+        if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
+        else if (ka) RAT_LAUNCH((sgemm3_kernel<true, false>), tiles * g.slices, GM_THREADS, smem3, stream, g);
+        else if (kb) RAT_LAUNCH((sgemm3_kernel<false, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
+        else RAT_LAUNCH((sgemm3_kernel<false, false>), tiles * g.slices, GM_THREADS, smem3, stream, g);
+    } else {
+        RAT_LAUNCH(sgemm_kernel, tiles * g.slices, GM_THREADS, (size_t)2 * GM_TILE * GM_LD * sizeof(float), stream, g);
+    }
     if (rat_check_launch("rat_sgemm")) return -1;
     if (g.slices > 1) {
         const size_t total = (size_t)M * N;
@@ -219,4 +328,10 @@ extern "C" int rat_sgemm_ws(int trans_a, int trans_b, int M, int N, int K, const
                             float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes,
                             void* stream) {
     return sgemm_launch(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int rat_sgemm_arith(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                               float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes,
+                               int arith, void* stream) {
+    return sgemm_launch(trans_a, trans_b, M, N, K, A, lda, B, ldb, C, ldc, bias, beta, workspace, workspace_bytes, stream, arith);
 }

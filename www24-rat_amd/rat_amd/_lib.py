@@ -77,6 +77,7 @@ _SIGNATURES = {
     "rat_sgemm": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P]),
     "rat_sgemm_workspace": (c_size_t, [c_int, c_int, c_int]),
     "rat_sgemm_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P, c_size_t, _P]),
+    "rat_sgemm_arith": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P, c_size_t, c_int, _P]),
     "rat_bn_workspace": (c_size_t, [c_int]),
     "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
     "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

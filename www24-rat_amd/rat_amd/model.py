@@ -247,6 +247,7 @@ class RAT_m2(BaseModel):
     # gate of tests/ holds at unchanged tolerances) at ~2.4x the MFMA rate; compiled for embedding_dim 64 with 8 heads x 10, other
     # shapes run exact fp32 whatever is selected.  kwarg / attribute `arith`: "auto" (= bf16x3 where compiled), "f32", "bf16x3".
     arith = "f32"
+    gemm_arith = "f32"
 
     def arith_modes(self):
         """arithmetic variants the loaded library offers for THIS model's encoder shapes ("f32" is always present)"""
@@ -258,6 +259,9 @@ class RAT_m2(BaseModel):
         return modes
 
     def set_arith(self, mode):
+        # the plain GEMMs (DNN head, composed attention) have a bf16x3 kernel for every shape: they follow the REQUEST, the fused
+        # encoder kernels what is compiled for their geometry
+        self.gemm_arith = "f32" if mode == "f32" else "bf16x3"
         if mode == "auto":
             mode = self.arith_modes()[-1]
         if mode not in self.arith_modes():
@@ -351,10 +355,10 @@ class RAT_m2(BaseModel):
                                       "implemented in the fused kernel (sequences up to 64 tokens)")
         xn = ops.layernorm_fwd(x, d, ntok, ln_g, ln_b, d, lib=lib)
         qkv = torch.empty((ntok, 3 * inner), dtype=torch.float32, device=x.device)
-        ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_qkv, d, qkv, 3 * inner, lib=lib)                     # to_qkv (no bias)
+        ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_qkv, d, qkv, 3 * inner, arith=self.gemm_arith, lib=lib)                     # to_qkv (no bias)
         o, lse = ops.attn_core_fwd_map(qkv, smap, heads, dh, save=True, lib=lib)
         y = x.clone()                                                                                     # the residual, accumulated by beta = 1
-        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, lib=lib)      # to_out + x
+        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, arith=self.gemm_arith, lib=lib)      # to_out + x
         return y, ((qkv, o, lse) if save else None)
 
     def _attn_layer_backward(self, desc, x_in, dy, att, smap, G):
@@ -394,13 +398,13 @@ class RAT_m2(BaseModel):
         dev = dy.device
         xn = ops.layernorm_fwd(x_in, d, ntok, ln_g, ln_b, d, lib=lib)                                     # recomputed, not stored
         do = torch.empty((ntok, inner), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, inner, d, dy, d, w_out, inner, do, inner, lib=lib)                          # dO = dy W_out
-        ops.sgemm(1, 0, d, inner, ntok, dy, d, o, inner, G(names[3]), inner, lib=lib)                     # dW_out = dy^T O
+        ops.sgemm(0, 0, ntok, inner, d, dy, d, w_out, inner, do, inner, arith=self.gemm_arith, lib=lib)                          # dO = dy W_out
+        ops.sgemm(1, 0, d, inner, ntok, dy, d, o, inner, G(names[3]), inner, arith=self.gemm_arith, lib=lib)                     # dW_out = dy^T O
         ops.colsum(dy, d, G(names[4]), ntok, d, lib=lib)
         dqkv = ops.attn_core_bwd_map(qkv, o, lse, do, smap, heads, dh, lib=lib)
         dxn = torch.empty((ntok, d), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_qkv, d, dxn, d, lib=lib)                   # d(norm(x)) = dQKV W_qkv
-        ops.sgemm(1, 0, 3 * inner, d, ntok, dqkv, 3 * inner, xn, d, G(names[2]), d, lib=lib)              # dW_qkv = dQKV^T norm(x)
+        ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_qkv, d, dxn, d, arith=self.gemm_arith, lib=lib)                   # d(norm(x)) = dQKV W_qkv
+        ops.sgemm(1, 0, 3 * inner, d, ntok, dqkv, 3 * inner, xn, d, G(names[2]), d, arith=self.gemm_arith, lib=lib)              # dW_qkv = dQKV^T norm(x)
         return ops.layernorm_bwd(x_in, d, dxn, ln_g, dxn, d, G(names[0]), G(names[1]), d, add=dy, lib=lib).view_as(x_in)
 
     def _build_encoder_descriptors(self):
@@ -846,7 +850,7 @@ class RAT_m2(BaseModel):
         if c["attn_dropout"] > 0 or c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers):
             return None                                    # dropout seeds are drawn on the host per step: not replayable
         graphs = self.__dict__.setdefault("_step_graphs", {})
-        key = (tuple(batch[0].shape), self.arith, self._world_size())
+        key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size())
         entry = graphs.get(key)
         if entry is None:
             if len(graphs) >= self.graph_shapes:
@@ -919,7 +923,7 @@ class RAT_m2(BaseModel):
                 W, bvec = mods[lin].weight.data, mods[lin].bias.data
                 N = W.shape[0]
                 z = torch.empty((B, N), dtype=torch.float32, device=x0.device)
-                ops.sgemm(0, 1, B, N, K, a_prev, lda, W, K, z, N, bias=bvec, lib=lib)
+                ops.sgemm(0, 1, B, N, K, a_prev, lda, W, K, z, N, bias=bvec, arith=self.gemm_arith, lib=lib)
                 if bn is not None:
                     m = mods[bn]
                     if training and self._sync_bn and self._world_size() > 1:         # SyncBN: statistics of the GLOBAL batch
@@ -941,7 +945,7 @@ class RAT_m2(BaseModel):
                 a_prev, lda, K = a, N, N
             W, bvec = mods[self._dnn_out].weight.data, mods[self._dnn_out].bias.data
             dnn_out = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
-            ops.sgemm(0, 1, B, 1, K, a_prev, lda, W, K, dnn_out, 1, bias=bvec, lib=lib)
+            ops.sgemm(0, 1, B, 1, K, a_prev, lda, W, K, dnn_out, 1, bias=bvec, arith=self.gemm_arith, lib=lib)
             if save:
                 saved["dnn_last"] = (a_prev, lda, K)
         # ---- encoder on the token grid
@@ -999,10 +1003,10 @@ class RAT_m2(BaseModel):
             pre = "dnn.dnn.%d." % self._dnn_out
             a_prev, lda, K = saved["dnn_last"]
             W = mods[self._dnn_out].weight.data
-            ops.sgemm(1, 0, 1, K, B, dlogit, 1, a_prev, lda, G(pre + "weight"), K, lib=lib)       # dW = dlogit^T a
+            ops.sgemm(1, 0, 1, K, B, dlogit, 1, a_prev, lda, G(pre + "weight"), K, arith=self.gemm_arith, lib=lib)       # dW = dlogit^T a
             ops.colsum(dlogit, 1, G(pre + "bias"), B, 1, lib=lib)
             da = torch.empty((B, K), dtype=torch.float32, device=dev)
-            ops.sgemm(0, 0, B, K, 1, dlogit, 1, W, K, da, K, lib=lib)                             # da = dlogit W
+            ops.sgemm(0, 0, B, K, 1, dlogit, 1, W, K, da, K, arith=self.gemm_arith, lib=lib)                             # da = dlogit W
             seeds = saved["seeds"]
             for li, ((lin, bn, pdrop), (a_in, lda_in, K_in, z, a, sm, sr)) in reversed(list(enumerate(zip(self._dnn_layers, saved["dnn"])))):
                 N = z.shape[1]
@@ -1019,10 +1023,10 @@ class RAT_m2(BaseModel):
                 else:
                     dz = ops.bn_relu_bwd(z, a, da, None, None, None, None, None, False, lib=lib)
                 pre = "dnn.dnn.%d." % lin
-                ops.sgemm(1, 0, N, K_in, B, dz, N, a_in, lda_in, G(pre + "weight"), K_in, lib=lib)  # dW = dz^T a_in
+                ops.sgemm(1, 0, N, K_in, B, dz, N, a_in, lda_in, G(pre + "weight"), K_in, arith=self.gemm_arith, lib=lib)  # dW = dz^T a_in
                 ops.colsum(dz, N, G(pre + "bias"), B, N, lib=lib)
                 da = torch.empty((B, K_in), dtype=torch.float32, device=dev)
-                ops.sgemm(0, 0, B, K_in, N, dz, N, mods[lin].weight.data, K_in, da, K_in, lib=lib)   # da_in = dz W
+                ops.sgemm(0, 0, B, K_in, N, dz, N, mods[lin].weight.data, K_in, da, K_in, arith=self.gemm_arith, lib=lib)   # da_in = dz W
             dflat = da                                                                             # [B, F*d]
         # ---- encoder, reversed
         dx = self._encoder_backward(saved, dx, G)

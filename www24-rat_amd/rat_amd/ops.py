@@ -433,15 +433,12 @@ def layernorm_bwd(x, x_stride, dy, gamma, dx, dx_stride, dgamma, dbeta, d, add=N
 
 
 # ----------------------------------------------------------------------------- K3
-def sgemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, beta=0.0, lib=None):
+def sgemm(ta, tb, M, N, K, A, lda, Bm, ldb, C, ldc, bias=None, beta=0.0, arith="f32", lib=None):
     lib = lib or get_lib()
     need = lib.size("rat_sgemm_workspace", M, N, K)
-    if need:                                       # long-K / few-tile products (weight gradients): split-K partial tiles
-        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=C.device)
-        lib.call("rat_sgemm_ws", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta),
-                 _p(ws), ws.numel() * 4, _stream(C))
-    else:
-        lib.call("rat_sgemm", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta), _stream(C))
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=C.device) if need else None   # long-K / few-tile products: split-K
+    lib.call("rat_sgemm_arith", int(ta), int(tb), M, N, K, _p(A), lda, _p(Bm), ldb, _p(C), ldc, _p(bias), float(beta),
+             _p(ws), ws.numel() * 4 if ws is not None else 0, 1 if arith == "bf16x3" else 0, _stream(C))
 
 
 def _bn_ws(N, device, lib):
