@@ -13,16 +13,23 @@ LIB = os.path.join(HERE, "librat_emu.so")
 
 
 def build(force=False):
+    # RAT_EMU_CXXFLAGS (e.g. "-DRAT_FWD_BOUND"): an experiment's compile-time variant of the kernels -> its own library file
+    extra = os.environ.get("RAT_EMU_CXXFLAGS", "").split()
+    if extra:
+        return _build(True, extra, os.path.join(HERE, "librat_emu_variant.so"), os.path.join(HERE, "obj_variant"))
+    return _build(force, [], LIB, os.path.join(HERE, "obj"))
+
+
+def _build(force, extra, LIB, objdir):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "hip_emu.h"), os.path.join(HERE, "hip_emu.cpp"),
                                                                    os.path.join(ROOT, "include", "rat_hip.h")]
     h = hashlib.sha256()
     for p in deps:
         h.update(open(p, "rb").read())
-    stamp = os.path.join(HERE, "librat_emu.digest")
+    stamp = LIB.replace(".so", ".digest")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
         return LIB
-    objdir = os.path.join(HERE, "obj")
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
@@ -30,7 +37,7 @@ def build(force=False):
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-DRAT_EMU", "-I", HERE, "-I", CSRC, "-x", "c++", "-c", s, "-o", o,
-               "-Wno-attributes", "-ffp-contract=off"]
+               "-Wno-attributes", "-ffp-contract=off"] + extra
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for s, p in procs:
         out, _ = p.communicate()

@@ -95,6 +95,12 @@ static inline float atomicAdd(float* p, float v) {
 }
 static inline int atomicAdd(int* p, int v) { return std::atomic_ref<int>(*p).fetch_add(v); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_add(v); }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    std::atomic_ref<unsigned> r(*p);
+    unsigned old = r.load();
+    while (old < v && !r.compare_exchange_weak(old, v)) {}
+    return old;
+}
 
 typedef float f32x4 __attribute__((vector_size(16)));
 

@@ -118,7 +118,7 @@ if __name__ == "__main__" and "sgemm" not in sys.argv:
     main()
 
 
-def sgemm_bench(reps=10):
+def sgemm_bench(reps=10, arith="f32"):
     """DNN-head GEMM shapes of the north-star config (B=4096, 1280 -> 400 -> 400 -> 400 -> 1)."""
     dev = "cuda"
     B = 4096
@@ -137,11 +137,12 @@ def sgemm_bench(reps=10):
         A = torch.randn(*sa, device=dev)
         Bm = torch.randn(*sb, device=dev)
         C = torch.empty(M, N, device=dev)
-        ms = timeit(lambda: ops.sgemm(ta, tb, M, N, K, A, sa[1], Bm, sb[1], C, N), reps)
+        ms = timeit(lambda: ops.sgemm(ta, tb, M, N, K, A, sa[1], Bm, sb[1], C, N, arith=arith), reps)
         tot += ms
-        print("sgemm %-10s M=%5d N=%5d K=%5d  %.4f ms  %.1f TFLOP/s" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
-    print("sgemm total %.3f ms" % tot)
+        print("sgemm %-6s %-10s M=%5d N=%5d K=%5d  %.4f ms  %.1f TFLOP/s" % (arith, name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+    print("sgemm %s total %.3f ms" % (arith, tot))
 
 
 if __name__ == "__main__" and "sgemm" in sys.argv:
-    sgemm_bench()
+    sgemm_bench(arith="f32")
+    sgemm_bench(arith="bf16x3")

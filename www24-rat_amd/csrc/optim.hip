@@ -95,6 +95,16 @@ clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __re
 // "embedding_layer" tensors, base_model.py:86), the rest lam_b (net_regularizer).
 __device__ __forceinline__ float4 opt_ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
 __device__ __forceinline__ void opt_st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+// streaming store for data nothing reads before the next step's sweep (moments, the zeroed gradient): keeps them out of the caches the
+// embedding gather that follows wants for the table rows
+__device__ __forceinline__ void opt_st4_stream(float* p, int64_t i4, float4 v) {
+#if defined(RAT_OPT_NT) && !defined(RAT_EMU)
+    f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p) + i4);
+#else
+    reinterpret_cast<float4*>(p)[i4] = v;
+#endif
+}
 
 __global__ void __launch_bounds__(OPT_THREADS)
 sumsq_reg_kernel(const float* __restrict__ g, const float* __restrict__ w, int64_t n, int64_t n_split, float lam_a, float lam_b,
@@ -170,8 +180,8 @@ clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __re
             opt_adam1(wv.y, gv.y, mv.y, vv.y, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
             opt_adam1(wv.z, gv.z, mv.z, vv.z, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
             opt_adam1(wv.w, gv.w, mv.w, vv.w, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
-            opt_st4(w, i, wv); opt_st4(m, i, mv); opt_st4(v, i, vv);
-            if (zero_g) opt_st4(g, i, make_float4(0.f, 0.f, 0.f, 0.f));
+            opt_st4(w, i, wv); opt_st4_stream(m, i, mv); opt_st4_stream(v, i, vv);
+            if (zero_g) opt_st4_stream(g, i, make_float4(0.f, 0.f, 0.f, 0.f));
         }
         head = n4 << 2;
     }

@@ -711,12 +711,24 @@ class RAT_m2(BaseModel):
         kept, to be run again between the graph segments of every replay."""
         return self._tape.between_segments(fn) if self._tape is not None else fn()
 
+    def _staged(self, t):
+        """device tensors under the gloo backend (GPU tests that run two ranks on ONE device, where RCCL refuses): the collective
+        goes through host copies.  RCCL ("nccl") and CPU tensors are used directly."""
+        import torch.distributed as dist
+        return t.is_cuda and dist.get_backend() == "gloo"
+
     def _all_gather_flat(self, t):
         """[n] -> [world * n], ranks in order (RCCL all-gather on the GPU, gloo in the CPU tests)."""
         import torch.distributed as dist
         world = self._world_size()
         out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
-        if t.is_cuda:
+        if self._staged(t):
+            def run():
+                parts = [torch.empty(t.numel(), dtype=t.dtype) for _ in range(world)]
+                dist.all_gather(parts, t.detach().reshape(-1).cpu())
+                out.copy_(torch.cat(parts))
+            self._collective(run)
+        elif t.is_cuda:
             self._collective(lambda: dist.all_gather_into_tensor(out, t))
         else:
             self._collective(lambda: dist.all_gather(list(out.view(world, -1).unbind(0)), t))
@@ -724,7 +736,14 @@ class RAT_m2(BaseModel):
 
     def _all_reduce_sum(self, t):
         import torch.distributed as dist
-        self._collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        if self._staged(t):
+            def run():
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            self._collective(run)
+        else:
+            self._collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
         return t
 
     def check_id_errors(self):
@@ -1042,8 +1061,19 @@ class RAT_m2(BaseModel):
             import torch.distributed as dist
             handle, part = [None], gflat[n_dense0:]
 
-            def start():
-                handle[0] = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True)
+            if self._staged(part):
+                class _Done:
+                    def wait(self):
+                        return True
+
+                def start():
+                    h = part.detach().cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                    part.copy_(h)
+                    handle[0] = _Done()
+            else:
+                def start():
+                    handle[0] = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True)
             self._collective(start)
             self._pending_reduce = (handle, gflat)
         if saved["seeds"] is not None and c["emb_dropout"] > 0:
