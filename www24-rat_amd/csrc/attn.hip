@@ -1009,7 +1009,7 @@ constexpr size_t B3_W_QKV = (size_t)15 * 2 * 3 * 1024, B3_W_OUT = (size_t)4 * 3 
                  B3_W_QKVT = (size_t)4 * 8 * 3 * 1024;
 constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
 
-constexpr size_t b3_fwd_smem() { return (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8 + 64 * 4; }
+constexpr size_t b3_fwd_smem() { return (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8; }
 
 // LayerNorm of one row piece into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns [8 sub, 8 sub + 8) = exactly
 // one 16-byte piece, handed over in two float4 (loaded by the caller, usually a whole chunk ahead); same arithmetic, in the same
@@ -1143,7 +1143,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
     float* qkv = reinterpret_cast<float*>(smem + 3 * B3_XP);                // [64][244] fp32 Q|K|V; O overwrites Q
     const PlanesO op{smem + 3 * B3_XP + 64 * B3_LDQ * 4};                   // O planes (row operand of the output projection)
     int64_t* const rowtok0 = reinterpret_cast<int64_t*>(smem + 3 * B3_XP + 64 * B3_LDQ * 4 + 3 * B3_OP);
-    unsigned* const kmx = reinterpret_cast<unsigned*>(rowtok0 + 2 * ATT_ROWS);     // [sequence slot][head]: max_j |k_j|^2 (float bits)
     float* ys = reinterpret_cast<float*>(smem);                             // [64][68] over the (then dead) x planes
     constexpr int LDY = B3_D + 4;
     const int L = a.L;
@@ -1175,9 +1174,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         float4 x0, x1;                                           // kept: the residual of the plain PreNorm(Attention)(x) + x layer
         b3_load_piece(a.x, rowtok, x0, x1);
         b3_layer_norm_to_planes(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr);
-#ifdef RAT_FWD_BOUND
-        if (threadIdx.x < 64) kmx[threadIdx.x] = 0u;
-#endif
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
             map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
@@ -1191,112 +1187,20 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
         });
         __syncthreads();
-#ifdef RAT_FWD_BOUND
-        {   // max_j |k_j|^2 per (sequence, head): thread (row, head) adds its row's norm with an LDS atomic max (non-negative floats
-            // order like their bit patterns)
-            const int r = threadIdx.x >> 3, hh = threadIdx.x & 7;
-            if (r < rows) {
-                HeadVec<B3_DH> kr;
-                kr.load(qkv + (size_t)r * B3_LDQ + B3_I + hh * B3_DH, B3_DH);
-                atomicMax(kmx + (r / L) * B3_H + hh, rat_fbits(kr.dot(kr)));
-            }
-        }
-        __syncthreads();
-#endif
         RAT_PROF_MARK(1);
         // softmax(Q K^T * scale) V on the VALU — identical to attn_fwd_kernel<64, 10>.  (A two-stage form for L <= 24 — the row of scores
         //  kept in registers, max first, then ONE exponential and a plain packed axpy per key instead of the online rescaling: 110
         //  instead of 180 VALU cycles per pair — measured 4-10 % SLOWER, one key or three keys per trip alike; 5 / 6 / 7 keys per trip
         //  instead of 3: no change; three queries per lane on a third of the keys (a third of the LDS bytes per pair, partial softmax
-        //  states merged by lane shuffles): 9-17 % slower.  tools/ab_attn.sh.)
+        //  states merged by lane shuffles): 9-17 % slower.  tools/ab_attn.sh.  Round 3: two queries per lane over ALL keys (half the LDS
+        //  bytes per pair, bit-identical): +9.5 % / +4 % at L = 21 / 11; softmax against the Cauchy-Schwarz bound |q| max|k| (no running
+        //  maximum, no rescaling, independent keys): +-0 / +3 % — tools/experiments/attn_fwd3_core_variants.hip.txt.)
         float pf = 0.f;
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)   // (no prefetch: +2-3 %, same-box A/B)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
         typedef HeadVec<B3_DH> HV;
-        const float sl2 = a.scale * RAT_LOG2E;
-#ifdef RAT_FWD_TWO_QUERIES
-        // TWO queries per lane (round 3 experiment, -DRAT_FWD_TWO_QUERIES): a lane that owns queries 2 ip and 2 ip + 1 uses every K / V
-        // row it fetches twice — half the LDS bytes per (query, key) pair, the same VALU work on half as many waves; per query the
-        // operations and their order are unchanged (bit-identical results).  MEASURED SLOWER, same box, 3 rounds (tools/kbench.py):
-        // 0.700 against 0.640 ms at L = 21, 0.544 against 0.522 ms at L = 11 — with 3.4 instead of 6.9 busy waves per work-group the
-        // loop's dependent chain (row read -> dot -> max -> exp2 -> rescale) is no longer covered: the core is latency-bound, not
-        // LDS-byte-bound.
-        const int npair = (L + 1) >> 1;
-        const int ntasks = nsq * B3_H * npair;
-        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
-            const int ip = task % npair;
-            const int h = (task / npair) % B3_H;
-            const int sq = task / (npair * B3_H);
-            const int i0 = 2 * ip, i1 = (2 * ip + 1 < L) ? 2 * ip + 1 : 2 * ip;       // odd L: the last lane's second query is a repeat
-            const bool two = 2 * ip + 1 < L;
-            const int row0 = sq * L + i0, row1 = sq * L + i1;
-            float* qp0 = qkv + (size_t)row0 * B3_LDQ + h * B3_DH;
-            float* qp1 = qkv + (size_t)row1 * B3_LDQ + h * B3_DH;
-            HV q0, q1, o0, o1;
-            q0.load(qp0, B3_DH);
-            q1.load(qp1, B3_DH);
-            o0.zero();
-            o1.zero();
-            float m0 = -INFINITY, l0 = 0.f, m1 = -INFINITY, l1 = 0.f;
-            const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + h * B3_DH;
-            int j = 0;
-            for (; j + 2 <= L; j += 2) {
-                HV kk[2], vv[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float* kp = kbase + (size_t)(j + u) * B3_LDQ;
-                    kk[u].load(kp, B3_DH);
-                    vv[u].load(kp + B3_I, B3_DH);
-                }
-                float sa[2], sb[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    sa[u] = q0.dot(kk[u]) * sl2;
-                    sb[u] = q1.dot(kk[u]) * sl2;
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float mn0 = fmaxf(m0, sa[u]), mn1 = fmaxf(m1, sb[u]);
-                    const float c0 = rat_exp2(m0 - mn0), c1 = rat_exp2(m1 - mn1);
-                    const float p0 = rat_exp2(sa[u] - mn0), p1 = rat_exp2(sb[u] - mn1);
-                    l0 = l0 * c0 + p0;
-                    l1 = l1 * c1 + p1;
-                    o0.scale_axpy(c0, p0, vv[u]);
-                    o1.scale_axpy(c1, p1, vv[u]);
-                    m0 = mn0;
-                    m1 = mn1;
-                }
-            }
-            for (; j < L; ++j) {
-                const float* kp = kbase + (size_t)j * B3_LDQ;
-                HV kv, vv;
-                kv.load(kp, B3_DH);
-                vv.load(kp + B3_I, B3_DH);
-                const float sa = q0.dot(kv) * sl2, sb = q1.dot(kv) * sl2;
-                const float mn0 = fmaxf(m0, sa), mn1 = fmaxf(m1, sb);
-                const float c0 = rat_exp2(m0 - mn0), c1 = rat_exp2(m1 - mn1);
-                const float p0 = rat_exp2(sa - mn0), p1 = rat_exp2(sb - mn1);
-                l0 = l0 * c0 + p0;
-                l1 = l1 * c1 + p1;
-                o0.scale_axpy(c0, p0, vv);
-                o1.scale_axpy(c1, p1, vv);
-                m0 = mn0;
-                m1 = mn1;
-            }
-            const float inv0 = 1.0f / l0, inv1 = 1.0f / l1;
-            o0.store(qp0, B3_DH, inv0);
-            const int64_t tok0 = rowtok[row0];
-            if (a.o_save != nullptr) o0.store(a.o_save + tok0 * B3_I + h * B3_DH, B3_DH, inv0);
-            if (a.lse_save != nullptr) a.lse_save[tok0 * B3_H + h] = m0 + rat_log2(l0);
-            if (two) {
-                o1.store(qp1, B3_DH, inv1);
-                const int64_t tok1 = rowtok[row1];
-                if (a.o_save != nullptr) o1.store(a.o_save + tok1 * B3_I + h * B3_DH, B3_DH, inv1);
-                if (a.lse_save != nullptr) a.lse_save[tok1 * B3_H + h] = m1 + rat_log2(l1);
-            }
-        }
-#else
         const int ntasks = nsq * B3_H * L;
+        const float sl2 = a.scale * RAT_LOG2E;
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % L;
             const int h = (task / L) % B3_H;
@@ -1309,33 +1213,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             float m = -INFINITY, l = 0.f;
             const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + h * B3_DH;
             int j = 0;
-#ifdef RAT_FWD_BOUND
-            // Softmax against an UPPER BOUND of the scores instead of their running maximum: |q . k_j| <= |q| max_j |k_j| (Cauchy-
-            // Schwarz), so p_j = exp2(s_j - bound) <= 1 cannot overflow, and neither the maximum nor the rescaling of (l, o) is needed:
-            // the keys' contributions no longer form a dependent chain.  softmax and log-sum-exp do not depend on the reference point;
-            // if the bound is so loose that every p_j underflows (l tiny) the lane falls through to the exact online form below.
-            {
-                const float mb = sqrtf(q.dot(q) * rat_bitsf(kmx[sq * B3_H + h])) * sl2;
-                float lb = 0.f;
-                HV ob;
-                ob.zero();
-                for (int jj = 0; jj < L; ++jj) {
-                    const float* kp = kbase + (size_t)jj * B3_LDQ;
-                    HV kk1, vv1;
-                    kk1.load(kp, B3_DH);
-                    vv1.load(kp + B3_I, B3_DH);
-                    const float p = rat_exp2(fmaf(q.dot(kk1), sl2, -mb));
-                    lb += p;
-                    ob.axpy(p, vv1);
-                }
-                if (lb > 1e-30f) {
-                    m = mb;
-                    l = lb;
-                    o = ob;
-                    j = L;
-                }
-            }
-#endif
             for (; j + CORE_UNROLL <= L; j += CORE_UNROLL) {
                 HV kk[CORE_UNROLL], vv[CORE_UNROLL];
 #pragma unroll
@@ -1375,7 +1252,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             if (a.o_save != nullptr) o.store(a.o_save + tok * B3_I + h * B3_DH, B3_DH, inv);
             if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = m + rat_log2(l);
         }
-#endif
         __syncthreads();
         RAT_PROF_MARK(2);
         // O (the Q columns of the valid rows; padding rows are exact zeros) -> planes
