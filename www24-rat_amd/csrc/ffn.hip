@@ -947,6 +947,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             dyN[q] = ok ? ld4(a.dy + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
         }
     }
+    RAT_PROF_DECL
     for (; chunk < a.nchunks; chunk += gridDim.x) {
         const int64_t tok = chunk * FB_TOK + row;
         RatB3 xb[2], dyb[2];
@@ -973,6 +974,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
                     db2f[q].x += dyT[q].x; db2f[q].y += dyT[q].y; db2f[q].z += dyT[q].z; db2f[q].w += dyT[q].w;
                 }
         }
+        RAT_PROF_MARK(0);
         // ---- chain: h^T = W1 x^T (+ b1), dh^T = W2^T dy^T per hidden tile; gelu / gelu' on the accumulators
         RatB3 dbs[HT / 2];                                       // stacked dh' quads of tiles (2 t, 2 t + 1): the dx phase's B fragments
         // the even tile's dh' pieces are needed again when the odd tile's exist (f3_stack): carried in registers they were kept in
@@ -1027,6 +1029,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             db1a[i][2] += dp.z;
             db1a[i][3] += dp.w;
         }
+        RAT_PROF_MARK(1);
         // ---- partial dx^T over this half's hidden tiles: the stacked dh' quads of tiles (2 t, 2 t + 1) are the B fragment
         f32x4 dxa[KD];
 #pragma unroll
@@ -1052,11 +1055,19 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
 #pragma unroll
             for (int m = 0; m < KD0; ++m) st4(pxp(m), as_f4(dxa[m]));
         }
+        RAT_PROF_MARK(2);
         __syncthreads();
-        // the residual pieces of dy are requested unconditionally (rows past the end read token 0) and all of them before the first is
-        // used: a load inside a divergent branch is waited for inside the branch, i.e. one exposed L2 round trip per tile
+        RAT_PROF_MARK(3);
+        // the residual term + dy: this work-group holds dy already — as the three bf16 planes of the dy tile in LDS, whose sum
+        // h + m + l IS the fp32 value (the split is exact) — so the four columns a lane needs are rebuilt from three 8-byte LDS reads
+        // instead of a second trip to L2 (the global re-read was the exposed latency of this phase: 13.6 % of the iteration,
+        // profiles/round3/r3_phase_shares.txt)
         const bool live = tok < a.ntok;
-        const float* pr = a.dy + (live ? tok : 0) * D + 4 * g;
+        auto residual = [&](int m) {
+            unsigned h0, h1, m0, m1, l0, l1;
+            dysp.load_half(row, 4 * m + g, h0, h1, m0, m1, l0, l1);
+            return make_float4(rat_join(h0, m0, l0, 0), rat_join(h0, m0, l0, 1), rat_join(h1, m1, l1, 0), rat_join(h1, m1, l1, 1));
+        };
         auto finish = [&](int m, const float4& dr) {
             const float4 p = ld4(pxp(m));
             const float4 o = make_float4(dxa[m][0] + p.x + dr.x, dxa[m][1] + p.y + dr.y, dxa[m][2] + p.z + dr.z, dxa[m][3] + p.w + dr.w);
@@ -1066,16 +1077,16 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
         if (half == 0) {
             float4 r0 = zero4, r1 = zero4;
             if (a.add_dy) {                                         // uniform
-                r0 = ld4(pr);
-                r1 = ld4(pr + 16);
+                r0 = residual(0);
+                r1 = residual(1);
             }
             finish(0, r0);
             finish(1, r1);
         } else {
             float4 r0 = zero4, r1 = zero4;
             if (a.add_dy) {
-                r0 = ld4(pr + 32);
-                r1 = ld4(pr + 48);
+                r0 = residual(2);
+                r1 = residual(3);
             }
             finish(2, r0);
             finish(3, r1);
@@ -1089,6 +1100,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
                 dyN[q] = ok ? ld4(a.dy + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
             }
         }
+        RAT_PROF_MARK(4);
         // ---- dW1 += dh'^T x (tiles: hidden (w >> 2) + 2 i  x  d (w & 3)) ; dW2 += dy^T gelu(h) (tiles: d (w & 3)  x  hidden (w >> 2) + 2 i)
         {
             const RatB3 xb0 = xsp.col_frag(w & 3, 0), xb1 = xsp.col_frag(w & 3, 1);
@@ -1106,8 +1118,11 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
                 acc2[i] = rat_mfma3(ya1, gsp.col_frag(nt, 1), acc2[i]);
             }
         }
+        RAT_PROF_MARK(5);
         __syncthreads();
+        RAT_PROF_MARK(6);
     }
+    RAT_PROF_FLUSH(a.prof, 72);
 
     // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
