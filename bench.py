@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--step-times", action="store_true", help="print the host-side issue time of every timed step to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager fused step instead of hipGraph replays")
+    ap.add_argument("--graph-dp", action="store_true",
+                    help="N > 1: replay the step as graph segments with the collectives between them (default at N > 1: eager launches; the "
+                         "segmented path is proven with two gloo ranks on one GPU, tests/test_gpu_dp.py, but has not met RCCL yet)")
     ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the default N = 1 line (exact-fp32 run, per-rank B/8 shape, 100 M-row gather)")
@@ -407,8 +410,9 @@ def worker(args):
         b = synthetic.make_batch(spec, fm, seed=seed, device=dev, as_float64=False)
         return b if lo is None else tuple(t[lo:hi].contiguous() for t in b)
 
-    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph
+    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (world == 1 or args.graph_dp)
     model.use_graph = graph_mode
+    model.graph_under_dp = bool(args.graph_dp)
     model.graph_shapes = 8                       # weak / strong / per-rank shapes and both arithmetics each get their own graph
     region_info = {}
 

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(HERE)
 
 WORKER = r'''
 import os, sys
-ROOT, out, case_name, row_lists, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] == "1", int(sys.argv[5])
+ROOT, out, case_name, row_lists, steps, graph = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] == "1", int(sys.argv[5]), sys.argv[6] == "1"
 sys.path[:0] = [ROOT, os.path.join(ROOT, "www24-rat_amd"), os.path.join(ROOT, "tests")]
 import torch
 import torch.distributed as dist
@@ -39,10 +39,11 @@ if world > 1:
     per = batch[0].shape[0] // world
     batch = tuple(t[rank * per:(rank + 1) * per] for t in batch)
     model.row_list_exchange = row_lists
+    model.graph_under_dp = graph
 model.train()
 losses = [float(model.train_step(batch)) for _ in range(steps)]
 torch.cuda.synchronize()
-graphs = [e[1] for e in model._step_graphs.values() if e[1]]
+graphs = [e[1] for e in getattr(model, "_step_graphs", {}).values() if e[1]]
 segs = sum(isinstance(i, torch.cuda.CUDAGraph) for i in graphs[0].items) if graphs else 0
 torch.save({"flat": model._flat.detach().cpu(), "losses": losses, "segments": segs, "closures": (len(graphs[0].items) - segs) if graphs else 0,
             "noise": sorted(mc.noise_tensors(model)), "offsets": dict(model._offsets),
@@ -53,21 +54,22 @@ if world > 1:
 '''
 
 
-def _spawn(out, case, row_lists, steps, env_extra):
+def _spawn(out, case, row_lists, steps, env_extra, graph=True):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra)
-    return subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(out), case, "1" if row_lists else "0", str(steps)], env=env,
+    return subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(out), case, "1" if row_lists else "0", str(steps), "1" if graph else "0"], env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
 
-@pytest.mark.parametrize("row_lists", [True, False], ids=["row_lists", "dense_tables"])
-def test_two_ranks_on_one_gpu_replay_graph_segments_and_match_the_full_batch(tmp_path, row_lists):
+@pytest.mark.parametrize("row_lists,graph", [(True, True), (False, True), (True, False)], ids=["row_lists", "dense_tables", "eager_default"])
+def test_two_ranks_on_one_gpu_replay_graph_segments_and_match_the_full_batch(tmp_path, row_lists, graph):
+    """`eager_default`: graph_under_dp off — what a data-parallel run does unless asked otherwise (the fused step with eager launches)"""
     assert torch.cuda.is_available()
     case, steps = "kkbox_shape", 5          # batch 8 -> 4 per rank; BatchNorm on (SyncBN), wide part, two 3-id bag fields, d = 16
     port = 32500 + (os.getpid() % 2000)
     procs = [_spawn(tmp_path / "single.pt", case, row_lists, steps, {})]
     procs += [_spawn(tmp_path / ("rank%d.pt" % r), case, row_lists, steps,
-                     dict(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in (0, 1)]
+                     dict(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)), graph) for r in (0, 1)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
@@ -76,7 +78,10 @@ def test_two_ranks_on_one_gpu_replay_graph_segments_and_match_the_full_batch(tmp
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
     # one process: the whole step is ONE graph; a rank: segments with the collectives between them
     assert one["segments"] == 1 and one["closures"] == 0
-    assert r0["segments"] == r1["segments"] >= 8 and r0["closures"] == r0["segments"] - 1, (r0["segments"], r0["closures"])
+    if graph:
+        assert r0["segments"] == r1["segments"] >= 8 and r0["closures"] == r0["segments"] - 1, (r0["segments"], r0["closures"])
+    else:
+        assert r0["segments"] == r1["segments"] == 0
     keep = torch.ones_like(one["flat"], dtype=torch.bool)
     for name in one["noise"]:                # biases in front of BatchNorm: true gradient 0, Adam steps on rounding noise
         keep[one["offsets"][name]:one["offsets"][name] + one["sizes"][name]] = False

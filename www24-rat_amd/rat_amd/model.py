@@ -220,6 +220,8 @@ class RAT_m2(BaseModel):
         self._gbuf_clean = False       # True: the buffer is known to hold zeros (left so by the two-sweep optimizer)
         self._tape = None              # a StepGraph that is recording this model's training step (graph.py)
         self._sync_bn = bool(kwargs.get("sync_batch_norm", True))     # under data parallelism: BatchNorm over the GLOBAL batch
+        if "graph_under_dp" in kwargs:
+            self.graph_under_dp = bool(kwargs["graph_under_dp"])
         # how the embedding-table gradients are produced:
         #   "atomic" fp32 atomics into dense tables (fastest, not run-to-run reproducible); "sorted" the same dense tables from a
         #   stable sort + segmented reduction (bit-reproducible); "sparse" (unique rows, gradient rows) lists + lazy row Adam, no
@@ -859,11 +861,18 @@ class RAT_m2(BaseModel):
     row_list_exchange = None    # None: decide by traffic (_row_lists_travel_lighter); True / False: force (tests, experiments)
     _graph_test_splits = False  # tests: cut the captured step into segments the way collectives do under data parallelism
     use_graph = True           # capture the fused iteration into a hipGraph (CUDA devices only)
+    # Under data parallelism the captured step is a chain of graph segments with the collectives between them (graph.py).  That path is
+    # proven on one GPU with two gloo ranks (tests/test_gpu_dp.py) but has never met RCCL — no multi-GPU box was available to this build
+    # — and at the north-star shapes the step is GPU-bound with or without a graph (B = 512: 3.75 ms of kernels in a 3.76 ms step), so it
+    # is opt-in (`graph_under_dp=True` / bench.py --graph-dp) until it has run on a node.
+    graph_under_dp = False
     graph_warmup = 2           # eager fused steps of a batch shape before it is captured
     graph_shapes = 2           # at most this many batch shapes get a graph (the full batch and an epoch's tail batch)
 
     def _step_graph_for(self, batch):
         if not (self.use_graph and batch[0].is_cuda):
+            return None
+        if self._world_size() > 1 and not self.graph_under_dp:
             return None
         c = self._cfg
         if c["attn_dropout"] > 0 or c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers):
