@@ -4,6 +4,7 @@ surface of the built library, and the no-fallback rule."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -105,3 +106,20 @@ def test_compat_registers_fuxictr_namespace():
         for k in [k for k in sys.modules if k.startswith("fuxictr")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_cpu_baseline_runs_both_thread_settings_and_bounds_the_all_cores_attempt(monkeypatch):
+    """bench.py's cpu_baseline: the 32-thread run in-process, the all-cores run in a time-boxed CPU-only child (a 256-thread host needs
+    357 s per step at the full batch).  Tiny workload, an 'os.cpu_count() = 64' host: both complete; with a zero budget the child is ended
+    and the entry says so."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from rat_amd import synthetic
+    monkeypatch.setattr(bench.os, "cpu_count", lambda: 64)
+    spec = synthetic.WORKLOADS["tiny"]
+    out = bench.cpu_baseline("tiny", spec, 32, 1000, timed_steps=1, all_cores_budget_s=120.0)
+    assert [r["threads"] for r in out["runs"]] == [32, 64] and all(r["value"] for r in out["runs"])
+    assert out["value"] == max(r["value"] for r in out["runs"]) and out["kind"] == "port" and out["sample_batch"] == 32
+    out = bench.cpu_baseline("tiny", spec, 32, 1000, timed_steps=1, all_cores_budget_s=0.01)
+    assert out["runs"][1]["value"] is None and "ended" in out["runs"][1]["note"] and out["value"] == out["runs"][0]["value"]
