@@ -75,7 +75,9 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
         else:
             pool = _find(data_dir, "retrieval_pool")
         if rpath is None:
-            rpath = os.path.join(data_dir, "retrieval_%d_%s.npz" % (topk, split))
+            # stored next to the data in the data's own format: retrieval_{K}_{split}.h5 — the reference's file name and keys
+            # (data_generator.py:106-113) — when the split is an HDF5 file, .npz otherwise
+            rpath = os.path.join(data_dir, "retrieval_%d_%s%s" % (topk, split, ".h5" if dpath.endswith(".h5") else ".npz"))
             if shard[0] == 0:                                   # one rank computes and writes the file, the others wait for it
                 precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
             if shard[1] > 1:
@@ -89,7 +91,7 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
 def precompute_retrieval_file(data_path, pool_path, save_path, rcfg, feature_map, params):
     """DataGenerator's pre-retrieval branch (fuxictr/pytorch/data_generator.py:106-215) with the top-K search on the device
     (rat_bm25_topk); the result is stored next to the data like the reference's retrieval_{K}_{split}.h5 (keys indices /
-    values / lens; .npz because this image has no h5py)."""
+    values / lens) — as HDF5 through rat_amd.h5io when the split itself is an .h5 file, as .npz otherwise."""
     import numpy as np
     from rat_amd import retrieval
     if params["gpu"] < 0:
@@ -100,7 +102,11 @@ def precompute_retrieval_file(data_path, pool_path, save_path, rcfg, feature_map
                  "self / %s" % rcfg.get("split_type") if pool is None else "%d rows" % len(pool))
     cols = retrieval.used_col_indices(feature_map, rcfg)
     indices, values, lens = retrieval.precompute_retrieval(data, rcfg, cols, pool_array=pool, device="cuda:%d" % params["gpu"])
-    np.savez_compressed(save_path, indices=indices, values=values, lens=lens)
+    if save_path.endswith(".h5"):
+        from rat_amd import h5io
+        h5io.write_arrays(save_path, {"indices": np.asarray(indices), "values": np.asarray(values), "lens": np.asarray(lens)})
+    else:
+        np.savez_compressed(save_path, indices=indices, values=values, lens=lens)
 
 
 def main(argv=None):

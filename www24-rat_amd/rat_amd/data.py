@@ -5,7 +5,8 @@ The reference builds every sample in a Python ``__getitem__`` (``pool[retr_indic
 processes and collates float64 tensors; this class does the same gather with one vectorised fancy-index per batch and
 hands over int32 ids / float32 labels (the model converts once anyway).  On-disk formats: the reference's ``*.h5``
 (``data`` = float [N, L+1] with the label last; ``retrieval_{K}_{split}.h5`` with ``indices``/``values``/``lens``) are
-read when ``h5py`` is importable; ``.npz`` files with the same keys are always accepted.  A missing retrieval file is
+read through ``h5py`` when it is importable and otherwise through the HDF5 C library itself (``rat_amd/h5io.py``, ctypes over
+``libhdf5``); ``.npz`` files with the same keys are always accepted.  A missing retrieval file is
 computed on the device by ``rat_amd.retrieval.precompute_retrieval`` (run_expid.py), like the reference's DataGenerator does
 with BM25_topk_retrieval_v4."""
 import os
@@ -20,8 +21,14 @@ def load_array_file(path, keys):
         return {k: blob[k] for k in keys}
     try:
         import h5py
-    except ImportError as exc:
-        raise RuntimeError("%s is an HDF5 file and h5py is not installed; export it to .npz with keys %s" % (path, keys)) from exc
+    except ImportError:
+        # no h5py (this image): the HDF5 C library through ctypes (rat_amd/h5io.py) — same files, same keys
+        from . import h5io
+        try:
+            return h5io.read_arrays(path, keys)
+        except h5io.Hdf5Unavailable as exc:
+            raise RuntimeError("%s is an HDF5 file and neither h5py nor libhdf5 is available (%s); export it to .npz with keys %s"
+                               % (path, exc, keys)) from exc
     with h5py.File(path, "r") as hf:
         return {k: hf[k][:] for k in keys}
 
