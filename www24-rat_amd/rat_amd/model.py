@@ -549,6 +549,7 @@ class RAT_m2(BaseModel):
         self._lists_possible = row_aligned      # (sort + segmented reduction needs table rows on 16-byte boundaries)
         self._n_sparse = self._n_tab if mode == "sparse" else 0
         self._gbuf = None
+        self.__dict__.pop("_step_graphs", None)        # captured steps point into the old buffers
         self._build_descriptors()
         self.set_arith(self._arith_request)
 
