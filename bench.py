@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--step-times", action="store_true", help="print the host-side issue time of every timed step to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time the eager fused step instead of hipGraph replays")
+    ap.add_argument("--prune", action="store_true",
+                    help="time the product's default step (dead-token pruning of the last block ON) as the headline instead of the "
+                         "reference-work step; without it the pruned step is an extra object of the line")
     ap.add_argument("--graph-dp", action="store_true",
                     help="N > 1: replay the step as graph segments with the collectives between them (default at N > 1: eager launches; the "
                          "segmented path is proven with two gloo ranks on one GPU, tests/test_gpu_dp.py, but has not met RCCL yet)")
@@ -410,6 +413,12 @@ def worker(args):
         b = synthetic.make_batch(spec, fm, seed=seed, device=dev, as_float64=False)
         return b if lo is None else tuple(t[lo:hi].contiguous() for t in b)
 
+    # The headline `value` is measured with the reference's amount of work: every token of every block.  The product's default
+    # also prunes the last block's dead tokens (RAT_m2.prune_dead_tokens: identical predictions and gradients) — that step is timed
+    # separately and reported beside it as `dead_token_pruning`; --prune makes it the measured step instead.
+    can_prune = hasattr(model, "prune_dead_tokens") and args.model == "RAT_m2"
+    if can_prune:
+        model.prune_dead_tokens = bool(args.prune)
     graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (world == 1 or args.graph_dp)
     model.use_graph = graph_mode
     model.graph_under_dp = bool(args.graph_dp)
@@ -543,6 +552,18 @@ def worker(args):
                         "%d (SURVEY 8e partitioning), measured on this single GPU: value / the headline value = what the fixed per-step "
                         "costs leave of linear strong scaling before any communication" % B)
         del batches
+    pruned = None
+    if extras and can_prune and not args.prune:
+        model.prune_dead_tokens = True
+        batches = [make(1000 + i) for i in range(NBATCH)]
+        el, _ = timed_region(batches, args.steps, 3, "dead_token_pruning", kernel_pass=False)
+        pruned = dict(value=round(B * args.steps / el, 1), unit="samples/s", ms_per_step=round(el / args.steps * 1e3, 3),
+                      what="the product's default step: in the LAST encoder block only the class token's dependencies are computed "
+                           "(cross-sample attention over B instead of B*S sequences, the block MLP on one token per sample); predictions "
+                           "and gradients are those of the full computation (tests: check_pruning_equivalence, the golden cases, the "
+                           "full-size oracle comparisons all run with it on)")
+        model.prune_dead_tokens = False
+        del batches
     ev_over = event_overhead_ms() if rank == 0 else 0.0
     # the embedding gather on a table that cannot sit in any cache: BASELINE.json configs[3]'s 100 M rows x 64 floats = 25.6 GB
     gather_big = None
@@ -647,6 +668,10 @@ def worker(args):
                                         "regulariser folded in)" + (", replayed as a captured hipGraph; `kernels` / `roofline` / `targets` "
                                         "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
                                         else ", eager launches"))
+        result["config"]["dead_token_pruning"] = bool(can_prune and model.prune_dead_tokens)
+        if pruned is not None:
+            pruned["speedup"] = round(pruned["value"] / result["value"], 4)
+            result["dead_token_pruning"] = pruned
         if per_rank is not None:
             per_rank["ratio_to_headline"] = round(per_rank["value"] / result["value"], 4)
             result["per_rank_shape"] = per_rank

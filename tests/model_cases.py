@@ -183,3 +183,33 @@ def check_train_step_api(name, gpu, steps=2, **model_kw):
                 assert float(bad.double().mean()) < 1e-3 and float((a - r).abs().max()) <= 2.1e-3 * step, (k, step)
     assert all(p.grad is None for p in model.parameters()), "the fused step leaves no p.grad behind (zero_grad semantics)"
     return model
+
+
+def check_pruning_equivalence(name, gpu):
+    """RAT_m2.prune_dead_tokens (the last block computes only what the class token depends on) against the full computation on the
+    same weights and batch: the predictions must be the same numbers (per-sequence / per-token arithmetic does not depend on which
+    other rows are computed), the loss too, and every gradient must agree to summation-order rounding — the skipped rows contribute
+    exact zeros."""
+    case = gc.case_by_name(name)
+    out = {}
+    for prune in (True, False):
+        model = build_model(case, gpu=gpu, seed=1)
+        model.prune_dead_tokens = prune
+        load_weights(model, case)
+        batch = batch_of(case)
+        model.eval()
+        with torch.no_grad():
+            yp = model.forward(batch)["y_pred"].detach().cpu().clone()
+        model.train()
+        model.optimizer.zero_grad()
+        loss = model.get_total_loss(batch)
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+        out[prune] = (yp, float(loss), grads)
+    (ya, la, ga), (yb, lb, gb) = out[True], out[False]
+    assert torch.equal(ya, yb), "predictions differ with dead-token pruning"
+    assert abs(la - lb) < 1e-7
+    assert set(ga) == set(gb)
+    for k in ga:
+        scale = float(gb[k].abs().max()) + 1e-30
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * scale + 1e-9, (k, float((ga[k] - gb[k]).abs().max()), scale)

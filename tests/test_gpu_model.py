@@ -97,6 +97,11 @@ def test_train_step_graph_in_segments_with_eager_closures_between():
         assert float(bad.double().mean()) < 1e-3 and float((x - y).abs().max()) <= 1.05e-2, k
 
 
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape", "kkbox_shape", "northstar_shape", "bare_no_proj"])
+def test_dead_token_pruning_changes_nothing(name):
+    mc.check_pruning_equivalence(name, gpu=0)
+
+
 @pytest.mark.parametrize("name", mc.CHECKPOINT_CASES)
 def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):
     """`.model` files written by the reference's own RAT_m2 / m0 / m1 / m3 classes (tests/golden/make_golden_checkpoints.py)"""

@@ -41,6 +41,11 @@ def test_train_step_api_matches_the_reference_run(name):
     mc.check_train_step_api(name, gpu=-1)
 
 
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape"])
+def test_dead_token_pruning_changes_nothing(name):
+    mc.check_pruning_equivalence(name, gpu=-1)
+
+
 # `.model` files written by the reference classes themselves: one on the emulator, all four on the GPU
 @pytest.mark.parametrize("name", ["tiny_seq_bn"])
 def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):

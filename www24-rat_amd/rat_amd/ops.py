@@ -51,6 +51,11 @@ def cross_map(B, T, S):
     return RatSeqMap(nseq=B * S, L=T, q_div=S, hi_stride=T * S, lo_stride=1, pos_stride=S)
 
 
+def cross_map_label_token(B, T, S):
+    """the cross-sample sequences of token position 0 (the label / class token) only: B sequences of T tokens, S tokens apart"""
+    return RatSeqMap(nseq=B, L=T, q_div=1, hi_stride=T * S, lo_stride=0, pos_stride=S)
+
+
 def attn_params(ln_g, ln_b, w_qkv, w_out, b_out, planes=None):
     """planes: optional uint8 tensor of ``attn_planes_bytes`` bytes holding the bf16x3 fragment planes of these weights (filled by
     ``split_weights_batch`` from ``attn_split_jobs``); without it the bf16x3 entry points split the weights on every call."""
@@ -251,16 +256,18 @@ def attn_fwd(x, params, seqmap, d, heads, dim_head, save=False, eps=1e-5, out=No
 
 
 def attn_bwd(x, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=1e-5, workspace=None, arith="f32", dropout=(0.0, 0),
-             lib=None):
+             out=None, lib=None):
+    """out: where dx goes (default: a new tensor); `out is dy` is allowed — a work-group reads the dy rows of its sequences before it
+    writes their dx rows, and rows outside the map's sequences are left as they are."""
     if arith != "f32" or dropout[0] > 0:
         return attn_bwd_ex(x, dy, dy, o_save, lse, params, grads, seqmap, d, heads, dim_head, eps=eps, workspace=workspace,
-                           arith=arith, dropout=dropout, lib=lib)
+                           out=out, arith=arith, dropout=dropout, lib=lib)
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_attn_bwd_workspace", d, heads, dim_head)
     if workspace is None or workspace.numel() * 4 < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
-    dx = torch.empty_like(x)
+    dx = out if out is not None else torch.empty_like(x)
     lib.call("rat_attn_bwd", _p(x), _p(dy), _p(o_save), _p(lse), _p(dx), ctypes.byref(params), ctypes.byref(grads),
              _p(workspace), workspace.numel() * 4, ctypes.byref(seqmap), d, heads, dim_head, eps, _stream(x))
     return dx, workspace
