@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 4
+#define RAT_ABI_VERSION 5
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -87,6 +87,13 @@ int rat_batch_assemble(const int32_t* data_ids, const float* data_labels, const 
 typedef struct RatSeqMap {
     int64_t nseq;
     int32_t L;
+    int32_t queries; /* ABI v5 (the padding of v4): 0 or >= L — every position is a query.  0 < queries < L — only the outputs of
+                      * positions [0, queries) of each sequence are wanted: the forward may leave the other rows of y / o_save /
+                      * lse_save with unspecified (finite) contents, and the backward REQUIRES the dy rows of the other positions
+                      * to be zero (their queries contribute nothing; all positions still serve as keys and values, and dx is
+                      * complete).  The bf16x3 kernels skip the work; every other kernel computes all positions, which the
+                      * contract allows.  Used for the last encoder block, of whose output only x[:, 0][:, 0] is read
+                      * (RAT_m2.py:138-140). */
     int64_t q_div, hi_stride, lo_stride, pos_stride;
 } RatSeqMap;
 

@@ -145,6 +145,55 @@ def check_attn(lib, dev, case, mode, seed=2, arith="f32"):
                 assert torch.equal(a_, b_), ("planes split by the caller", name)
 
 
+def check_attn_queries(lib, dev, case, mode, nq=1, seed=5, arith="f32"):
+    """RatSeqMap.queries (include/rat_hip.h): only the outputs of positions [0, nq) of each sequence are wanted and the gradient rows
+    of the other positions are zero.  Against the oracle with exactly that gradient: y at the query positions, the WHOLE dx (every
+    position is a key and a value), every parameter gradient — and against the same kernels run without `queries` on the same
+    zero-padded dy (the contract says skipping the other queries changes nothing)."""
+    B, T, S, d, heads, dh, proj = case
+    rs = np.random.RandomState(seed)
+    x = rnd(rs, B, T, S, d)
+    ws = attn_weights(rs, d, heads, dh, proj)
+    dy = rnd(rs, B, T, S, d)
+    if mode == "intra":
+        dy[:, :, nq:, :] = 0.0
+        qsel = lambda t: t[:, :, :nq, :]                          # noqa: E731
+        full, part = ops.intra_map(B, T, S), ops.intra_map(B, T, S, queries=nq)
+    else:
+        dy[:, nq:, :, :] = 0.0
+        qsel = lambda t: t[:, :nq, :, :]                          # noqa: E731
+        full = ops.cross_map(B, T, S)
+        part = ops.cross_map(B, T, S)
+        part.queries = nq
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) if w is not None else None for w in ws]
+    ref = attn_reference(xr, *wr, heads, dh, mode)
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    wd = [w.to(dev) if w is not None else None for w in ws]
+    params = ops.attn_params(*wd)
+    names = ["ln_g", "ln_b", "w_qkv", "w_out", "b_out"]
+    res = {}
+    for key, smap in (("part", part), ("full", full)):
+        y, o_save, lse = ops.attn_fwd(xd, params, smap, d, heads, dh, save=True, arith=arith, lib=lib)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(o_save).all()) and bool(torch.isfinite(lse).all())
+        gs = [torch.zeros_like(w) if w is not None else None for w in wd]
+        dx, _ = ops.attn_bwd(xd, dyd, o_save, lse, params, ops.attn_params(*gs), smap, d, heads, dh, arith=arith, lib=lib)
+        res[key] = (y, dx, gs)
+    y, dx, gs = res["part"]
+    close(qsel(y), qsel(ref), 2e-5, 2e-5, "y at the query positions")
+    scale = max(1.0, (B * T * S) ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    for name, g, w in zip(names, gs, wr):
+        if w is not None:
+            close(g, w.grad, 1e-4, 1e-4 * scale, name)
+    y0, dx0, g0 = res["full"]
+    assert torch.equal(qsel(y), qsel(y0))
+    for name, a_, b_ in [("dx", dx, dx0)] + [(n, ga, gb) for n, ga, gb in zip(names, gs, g0) if ga is not None]:
+        err = float((a_ - b_).abs().max()) / (float(b_.abs().max()) + 1e-30)
+        assert err < 2e-6, ("queries vs all positions", name, err)
+
+
 def check_attn_dropout(lib, dev, case, mode, p=0.25, seed=123456789, arith="f32"):
     """Dropout behind the output projection (RAT_m2.py:186-189): y = Dropout(to_out(...)) + x.  The mask is a pure function of
     (seed, element index) — the generator of rat_dropout — so the reference uses the mask that rat_dropout produces on ones."""

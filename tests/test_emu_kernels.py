@@ -84,6 +84,15 @@ def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blo
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), "intra", arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode,nq,arith", [((2, 6, 21, 64, 8, 10, True), "intra", 1, "bf16x3"), ((3, 11, 4, 64, 8, 10, True), "cross", 1, "bf16x3"),
+                                                ((1, 3, 7, 64, 8, 10, True), "intra", 3, "bf16x3"), ((2, 3, 4, 8, 2, 4, True), "intra", 1, "f32"),
+                                                ((1, 2, 5, 64, 8, 10, True), "cross", 1, "f32")],
+                         ids=["b3_intra_L21", "b3_cross_L11", "b3_three_queries", "generic_ignores", "fast_f32_ignores"])
+def test_attn_with_a_subset_of_query_positions(emu, case, mode, nq, arith, two_blocks):
+    """RatSeqMap.queries: the bf16x3 kernels skip the other queries, the exact-fp32 kernels compute them all (both within the contract)"""
+    kc.check_attn_queries(emu, "cpu", case, mode, nq=nq, arith=arith)
+
+
 @pytest.mark.parametrize("case,arith", [((2, 3, 4, 8, 2, 4, True), "f32"), ((1, 2, 5, 64, 8, 10, True), "f32"), ((1, 3, 5, 64, 8, 10, True), "bf16x3")],
                          ids=["generic", "fast_f32", "bf16x3"])
 def test_attention_output_dropout(emu, case, arith):

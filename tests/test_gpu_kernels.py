@@ -62,6 +62,15 @@ def test_attn_fwd_bwd_bf16x3(lib, case, mode):
     kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode,nq,arith", [((4, 11, 21, 64, 8, 10, True), "intra", 1, "bf16x3"), ((40, 11, 21, 64, 8, 10, True), "intra", 1, "bf16x3"),
+                                                ((30, 11, 4, 64, 8, 10, True), "cross", 1, "bf16x3"), ((2, 3, 7, 64, 8, 10, True), "intra", 3, "bf16x3"),
+                                                ((2, 3, 4, 8, 2, 4, True), "intra", 1, "f32"), ((2, 4, 5, 64, 8, 10, True), "cross", 1, "f32")],
+                         ids=["b3_intra_L21", "b3_intra_many_chunks", "b3_cross_L11", "b3_three_queries", "generic_ignores", "fast_f32_ignores"])
+def test_attn_with_a_subset_of_query_positions(lib, case, mode, nq, arith):
+    """RatSeqMap.queries (the last encoder block's dead-token pruning): the bf16x3 kernels skip the other queries"""
+    kc.check_attn_queries(lib, "cuda", case, mode, nq=nq, arith=arith)
+
+
 @pytest.mark.parametrize("case", B3_CASES, ids=str)
 @pytest.mark.parametrize("mode", ["intra", "cross"])
 def test_attn_fwd_bf16x3_matrix_core(lib, case, mode, monkeypatch):

@@ -41,7 +41,7 @@ def test_train_step_api_matches_the_reference_run(name):
     mc.check_train_step_api(name, gpu=-1)
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape", "northstar_shape"])      # the last one: bf16x3 kernels, RatSeqMap.queries
 def test_dead_token_pruning_changes_nothing(name):
     mc.check_pruning_equivalence(name, gpu=-1)
 

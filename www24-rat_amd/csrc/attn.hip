@@ -61,6 +61,7 @@ struct AttnArgs {
     int64_t nseq, q_div, hi_stride, lo_stride, pos_stride;
     int64_t nchunks;
     int L, nsq_chunk;
+    int nq;              // RatSeqMap.queries: only the first nq positions of a sequence are QUERIES that matter (L: all of them)
     int d, heads, dh;
     float eps, scale;
     int vec_x, vec_wqkv, vec_wout;
@@ -1136,7 +1137,8 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, 
     }
 }
 
-template <bool EX>
+// QSUB: RatSeqMap.queries < L is honoured (a separate instantiation: the ordinary one must not carry a second trip count)
+template <bool EX, bool QSUB = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                 // LayerNorm(x) planes; later the fp32 output staging tile
@@ -1199,12 +1201,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)   // (no prefetch: +2-3 %, same-box A/B)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
         typedef HeadVec<B3_DH> HV;
-        const int ntasks = nsq * B3_H * L;
+        const int nq = QSUB ? a.nq : L;                          // queries that matter per sequence (RatSeqMap.queries; normally L)
+        const int ntasks = nsq * B3_H * nq;
         const float sl2 = a.scale * RAT_LOG2E;
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
-            const int i = task % L;
-            const int h = (task / L) % B3_H;
-            const int sq = task / (L * B3_H);
+            const int i = task % nq;
+            const int h = (task / nq) % B3_H;
+            const int sq = task / (nq * B3_H);
             const int row_i = sq * L + i;
             float* qp = qkv + (size_t)row_i * B3_LDQ + h * B3_DH;
             HV q, o, kv;
@@ -1251,6 +1254,18 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             const int64_t tok = rowtok[row_i];
             if (a.o_save != nullptr) o.store(a.o_save + tok * B3_I + h * B3_DH, B3_DH, inv);
             if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = m + rat_log2(l);
+        }
+        if (QSUB && nq < L) {                                    // the positions nobody asked for: O = 0, lse = 0 (defined, never used)
+            for (int e = threadIdx.x; e < rows * B3_H; e += ATT_THREADS) {
+                const int r = e / B3_H, h = e - r * B3_H;
+                if (r % L < nq) continue;
+                HV z;
+                z.zero();
+                z.store(qkv + (size_t)r * B3_LDQ + h * B3_DH, B3_DH, 1.0f);
+                const int64_t tok = rowtok[r];
+                if (a.o_save != nullptr) z.store(a.o_save + tok * B3_I + h * B3_DH, B3_DH, 1.0f);
+                if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = 0.f;
+            }
         }
         __syncthreads();
         RAT_PROF_MARK(2);
@@ -1750,7 +1765,7 @@ __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes
     epi(mt0 + 1, nt, acc[1]);
 }
 
-template <bool EX>
+template <bool EX, bool QSUB = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                  // LayerNorm(x)
@@ -1887,13 +1902,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         // row pos; step t: key (pos + t) mod L, (p, dS) handed to the key's owner by a lane shuffle, so nothing is recomputed: 25
         // instead of 35 packed FMAs per pair): correct, but +29 % at L = 21 and +16 % at L = 11 — its K / V / q / dO reads are a
         // different row per lane, while in both passes below all lanes of a group read the SAME row (an LDS broadcast).
+        // RatSeqMap.queries < L: the dy rows of the other positions are zero by contract, so their dQ is zero and they add nothing to
+        // dK / dV — pass 1 runs for nq queries per sequence, pass 2 sums over them.
         typedef HeadVec<B3_DH> HV;
-        const int ntasks = nsq * B3_H * L;
+        const int nq = QSUB ? a.nq : L;
+        const int ntasks = nsq * B3_H * L, nqtasks = QSUB ? nsq * B3_H * nq : ntasks;
         const float sl2 = a.scale * RAT_LOG2E;
-        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
-            const int i = task % L;
-            const int h = (task / L) % B3_H;
-            const int sq = task / (L * B3_H);
+        for (int task = threadIdx.x; task < nqtasks; task += ATT_THREADS) {
+            const int i = task % nq;
+            const int h = (task / nq) % B3_H;
+            const int sq = task / (nq * B3_H);
             const int row_i = sq * L + i;
             const int ho = h * B3_DH;
             float* opp = ob + (size_t)row_i * B3_LDT + ho;
@@ -1916,6 +1934,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             }
             dq.store(opp, B3_DH, a.scale);
         }
+        if (QSUB && nq < L) {
+            for (int e = threadIdx.x; e < nsq * L * B3_H; e += ATT_THREADS) {
+                const int r = e / B3_H, h = e - r * B3_H;
+                if (r % L < nq) continue;
+                HV z;
+                z.zero();
+                z.store(ob + (size_t)r * B3_LDT + h * B3_DH, B3_DH, 1.0f);    // dQ of a position that is no query
+            }
+        }
         __syncthreads();
         RAT_PROF_MARK(4);
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
@@ -1929,7 +1956,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             vv.load(kp + B3_I, B3_DH);
             dk.zero();
             dv.zero();
-            for (int i = 0; i < L; ++i) {
+            for (int i = 0; i < nq; ++i) {
                 const int row_i = sq * L + i;
                 t.load(dob + (size_t)row_i * B3_LDT + ho, B3_DH);
                 const float dp = t.dot(vv);
@@ -2136,6 +2163,7 @@ void fill_common(AttnArgs& a, const RatAttnParams* w, const RatSeqMap* map, int 
     a.lo_stride = map->lo_stride;
     a.pos_stride = map->pos_stride;
     a.L = map->L;
+    a.nq = (map->queries > 0 && map->queries < map->L) ? map->queries : map->L;
     a.nsq_chunk = ATT_ROWS / map->L;
     a.nchunks = (map->nseq + a.nsq_chunk - 1) / a.nsq_chunk;
     a.d = d;
@@ -2256,8 +2284,9 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         if (mfma_core && b3m_fits(a.L, a.nsq_chunk)) {
             if (plain) RAT_LAUNCH((attn_fwd3m_kernel<false>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_fwd3m_kernel<true>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
-        } else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
-        else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        } else if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);   // (computes every position)
         return rat_check_launch("rat_attn_fwd (bf16x3)");
     }
     const bool head_vec = aligned8(o_save);            // else the run-time dim_head kernel (4-byte accesses), which stops at DH_MAX
@@ -2346,8 +2375,9 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.outT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 2};
         W.qkvT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV + B3_W_OUTT), 8};
-        if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-        else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);       // (computes every position)
     } else if (!aligned8(o_save)) {                    // run-time dim_head kernel: 4-byte accesses, dim_head <= DH_MAX
         RAT_REQUIRE(dim_head <= DH_MAX, "o_save must be 8-byte aligned for dim_head 20");
         RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);

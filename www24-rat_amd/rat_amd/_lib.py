@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class RatField(Structure):
@@ -19,8 +19,8 @@ class RatField(Structure):
 
 
 class RatSeqMap(Structure):
-    _fields_ = [("nseq", c_int64), ("L", c_int32), ("q_div", c_int64), ("hi_stride", c_int64), ("lo_stride", c_int64),
-                ("pos_stride", c_int64)]
+    _fields_ = [("nseq", c_int64), ("L", c_int32), ("queries", c_int32), ("q_div", c_int64), ("hi_stride", c_int64),
+                ("lo_stride", c_int64), ("pos_stride", c_int64)]
 
 
 class RatAttnParams(Structure):

@@ -474,16 +474,19 @@ class RAT_m2(BaseModel):
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
         self._refresh_weight_planes()
         last = len(self._blocks) - 1
+        prune = self.prune_dead_tokens and self._attn_is_fused(cmap)
         for bi, blk in enumerate(self._blocks):
             inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
-            xa, a1 = self._attn_layer_forward(blk["intra"], x, imap, save, out=x if inplace else None)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            if bi == last and self.prune_dead_tokens and self._attn_is_fused(cmap):
+            if bi == last and prune:
                 # Only token (t = 0, s = 0) of the encoder's output is ever read (RAT_m2.py:138-140: x[:, 0][:, 0]).  In the LAST block
-                # that token depends on the cross-sample sequence of token position 0 alone (B sequences instead of B S) and on the
-                # feed-forward of ONE token per sample; every other output of these two layers is dead — computed by the reference,
-                # read by nobody, with a gradient of exactly zero.  They are not computed: same y_pred, same gradients.
-                cm0 = ops.cross_map_label_token(B, T, S)
+                # that token depends on the cross-sample sequence of token position 0 alone (B sequences instead of B S) — of which
+                # only position 0 is a query —, on the feed-forward of ONE token per sample, and on the intra-sample layer's output
+                # at token position 0 of every sample (all S positions are its keys and values, ONE is a query: RatSeqMap.queries).
+                # Every other output of these three layers is dead — computed by the reference, read by nobody, with a gradient of
+                # exactly zero.  They are not computed: same y_pred, same gradients.
+                xa, a1 = self._attn_layer_forward(blk["intra"], x, ops.intra_map(B, T, S, queries=1), save, out=x if inplace else None)
+                cm0 = ops.cross_map_label_token(B, T, S, queries=1)
                 xb, a2 = self._attn_layer_forward(blk["cross"], xa, cm0, save, out=xa if not save else None)
                 xcls_in = xb[:, 0, 0, :].contiguous()                                  # [B, d]
                 xc = ops.ffn_fwd(xcls_in, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)
@@ -491,6 +494,7 @@ class RAT_m2(BaseModel):
                     saved["blocks"].append((x, a1, xa, a2, xcls_in))
                     saved["pruned"] = True
                 return xc, d
+            xa, a1 = self._attn_layer_forward(blk["intra"], x, imap, save, out=x if inplace else None)
             xb, a2 = self._attn_layer_forward(blk["cross"], xa, cmap, save, out=xa if not save else None)
             xc = ops.ffn_fwd(xb, w1, b1, w2, b2, d, H, out=xb if not save else None, arith=self.arith, lib=lib)
             if save:
@@ -516,9 +520,10 @@ class RAT_m2(BaseModel):
                 dgrid[:, 0, 0, :] = dcls
                 # cross-sample attention backward over the B sequences of token position 0, IN PLACE: their rows of dgrid become dx,
                 # every other row stays zero — exactly the gradient the intra-sample layer below would have been handed
-                cm0 = ops.cross_map_label_token(B, T, S)
+                # (both layers with ONE query position per sequence — RatSeqMap.queries —: the gradient rows of the others are zero)
+                cm0 = ops.cross_map_label_token(B, T, S, queries=1)
                 dx = self._attn_layer_backward(blk["cross"], xa, dgrid, a2, cm0, G, out=dgrid)
-                dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G)
+                dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, ops.intra_map(B, T, S, queries=1), G)
                 continue
             dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
                                 planes=blk["ffn_planes"], lib=lib)
@@ -886,9 +891,9 @@ class RAT_m2(BaseModel):
             self._inv_world_t, self._inv_world_n = t, world
         return t
 
-    # Dead-token pruning of the last encoder block (see _encoder_forward): on by default — identical predictions and gradients, two
-    # layers of the sixteen shrink to 1/S and 1/(T S) of their size.  bench.py reports the step with it OFF as its headline value (the
-    # reference's amount of work) and the step with it ON beside it.
+    # Dead-token pruning of the last encoder block (see _encoder_forward): on by default — identical predictions and gradients; of the
+    # twelve encoder layers (depth 4) two shrink to 1/S and 1/(T S) of their size and one keeps a single query per sequence.  bench.py
+    # reports the step with it OFF as its headline value (the reference's amount of work) and the step with it ON beside it.
     prune_dead_tokens = True
     row_list_exchange = None    # None: decide by traffic (_row_lists_travel_lighter); True / False: force (tests, experiments)
     _graph_test_splits = False  # tests: cut the captured step into segments the way collectives do under data parallelism

@@ -43,17 +43,18 @@ def field_table(fields, tables, device):
     return raw.to(device)
 
 
-def intra_map(B, T, S):
-    return RatSeqMap(nseq=B * T, L=S, q_div=B * T, hi_stride=0, lo_stride=S, pos_stride=1)
+def intra_map(B, T, S, queries=0):
+    """queries: RatSeqMap.queries — 0 = every position; n: only the outputs of positions [0, n) of each sequence are wanted"""
+    return RatSeqMap(nseq=B * T, L=S, queries=queries, q_div=B * T, hi_stride=0, lo_stride=S, pos_stride=1)
 
 
 def cross_map(B, T, S):
     return RatSeqMap(nseq=B * S, L=T, q_div=S, hi_stride=T * S, lo_stride=1, pos_stride=S)
 
 
-def cross_map_label_token(B, T, S):
+def cross_map_label_token(B, T, S, queries=0):
     """the cross-sample sequences of token position 0 (the label / class token) only: B sequences of T tokens, S tokens apart"""
-    return RatSeqMap(nseq=B, L=T, q_div=1, hi_stride=T * S, lo_stride=0, pos_stride=S)
+    return RatSeqMap(nseq=B, L=T, queries=queries, q_div=1, hi_stride=T * S, lo_stride=0, pos_stride=S)
 
 
 def attn_params(ln_g, ln_b, w_qkv, w_out, b_out, planes=None):
