@@ -77,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--prune", action="store_true",
                     help="time the product's default step (dead-token pruning of the last block ON) as the headline instead of the "
                          "reference-work step; without it the pruned step is an extra object of the line")
+    ap.add_argument("--dp-rehearsal", action="store_true",
+                    help="with one rank: run the N > 1 code path anyway (RCCL process group of one rank, the model's data-parallel "
+                         "path with every collective issued, barriers, weak and strong regions) — the 1-GPU rehearsal of the scaling job")
     ap.add_argument("--graph-dp", action="store_true",
                     help="N > 1: replay the step as graph segments with the collectives between them (default at N > 1: eager launches; the "
                          "segmented path is proven with two gloo ranks on one GPU, tests/test_gpu_dp.py, but has not met RCCL yet)")
@@ -380,9 +383,27 @@ def worker(args):
     else:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    # --dp-rehearsal: ONE rank goes through everything the N > 1 run goes through — an RCCL process group, the data-parallel code path
+    # of the model (dp_single_rank: every collective of the step is issued), the barriers and the max-over-ranks reduction of this
+    # file, the weak AND the strong region.  It is the only way to put the N > 1 bench on the one GPU of a gpurun box.
+    dp = world > 1 or args.dp_rehearsal
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout must carry the one JSON line only, so
+        # file descriptor 1 points at stderr until the first collective is through
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)
+            if not dry:
+                dist.barrier()
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
 
     spec = synthetic.WORKLOADS[args.workload]
     if args.batch:
@@ -398,13 +419,15 @@ def worker(args):
     model = getattr(models, args.model)(fm, **kwargs)
     if args.arith is not None:
         model.set_arith(args.arith)
+    if args.dp_rehearsal and world == 1:
+        model.dp_single_rank = True
     B = spec["batch"]
     dev = model.device if not dry else None
     model.train()
     timer = KernelTimer(model._lib, everything=args.time_all_kernels, host_events=dry)
 
     def sync():
-        if world > 1:
+        if dp:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize()
@@ -419,7 +442,7 @@ def worker(args):
     can_prune = hasattr(model, "prune_dead_tokens") and args.model == "RAT_m2"
     if can_prune:
         model.prune_dead_tokens = bool(args.prune)
-    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (world == 1 or args.graph_dp)
+    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or args.graph_dp)
     model.use_graph = graph_mode
     model.graph_under_dp = bool(args.graph_dp)
     model.graph_shapes = 8                       # weak / strong / per-rank shapes and both arithmetics each get their own graph
@@ -466,7 +489,7 @@ def worker(args):
             stamps.append(time.perf_counter())
             print("%s step issue times (ms): %s" % (label, " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(stamps, stamps[1:]))),
                   file=sys.stderr)
-        if world > 1:
+        if dp:
             t = torch.tensor([elapsed], dtype=torch.float64, device=model.device if not dry else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t[0])
@@ -512,8 +535,8 @@ def worker(args):
         ts = sorted(s_.elapsed_time(e_) for s_, e_ in evs)
         return ts[len(ts) // 2]
 
-    want_weak = world == 1 or args.scaling in ("both", "weak")
-    want_strong = world > 1 and args.scaling in ("both", "strong")
+    want_weak = not dp or args.scaling in ("both", "weak")
+    want_strong = dp and args.scaling in ("both", "strong")
     weak = strong = None
     if want_weak:                                  # every rank its own batches of B samples
         batches = [make(1000 + 16 * rank + i) for i in range(NBATCH)]
@@ -527,7 +550,7 @@ def worker(args):
 
     # exact-fp32 arithmetic timed beside the default one in the SAME invocation; N = 1 only
     alt = None
-    if world == 1 and args.arith is None and not args.no_extras and hasattr(model, "arith_modes") and len(model.arith_modes()) > 1:
+    if not dp and args.arith is None and not args.no_extras and hasattr(model, "arith_modes") and len(model.arith_modes()) > 1:
         default_arith = model.arith
         other = [m for m in model.arith_modes() if m != default_arith][0]
         model.set_arith(other)
@@ -538,7 +561,7 @@ def worker(args):
         model.set_arith(default_arith)
         del batches
 
-    extras = world == 1 and not args.no_extras and not dry
+    extras = not dp and not args.no_extras and not dry
     if alt is not None and args.no_extras:
         alt = None
     # §8e's strong-scaling partitioning on ONE GPU: the per-rank shape of an 8-GPU run of the global batch (B/8 samples per step)
@@ -655,7 +678,7 @@ def worker(args):
                                   embedding_dim=spec["d"], batch_per_gpu=per_rank_batch, global_batch=gbatch, heads=spec["num_heads"],
                                   dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
                                   dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam", embedding_grad=model._grad_mode,
-                                  embedding_regularizer=model._cfg["lam_emb"], sync_batch_norm=bool(world > 1 and spec["batch_norm"]),
+                                  embedding_regularizer=model._cfg["lam_emb"], sync_batch_norm=bool(dp and spec["batch_norm"]),
                                   parallelism="dp%d" % world),
                       roofline=roofline, targets=targets, kernels=kernels)
         if strong is not None and weak is not None:
@@ -669,6 +692,8 @@ def worker(args):
                                         "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
                                         else ", eager launches"))
         result["config"]["dead_token_pruning"] = bool(can_prune and model.prune_dead_tokens)
+        if args.dp_rehearsal:
+            result["dp_rehearsal"] = "one rank through the N > 1 code path (RCCL group of one rank, every collective of the step issued)"
         if pruned is not None:
             pruned["speedup"] = round(pruned["value"] / result["value"], 4)
             result["dead_token_pruning"] = pruned
@@ -681,12 +706,12 @@ def worker(args):
             result["config"]["variant"] = args.model
         if dry:
             result["dry_run_cpu"] = True
-        if world == 1 and not args.no_cpu_baseline and not dry:
+        if not dp and not args.no_cpu_baseline and not dry:
             result["cpu_baseline"] = cpu_baseline(args.workload, spec, args.cpu_batch or B, seed=1000, model=args.model,
                                                   timed_steps=args.cpu_steps)
         print(json.dumps(result))
         sys.stdout.flush()
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
     return 0

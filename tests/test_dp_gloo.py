@@ -45,6 +45,9 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, r
     per = batch[0].shape[0] // world
     shard = tuple(t[rank * per:(rank + 1) * per] for t in batch)
     model.train()
+    if world == 1:
+        model.dp_single_rank = True           # one rank through the data-parallel path (what tests/test_gpu_rccl.py does with RCCL)
+        assert model._dp()
     merges, inner = [0], model._merge_sparse
 
     def counting_merge(part):
@@ -107,3 +110,37 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists):
         np.testing.assert_allclose(r0["buffers"][k].numpy(), v.numpy(), rtol=2e-5, atol=atol)
     # each rank reports (local BCE + reg)/world; their sum is the full-batch loss
     assert abs(float(r0["loss"] + r1["loss"]) - float(full_loss)) < 1e-5
+
+
+@pytest.mark.parametrize("row_lists", [True, False], ids=["row_lists", "dense_tables"])
+def test_one_rank_through_the_data_parallel_path_equals_the_plain_step(row_lists):
+    """`dp_single_rank`: a process group of ONE rank issues every collective of the step (SyncBN all-gathers, the async dense-net
+    all-reduce, the row-list all-gathers + merge or the dense table all-reduce) and must land where the plain step lands — the
+    CPU twin of tests/test_gpu_rccl.py, which runs the same thing on RCCL."""
+    _setup_paths()
+    import build_emu
+    import rat_amd._lib as L
+    emu_path = build_emu.build()
+    old = L._default
+    L._default = L.RatLib(emu_path)
+    try:
+        case, model, batch = _make("tiny_seq_bn", True)
+        assert not model._dp()
+        model.train()
+        for _ in range(2):
+            full_loss = model.train_step(batch)
+        ref = model._flat.clone()
+        import model_cases as mc
+        keep = torch.ones_like(ref, dtype=torch.bool)
+        for name in mc.noise_tensors(model):
+            o = model._offsets[name]
+            keep[o:o + model._params[name].numel()] = False
+    finally:
+        L._default = old
+    port = 27500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_worker, args=(1, port, "tiny_seq_bn", emu_path, out_dir, True, row_lists), nprocs=1, join=True)
+        r0 = torch.load(os.path.join(out_dir, "rank0.pt"))
+    assert r0["merges"] == (4 if row_lists else 0)
+    np.testing.assert_allclose(r0["flat"][keep].numpy(), ref[keep].numpy(), rtol=2e-4, atol=2e-6)
+    assert abs(float(r0["loss"]) - float(full_loss)) < 1e-5

@@ -191,7 +191,7 @@ class BaseModel(nn.Module):
     def _agreed_value(self, value):
         """Data parallelism: all ranks act on rank 0's monitored value (validation shards may differ per rank; a rank that
         stopped or decayed alone would dead-lock the next all-reduce)."""
-        if self._world_size() > 1:
+        if self._dp():
             import torch.distributed as dist
             box = torch.tensor([value], dtype=torch.float64, device=self.device if self.device.type == "cuda" else "cpu")
             dist.broadcast(box, src=0)
@@ -207,7 +207,7 @@ class BaseModel(nn.Module):
     def _save_checkpoint(self):
         if self._rank() == 0:
             self.save_weights(self.checkpoint)
-        if self._world_size() > 1:
+        if self._dp():
             import torch.distributed as dist
             dist.barrier()
 
@@ -346,6 +346,18 @@ class BaseModel(nn.Module):
     def _world_size(self):
         import torch.distributed as dist
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    # A process group of ONE rank normally trains like a single process (no collective is issued).  dp_single_rank = True sends it
+    # through the data-parallel code path anyway — every all-reduce / all-gather / barrier of a step, on one rank: the only way a
+    # 1-GPU box can put the RCCL calls of the N > 1 path on real hardware (tests/test_gpu_rccl.py).
+    dp_single_rank = False
+
+    def _dp(self):
+        """the data-parallel code path is active"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or self.dp_single_rank
 
     def _rank(self):
         import torch.distributed as dist

@@ -689,7 +689,7 @@ class RAT_m2(BaseModel):
         deterministic plan + segmented reduction on every rank (28.8 MB per rank at the north-star strong-scaling shape instead of
         a 257 MB all-reduce; the regulariser's lambda*W is replica-identical and never travels); otherwise one dense all-reduce.
         `g`: the flat gradient buffer when the caller holds it (the fused step; p.grad is not populated there)."""
-        if self._world_size() == 1:
+        if not self._dp():
             return
         explicit = g is not None
         if g is None:
@@ -787,11 +787,11 @@ class RAT_m2(BaseModel):
         the training loop synchronises anyway: end of an epoch / of an evaluation) and raises like the reference would."""
         world = self._world_size()
         if self._id_errors is None:
-            if world == 1:
+            if not self._dp():
                 return
             self._id_errors = torch.zeros(2, dtype=torch.int32, device=self.device)
         counts = self._id_errors
-        if world > 1:            # every rank raises together (a rank that raised alone would leave the others in the next collective)
+        if self._dp():           # every rank raises together (a rank that raised alone would leave the others in the next collective)
             counts = self._all_reduce_sum(counts.clone())
         bad_ids, bad_labels = [int(v) for v in counts.tolist()]
         if bad_ids or bad_labels:
@@ -859,7 +859,7 @@ class RAT_m2(BaseModel):
         _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
         if self._graph_test_splits:
             self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
-        self._run_backward(saved, inv, None, table_lists=world > 1 and self._row_lists_travel_lighter(batch[0].shape, world))
+        self._run_backward(saved, inv, None, table_lists=self._dp() and self._row_lists_travel_lighter(batch[0].shape, world))
         if self._graph_test_splits:
             self._collective(lambda: None)
         g = self._last_gflat
@@ -909,13 +909,13 @@ class RAT_m2(BaseModel):
     def _step_graph_for(self, batch):
         if not (self.use_graph and batch[0].is_cuda):
             return None
-        if self._world_size() > 1 and not self.graph_under_dp:
+        if self._dp() and not self.graph_under_dp:
             return None
         c = self._cfg
         if c["attn_dropout"] > 0 or c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers):
             return None                                    # dropout seeds are drawn on the host per step: not replayable
         graphs = self.__dict__.setdefault("_step_graphs", {})
-        key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), bool(self.prune_dead_tokens))
+        key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens))
         entry = graphs.get(key)
         if entry is None:
             if len(graphs) >= self.graph_shapes:
@@ -991,7 +991,7 @@ class RAT_m2(BaseModel):
                 ops.sgemm(0, 1, B, N, K, a_prev, lda, W, K, z, N, bias=bvec, arith=self.gemm_arith, lib=lib)
                 if bn is not None:
                     m = mods[bn]
-                    if training and self._sync_bn and self._world_size() > 1:         # SyncBN: statistics of the GLOBAL batch
+                    if training and self._sync_bn and self._dp():                     # SyncBN: statistics of the GLOBAL batch
                         a, sm, sr, gstats = ops.bn_relu_fwd_sync(z, m.weight.data, m.bias.data, m.running_mean, m.running_var,
                                                                  self._all_gather_flat, eps=m.eps, momentum=m.momentum, lib=lib)
                         sm = (sm, gstats)
@@ -1101,7 +1101,7 @@ class RAT_m2(BaseModel):
         if g_reg is not None and c["lam_net"] > 0:
             g_reg_dev = g_reg.reshape(1).to(torch.float32).contiguous()
             ops.l2_reg(self._flat[self._n_emb:], gflat[n_dense0:], c["lam_net"], None, lam_scale_dev=g_reg_dev, lib=lib)
-        if self._world_size() > 1 and n_dense0 < gflat.numel() and self._gbuf is not None and gflat is self._gbuf[0]:
+        if self._dp() and n_dense0 < gflat.numel() and self._gbuf is not None and gflat is self._gbuf[0]:
             # (a fresh buffer means some p.grad was still held — gradient accumulation: autograd will ADD this buffer into p.grad,
             # so nothing is reduced early; _exchange_gradients falls back to one all-reduce of the accumulated gradients)
             import torch.distributed as dist
