@@ -15,6 +15,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from conftest import twin
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -65,7 +67,8 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, r
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch_norm,row_lists", [(False, True), (True, True), (True, False)], ids=["bn_off", "sync_bn", "sync_bn_dense_tables"])
+@pytest.mark.parametrize("batch_norm,row_lists", [twin(False, True, id="bn_off"), pytest.param(True, True, id="sync_bn"),
+                                                  pytest.param(True, False, id="sync_bn_dense_tables")])
 def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists):
     _setup_paths()
     import build_emu
@@ -112,7 +115,7 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists):
     assert abs(float(r0["loss"] + r1["loss"]) - float(full_loss)) < 1e-5
 
 
-@pytest.mark.parametrize("row_lists", [True, False], ids=["row_lists", "dense_tables"])
+@pytest.mark.parametrize("row_lists", [pytest.param(True, id="row_lists"), twin(False, id="dense_tables")])
 def test_one_rank_through_the_data_parallel_path_equals_the_plain_step(row_lists):
     """`dp_single_rank`: a process group of ONE rank issues every collective of the step (SyncBN all-gathers, the async dense-net
     all-reduce, the row-list all-gathers + merge or the dense table all-reduce) and must land where the plain step lands — the

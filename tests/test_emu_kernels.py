@@ -6,6 +6,7 @@ import os
 import sys
 
 import pytest
+from conftest import gpu_twin, twin
 
 import kernel_cases as kc
 from rat_amd._lib import RatLib
@@ -70,8 +71,8 @@ def test_attn_fwd_bwd_bf16x3(emu, mode, two_blocks):
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), mode, arith="bf16x3")
 
 
-@pytest.mark.parametrize("case,mode", [((1, 11, 4, 64, 8, 10, True), "cross"), ((1, 2, 33, 64, 8, 10, True), "intra"),
-                                       ((3, 16, 2, 64, 8, 10, True), "cross")], ids=["L11", "L33", "L16"])
+@pytest.mark.parametrize("case,mode", [pytest.param((1, 11, 4, 64, 8, 10, True), "cross", id="L11"), pytest.param((1, 2, 33, 64, 8, 10, True), "intra", id="L33"),
+                                       twin((3, 16, 2, 64, 8, 10, True), "cross", id="L16")])
 def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, monkeypatch):
     """attn_fwd3m_kernel (QK^T and PV on the bf16 MFMA as well; opt-in: measured slower than the VALU core): one key
     block with masked keys (L = 11), exactly one block (16), three blocks with one sequence per chunk (33)"""
@@ -79,15 +80,17 @@ def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, monkey
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
 
 
+@gpu_twin
 def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blocks, monkeypatch):
     monkeypatch.setenv("RAT_ATTN_FWD_CORE", "mfma")
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), "intra", arith="bf16x3")
 
 
-@pytest.mark.parametrize("case,mode,nq,arith", [((2, 6, 21, 64, 8, 10, True), "intra", 1, "bf16x3"), ((3, 11, 4, 64, 8, 10, True), "cross", 1, "bf16x3"),
-                                                ((1, 3, 7, 64, 8, 10, True), "intra", 3, "bf16x3"), ((2, 3, 4, 8, 2, 4, True), "intra", 1, "f32"),
-                                                ((1, 2, 5, 64, 8, 10, True), "cross", 1, "f32")],
-                         ids=["b3_intra_L21", "b3_cross_L11", "b3_three_queries", "generic_ignores", "fast_f32_ignores"])
+@pytest.mark.parametrize("case,mode,nq,arith", [pytest.param((2, 6, 21, 64, 8, 10, True), "intra", 1, "bf16x3", id="b3_intra_L21"),
+                                                twin((3, 11, 4, 64, 8, 10, True), "cross", 1, "bf16x3", id="b3_cross_L11"),
+                                                pytest.param((1, 3, 7, 64, 8, 10, True), "intra", 3, "bf16x3", id="b3_three_queries"),
+                                                pytest.param((2, 3, 4, 8, 2, 4, True), "intra", 1, "f32", id="generic_ignores"),
+                                                twin((1, 2, 5, 64, 8, 10, True), "cross", 1, "f32", id="fast_f32_ignores")])
 def test_attn_with_a_subset_of_query_positions(emu, case, mode, nq, arith, two_blocks):
     """RatSeqMap.queries: the bf16x3 kernels skip the other queries, the exact-fp32 kernels compute them all (both within the contract)"""
     kc.check_attn_queries(emu, "cpu", case, mode, nq=nq, arith=arith)

@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 import pytest
+from conftest import twin
 import torch
 
 import golden_cases as gc
@@ -36,12 +37,12 @@ def test_eval_forward(name):
 
 
 # BaseModel.train_step = the fused iteration (two-sweep optimizer with the regulariser folded in, no autograd node)
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "m1_tiny_seq"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", twin("m1_tiny_seq")])
 def test_train_step_api_matches_the_reference_run(name):
     mc.check_train_step_api(name, gpu=-1)
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape", "northstar_shape"])      # the last one: bf16x3 kernels, RatSeqMap.queries
+@pytest.mark.parametrize("name", [twin("tiny_seq_bn"), twin("mltag_shape"), "northstar_shape"])      # the last one: bf16x3 kernels, RatSeqMap.queries
 def test_dead_token_pruning_changes_nothing(name):
     mc.check_pruning_equivalence(name, gpu=-1)
 

@@ -6,6 +6,7 @@ import tempfile
 
 import numpy as np
 import pytest
+from conftest import gpu_twin
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -45,6 +46,7 @@ def test_merge_of_gathered_row_lists_and_row_adam(emu):
     sc.check_merge_rows(emu, "cpu")
 
 
+@gpu_twin
 def test_sorted_mode_equals_atomic_mode_and_is_reproducible(emu_default):
     sc.check_model_sorted_equals_atomic("tiny_seq_bn", gpu=-1)
 

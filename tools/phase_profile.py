@@ -12,6 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "www24-rat_amd")):
     sys.path.insert(0, p)
 os.environ["RAT_HIP_LIBRARY"] = os.path.join(ROOT, "www24-rat_amd", "lib", "librat_hip_prof.so")
+import build as _build  # noqa: E402
+
+_build.build(prof=True)          # a no-op when the stamped library matches the sources (a stale one would fail the ABI check)
 
 import torch  # noqa: E402
 from rat_amd import synthetic  # noqa: E402
