@@ -4,6 +4,7 @@
 namespace emu {
 thread_local Block* g_block = nullptr;
 thread_local dim3 g_tid, g_bid, g_bdim, g_gdim;
+thread_local unsigned g_coll = 0;
 
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
     const unsigned nthreads = block.x * block.y * block.z;
@@ -15,20 +16,21 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
     for (unsigned b = 0; b < grid.x; ++b) {
         Block blk;
         blk.nthreads = nthreads;
-        blk.block_barrier = std::make_unique<std::barrier<>>(nthreads);
+        blk.block_barrier = std::make_unique<YieldBarrier>(nthreads);
         for (unsigned w = 0; w < nwaves; ++w) {
             unsigned lanes = std::min(64u, nthreads - w * 64);
-            blk.wave_barrier.push_back(std::make_unique<std::barrier<>>(lanes));
+            blk.wave_barrier.push_back(std::make_unique<YieldBarrier>(lanes));
         }
-        blk.xa.assign(nwaves * 64, 0.f);
-        blk.xb.assign(nwaves * 64, 0.f);
-        blk.xw.assign(nwaves * 64 * 8, 0u);
+        blk.xa.assign(nwaves * 2 * 64, 0.f);           // (x 2: see emu::slot)
+        blk.xb.assign(nwaves * 2 * 64, 0.f);
+        blk.xw.assign(nwaves * 2 * 64 * 8, 0u);
         blk.smem.assign(smem + 64, 0x7f);   // poison: uninitialised LDS reads show up as NaN-ish garbage
         std::vector<std::thread> threads;
         threads.reserve(nthreads);
         for (unsigned t = 0; t < nthreads; ++t) {
             threads.emplace_back([&, t]() {
                 g_block = &blk;
+                g_coll = 0;
                 g_tid = dim3(t);
                 g_bid = dim3(b);
                 g_bdim = block;
