@@ -118,7 +118,10 @@ typedef struct RatAttnParams {      /* HOST struct of device pointers; state_dic
 typedef struct RatSplitJob {
     const float* w; /* source matrix, row-major with leading dimension ld                                   */
     void* out;      /* fragment planes of B[k][n] = transpose ? w[k*ld + n] : w[n*ld + k], n < N, k < K       */
-    int32_t N, K, ld, transpose, perm, reserved;
+    int32_t N, K, ld, transpose, perm;
+    int32_t reserved; /* 0, or n_valid | k_valid << 16: the matrix has only n_valid of the N rows / k_valid of the K columns the planes
+                       * cover (0 = all); the rest is written as zeros.  Filled in by rat_*_split_jobs for layers narrower than the
+                       * kernels' tiles (embedding_dim 40 / 48 / 56 inside the 64-wide bf16x3 tiles). */
 } RatSplitJob;
 size_t rat_attn_planes_bytes(int d, int heads, int dim_head);
 int rat_attn_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes, RatSplitJob* jobs_out /* [4] */);

@@ -71,6 +71,19 @@ def test_attn_fwd_bwd_bf16x3(emu, mode, two_blocks):
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode", [pytest.param((1, 3, 14, 40, 8, 10, True), "intra", id="d40_L14"), pytest.param((2, 6, 5, 40, 8, 10, True), "cross", id="d40_L6"),
+                                       twin((1, 2, 9, 56, 8, 10, True), "intra", id="d56_L9")])
+def test_attn_fwd_bwd_bf16x3_narrower_embedding(emu, case, mode, two_blocks):
+    """embedding_dim 40 (the shipped KKBox config) / 48 / 56 inside the 64-wide tiles of the bf16x3 kernels: 160-byte rows, pieces beyond
+    d zero, LayerNorm over d columns, zero-padded weight planes, d-wide gradient slabs"""
+    kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
+
+
+def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
+    kc.check_attn_queries(emu, "cpu", (2, 3, 7, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
+    kc.check_attn_dropout(emu, "cpu", (1, 3, 5, 40, 8, 10, True), "cross", arith="bf16x3")
+
+
 @pytest.mark.parametrize("case,mode", [pytest.param((1, 11, 4, 64, 8, 10, True), "cross", id="L11"), pytest.param((1, 2, 33, 64, 8, 10, True), "intra", id="L33"),
                                        twin((3, 16, 2, 64, 8, 10, True), "cross", id="L16")])
 def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, monkeypatch):

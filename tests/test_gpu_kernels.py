@@ -62,6 +62,21 @@ def test_attn_fwd_bwd_bf16x3(lib, case, mode):
     kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("d", [40, 48, 56])
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attn_fwd_bwd_bf16x3_narrower_embedding(lib, d, mode):
+    """embedding_dim 40 (the shipped KKBox config) / 48 / 56 inside the 64-wide tiles of the bf16x3 kernels; many chunks per work-group"""
+    kc.check_attn(lib, "cuda", (40, 6, 14, d, 8, 10, True), mode, arith="bf16x3")
+    kc.check_attn(lib, "cuda", (3, 5, 3, d, 8, 10, True), mode, arith="bf16x3")
+
+
+def test_attn_narrower_embedding_with_queries_and_dropout(lib):
+    kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
+    kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "cross", nq=1, arith="bf16x3")
+    kc.check_attn_dropout(lib, "cuda", (4, 6, 14, 40, 8, 10, True), "intra", arith="bf16x3")
+    kc.check_attn_dropout(lib, "cuda", (4, 6, 14, 40, 8, 10, True), "cross", arith="bf16x3")
+
+
 @pytest.mark.parametrize("case,mode,nq,arith", [((4, 11, 21, 64, 8, 10, True), "intra", 1, "bf16x3"), ((40, 11, 21, 64, 8, 10, True), "intra", 1, "bf16x3"),
                                                 ((30, 11, 4, 64, 8, 10, True), "cross", 1, "bf16x3"), ((2, 3, 7, 64, 8, 10, True), "intra", 3, "bf16x3"),
                                                 ((2, 3, 4, 8, 2, 4, True), "intra", 1, "f32"), ((2, 4, 5, 64, 8, 10, True), "cross", 1, "f32")],

@@ -1015,21 +1015,27 @@ constexpr size_t b3_fwd_smem() { return (size_t)3 * B3_XP + (size_t)64 * B3_LDQ 
 // LayerNorm of one row piece into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns [8 sub, 8 sub + 8) = exactly
 // one 16-byte piece, handed over in two float4 (loaded by the caller, usually a whole chunk ahead); same arithmetic, in the same
 // order, as layer_norm_rows above.
+// DPAD (embedding_dim d < 64, a multiple of 8, run inside the 64-wide tiles): `colok` says whether this thread's 8 columns exist; the
+// pieces beyond d arrive as zeros (they add nothing to the mean), are left out of the variance, and leave as zeros (gamma = beta = 0).
+template <bool DPAD = false>
 __device__ __forceinline__ void b3_layer_norm_to_planes(bool valid, const float4& v0, const float4& v1, float eps, const PlanesX& xp,
-                                                        const float (&gam)[8], const float (&bet)[8], float* mu_out, float* rs_out) {
+                                                        const float (&gam)[8], const float (&bet)[8], float* mu_out, float* rs_out,
+                                                        int dreal = B3_D, bool colok = true) {
     const int r = threadIdx.x >> 3, sub = threadIdx.x & 7;
     const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    const float dn = DPAD ? (float)dreal : (float)B3_D;
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) s += xv[k];
-    const float mean = rat_group_sum<8>(s) / (float)B3_D;
+    const float mean = rat_group_sum<8>(s) / dn;
     float v = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float t = xv[k] - mean;
         v += t * t;
     }
-    const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / (float)B3_D + eps);
+    if (DPAD) v = colok ? v : 0.f;
+    const float rstd = 1.0f / sqrtf(rat_group_sum<8>(v) / dn + eps);
     float y[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) y[k] = valid ? (xv[k] - mean) * rstd * gam[k] + bet[k] : 0.f;
@@ -1062,6 +1068,10 @@ __device__ __forceinline__ void b3_zero_unless(bool valid, float4& v) {
 // this thread's 8-column piece of its row: byte offset of the piece in a [tokens][64] array
 __device__ __forceinline__ uint32_t b3_piece_off(int64_t tok) {
     return (uint32_t)(tok >= 0 ? tok : 0) * (uint32_t)(B3_D * 4) + 32u * (threadIdx.x & 7);
+}
+// DPAD: rows are d floats; a thread whose piece does not exist points at piece 0 (its loads are unconditional and zeroed afterwards)
+__device__ __forceinline__ uint32_t b3_piece_off_d(int64_t tok, int d, bool colok) {
+    return (uint32_t)(tok >= 0 ? tok : 0) * (uint32_t)(d * 4) + (colok ? 32u * (threadIdx.x & 7) : 0u);
 }
 // the [64][80] O tile: 1280 float4 over 512 threads; element e -> row e / 20, float4 e % 20
 struct B3RowFetchO {
@@ -1096,12 +1106,12 @@ struct B3RowFetchO {
     }
 };
 
-__device__ __forceinline__ void b3_load_piece(const float* src, const int64_t* rowtok, float4& v0, float4& v1) {
+__device__ __forceinline__ void b3_load_piece(const float* src, const int64_t* rowtok, float4& v0, float4& v1, int d = B3_D, bool colok = true) {
     const int64_t tok = rowtok[threadIdx.x >> 3];
     v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tok >= 0) {
-        v0 = *reinterpret_cast<const float4*>(src + tok * B3_D + 8 * (threadIdx.x & 7));
-        v1 = *reinterpret_cast<const float4*>(src + tok * B3_D + 8 * (threadIdx.x & 7) + 4);
+    if (tok >= 0 && colok) {
+        v0 = *reinterpret_cast<const float4*>(src + tok * d + 8 * (threadIdx.x & 7));
+        v1 = *reinterpret_cast<const float4*>(src + tok * d + 8 * (threadIdx.x & 7) + 4);
     }
 }
 
@@ -1138,7 +1148,8 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, 
 }
 
 // QSUB: RatSeqMap.queries < L is honoured (a separate instantiation: the ordinary one must not carry a second trip count)
-template <bool EX, bool QSUB = false>
+// DPAD: embedding_dim 40 / 48 / 56 inside the 64-wide tiles (zero-padded weight planes; see b3_layer_norm_to_planes)
+template <bool EX, bool QSUB = false, bool DPAD = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                 // LayerNorm(x) planes; later the fp32 output staging tile
@@ -1151,11 +1162,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
 
     for (int e = threadIdx.x; e < 3 * B3_OP / 4; e += ATT_THREADS) reinterpret_cast<float*>(op.base)[e] = 0.f;   // incl. the slack
     for (int e = threadIdx.x; e < 64 * (B3_LDQ - B3_Q3); e += ATT_THREADS) qkv[(e >> 2) * B3_LDQ + B3_Q3 + (e & 3)] = 0.f;
+    const int dreal = DPAD ? a.d : B3_D;
+    const bool colok = !DPAD || 8 * (int)(threadIdx.x & 7) < dreal;
     float gam[8], bet[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        gam[k] = a.ln_g[8 * (threadIdx.x & 7) + k];
-        bet[k] = a.ln_b[8 * (threadIdx.x & 7) + k];
+        gam[k] = colok ? a.ln_g[8 * (threadIdx.x & 7) + k] : 0.f;
+        bet[k] = colok ? a.ln_b[8 * (threadIdx.x & 7) + k] : 0.f;
     }
     {
         int nsq0, rows0;
@@ -1174,8 +1187,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             rows = nsq * a.L;
         }
         float4 x0, x1;                                           // kept: the residual of the plain PreNorm(Attention)(x) + x layer
-        b3_load_piece(a.x, rowtok, x0, x1);
-        b3_layer_norm_to_planes(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr);
+        b3_load_piece(a.x, rowtok, x0, x1, dreal, colok);
+        b3_layer_norm_to_planes<DPAD>(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr, dreal, colok);
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
             map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
@@ -1199,7 +1212,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         //  maximum, no rescaling, independent keys): +-0 / +3 % — tools/experiments/attn_fwd3_core_variants.hip.txt.)
         float pf = 0.f;
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)   // (no prefetch: +2-3 %, same-box A/B)
-            pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, B3_D);
+            pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, dreal);
         typedef HeadVec<B3_DH> HV;
         const int nq = QSUB ? a.nq : L;                          // queries that matter per sequence (RatSeqMap.queries; normally L)
         const int ntasks = nsq * B3_H * nq;
@@ -1282,22 +1295,22 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         // y = O W_out^T + b_out (+ residual), staged through LDS for whole-row stores
         b3_gemm_rows<3>(op, W.out, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
-            const float bias = a.b_out[col];
+            const float bias = (!DPAD || col < dreal) ? a.b_out[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ys[(size_t)rat_acc_row(mt, r) * LDY + col] = acc[r] + bias;
         });
         __syncthreads();
         RAT_PROF_MARK(4);
         if (EX) {
-            store_rows_residual(a.y, ys, LDY, a.res, rowtok, rows, B3_D, true, a.out_scale, &a.drop);
+            store_rows_residual(a.y, ys, LDY, a.res, rowtok, rows, dreal, true, a.out_scale, &a.drop);
         } else {                                                 // y = tile + x, the x piece still in registers: no global re-read
             const int r = threadIdx.x >> 3, sb = threadIdx.x & 7;
             const int64_t tok = rowtok[r];
-            if (tok >= 0) {
+            if (tok >= 0 && colok) {
                 const float4 t0 = *reinterpret_cast<const float4*>(ys + (size_t)r * LDY + 8 * sb);
                 const float4 t1 = *reinterpret_cast<const float4*>(ys + (size_t)r * LDY + 8 * sb + 4);
-                *reinterpret_cast<float4*>(a.y + tok * B3_D + 8 * sb) = make_float4(t0.x + x0.x, t0.y + x0.y, t0.z + x0.z, t0.w + x0.w);
-                *reinterpret_cast<float4*>(a.y + tok * B3_D + 8 * sb + 4) = make_float4(t1.x + x1.x, t1.y + x1.y, t1.z + x1.z, t1.w + x1.w);
+                *reinterpret_cast<float4*>(a.y + tok * dreal + 8 * sb) = make_float4(t0.x + x0.x, t0.y + x0.y, t0.z + x0.z, t0.w + x0.w);
+                *reinterpret_cast<float4*>(a.y + tok * dreal + 8 * sb + 4) = make_float4(t1.x + x1.x, t1.y + x1.y, t1.z + x1.z, t1.w + x1.w);
             }
         }
         __syncthreads();
@@ -1765,7 +1778,7 @@ __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes
     epi(mt0 + 1, nt, acc[1]);
 }
 
-template <bool EX, bool QSUB = false>
+template <bool EX, bool QSUB = false, bool DPAD = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                  // LayerNorm(x)
@@ -1782,6 +1795,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
     int64_t* const rowtok0 = reinterpret_cast<int64_t*>(dlt + ATT_ROWS * B3_H);
     const int L = a.L;
     const int r_own = threadIdx.x >> 3, sub = threadIdx.x & 7;               // this thread's (row slot, 8-column piece)
+    const int dreal = DPAD ? a.d : B3_D;                                     // DPAD: embedding_dim 40 / 48 / 56 inside the 64-wide tiles
+    const bool colok = !DPAD || 8 * sub < dreal;
 
     f32x4 accq[QSLOTS], acco[OSLOTS];                                        // persistent dW_qkv / dW_out^T tiles
 #pragma unroll
@@ -1792,7 +1807,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
 #pragma unroll
     for (int k = 0; k < 8; ++k) dgam[k] = dbet[k] = dbo[k] = 0.f;
     float* const lnw = reinterpret_cast<float*>(rowtok0 + 2 * ATT_ROWS);     // [2][64] LayerNorm gamma | beta (kept out of the registers)
-    if (threadIdx.x < 2 * B3_D) lnw[threadIdx.x] = threadIdx.x < B3_D ? a.ln_g[threadIdx.x] : a.ln_b[threadIdx.x - B3_D];
+    if (threadIdx.x < 2 * B3_D) {
+        const int c = threadIdx.x < B3_D ? threadIdx.x : threadIdx.x - B3_D;
+        lnw[threadIdx.x] = (DPAD && c >= dreal) ? 0.f : (threadIdx.x < B3_D ? a.ln_g[c] : a.ln_b[c]);
+    }
     for (int e = threadIdx.x; e < (int)((B3_OFF_MISC - B3_OFF_QKV) / 4); e += ATT_THREADS) qkv[e] = 0.f;   // pad columns, slack
     {
         int nsq0, rows0;
@@ -1815,19 +1833,19 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             // (also with the touched value waited for right after pass 1 instead of at the end of the iteration);
             // requesting the next chunk's rows a phase or two early (P4, P5, P6) +8-10 % — the registers that carry them across the
             // GEMM phases come back as spills, and a spill reload is a scratch load that waits for vmcnt(0).
-            const bool valid = tok_own >= 0;
-            const uint32_t po = b3_piece_off(tok_own);
+            const bool valid = tok_own >= 0 && colok;
+            const uint32_t po = DPAD ? b3_piece_off_d(tok_own, dreal, colok) : b3_piece_off(tok_own);
             B3RowFetchO fo;
             float4 x0 = b3_ld4(a.x, po), x1 = b3_ld4(a.x, po + 16u);
             float4 d0 = b3_ld4(a.dy, po), d1 = b3_ld4(a.dy, po + 16u);
             fo.issue(a.o_save, rowtok);
-            float lsen = b3_ld1(a.lse_save, (uint32_t)(valid ? tok_own : 0) * (uint32_t)(B3_H * 4) + 4u * sub);
+            float lsen = b3_ld1(a.lse_save, (uint32_t)(tok_own >= 0 ? tok_own : 0) * (uint32_t)(B3_H * 4) + 4u * sub);
             RAT_SCHED_FENCE();                                               // every request is out before anything is consumed
             b3_zero_unless(valid, x0);
             b3_zero_unless(valid, x1);
             b3_zero_unless(valid, d0);
             b3_zero_unless(valid, d1);
-            lsen = valid ? lsen : 0.f;
+            lsen = tok_own >= 0 ? lsen : 0.f;
             {
                 float gam[8], bet[8];
 #pragma unroll
@@ -1835,10 +1853,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                     gam[k] = lnw[8 * sub + k];
                     bet[k] = lnw[B3_D + 8 * sub + k];
                 }
-                b3_layer_norm_to_planes(tok_own >= 0, x0, x1, a.eps, xp, gam, bet, mu, rs);
+                b3_layer_norm_to_planes<DPAD>(tok_own >= 0, x0, x1, a.eps, xp, gam, bet, mu, rs, dreal, colok);
             }
-            if (EX && a.drop.threshold != 0 && tok_own >= 0) {               // dy through the projection's Dropout
-                const int64_t i0 = tok_own * B3_D + 8 * sub;
+            if (EX && a.drop.threshold != 0 && valid) {                      // dy through the projection's Dropout
+                const int64_t i0 = tok_own * dreal + 8 * sub;
                 d0.x = a.drop.apply(d0.x, i0); d0.y = a.drop.apply(d0.y, i0 + 1); d0.z = a.drop.apply(d0.z, i0 + 2); d0.w = a.drop.apply(d0.w, i0 + 3);
                 d1.x = a.drop.apply(d1.x, i0 + 4); d1.y = a.drop.apply(d1.y, i0 + 5); d1.z = a.drop.apply(d1.z, i0 + 6); d1.w = a.drop.apply(d1.w, i0 + 7);
             }
@@ -2034,12 +2052,12 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         RAT_PROF_MARK(8);
         // ---- P6: LayerNorm backward + the added gradient: dx = add + rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dxn * gamma
         {
-            const bool valid = tok_own >= 0;
+            const bool valid = tok_own >= 0 && colok;
             const float mean = mu[r_own], rstd = rs[r_own];
             const float* addp = EX ? a.add : a.dy;
             float xh[8], gg[8], ad[8], out[8], gam[8];
             float4 xv2[2], av2[2];
-            const uint32_t po = b3_piece_off(tok_own);
+            const uint32_t po = DPAD ? b3_piece_off_d(tok_own, dreal, colok) : b3_piece_off(tok_own);
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 xv2[k] = b3_ld4(a.x, po + 16u * k);
@@ -2071,8 +2089,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 s1 += gw;
                 s2 += gw * xh[k];
             }
-            s1 = rat_group_sum<8>(s1) / (float)B3_D;
-            s2 = rat_group_sum<8>(s2) / (float)B3_D;
+            s1 = rat_group_sum<8>(s1) / (DPAD ? (float)dreal : (float)B3_D);
+            s2 = rat_group_sum<8>(s2) / (DPAD ? (float)dreal : (float)B3_D);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float gw = valid ? gg[k] * gam[k] : 0.f;
@@ -2092,25 +2110,26 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
 
     // ---- this work-group's parameter-gradient slab: [dW_qkv | dW_out | db_out | dgamma | dbeta]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
-    float* s_wqkv = slab;
-    float* s_wout = s_wqkv + (int64_t)B3_Q3 * B3_D;
-    float* s_bout = s_wout + (int64_t)B3_D * B3_I;
-    float* s_gam = s_bout + B3_D;
-    float* s_bet = s_gam + B3_D;
+    float* s_wqkv = slab;                                                    // (the host's layout: [3 I][d], [d][I], [d], [d], [d])
+    float* s_wout = s_wqkv + (int64_t)B3_Q3 * dreal;
+    float* s_bout = s_wout + (int64_t)dreal * B3_I;
+    float* s_gam = s_bout + dreal;
+    float* s_bet = s_gam + dreal;
     {
         const int w = rat_wave(), col = rat_acc_col(w & 3);
 #pragma unroll
         for (int i = 0; i < QSLOTS; ++i) {
             const int mt = (w >> 2) + 2 * i;
-            if (mt < B3_Q3 / 16)
+            if (mt < B3_Q3 / 16 && (!DPAD || col < dreal))
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_wqkv[(int64_t)rat_acc_row(mt, r) * B3_D + col] = accq[i][r];
+                for (int r = 0; r < 4; ++r) s_wqkv[(int64_t)rat_acc_row(mt, r) * dreal + col] = accq[i][r];
         }
         if (w < B3_I / 16)
 #pragma unroll
             for (int nt = 0; nt < OSLOTS; ++nt)
+                if (!DPAD || rat_acc_col(nt) < dreal)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_wout[(int64_t)rat_acc_col(nt) * B3_I + rat_acc_row(w, r)] = acco[nt][r];
+                    for (int r = 0; r < 4; ++r) s_wout[(int64_t)rat_acc_col(nt) * B3_I + rat_acc_row(w, r)] = acco[nt][r];
     }
     // db_out / dgamma / dbeta: 64 row-slot partials per column -> LDS -> fixed-order column sums
     float* red = reinterpret_cast<float*>(smem);                             // [64][68]
@@ -2121,7 +2140,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[(size_t)r_own * B3_LDN + 8 * sub + k] = which == 0 ? dbo[k] : (which == 1 ? dgam[k] : dbet[k]);
         __syncthreads();
-        if (threadIdx.x < B3_D) {
+        if ((int)threadIdx.x < dreal) {
             float sacc = 0.f;
             for (int rr = 0; rr < ATT_ROWS; ++rr) sacc += red[(size_t)rr * B3_LDN + threadIdx.x];
             outs[which][threadIdx.x] = sacc;
@@ -2198,10 +2217,16 @@ extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_
                            nullptr, 0, stream);
 }
 
-// bf16x3 kernels exist for the north-star geometry only; every other shape runs the exact-fp32 kernels whatever `arith` says
+// bf16x3 kernels exist for the north-star geometry (embedding_dim 64, 8 heads x 10) and, inside the same 64-wide tiles, for
+// embedding_dim 40 / 48 / 56 with the same heads (DPAD: the shipped KKBox config is d = 40); every other shape runs the exact-fp32
+// kernels whatever `arith` says
+static bool b3_dim(int d) { return d == B3_D || d == 40 || d == 48 || d == 56; }
+static bool b3_geom(int d, int heads, int dim_head) { return b3_dim(d) && heads == B3_H && dim_head == B3_DH; }
 static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
-    return d == B3_D && heads == B3_H && dim_head == B3_DH && w->w_out != nullptr;
+    return b3_geom(d, heads, dim_head) && w->w_out != nullptr;
 }
+// `valid` of the split jobs whose N is the embedding dimension (rat_split_weights: n_valid)
+static int b3_nvalid(int d) { return d == B3_D ? 0 : d; }
 // ... and only while every token's byte offset in the widest array (o_save: 320 B per token) fits 32 bits (b3_ld4)
 static bool b3_off32_ok(const RatSeqMap* m) {
     if (m->hi_stride < 0 || m->lo_stride < 0 || m->pos_stride < 0) return false;
@@ -2211,22 +2236,23 @@ static bool b3_off32_ok(const RatSeqMap* m) {
 }
 
 extern "C" size_t rat_attn_fwd_workspace(int d, int heads, int dim_head) {
-    return (d == B3_D && heads == B3_H && dim_head == B3_DH) ? B3_W_QKV + B3_W_OUT : 0;
+    return b3_geom(d, heads, dim_head) ? B3_W_QKV + B3_W_OUT : 0;
 }
 
 // RatAttnParams.planes: [W_qkv | W_out^T | W_qkv^T | W_out] fragment planes (the backward's three first, the forward's second one last)
 extern "C" size_t rat_attn_planes_bytes(int d, int heads, int dim_head) {
-    return (d == B3_D && heads == B3_H && dim_head == B3_DH) ? B3_W_BYTES : 0;
+    return b3_geom(d, heads, dim_head) ? B3_W_BYTES : 0;
 }
 extern "C" int rat_attn_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes, RatSplitJob* jobs_out) {
     RAT_REQUIRE(w_host && jobs_out, "null pointer");
     if (!b3_shape(d, heads, dim_head, w_host) || planes == nullptr) return 0;
     RAT_REQUIRE(aligned16(planes) && w_host->w_qkv, "planes must be 16-byte aligned");
     char* ws = static_cast<char*>(planes);
-    jobs_out[0] = RatSplitJob{w_host->w_qkv, ws, B3_Q3, B3_D, B3_D, 0, 0, 0};                                        // forward + backward
-    jobs_out[1] = RatSplitJob{w_host->w_out, ws + B3_W_QKV, B3_I, B3_D, B3_I, 1, 0, 0};                               // backward: dO
-    jobs_out[2] = RatSplitJob{w_host->w_qkv, ws + B3_W_QKV + B3_W_OUTT, B3_D, B3_Q3, B3_D, 1, 0, 0};                  // backward: d(LN out)
-    jobs_out[3] = RatSplitJob{w_host->w_out, ws + B3_W_QKV + B3_W_OUTT + B3_W_QKVT, B3_D, B3_I, B3_I, 0, 0, 0};       // forward: out-proj
+    // (d < 64: K = d is padded to 64 by the split itself; where N is the embedding dimension the planes cover 64 rows, d of them real)
+    jobs_out[0] = RatSplitJob{w_host->w_qkv, ws, B3_Q3, d, d, 0, 0, 0};                                                        // forward + backward
+    jobs_out[1] = RatSplitJob{w_host->w_out, ws + B3_W_QKV, B3_I, d, B3_I, 1, 0, 0};                                          // backward: dO
+    jobs_out[2] = RatSplitJob{w_host->w_qkv, ws + B3_W_QKV + B3_W_OUTT, B3_D, B3_Q3, d, 1, 0, b3_nvalid(d)};                  // backward: d(LN out)
+    jobs_out[3] = RatSplitJob{w_host->w_out, ws + B3_W_QKV + B3_W_OUTT + B3_W_QKVT, B3_D, B3_I, B3_I, 0, 0, b3_nvalid(d)};     // forward: out-proj
     return 4;
 }
 
@@ -2257,7 +2283,9 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
     const bool plain = res == x && out_scale == 1.0f && a.drop.threshold == 0;
     const bool have_planes = w_host->planes != nullptr && aligned16(w_host->planes);
-    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) &&
+    const bool dpad = d != B3_D && b3_dim(d) && heads == fast_heads(dim_head) && aligned16(x) && aligned16(y) && aligned16(res) &&
+                      aligned16(o_save) && aligned16(lse_save) && aligned16(w_host->w_qkv) && aligned16(w_host->w_out);
+    if (arith == RAT_ARITH_BF16X3 && (fast == 64 || dpad) && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) &&
         (have_planes || (workspace != nullptr && workspace_bytes >= B3_W_QKV + B3_W_OUT && aligned16(workspace)))) {
         const char* p_qkv;
         const char* p_out;
@@ -2266,8 +2294,8 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
             p_out = p_qkv + B3_W_QKV + B3_W_OUTT + B3_W_QKVT;
         } else {
             char* ws = reinterpret_cast<char*>(workspace);
-            if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, ws, stream) ||
-                rat_launch_split_weights(w_host->w_out, B3_D, B3_I, B3_I, 0, ws + B3_W_QKV, stream)) return -1;
+            if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, d, d, 0, ws, stream) ||
+                rat_launch_split_weights(w_host->w_out, B3_D, B3_I, B3_I, 0, ws + B3_W_QKV, stream, 0, b3_nvalid(d))) return -1;
             p_qkv = ws;
             p_out = ws + B3_W_QKV;
         }
@@ -2281,7 +2309,11 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         // matrix pipe saves is spent on the VALU again, splitting Q|K|V and P into bf16 chunks and laying them out — so it is opt-in.
         const char* core_env = getenv("RAT_ATTN_FWD_CORE");
         const bool mfma_core = core_env != nullptr && std::string(core_env) == "mfma";
-        if (mfma_core && b3m_fits(a.L, a.nsq_chunk)) {
+        if (dpad) {
+            if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+            else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false, false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+            else RAT_LAUNCH((attn_fwd3_kernel<true, false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        } else if (mfma_core && b3m_fits(a.L, a.nsq_chunk)) {
             if (plain) RAT_LAUNCH((attn_fwd3m_kernel<false>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_fwd3m_kernel<true>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
         } else if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
@@ -2317,7 +2349,7 @@ extern "C" int rat_attn_fused_supported(int d, int heads, int dim_head, int L) {
 extern "C" size_t rat_attn_bwd_workspace(int d, int heads, int dim_head) {
     const AttnGeom g(d, heads, dim_head);
     const size_t slabs = (size_t)256 * (size_t)g.slab_floats() * sizeof(float);
-    const bool b3 = d == B3_D && heads == B3_H && dim_head == B3_DH;         // + the pre-split weight fragments of the bf16x3 kernel
+    const bool b3 = b3_geom(d, heads, dim_head);                             // + the pre-split weight fragments of the bf16x3 kernel
     return slabs + (b3 ? B3_W_QKV + B3_W_OUTT + B3_W_QKVT : 0);
 }
 
@@ -2359,23 +2391,29 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const size_t smem = g.bwd_smem(heads);
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
-    if (arith == RAT_ARITH_BF16X3 && fast == 64 && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) && aligned16(workspace) &&
+    const bool dpad = d != B3_D && b3_dim(d) && heads == fast_heads(dim_head) && aligned16(x) && aligned16(dy) && aligned16(add) &&
+                      aligned16(o_save) && aligned16(dx) && aligned16(w_host->w_qkv) && aligned16(w_host->w_out);
+    if (arith == RAT_ARITH_BF16X3 && (fast == 64 || dpad) && b3_shape(d, heads, dim_head, w_host) && b3_off32_ok(map_host) && aligned16(workspace) &&
         (a.slab_stride * 256 * 4) % 16 == 0) {
         const char* ws;
         if (w_host->planes != nullptr && aligned16(w_host->planes)) {     // split once per step by the caller (rat_split_weights_batch)
             ws = static_cast<const char*>(w_host->planes);
         } else {
             char* wsw = reinterpret_cast<char*>(workspace) + (size_t)256 * a.slab_stride * sizeof(float);
-            if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, B3_D, B3_D, 0, wsw, stream) ||
-                rat_launch_split_weights(w_host->w_out, B3_I, B3_D, B3_I, 1, wsw + B3_W_QKV, stream) ||
-                rat_launch_split_weights(w_host->w_qkv, B3_D, B3_Q3, B3_D, 1, wsw + B3_W_QKV + B3_W_OUTT, stream)) return -1;
+            if (rat_launch_split_weights(w_host->w_qkv, B3_Q3, d, d, 0, wsw, stream) ||
+                rat_launch_split_weights(w_host->w_out, B3_I, d, B3_I, 1, wsw + B3_W_QKV, stream) ||
+                rat_launch_split_weights(w_host->w_qkv, B3_D, B3_Q3, d, 1, wsw + B3_W_QKV + B3_W_OUTT, stream, 0, b3_nvalid(d))) return -1;
             ws = wsw;
         }
         Attn3W W{};
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.outT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 2};
         W.qkvT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV + B3_W_OUTT), 8};
-        if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        if (dpad) {
+            if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+            else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+            else RAT_LAUNCH((attn_bwd3_kernel<true, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        } else if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);       // (computes every position)
     } else if (!aligned8(o_save)) {                    // run-time dim_head kernel: 4-byte accesses, dim_head <= DH_MAX

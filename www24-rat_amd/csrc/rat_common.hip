@@ -114,8 +114,16 @@ int rat_launch_transpose(const float* src, float* dst, int R, int C, void* strea
 }
 
 // weights -> fragment-major bf16x3 planes (rat_device.h RatWPlanes): one thread per (n tile, K step, lane)
+// `valid` (RatSplitJob.reserved): 0, or n_valid | k_valid << 16 — the matrix has only n_valid of the N rows / k_valid of the K columns the
+// planes cover (0 = all of them); the rest of the planes is zeros.  That is how a narrower layer runs inside fixed-size tiles.
+__device__ __forceinline__ void rat_split_bounds(int N, int K, int valid, int& nv, int& kv) {
+    nv = (valid & 0xffff) ? (valid & 0xffff) : N;
+    kv = (valid >> 16) ? (valid >> 16) : K;
+}
 __global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __restrict__ w, int N, int K, int ld, int transpose, int perm,
-                                                                rat_u4* __restrict__ out, int ntiles, int steps) {
+                                                                rat_u4* __restrict__ out, int ntiles, int steps, int valid) {
+    int nv, kv;
+    rat_split_bounds(N, K, valid, nv, kv);
     const int total = ntiles * steps * 64;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int lane = e & 63, fs = e >> 6, nt = fs / steps, s = fs - nt * steps;
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __r
             // perm: k slot j of lane group g <-> k = 32 s + 4 g + j (j < 4), 32 s + 16 + 4 g + (j - 4) (j >= 4) — the order in which
             // two stacked 16-row accumulator tiles present their rows as a B fragment (ffn.hip)
             const int k = 32 * s + (perm ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);
-            v[j] = (n < N && k < K) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
+            v[j] = (n < nv && k < kv) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
         }
         rat_u4 h, m, l;
         rat_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
@@ -147,6 +155,8 @@ __global__ void __launch_bounds__(256) rat_split_weights_batch_kernel(RatSplitTa
     const float* __restrict__ w = jb.w;
     rat_u4* __restrict__ out = static_cast<rat_u4*>(jb.out);
     const int N = jb.N, K = jb.K, ld = jb.ld, transpose = jb.transpose, perm = jb.perm;
+    int nv, kv;
+    rat_split_bounds(N, K, jb.reserved, nv, kv);
     const int ntiles = (N + 15) / 16, steps = (K + 31) / 32, total = ntiles * steps * 64;
     for (int e = bx * 256 + threadIdx.x; e < total; e += per_job * 256) {
         const int lane = e & 63, fs = e >> 6, nt = fs / steps, s = fs - nt * steps;
@@ -155,7 +165,7 @@ __global__ void __launch_bounds__(256) rat_split_weights_batch_kernel(RatSplitTa
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 32 * s + (perm ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);      // as rat_split_weights_kernel
-            v[j] = (n < N && k < K) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
+            v[j] = (n < nv && k < kv) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
         }
         rat_u4 h, m, l;
         rat_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
@@ -185,10 +195,10 @@ extern "C" int rat_split_weights_batch(const RatSplitJob* jobs_host, int njobs, 
     return 0;
 }
 
-int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm) {
+int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm, int valid) {
     const int ntiles = (N + 15) / 16, steps = (K + 31) / 32;
     const int blocks = (ntiles * steps * 64 + 255) / 256;
     RAT_LAUNCH(rat_split_weights_kernel, (unsigned)blocks, 256, 0, stream, w, N, K, ld, transpose, perm, static_cast<rat_u4*>(out), ntiles,
-               steps);
+               steps, valid);
     return rat_check_launch("rat_split_weights");
 }

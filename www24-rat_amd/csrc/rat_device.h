@@ -693,7 +693,7 @@ struct RatWPlanes {
 };
 // B[k][n] = transpose ? w[k * ld + n] : w[n * ld + k] for n < N, k < K (zero beyond); out: rat_wplanes_bytes(N, K) bytes
 inline size_t rat_wplanes_bytes(int N, int K) { return (size_t)((N + 15) / 16) * ((K + 31) / 32) * 3 * 64 * 16; }
-int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm = 0);
+int rat_launch_split_weights(const float* w, int N, int K, int ld, int transpose, void* out, void* stream, int perm = 0, int valid = 0);
 
 // row/col of accumulator register r of a 16x16 tile
 __device__ __forceinline__ int rat_acc_row(int tile_m, int r) { return tile_m * 16 + (rat_lane() >> 4) * 4 + r; }
