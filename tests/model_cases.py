@@ -208,7 +208,7 @@ def check_pruning_equivalence(name, gpu):
         out[prune] = (yp, float(loss), grads)
     (ya, la, ga), (yb, lb, gb) = out[True], out[False]
     assert torch.equal(ya, yb), "predictions differ with dead-token pruning"
-    assert abs(la - lb) < 1e-7
+    assert abs(la - lb) < 5e-7 * max(1.0, abs(lb))         # (the loss sums go through atomics: a few ulps of an O(1) number run to run)
     assert set(ga) == set(gb)
     for k in ga:
         scale = float(gb[k].abs().max()) + 1e-30

@@ -147,6 +147,13 @@ def test_attn_ex_fwd_bwd(emu, case, mode, res_mode, out_scale, softmax_scale):
     kc.check_attn_ex(emu, "cpu", case, mode, res_mode, out_scale, softmax_scale)
 
 
+def test_ffn_bf16x3_narrower_layer(emu, two_blocks):
+    """(40, 80) — the shipped KKBox feed-forward — inside the (64, 128) tiles of the bf16x3 kernels: zero-padded weight planes / staged
+    weights, guarded token fragments, (hidden, d)-shaped gradient slabs"""
+    kc.check_ffn(emu, "cpu", 150, 40, 80, arith="bf16x3")
+    kc.check_ffn_res(emu, "cpu", 77, 40, 80, True, arith="bf16x3")
+
+
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (77, 64, 128), (45, 16, 32)])
 def test_ffn_fwd_bwd(emu, ntok, d, hidden):
     kc.check_ffn(emu, "cpu", ntok, d, hidden)

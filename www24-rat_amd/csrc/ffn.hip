@@ -534,32 +534,40 @@ typedef RatPlanes<128, 7, F3_H * 128> PlanesW1;          // [128 hidden][64 d]
 typedef RatPlanes<256, 15, F3_D * 256> PlanesW2;         // [64 d][128 hidden, permuted]
 constexpr size_t f3_fwd_smem() { return (size_t)3 * F3_H * 128 + (size_t)3 * F3_D * 256 + (size_t)(F3_H + F3_D) * 4; }
 
+// DPAD: a narrower layer (embedding_dim 40 / 48 / 56, hidden = 2 d) inside the (64, 128) tiles — rows / columns beyond (d, hidden) are
+// zeros in the staged planes, the biases and the token fragments, so they add nothing anywhere (gelu(0) = 0).
+template <bool DPAD = false>
 __device__ __forceinline__ void f3_stage_weights(const FfnArgs& a, const PlanesW1& w1p, const PlanesW2& w2p, int nthreads) {
+    const int d = DPAD ? a.d : F3_D, hid = DPAD ? a.hidden : F3_H;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int e = threadIdx.x; e < F3_H * (F3_D / 8); e += nthreads) {
         const int r = e / (F3_D / 8), o = e - r * (F3_D / 8);
         rat_u4 h, m, l;
-        rat_split8(ld4(a.w1 + (size_t)r * F3_D + 8 * o), ld4(a.w1 + (size_t)r * F3_D + 8 * o + 4), h, m, l);
+        const bool ok = !DPAD || (r < hid && 8 * o < d);
+        rat_split8(ok ? ld4(a.w1 + (size_t)r * d + 8 * o) : z4, ok ? ld4(a.w1 + (size_t)r * d + 8 * o + 4) : z4, h, m, l);
         w1p.store(r, o, h, m, l);
     }
     for (int e = threadIdx.x; e < F3_D * (F3_H / 8); e += nthreads) {
         const int r = e / (F3_H / 8), o = e - r * (F3_H / 8), t = o >> 2, g = o & 3;
         rat_u4 h, m, l;
-        rat_split8(ld4(a.w2 + (size_t)r * F3_H + 32 * t + 4 * g), ld4(a.w2 + (size_t)r * F3_H + 32 * t + 16 + 4 * g), h, m, l);
+        const bool ok0 = !DPAD || (r < d && 32 * t + 4 * g < hid), ok1 = !DPAD || (r < d && 32 * t + 16 + 4 * g < hid);
+        rat_split8(ok0 ? ld4(a.w2 + (size_t)r * hid + 32 * t + 4 * g) : z4, ok1 ? ld4(a.w2 + (size_t)r * hid + 32 * t + 16 + 4 * g) : z4, h, m, l);
         w2p.store(r, o, h, m, l);
     }
 }
 
-template <bool XRES>
+template <bool XRES, bool DPAD = false>
 __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t3_kernel(FfnArgs a) {
     constexpr int D = F3_D, H = F3_H;
+    const int dr = DPAD ? a.d : D, hid = DPAD ? a.hidden : H;                // the layer's real width / hidden width
     RAT_DYN_SMEM(smem);
     const PlanesW1 w1p{smem};
     const PlanesW2 w2p{smem + 3 * H * 128};
     float* b1s = reinterpret_cast<float*>(smem + 3 * H * 128 + 3 * D * 256);
     float* b2s = b1s + H;
-    f3_stage_weights(a, w1p, w2p, FT_THREADS);
-    for (int e = threadIdx.x; e < H; e += FT_THREADS) b1s[e] = a.b1[e];
-    for (int e = threadIdx.x; e < D; e += FT_THREADS) b2s[e] = a.b2[e];
+    f3_stage_weights<DPAD>(a, w1p, w2p, FT_THREADS);
+    for (int e = threadIdx.x; e < H; e += FT_THREADS) b1s[e] = (!DPAD || e < hid) ? a.b1[e] : 0.f;
+    for (int e = threadIdx.x; e < D; e += FT_THREADS) b2s[e] = (!DPAD || e < dr) ? a.b2[e] : 0.f;
     __syncthreads();
 
     const int l = rat_lane(), n = l & 15, g = l >> 4;
@@ -572,7 +580,10 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t3_kernel(FfnArgs a) {
         const int64_t tk = t * 16 + n;
         const bool ok = t < ntiles && tk < a.ntok;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+        for (int q = 0; q < 4; ++q) {
+            const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+            xN[q] = (ok && (!DPAD || c < dr)) ? ld4(a.x + tk * dr + c) : zero4;
+        }
     }
     for (; t < ntiles; t += stride) {
         const int64_t tok = t * 16 + n;
@@ -588,19 +599,23 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t3_kernel(FfnArgs a) {
             const int64_t tk = (t + stride) * 16 + n;
             const bool ok = t + stride < ntiles && tk < a.ntok;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+                xN[q] = (ok && (!DPAD || c < dr)) ? ld4(a.x + tk * dr + c) : zero4;
+            }
         }
         f32x4 yo[D / 16];
 #pragma unroll
         for (int c = 0; c < D / 16; ++c) {
             float4 r0 = zero4;
             const float* rp = XRES ? a.x : a.res;
-            if (rp != nullptr && tok < a.ntok) r0 = ld4(rp + tok * D + 16 * c + 4 * g);
+            if (rp != nullptr && tok < a.ntok && (!DPAD || 16 * c + 4 * g < dr)) r0 = ld4(rp + tok * dr + 16 * c + 4 * g);
             const float4 bs = ld4(b2s + 16 * c + 4 * g);
             yo[c] = f32x4{bs.x + r0.x, bs.y + r0.y, bs.z + r0.z, bs.w + r0.w};
         }
 #pragma unroll
         for (int p = 0; p < H / 32; ++p) {
+            if (DPAD && 32 * p >= hid) break;                                // (uniform) hidden tiles that do not exist
             f32x4 c0 = as_v4(ld4(b1s + 32 * p + 4 * g)), c1 = as_v4(ld4(b1s + 32 * p + 16 + 4 * g));
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -623,7 +638,8 @@ __global__ void __launch_bounds__(FT_THREADS) ffn_fwd_t3_kernel(FfnArgs a) {
         }
         if (tok < a.ntok) {
 #pragma unroll
-            for (int m = 0; m < D / 16; ++m) st4(a.y + tok * D + 16 * m + 4 * g, as_f4(yo[m]));
+            for (int m = 0; m < D / 16; ++m)
+                if (!DPAD || 16 * m + 4 * g < dr) st4(a.y + tok * dr + 16 * m + 4 * g, as_f4(yo[m]));
         }
     }
 }
@@ -916,8 +932,10 @@ __device__ __forceinline__ RatB3 f3_stack(const HalfPieces& lo, const HalfPieces
     return RatB3{rat_as_bf16x8(h), rat_as_bf16x8(m), rat_as_bf16x8(l)};
 }
 
+template <bool DPAD = false>
 __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W W) {
     constexpr int D = F3_D, H = F3_H, KD = D / 16, HT = 4, SL = 4;
+    const int dr = DPAD ? a.d : D, hid = DPAD ? a.hidden : H;                // DPAD: see ffn_fwd_t3_kernel
     RAT_DYN_SMEM(smem);
     const PlanesT64 xsp{smem};
     const PlanesT64 dysp{smem + 3 * 64 * 128};
@@ -943,8 +961,10 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
         const bool ok = chunk < a.nchunks && tk < a.ntok;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
-            dyN[q] = ok ? ld4(a.dy + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+            const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+            const bool okc = ok && (!DPAD || c < dr);
+            xN[q] = okc ? ld4(a.x + tk * dr + c) : zero4;
+            dyN[q] = okc ? ld4(a.dy + tk * dr + c) : zero4;
         }
     }
     RAT_PROF_DECL
@@ -984,7 +1004,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
 #pragma unroll
         for (int i = 0; i < HT; ++i) {
             const int m = HT * half + i;
-            f32x4 c0 = as_v4(ld4(a.b1 + 16 * m + 4 * g)), c1 = rat_zero4();
+            f32x4 c0 = (!DPAD || 16 * m + 4 * g < hid) ? as_v4(ld4(a.b1 + 16 * m + 4 * g)) : rat_zero4(), c1 = rat_zero4();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const RatB3 a0 = W.w1(m, s), a1 = W.w2t(m, s);
@@ -1068,10 +1088,10 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             dysp.load_half(row, 4 * m + g, h0, h1, m0, m1, l0, l1);
             return make_float4(rat_join(h0, m0, l0, 0), rat_join(h0, m0, l0, 1), rat_join(h1, m1, l1, 0), rat_join(h1, m1, l1, 1));
         };
-        auto finish = [&](int m, const float4& dr) {
+        auto finish = [&](int m, const float4& rsd) {
             const float4 p = ld4(pxp(m));
-            const float4 o = make_float4(dxa[m][0] + p.x + dr.x, dxa[m][1] + p.y + dr.y, dxa[m][2] + p.z + dr.z, dxa[m][3] + p.w + dr.w);
-            if (live) st4(a.y + tok * D + 16 * m + 4 * g, o);
+            const float4 o = make_float4(dxa[m][0] + p.x + rsd.x, dxa[m][1] + p.y + rsd.y, dxa[m][2] + p.z + rsd.z, dxa[m][3] + p.w + rsd.w);
+            if (live && (!DPAD || 16 * m + 4 * g < dr)) st4(a.y + tok * dr + 16 * m + 4 * g, o);
         };
         static_assert(KD0 == 2, "two dx tiles per half");
         if (half == 0) {
@@ -1096,8 +1116,10 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             const bool ok = chunk + gridDim.x < a.nchunks && tk < a.ntok;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                xN[q] = ok ? ld4(a.x + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
-                dyN[q] = ok ? ld4(a.dy + tk * D + 32 * (q >> 1) + 8 * g + 4 * (q & 1)) : zero4;
+                const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+                const bool okc = ok && (!DPAD || c < dr);
+                xN[q] = okc ? ld4(a.x + tk * dr + c) : zero4;
+                dyN[q] = okc ? ld4(a.dy + tk * dr + c) : zero4;
             }
         }
         RAT_PROF_MARK(4);
@@ -1126,17 +1148,19 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
 
     // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
-    float* s_w1 = slab;
-    float* s_w2 = s_w1 + (int64_t)H * D;
-    float* s_b1 = s_w2 + (int64_t)D * H;
-    float* s_b2 = s_b1 + H;
+    float* s_w1 = slab;                                           // (the host's layout: [hidden][d], [d][hidden], [hidden], [d])
+    float* s_w2 = s_w1 + (int64_t)hid * dr;
+    float* s_b1 = s_w2 + (int64_t)dr * hid;
+    float* s_b2 = s_b1 + hid;
 #pragma unroll
     for (int i = 0; i < SL; ++i) {
         const int t2 = (w >> 2) + 2 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            s_w1[(int64_t)rat_acc_row(t2, r) * D + rat_acc_col(w & 3)] = acc1[i][r];
-            s_w2[(int64_t)rat_acc_row(w & 3, r) * H + rat_acc_col(t2)] = acc2[i][r];
+            if (!DPAD || (rat_acc_row(t2, r) < hid && rat_acc_col(w & 3) < dr))
+                s_w1[(int64_t)rat_acc_row(t2, r) * dr + rat_acc_col(w & 3)] = acc1[i][r];
+            if (!DPAD || (rat_acc_row(w & 3, r) < dr && rat_acc_col(t2) < hid))
+                s_w2[(int64_t)rat_acc_row(w & 3, r) * hid + rat_acc_col(t2)] = acc2[i][r];
         }
     }
     {   // bias gradients: per-token-column partials -> LDS [feature][64 token columns] -> fixed-order sums
@@ -1161,12 +1185,26 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
             const float* src = c < H ? red1 + c * LR : red2 + (c - H) * LR;
             float sacc = 0.f;
             for (int k = 0; k < FB_TOK; ++k) sacc += src[k];
-            if (c < H) s_b1[c] = sacc; else s_b2[c - H] = sacc;
+            if (c < H) {
+                if (!DPAD || c < hid) s_b1[c] = sacc;
+            } else if (!DPAD || c - H < dr) {
+                s_b2[c - H] = sacc;
+            }
         }
     }
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the bf16x3 kernels also serve (d, 2 d) for d = 40 / 48 / 56 inside their (64, 128) tiles (DPAD; the shipped KKBox config is (40, 80))
+bool f3_dpad_dims(int d, int hidden) { return (d == 40 || d == 48 || d == 56) && hidden == 2 * d; }
+bool f3_dims(int d, int hidden) { return (d == F3_D && hidden == F3_H) || f3_dpad_dims(d, hidden); }
+bool f3_dpad(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
+    if (!f3_dpad_dims(a.d, a.hidden)) return false;
+    for (const void* p : ptrs)
+        if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return false;
+    return (reinterpret_cast<uintptr_t>(a.w1) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w2) & 15) == 0;
+}
 
 int ffn_fast_dim(const FfnArgs& a, std::initializer_list<const void*> ptrs) {
     if (a.hidden != 2 * a.d) return 0;              // the compiled fast shapes are (d, 2 d) = (64, 128), (16, 32)
@@ -1223,7 +1261,10 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
     const int64_t wtiles = ((ntok + 15) / 16 + FT_WAVES - 1) / FT_WAVES;
     const unsigned tgrid = (unsigned)(wtiles < rat_max_blocks() ? wtiles : rat_max_blocks());
     const bool xres = res == x;
-    if (fast == 64 && hidden == 128 && arith == RAT_ARITH_BF16X3) {
+    if (arith == RAT_ARITH_BF16X3 && f3_dpad(a, {x, y, b1, b2, res})) {
+        if (xres) RAT_LAUNCH((ffn_fwd_t3_kernel<true, true>), tgrid, FT_THREADS, f3_fwd_smem(), stream, a);
+        else RAT_LAUNCH((ffn_fwd_t3_kernel<false, true>), tgrid, FT_THREADS, f3_fwd_smem(), stream, a);
+    } else if (fast == 64 && hidden == 128 && arith == RAT_ARITH_BF16X3) {
         if (xres) RAT_LAUNCH((ffn_fwd_t3_kernel<true>), tgrid, FT_THREADS, f3_fwd_smem(), stream, a);
         else RAT_LAUNCH((ffn_fwd_t3_kernel<false>), tgrid, FT_THREADS, f3_fwd_smem(), stream, a);
     } else if (fast == 64 && hidden == 128) {
@@ -1241,19 +1282,21 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
 extern "C" size_t rat_ffn_bwd_workspace(int d, int hidden) {
     const FfnGeom g(d, hidden);
     const size_t fp32 = ((size_t)256 * (size_t)g.slab_floats() + 2 * (size_t)d * hidden) * sizeof(float);   // slabs + w1^T + w2^T
-    return fp32 + ((d == F3_D && hidden == F3_H) ? 3 * F3_WP + 16 : 0);                                      // + bf16x3 weight fragments
+    return fp32 + (f3_dims(d, hidden) ? 3 * F3_WP + 16 : 0);                                                 // + bf16x3 weight fragments
 }
 
 // `planes` of rat_ffn_bwd_res: [W1 | W2^T | W1^T (hidden index permuted)] fragment planes
-extern "C" size_t rat_ffn_planes_bytes(int d, int hidden) { return (d == F3_D && hidden == F3_H) ? 3 * F3_WP : 0; }
+extern "C" size_t rat_ffn_planes_bytes(int d, int hidden) { return f3_dims(d, hidden) ? 3 * F3_WP : 0; }
 extern "C" int rat_ffn_split_jobs(const float* w1, const float* w2, int d, int hidden, void* planes, RatSplitJob* jobs_out) {
     RAT_REQUIRE(w1 && w2 && jobs_out, "null pointer");
-    if (!(d == F3_D && hidden == F3_H) || planes == nullptr) return 0;
+    if (!f3_dims(d, hidden) || planes == nullptr) return 0;
     RAT_REQUIRE(aligned16(planes), "planes must be 16-byte aligned");
     char* ws = static_cast<char*>(planes);
-    jobs_out[0] = RatSplitJob{w1, ws, F3_H, F3_D, F3_D, 0, 0, 0};                    // A[hidden][d]   = w1[hidden][d]
-    jobs_out[1] = RatSplitJob{w2, ws + F3_WP, F3_H, F3_D, F3_H, 1, 0, 0};            // A[hidden][d]   = w2[d][hidden]
-    jobs_out[2] = RatSplitJob{w1, ws + 2 * F3_WP, F3_D, F3_H, F3_D, 1, 1, 0};        // A[d][hidden*] = w1[hidden][d]
+    // narrower layers: the planes cover (128, 64); `reserved` = n_valid | k_valid << 16 says how much of them is the matrix
+    const int pad = d != F3_D;
+    jobs_out[0] = RatSplitJob{w1, ws, F3_H, d, d, 0, 0, pad ? hidden : 0};                                  // A[hidden][d]   = w1[hidden][d]
+    jobs_out[1] = RatSplitJob{w2, ws + F3_WP, F3_H, d, hidden, 1, 0, pad ? hidden : 0};                     // A[hidden][d]   = w2[d][hidden]
+    jobs_out[2] = RatSplitJob{w1, ws + 2 * F3_WP, F3_D, F3_H, d, 1, 1, pad ? (d | (hidden << 16)) : 0};     // A[d][hidden*] = w1[hidden][d]
     return 3;
 }
 
@@ -1293,23 +1336,27 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     const int fast = ffn_fast_dim(a, {x, dy, dx, b1});
-    if (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3) {
+    const bool dpad = arith == RAT_ARITH_BF16X3 && f3_dpad(a, {x, dy, dx, b1});
+    const bool b3 = dpad || (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3);
+    if (b3) {
         const char* ws;
         if (planes != nullptr && aligned16(planes)) {            // split once per step by the caller (rat_split_weights_batch)
             ws = static_cast<const char*>(planes);
         } else {
             uintptr_t wsb = reinterpret_cast<uintptr_t>(workspace + (size_t)256 * a.slab_stride + 2 * (size_t)d * hidden);
             char* wsw = reinterpret_cast<char*>((wsb + 15) & ~(uintptr_t)15);
-            if (rat_launch_split_weights(w1, F3_H, F3_D, F3_D, 0, wsw, stream) ||                          // A[hidden][d]   = w1[hidden][d]
-                rat_launch_split_weights(w2, F3_H, F3_D, F3_H, 1, wsw + F3_WP, stream) ||                  // A[hidden][d]   = w2[d][hidden]
-                rat_launch_split_weights(w1, F3_D, F3_H, F3_D, 1, wsw + 2 * F3_WP, stream, 1)) return -1;  // A[d][hidden*] = w1[hidden][d]
+            if (rat_launch_split_weights(w1, F3_H, d, d, 0, wsw, stream, 0, dpad ? hidden : 0) ||                           // A[hidden][d]   = w1[hidden][d]
+                rat_launch_split_weights(w2, F3_H, d, hidden, 1, wsw + F3_WP, stream, 0, dpad ? hidden : 0) ||              // A[hidden][d]   = w2[d][hidden]
+                rat_launch_split_weights(w1, F3_D, F3_H, d, 1, wsw + 2 * F3_WP, stream, 1, dpad ? (d | (hidden << 16)) : 0))  // A[d][hidden*] = w1[hidden][d]
+                return -1;
             ws = wsw;
         }
         Ffn3W W{};
         W.w1 = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.w2t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + F3_WP), 2};
         W.w1t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + 2 * F3_WP), 4};
-        RAT_LAUNCH(ffn_bwd_t3_kernel, blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+        if (dpad) RAT_LAUNCH((ffn_bwd_t3_kernel<true>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+        else RAT_LAUNCH((ffn_bwd_t3_kernel<false>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
     } else
     if (fast) {
         float* w1t = workspace + (size_t)256 * a.slab_stride;
@@ -1318,7 +1365,7 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
         a.w1t = w1t;
         a.w2t = w2t;
     }
-    if (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3) {
+    if (b3) {
         // launched above
     } else if (fast == 64 && hidden == 128) {
         RAT_LAUNCH((ffn_bwd_t_kernel<64, 128>), blocks, FB_THREADS, (FfnBTGeom<64, 128>::smem), stream, a);
