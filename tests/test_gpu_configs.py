@@ -4,7 +4,7 @@
     configs[1]  synthetic_F20_V1M_K10_d64_B4096     (north star; forward / AUC checks live in test_gpu_fullsize.py)
     configs[2]  kkbox_like_F13_K10_d64_B4096        (fused <64,10> kernels at S = 14)
     configs[4]  tmall_like_F8_K30_d64_h32_B4096     (32 x 10 heads at d = 64: GROUPED mode, four 8-head launches of <64,10>, L = 31 / 9)
-    + the reference's own KKBox geometry kkbox_real_F13_K5_d40_B4096 (embedding_dim 40: the generic <0,10> kernels)
+    + the reference's own KKBox geometry kkbox_real_F13_K5_d40_B4096 (embedding_dim 40: the bf16x3 kernels inside their 64-wide tiles)
     (configs[3] is the 8-GPU / 100 M-row config: its per-rank shape is covered by tests/test_sparse_grad.py)
 
 Two kinds of checks per workload, both against the reference-pinned oracle (oracle/rat_m2_oracle.py) with FULL-SIZE parameters
