@@ -29,8 +29,16 @@ WORKLOADS = {
     # moments; no dense gradient: row-sparse lists + rat_adam_rows), global batch 8192 over 8 GPUs = 1024 per rank
     "synthetic_F40_V100M_K10_d64_B1024": dict(F=40, total_vocab=100_000_000, K=10, d=64, batch=1024, embedding_regularizer=0.0,
                                               embedding_grad="sparse", **KKBOX_HYPER),
-    # the reference's own KKBox experiment (configs/RAT_m2/kkbox_x1/model_config.yaml: embedding_dim 40, K = 5): generic-geometry kernels
+    # the reference's own KKBox experiment (configs/RAT_m2/kkbox_x1/model_config.yaml: embedding_dim 40, K = 5): the bf16x3 kernels
+    # inside their 64-wide tiles
     "kkbox_real_F13_K5_d40_B4096": dict(F=13, total_vocab=92_000, K=5, d=40, batch=4096, **KKBOX_HYPER),
+    # the two other shipped experiments at their own geometry (configs/RAT_m2/movielenslatest_x1, tmall_x1_002; topK = 5 in
+    # configs/datasets/*.yaml): embedding_dim 10 — generic exact-fp32 kernels (Tmall's 32 heads x 10 in groups of 8)
+    "movielens_real_F3_K5_d10_B4096": dict(F=3, total_vocab=90_000, K=5, d=10, batch=4096, num_heads=2, dim_head=10, depth=4,
+                                           scale_dim=4, dnn_hidden_units=[400, 400, 400], batch_norm=False, use_wide=True,
+                                           learning_rate=1e-3),
+    "tmall_real_F9_K5_d10_h32_B4096": dict(F=9, total_vocab=1_500_000, K=5, d=10, batch=4096, num_heads=32, dim_head=10, depth=4,
+                                           scale_dim=2, dnn_hidden_units=[200, 80], batch_norm=True, use_wide=True, learning_rate=1e-3),
     # bench.py --dry-run-cpu (plumbing check of the multi-process launch over gloo + the host-emulated kernels)
     "dryrun": dict(F=3, total_vocab=90, K=2, d=16, batch=8, num_heads=2, dim_head=10, depth=1, scale_dim=2,
                    dnn_hidden_units=[16], batch_norm=True, use_wide=True, learning_rate=1e-3),
