@@ -374,7 +374,7 @@ class RAT_m2(BaseModel):
             dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, arith=self.arith,
                                  dropout=att[2], out=out, lib=lib)
             return dx
-        assert out is None, "in-place attention backward is wired for the fused kernel only"
+        assert out is None or mode == "grouped", "a caller-provided gradient grid is wired for the fused and the grouped kernels only"
         if mode == "grouped":
             groups, ig = heads // per, per * dh
             ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, per, dh))
@@ -383,7 +383,7 @@ class RAT_m2(BaseModel):
             t_lng, t_lnb, t_b = torch.empty_like(g_lng), torch.empty_like(g_lnb), torch.empty_like(g_bout)
             t_w = torch.empty((3 * ig, d), dtype=torch.float32, device=dy.device)
             t_wo = torch.empty((d, ig), dtype=torch.float32, device=dy.device)
-            dx = None
+            dx = out                                     # (a caller's grid: must NOT be dy itself — every group reads dy)
             for g, (w_g, wo_g, params_g, zb, o, l, drop) in enumerate(att):
                 first = g == 0
                 grads_g = ops.attn_params(g_lng if first else t_lng, g_lnb if first else t_lnb, t_w, t_wo, g_bout if first else t_b)
@@ -474,7 +474,7 @@ class RAT_m2(BaseModel):
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
         self._refresh_weight_planes()
         last = len(self._blocks) - 1
-        prune = self.prune_dead_tokens and self._attn_is_fused(cmap)
+        prune = self.prune_dead_tokens and self._attn_mode(cmap)[0] in ("fused", "grouped")
         for bi, blk in enumerate(self._blocks):
             inplace = (not save) and (bi > 0 or x is not x0)   # eval: x0 must survive (DNN input), later grids are reused
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
@@ -522,7 +522,9 @@ class RAT_m2(BaseModel):
                 # every other row stays zero — exactly the gradient the intra-sample layer below would have been handed
                 # (both layers with ONE query position per sequence — RatSeqMap.queries —: the gradient rows of the others are zero)
                 cm0 = ops.cross_map_label_token(B, T, S, queries=1)
-                dx = self._attn_layer_backward(blk["cross"], xa, dgrid, a2, cm0, G, out=dgrid)
+                # (wide heads run in groups and every group reads dy again: there the result goes to a second zero grid)
+                dxg = dgrid if self._attn_is_fused(cm0) else torch.zeros_like(dgrid)
+                dx = self._attn_layer_backward(blk["cross"], xa, dgrid, a2, cm0, G, out=dxg)
                 dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, ops.intra_map(B, T, S, queries=1), G)
                 continue
             dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
