@@ -439,7 +439,7 @@ def worker(args):
     # The headline `value` is measured with the reference's amount of work: every token of every block.  The product's default
     # also prunes the last block's dead tokens (RAT_m2.prune_dead_tokens: identical predictions and gradients) — that step is timed
     # separately and reported beside it as `dead_token_pruning`; --prune makes it the measured step instead.
-    can_prune = hasattr(model, "prune_dead_tokens") and args.model == "RAT_m2"
+    can_prune = hasattr(model, "prune_dead_tokens") and args.model in ("RAT_m2", "RAT_m3")
     if can_prune:
         model.prune_dead_tokens = bool(args.prune)
     graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or args.graph_dp)

@@ -97,7 +97,8 @@ def test_train_step_graph_in_segments_with_eager_closures_between():
         assert float(bad.double().mean()) < 1e-3 and float((x - y).abs().max()) <= 1.05e-2, k
 
 
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape", "kkbox_shape", "northstar_shape", "bare_no_proj", "tmall_real_heads", "tmall_shape"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "mltag_shape", "kkbox_shape", "northstar_shape", "bare_no_proj", "tmall_real_heads", "tmall_shape",
+                                  "m3_tiny_seq", "m3_northstar_shape", "m3_mltag_shape"])
 def test_dead_token_pruning_changes_nothing(name):
     mc.check_pruning_equivalence(name, gpu=0)
 

@@ -1318,12 +1318,28 @@ class RAT_m3(RAT_m2):
         d, H = c["d"], c["hidden"]
         h, dh, sc = self._m3_heads, self._m3_dh, self._m3_scale
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
-        for blk in self._blocks:
+        last = len(self._blocks) - 1
+        for bi, blk in enumerate(self._blocks):
             wq, wks, wvs, wkt, wvt = [self._p(n) for n in blk["proj"]]
             torch.cat([wq, wks, wvs], dim=0, out=blk["w_s"])
             torch.cat([wq, wkt, wvt], dim=0, out=blk["w_t"])
             ps = self._m3_params(blk, "intra", blk["w_s"], self._p)
             pt = self._m3_params(blk, "cross", blk["w_t"], self._p)
+            if bi == last and self.prune_dead_tokens:
+                # Dead-token pruning (RAT_m2._encoder_forward): the head reads x[:, 0][:, 0] only (RAT_m3.py:128-129), and in
+                # the LAST block that token needs the intra-sample attention of the target sample's sequence and the cross-sample
+                # attention of token position 0's sequence — B sequences each instead of B T and B S — and the MLP on one token.
+                im0, cm0 = ops.intra_map_target_sample(B, T, S), ops.cross_map_label_token(B, T, S)
+                out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, im0, d, h, dh, sc, 0.5, save=save, lib=lib)
+                out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cm0, d, h, dh, sc, 0.5, save=save, out=out, lib=lib)
+                out_cls = out.view(B, T, S, d)[:, 0, 0, :].contiguous()
+                x_cls = x.view(B, T, S, d)[:, 0, 0, :].contiguous()
+                w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+                xc = ops.ffn_fwd_res(out_cls, x_cls, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)
+                if save:
+                    saved["blocks"].append((x, o_s, l_s, o_t, l_t, out_cls))
+                    saved["pruned"] = True
+                return xc, d
             out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, imap, d, h, dh, sc, 0.5, save=save, lib=lib)             # 0.5 * intra(x)
             out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cmap, d, h, dh, sc, 0.5, save=save, out=out, lib=lib)     # += 0.5 * cross(x)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
@@ -1344,7 +1360,8 @@ class RAT_m3(RAT_m2):
         ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
         g_s = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
         g_t = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
-        for blk, (x_in, o_s, l_s, o_t, l_t, out) in zip(reversed(self._blocks), reversed(saved["blocks"])):
+        pruned = bool(saved.get("pruned"))
+        for bi, (blk, (x_in, o_s, l_s, o_t, l_t, out)) in enumerate(zip(reversed(self._blocks), reversed(saved["blocks"]))):
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             gw = [G(n) for n in blk["ffn"]]
             dout, _ = ops.ffn_bwd_res(out, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
@@ -1353,9 +1370,20 @@ class RAT_m3(RAT_m2):
             pt = self._m3_params(blk, "cross", blk["w_t"], self._p)
             gs = self._m3_params(blk, "intra", g_s, G)
             gt = self._m3_params(blk, "cross", g_t, G)
-            # dx = dy (the MLP residual) + cross backward + intra backward, accumulated in place
-            dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, cmap, d, h, dh, sc, 0.5, workspace=ws_attn, lib=lib)
-            dxn, _ = ops.attn_bwd_ex(x_in, dout, dxn, o_s, l_s, ps, gs, imap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dxn, lib=lib)
+            amap, bmap = cmap, imap
+            if bi == 0 and pruned:        # the last block (see _encoder_forward): `out`, dx, dout are the class tokens' [B, d] rows
+                dgrid = torch.zeros((B, T, S, d), dtype=torch.float32, device=dx.device)
+                dgrid[:, 0, 0, :] = dx                              # the residual of x' = mlp(out) + x
+                dog = torch.zeros((B, T, S, d), dtype=torch.float32, device=dx.device)
+                dog[:, 0, 0, :] = dout
+                dx, dout = dgrid, dog
+                amap, bmap = ops.cross_map_label_token(B, T, S), ops.intra_map_target_sample(B, T, S)
+                # in place: the rows of the two B-sequence maps receive their gradient, every other row stays zero
+                dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, amap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dx, lib=lib)
+            else:
+                # dx = dy (the MLP residual) + cross backward + intra backward, accumulated in place
+                dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, amap, d, h, dh, sc, 0.5, workspace=ws_attn, lib=lib)
+            dxn, _ = ops.attn_bwd_ex(x_in, dout, dxn, o_s, l_s, ps, gs, bmap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dxn, lib=lib)
             gq, gks, gvs, gkt, gvt = [G(n) for n in blk["proj"]]
             torch.add(g_s[:inner], g_t[:inner], out=gq)                    # W_q is used by both attentions
             gks.copy_(g_s[inner:2 * inner])

@@ -57,6 +57,11 @@ def cross_map_label_token(B, T, S, queries=0):
     return RatSeqMap(nseq=B, L=T, queries=queries, q_div=1, hi_stride=T * S, lo_stride=0, pos_stride=S)
 
 
+def intra_map_target_sample(B, T, S, queries=0):
+    """the intra-sample sequences of retrieved-sample index 0 (the target) only: B sequences of S tokens"""
+    return RatSeqMap(nseq=B, L=S, queries=queries, q_div=1, hi_stride=T * S, lo_stride=0, pos_stride=1)
+
+
 def attn_params(ln_g, ln_b, w_qkv, w_out, b_out, planes=None):
     """planes: optional uint8 tensor of ``attn_planes_bytes`` bytes holding the bf16x3 fragment planes of these weights (filled by
     ``split_weights_batch`` from ``attn_split_jobs``); without it the bf16x3 entry points split the weights on every call."""
