@@ -137,3 +137,40 @@ def test_auc_and_logloss_match_the_oracle_within_1e4(setup):
     mine = evaluate_metrics(y_true, full[rows].numpy(), ["AUC", "logloss"])
     want = evaluate_metrics(y_true, ref, ["AUC", "logloss"])
     assert abs(mine["AUC"] - want["AUC"]) < 1e-4 and abs(mine["logloss"] - want["logloss"]) < 1e-4, (mine, want)
+
+
+def test_dead_token_pruning_at_the_full_size(setup):
+    """BASELINE.json configs[1] at its full size, whole batch of 4096: the product's default step (the last block computes only what
+    x[:, 0][:, 0] depends on — RAT_m2.prune_dead_tokens, also RAT_m3) against the same model with every token of every block computed:
+    bit-equal eval predictions, the same training loss, every gradient tensor within summation-order rounding of its largest element."""
+    spec, fm, model, batch, which = setup
+    if which not in ("RAT_m2", "RAT_m3"):
+        pytest.skip("the cascaded / joint variants are not pruned")
+    assert model.prune_dead_tokens is True, "pruning is the default"
+    preds = {}
+    for prune in (True, False):                      # (both before any training-mode pass: that one moves BatchNorm's running statistics)
+        model.prune_dead_tokens = prune
+        preds[prune] = _predict(model, batch)
+    assert torch.equal(preds[True], preds[False]), "predictions differ with dead-token pruning"
+    res = {}
+    for prune in (True, False):
+        model.prune_dead_tokens = prune
+        model.train()
+        model.optimizer.zero_grad()
+        loss = model.get_total_loss(batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[prune] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+        model.optimizer.zero_grad()
+    model.prune_dead_tokens = True
+    (la, ga), (lb, gb) = res[True], res[False]
+    assert abs(la - lb) < 3e-6 * max(1.0, abs(lb))        # (the regulariser's sum of 65 M squares goes through atomics: ~10 ulps run to run)
+    assert set(ga) == set(gb)
+    worst = 0.0
+    for k in ga:
+        scale = float(gb[k].abs().max()) + 1e-30
+        err = float((ga[k] - gb[k]).abs().max()) / scale
+        worst = max(worst, err)
+        assert err <= 4e-6, (k, err)
+    print("%s at B = %d: pruned vs full — predictions bit-equal, worst gradient difference %.1e of the tensor's largest element over %d tensors"
+          % (which, spec["batch"], worst, len(ga)))
