@@ -33,7 +33,14 @@ import model_cases as mc
 rccl = mode != "plain"
 if rccl:
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        probe = torch.ones(4, device="cuda:0")
+        dist.all_reduce(probe)                    # the communicator comes up with the first collective
+        torch.cuda.synchronize()
+    except Exception as exc:                      # no usable RCCL in this environment: nothing this test could say (exit code 77 = skip)
+        print("RCCL_UNAVAILABLE: %s: %s" % (type(exc).__name__, exc))
+        sys.exit(77)
 case = dict(gc.case_by_name(case_name))
 model = mc.build_model(case, gpu=0, seed=1)
 mc.load_weights(model, case)
@@ -70,6 +77,8 @@ def _run(out, case, mode, steps, port):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", WORKER, ROOT, str(out), case, mode, str(steps)], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
+    if r.returncode == 77 and "RCCL_UNAVAILABLE" in r.stdout:
+        pytest.skip("RCCL could not bring up a one-rank communicator here: " + r.stdout.strip().splitlines()[-1][:300])
     assert r.returncode == 0, r.stdout[-3000:]
     return torch.load(str(out))
 
