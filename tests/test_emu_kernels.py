@@ -79,6 +79,13 @@ def test_attn_fwd_bwd_bf16x3_narrower_embedding(emu, case, mode, two_blocks):
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
 
 
+def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(emu, two_blocks, monkeypatch):
+    """for L <= 12 pass 1 of attn_bwd3_kernel leaves P in LDS and pass 2 reads it (the default; RAT_ATTN_BWD_PH=0 recomputes) — both forms"""
+    kc.check_attn(emu, "cpu", (2, 3, 7, 64, 8, 10, True), "intra", arith="bf16x3")
+    monkeypatch.setenv("RAT_ATTN_BWD_PH", "0")
+    kc.check_attn(emu, "cpu", (3, 11, 4, 64, 8, 10, True), "cross", arith="bf16x3")
+
+
 def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
     kc.check_attn_queries(emu, "cpu", (2, 3, 7, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
     kc.check_attn_dropout(emu, "cpu", (1, 3, 5, 40, 8, 10, True), "cross", arith="bf16x3")

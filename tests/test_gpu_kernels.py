@@ -70,6 +70,14 @@ def test_attn_fwd_bwd_bf16x3_narrower_embedding(lib, d, mode):
     kc.check_attn(lib, "cuda", (3, 5, 3, d, 8, 10, True), mode, arith="bf16x3")
 
 
+def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(lib, monkeypatch):
+    """for L <= 12 pass 1 of attn_bwd3_kernel leaves P in LDS and pass 2 reads it (the default; RAT_ATTN_BWD_PH=0 recomputes) — both forms"""
+    kc.check_attn(lib, "cuda", (40, 11, 21, 64, 8, 10, True), "cross", arith="bf16x3")
+    kc.check_attn(lib, "cuda", (7, 3, 12, 64, 8, 10, True), "intra", arith="bf16x3")
+    monkeypatch.setenv("RAT_ATTN_BWD_PH", "0")
+    kc.check_attn(lib, "cuda", (40, 11, 21, 64, 8, 10, True), "cross", arith="bf16x3")
+
+
 def test_attn_narrower_embedding_with_queries_and_dropout(lib):
     kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
     kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "cross", nq=1, arith="bf16x3")

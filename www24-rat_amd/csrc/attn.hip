@@ -1778,7 +1778,9 @@ __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes
     epi(mt0 + 1, nt, acc[1]);
 }
 
-template <bool EX, bool QSUB = false, bool DPAD = false>
+// PH: sequences of at most 12 tokens — the probabilities P of pass 1 fit the (then dead) dy planes (64 rows x L x 8 heads x 4 B <= 24 KB)
+// and are handed to pass 2, which then needs neither the q . k product nor the exponential again
+template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                  // LayerNorm(x)
@@ -1942,12 +1944,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             dlt[row_i * B3_H + h] = delta;
             const float lse = lses[row_i * B3_H + h];
             const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + ho;
+            float* const prow = PH ? dxn + ((sq * B3_H + h) * L + i) * L : nullptr;     // P[(sequence, head)][query i][key j]
             for (int j = 0; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * B3_LDQ;
                 kv.load(kp + B3_I, B3_DH);
                 const float dp = go.dot(kv);
                 kv.load(kp, B3_DH);
                 const float p = rat_exp2(q.dot(kv) * sl2 - lse);
+                if (PH) prow[j] = p;
                 dq.axpy(p * (dp - delta), kv);
             }
             dq.store(opp, B3_DH, a.scale);
@@ -1978,10 +1982,12 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 const int row_i = sq * L + i;
                 t.load(dob + (size_t)row_i * B3_LDT + ho, B3_DH);
                 const float dp = t.dot(vv);
-                const float lse = lses[row_i * B3_H + h], delta = dlt[row_i * B3_H + h];
+                const float delta = dlt[row_i * B3_H + h];
                 HV qv;
                 qv.load(qkv + (size_t)row_i * B3_LDQ + ho, B3_DH);
-                const float p = rat_exp2(qv.dot(kk) * sl2 - lse);
+                float p;
+                if (PH) p = dxn[((sq * B3_H + h) * L + i) * L + j];           // consecutive lanes = consecutive keys: conflict-free
+                else p = rat_exp2(qv.dot(kk) * sl2 - lses[row_i * B3_H + h]);
                 dv.axpy(p, t);
                 dk.axpy(p * (dp - delta), qv);
             }
@@ -2225,6 +2231,12 @@ static bool b3_geom(int d, int heads, int dim_head) { return b3_dim(d) && heads 
 static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
     return b3_geom(d, heads, dim_head) && w->w_out != nullptr;
 }
+// PH instantiation of attn_bwd3_kernel: P of a chunk inside the dy planes' 24 KB
+static bool b3_ph_fits(int L, int nsq_chunk) { return (size_t)nsq_chunk * B3_H * L * L * 4 <= (size_t)3 * B3_XP; }
+static bool b3_ph_enabled() {                          // on unless RAT_ATTN_BWD_PH=0 (same-box A/B: L = 11 1.2477 -> 1.2322 ms, -1.2 %)
+    const char* e = getenv("RAT_ATTN_BWD_PH");
+    return e == nullptr || e[0] != '0';
+}
 // `valid` of the split jobs whose N is the embedding dimension (rat_split_weights: n_valid)
 static int b3_nvalid(int d) { return d == B3_D ? 0 : d; }
 // ... and only while every token's byte offset in the widest array (o_save: 320 B per token) fits 32 bits (b3_ld4)
@@ -2414,6 +2426,8 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
             else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_bwd3_kernel<true, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         } else if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (a.add_lds && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())
+            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);       // (computes every position)
     } else if (!aligned8(o_save)) {                    // run-time dim_head kernel: 4-byte accesses, dim_head <= DH_MAX
