@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "www24-rat_amd")):
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, exact fp32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the sparsity figures are never used)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
+ROCPROF_NOTE = "profiles/round4/r4_bench_kernel_stats.csv (in the step), r4_gather_V100M_kernel_stats.csv (25.6 GB table)"
 NBATCH = 4                        # distinct batches rotated through the timed loop
 # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected with rocprofv3 in
 # separate runs (bench.py cannot host the profiler) and committed next to the kernel stats; valid for the north-star shapes only
@@ -323,7 +324,7 @@ def cpu_baseline(workload, spec, batch_size, seed, model="RAT_m2", timed_steps=3
                        "thread count of `runs`" % (timed_steps, batch_size, spec["F"], spec["K"], spec["d"], spec["total_vocab"], ncpu))
 
 
-def big_table_gather(lib, device, ev_over, rows_per_field=2_500_000, F=40, d=64, K=10, B=1024, reps=12):
+def big_table_gather(lib, device, rows_per_field=2_500_000, F=40, d=64, K=10, B=1024, reps=12):
     """rat_gather_fwd at BASELINE.json configs[3]'s per-rank shape on its REAL table: F = 40 fields x 2.5 M rows x 64 floats = 25.6 GB
     in HBM (uniform random ids: no cache can hold it), B = 1024, T = 11 -> 450 560 row reads of 256 B per launch.  The table is
     allocated and filled on the device for this measurement only and freed afterwards."""
@@ -351,16 +352,15 @@ def big_table_gather(lib, device, ev_over, rows_per_field=2_500_000, F=40, d=64,
         ops.gather_fwd(idxs[i % 4], labels, ftab, F, label_tab, B, T, F, d, lib=lib)
         e_.record()
     torch.cuda.synchronize()
-    raw = sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps
-    ms = max(raw - ev_over, 1e-6)
+    ms = sum(s_.elapsed_time(e_) for s_, e_ in evs) / reps    # the HIP-event pair as it stands: nothing subtracted
     nbytes = B * (T * F * d * 4 + T * S * d * 4 + T * F * 4)
     del table, tabs
     torch.cuda.empty_cache()
     return dict(bound="hbm", what="rat_gather_fwd alone at configs[3]'s per-rank shape (F=40, B=1024, K=10, d=64) on a 25.6 GB table "
                 "(100 M rows), uniform ids, %d launches over 4 id sets" % reps, avg_launch_ms=round(ms, 4),
-                avg_launch_ms_event_pair=round(raw, 4), event_pair_overhead_ms=round(ev_over, 4), algorithmic_bytes=nbytes,
-                achieved_GBps=round(nbytes / (ms * 1e-3) / 1e9, 1), frac_of_8TBps=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                frac_of_8TBps_event_pair=round(nbytes / (raw * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+                timing="HIP-event pair around the launch, nothing subtracted; rocprofv3 durations of the same kernel: " + ROCPROF_NOTE,
+                algorithmic_bytes=nbytes, achieved_GBps=round(nbytes / (ms * 1e-3) / 1e9, 1),
+                frac_of_8TBps=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
 
 
 # ------------------------------------------------------------------------------------------------- the worker
@@ -514,27 +514,6 @@ def worker(args):
         region_info[label] = info
         return elapsed, (timer.summary(steps) if (kernel_pass or not graph_mode) else {})
 
-    def event_overhead_ms(n=60):
-        """what a HIP-event pair adds to a launch it brackets: the bracketed time of the smallest launch the C ABI offers (rat_sumsq
-        of ONE element: a one-block kernel of ~2 us whose own run time is part of the figure).  Subtracted from the bracketed
-        times of the ~0.1 ms gather kernels in `targets` (raw values are printed beside); irrelevant for the ms-scale kernels."""
-        if dry:
-            return 0.0
-        from rat_amd import ops
-        x = torch.ones(1, dtype=torch.float32, device=model.device)
-        out = torch.zeros(1, dtype=torch.float32, device=model.device)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        for s_, e_ in evs:
-            s_.record(), e_.record()
-        torch.cuda.synchronize()
-        for s_, e_ in evs:
-            s_.record()
-            ops.sumsq(x, out, lib=model._lib)
-            e_.record()
-        torch.cuda.synchronize()
-        ts = sorted(s_.elapsed_time(e_) for s_, e_ in evs)
-        return ts[len(ts) // 2]
-
     want_weak = not dp or args.scaling in ("both", "weak")
     want_strong = dp and args.scaling in ("both", "strong")
     weak = strong = None
@@ -587,11 +566,10 @@ def worker(args):
                            "full-size oracle comparisons all run with it on)")
         model.prune_dead_tokens = False
         del batches
-    ev_over = event_overhead_ms() if rank == 0 else 0.0
     # the embedding gather on a table that cannot sit in any cache: BASELINE.json configs[3]'s 100 M rows x 64 floats = 25.6 GB
     gather_big = None
     if extras and args.workload == "synthetic_F20_V1M_K10_d64_B4096" and args.model == "RAT_m2":
-        gather_big = big_table_gather(model._lib, model.device, ev_over)
+        gather_big = big_table_gather(model._lib, model.device)
 
     if rank == 0:
         primary, per_rank_batch, scaling = (weak, B, "weak") if weak is not None else (strong, B // world, "strong")
@@ -646,13 +624,13 @@ def worker(args):
         for nm in ("rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted"):
             p = pooled.get(nm)
             if p and p["n"] > 0 and p["bound"] == "hbm":
-                raw_ms = p["ms"] / p["n"]
-                ms = max(raw_ms - ev_over, 1e-6)             # the HIP-event pair's own cost taken out (event_overhead_ms)
+                ms = p["ms"] / p["n"]                         # the HIP-event pair as it stands (no overhead subtraction)
                 gbs = p["amount"] / p["n"] / (ms * 1e-3) / 1e9
-                targets[nm] = dict(bound="hbm", avg_launch_ms=round(ms, 4), avg_launch_ms_event_pair=round(raw_ms, 4),
-                                   event_pair_overhead_ms=round(ev_over, 4), algorithmic_bytes=round(p["amount"] / p["n"]),
-                                   achieved_GBps=round(gbs, 1), frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4),
-                                   frac_of_8TBps_event_pair=round(p["amount"] / p["n"] / (raw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+                targets[nm] = dict(bound="hbm", avg_launch_ms=round(ms, 4),
+                                   timing="HIP-event pair around the launch inside the training step, nothing subtracted; rocprofv3 "
+                                          "durations of the same kernel: " + ROCPROF_NOTE,
+                                   algorithmic_bytes=round(p["amount"] / p["n"]), achieved_GBps=round(gbs, 1),
+                                   frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4))
         if gather_big is not None:
             targets["rat_gather_fwd_V100M"] = gather_big
         T = spec["K"] + 1

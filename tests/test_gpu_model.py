@@ -71,6 +71,76 @@ def test_train_step_graph_with_sorted_and_sparse_table_gradients(name, mode):
         assert float(bad.double().mean()) < 1e-3 and float((x - y).abs().max()) <= 1.05e-2, (k, float((x - y).abs().max()))
 
 
+@pytest.mark.parametrize("mode", ["sorted", "sparse"])
+def test_train_step_graphs_of_two_batch_shapes_keep_their_plans(mode):
+    """a captured step has the sort plan's workspace / count pointers baked in.  Shape A is captured, then an
+    epoch's tail batch (shape B) builds its own plan — which used to REPLACE A's, so that every later replay of A sorted and reduced
+    through a freed block.  Run A x4 (capture at 3), B x4 (capture), garbage allocations in between, A x2 again: the graph model must
+    follow an eager twin, and A's plan object must still be the one the first capture saw."""
+    kw = dict(embedding_grad=mode)
+    if mode == "sparse":
+        kw["embedding_regularizer"] = 0.0
+    case = gc.case_by_name("northstar_shape")
+    a = mc.build_model(case, gpu=0, seed=1, **kw)
+    b = mc.build_model(case, gpu=0, seed=1, **kw)
+    mc.load_weights(a, case), mc.load_weights(b, case)
+    b.use_graph = False
+    full = mc.batch_of(case)
+    nb = full[0].shape[0]
+    tail = tuple(t[: max(1, nb // 2)].contiguous() for t in full)
+    a.train(), b.train()
+    plans_a = None
+    schedule = [full] * 4 + [tail] * 4 + [full] * 2 + [tail] + [full]
+    for step, batch in enumerate(schedule):
+        la, lb = float(a.train_step(batch)), float(b.train_step(batch))
+        assert abs(la - lb) < 2e-6, (step, la, lb)
+        if step == 3:
+            plans_a = {k: id(v) for k, v in a._ws.items() if isinstance(k, tuple) and k[0] == "plan"}
+        if step in (7, 9):      # whatever the allocator handed back is overwritten before the next replay
+            junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(64)]
+            del junk
+    assert sum(1 for e in a._step_graphs.values() if e[1]) == 2
+    for k, v in plans_a.items():
+        assert id(a._ws[k]) == v, "the plan of the first captured shape was replaced: %r" % (k,)
+    noise = mc.noise_tensors(a)
+    for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
+        if k.endswith("num_batches_tracked") or k in noise or k.endswith("running_mean"):
+            continue
+        x, y = va.detach().cpu().double(), vb.detach().cpu().double()
+        assert bool(torch.isfinite(x).all()), k
+        bad = (x - y).abs() > 3e-5 + 3e-4 * y.abs()
+        assert float(bad.double().mean()) < 1e-3 and float((x - y).abs().max()) <= 2.5e-2, (k, float((x - y).abs().max()))
+
+
+def test_a_changed_clip_norm_takes_a_new_capture():
+    """max_gradient_norm (and the other baked launch arguments) are part of the step-graph key"""
+    case = gc.case_by_name("tiny_seq_bn")
+    a = mc.build_model(case, gpu=0, seed=1)
+    mc.load_weights(a, case)
+    batch = mc.batch_of(case)
+    a.train()
+    for _ in range(3):
+        a.train_step(batch)
+    assert sum(1 for e in a._step_graphs.values() if e[1]) == 1
+    a._max_gradient_norm = 1e-3
+    a.graph_shapes = 4
+    for _ in range(3):
+        a.train_step(batch)
+    assert sum(1 for e in a._step_graphs.values() if e[1]) == 2
+    b = mc.build_model(case, gpu=0, seed=1)
+    mc.load_weights(b, case)
+    b.use_graph = False
+    b.train()
+    for i in range(6):
+        b._max_gradient_norm = 10.0 if i < 3 else 1e-3
+        b.train_step(batch)
+    noise = mc.noise_tensors(a)
+    for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
+        if k.endswith("num_batches_tracked") or k in noise or k.endswith("running_mean"):
+            continue
+        assert float((va - vb).abs().max()) <= 1.3e-2, k
+
+
 def test_train_step_graph_in_segments_with_eager_closures_between():
     """what a captured step looks like under data parallelism: collectives are not captured, they run eagerly BETWEEN graph segments
     (StepGraph.between_segments).  One GPU has no collectives, so the model's test knob inserts two no-op ones: 3 segments + 2

@@ -734,8 +734,11 @@ class RAT_m2(BaseModel):
         all_rows = self._all_gather_flat(rows)
         all_grads = self._all_gather_flat(grads.reshape(-1))
         all_counts = self._all_gather_flat(count)
-        plan = ops.sparse_plan_rows(all_rows, all_counts, cap, world, total_rows, plan=self._ws.get(("merge", width)), lib=lib)
-        self._ws[("merge", width)] = plan
+        # plans are cached PER SIZE and never dropped: a captured step (graph.StepGraph) has the plan's workspace / count
+        # pointers baked in, and a second batch shape (an epoch's tail batch) must not hand that memory back to the allocator
+        pkey = ("merge", width, cap * world)
+        plan = ops.sparse_plan_rows(all_rows, all_counts, cap, world, total_rows, plan=self._ws.get(pkey), lib=lib)
+        self._ws[pkey] = plan
         ncap = min(cap * world, total_rows)
         out_rows = torch.empty(ncap, dtype=torch.int32, device=rows.device)
         out_grads = torch.empty((ncap, width), dtype=torch.float32, device=rows.device)
@@ -917,7 +920,11 @@ class RAT_m2(BaseModel):
         if c["attn_dropout"] > 0 or c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers):
             return None                                    # dropout seeds are drawn on the host per step: not replayable
         graphs = self.__dict__.setdefault("_step_graphs", {})
-        key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens))
+        group = self.optimizer.param_groups[0]
+        key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens),
+               # kernel arguments and control flow the recorded launches carry: a change of any of them takes a new capture
+               self._max_gradient_norm, tuple(group["betas"]), group["eps"], c["lam_emb"], c["lam_net"], self._grad_mode,
+               self.row_list_exchange, bool(self._graph_test_splits), bool(self._validate_ids))
         entry = graphs.get(key)
         if entry is None:
             if len(graphs) >= self.graph_shapes:
@@ -1032,6 +1039,8 @@ class RAT_m2(BaseModel):
     def _workspace(self, key, nbytes):
         ws = self._ws.get(key)
         if ws is None or ws.numel() * 4 < nbytes:
+            if ws is not None:                                   # a captured step may have this buffer's address baked in
+                self._ws.setdefault("retired", []).append(ws)
             ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.device)
             self._ws[key] = ws
         return ws
@@ -1152,9 +1161,10 @@ class RAT_m2(BaseModel):
         d, F = c["d"], c["nf"]
         dev = dx.device
         rows_feat = self._n_feat // d
+        # one plan per batch size, kept for the model's life: captured steps point into its workspace (see _merge_sparse)
         plan = ops.sparse_plan_ids(idx, self._ftab, self._col2field, F, self._flat, d, rows_feat, B, T, L,
-                                   plan=self._ws.get(("plan", 0)), lib=lib)
-        self._ws[("plan", 0)] = plan
+                                   plan=self._ws.get(("plan", 0, B * T * L)), lib=lib)
+        self._ws[("plan", 0, B * T * L)] = plan
         sparse = []
         if mode == "sorted":
             ops.sparse_reduce_grid(plan, dx, dflat, self._col2field, B, T, L, F, d, dense_base=gflat, lib=lib)
@@ -1168,8 +1178,8 @@ class RAT_m2(BaseModel):
             rows_lr = self._n_tab - self._n_feat
             lr_base = self._flat[self._n_feat:]
             plan_lr = ops.sparse_plan_ids(idx, self._lr_ftab, self._col2field, F, lr_base, 1, rows_lr, B, T, L, target_only=True,
-                                          plan=self._ws.get(("plan", 1)), lib=lib)
-            self._ws[("plan", 1)] = plan_lr
+                                          plan=self._ws.get(("plan", 1, B * L)), lib=lib)
+            self._ws[("plan", 1, B * L)] = plan_lr
             if mode == "sorted":
                 ops.sparse_reduce_scalar(plan_lr, dlogit, B, L, dense_base=gflat[self._n_feat:], lib=lib)
             else:
