@@ -12,7 +12,9 @@
  *    device, is re-entrant and keeps no global mutable state (forward runs on the Python main thread,
  *    backward on autograd's device thread);
  *  - return value 0 = launched, negative = rejected (message via rat_last_error(), thread-local);
- *  - all arithmetic is IEEE fp32; ids are int32; token grids are row-major [B][T][S][d]
+ *  - results are fp32; the default arithmetic of the encoder / head GEMMs is RAT_ARITH_BF16X3 (3-way bf16 split, six of the
+ *    nine cross products, fp32 accumulate: fp32-class, not bit-identical to an fp32 FMA chain), RAT_ARITH_F32 selects exact
+ *    IEEE fp32 MFMA; everything else (softmax, LayerNorm, GELU, optimizer) is IEEE fp32; ids are int32; token grids are row-major [B][T][S][d]
  *    (sample-in-batch, target||retrieved sample, label||field token, embedding dim).
  */
 #ifndef RAT_HIP_H_
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 5
+#define RAT_ABI_VERSION 6
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -107,6 +109,9 @@ typedef struct RatAttnParams {      /* HOST struct of device pointers; state_dic
                    * 16-byte aligned) as written by rat_split_weights_batch from the jobs of rat_attn_split_jobs — valid until
                    * the weights change.  NULL: rat_attn_fwd_ex / rat_attn_bwd_ex derive them themselves (2 - 3 small launches
                    * per call).  Ignored in the struct that receives gradients. */
+    const uint64_t* drop_seed_dev; /* ABI v6, optional: DEVICE location of this layer's dropout seed (one of the words rat_dropout_seeds
+                   * writes).  When set, rat_attn_fwd_ex / rat_attn_bwd_ex read the seed there and ignore their `dropout_seed` argument:
+                   * a training step captured into a hipGraph then draws a new mask on every replay.  NULL: the by-value seed. */
 } RatAttnParams;
 
 /* ---- bf16x3 weight planes, once per optimizer step instead of once per call ------------------------------------------------
@@ -394,6 +399,12 @@ int rat_adam_rows_dev(float* w_base, float* m_base, float* v_base, const int32_t
  * with a counter-based mask, so the backward pass calls the same function on the gradient with the same seed.
  * In place (y == x) is allowed. */
 int rat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* ABI v6 — the same with the seed read from device memory, and the once-per-training-step refresh of a model's seed words:
+ * counter_dev[0] += 1; seeds_dev[i] = mix(base_seed, counter, i), i < n.  nn.Dropout draws from torch's generator on every call
+ * (RAT_m2.py:135,186-189, deep.py:133-134); here the generator's state is (base_seed, counter) on the device, so forward and backward
+ * of a step agree on the masks (backward reads the same words) and a captured step needs no host-drawn seed. */
+int rat_dropout_dev(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, void* stream);
+int rat_dropout_seeds(uint64_t* seeds_dev, int n, uint64_t base_seed, uint64_t* counter_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,45 @@ def test_train_step_graphs_of_two_batch_shapes_keep_their_plans(mode):
         assert float(bad.double().mean()) < 1e-3 and float((x - y).abs().max()) <= 2.5e-2, (k, float((x - y).abs().max()))
 
 
+@pytest.mark.parametrize("name", ["kkbox_shape", "tmall_real_heads"])
+def test_train_step_graph_replays_with_dropout(name):
+    """the shipped KKBox / Tmall configs have emb_dropout 0.1 (Tmall also net_dropout 0.08) and used to stay eager
+    because the seeds were drawn on the host.  The generator state now lives on the device (rat_dropout_seeds), so the captured step
+    draws new masks on every replay: a graph model and an eager twin with the same base seed must agree step by step, and the
+    loss on the SAME batch must move from step to step by more than Adam alone would explain identically in both."""
+    case = gc.case_by_name(name)
+    kw = dict(emb_dropout=0.1, net_dropout=0.08, dropout=0.05)
+    models = []
+    for use_graph in (True, False):
+        torch.manual_seed(4321)                      # the base seed is drawn from torch's generator at the first training forward
+        m = mc.build_model(case, gpu=0, seed=1, **kw)
+        mc.load_weights(m, case)
+        m.use_graph = use_graph
+        m.train()
+        models.append(m)
+    a, b = models
+    batch = mc.batch_of(case)
+    losses = []
+    for step in range(6):
+        torch.manual_seed(99 + step)
+        la = float(a.train_step(batch))
+        torch.manual_seed(99 + step)
+        lb = float(b.train_step(batch))
+        assert abs(la - lb) < 2e-6 * max(1.0, abs(lb)), (step, la, lb)
+        losses.append(la)
+    assert any(e[1] for e in a._step_graphs.values()), "the step with dropout was not captured"
+    assert int(a._drop_counter) == 6 and int(b._drop_counter) == 6
+    # the masks really change between replays: with a frozen mask the eval-mode prediction drift alone would be monotone and tiny
+    a.eval(), b.eval()
+    with torch.no_grad():
+        ya, yb = a.forward(batch)["y_pred"], b.forward(batch)["y_pred"]
+    assert float((ya - yb).abs().max()) < 2e-3      # (six Adam steps on rounding-level gradient differences; the per-step losses above are the check)
+    words = a._drop_words.clone()
+    a.train()
+    a.train_step(batch)
+    assert not torch.equal(words, a._drop_words)
+
+
 def test_a_changed_clip_norm_takes_a_new_capture():
     """max_gradient_norm (and the other baked launch arguments) are part of the step-graph key"""
     case = gc.case_by_name("tiny_seq_bn")

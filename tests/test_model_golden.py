@@ -63,12 +63,14 @@ def test_two_training_steps(name):
 
 
 def test_dropout_training_is_consistent():
-    """emb_dropout / net_dropout > 0: masks are counter-based, so (a) the backward pass re-derives the forward's mask —
-    checked by a finite-difference probe of one embedding row through the whole model — and (b) eval ignores dropout."""
+    """emb_dropout / net_dropout / attention dropout > 0: masks are counter-based functions of per-layer seed words that live on
+    the device (rat_dropout_seeds: base seed from torch's generator once, a device counter per training forward), so (a) the
+    backward pass re-derives the forward's mask — checked by a finite-difference probe of one embedding row through the whole
+    model —, (b) eval ignores dropout, (c) consecutive steps draw different masks and (d) the same seed gives the same run."""
     import rat_amd.ops as ops
     case = dict(gc.case_by_name("tiny_seq_bn"))
     case["batch_norm"] = False
-    model = mc.build_model(case, gpu=-1, seed=1, emb_dropout=0.3, net_dropout=0.25)
+    model = mc.build_model(case, gpu=-1, seed=1, emb_dropout=0.3, net_dropout=0.25, dropout=0.2)
     mc.load_weights(model, case)
     batch = mc.batch_of(case)
     model.eval()
@@ -90,13 +92,23 @@ def test_dropout_training_is_consistent():
     for sgn in (+1, -1):
         with torch.no_grad():
             p.data[row, 3] += sgn * eps
-        torch.manual_seed(123)                       # same dropout seeds -> same masks
+        model._drop_counter.zero_()                  # the generator state of the step above -> the same masks
         with torch.no_grad():
             vals.append(float(model.get_total_loss(batch)))
         with torch.no_grad():
             p.data[row, 3] -= sgn * eps
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - float(g[row, 3])) < 5e-3 * max(1.0, abs(fd)), (fd, float(g[row, 3]))
+    # (c) a second step draws other masks; (d) the base seed comes from torch's generator
+    l1 = float(vals[0])
+    with torch.no_grad():
+        l2 = float(model.get_total_loss(batch))
+    assert abs(l2 - l1) > 1e-7
+    twin = mc.build_model(case, gpu=-1, seed=1, emb_dropout=0.3, net_dropout=0.25, dropout=0.2)
+    mc.load_weights(twin, case)
+    twin.train()
+    torch.manual_seed(123)
+    assert float(twin.get_total_loss(batch)) == float(loss)
     # the mask really drops ~p of the elements and rescales the rest
     x = torch.ones(100000)
     y = ops.dropout(x, 0.3, 77)

@@ -28,7 +28,9 @@ PHASES = {
     24: ("ffn_fwd", ["load", "W1 gemm + gelu", "W2 gemm + store"]),
     36: ("ffn_bwd", ["load", "W1 gemm + gelu", "dW2", "dh gemm", "dx gemm + dW1"]),
     48: ("attn_fwd bf16x3", ["LN -> planes", "QKV gemm (+ operand layouts)", "softmax(QK)V core", "O -> planes", "out-proj", "store"]),
-    72: ("ffn_bwd_t (wave 0)", ["consume + stage", "h / dh chain + gelu", "dx partial", "barrier 1", "dx store + prefetch issue", "dW1, dW2", "barrier 2"]),
+    72: ("ffn_bwd_t4 (wave 0; RAT_FFN_BWD=t3: consume + stage | chain | dx partial | barrier 1 | dx store + prefetch | dW | barrier 2)",
+         ["split x / dy -> planes", "barrier 1", "h / dh chain + gelu (hidden tile 0)", "barrier 2", "prefetch issue + dx gemm + store", "dW1, dW2",
+          "barrier 3"]),
     60: ("attn_bwd bf16x3", ["loads, LN, planes", "QKV gemm (wave 0)", "dO gemm (wave 0)", "dW_out + barrier", "pass1 (dQ)", "pass2 (dK,dV)",
                              "dQKV -> planes", "dXn gemm (wave 0)", "dW_qkv + barrier", "LN bwd + store"]),
 }

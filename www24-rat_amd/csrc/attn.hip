@@ -1010,7 +1010,8 @@ constexpr size_t B3_W_QKV = (size_t)15 * 2 * 3 * 1024, B3_W_OUT = (size_t)4 * 3 
                  B3_W_QKVT = (size_t)4 * 8 * 3 * 1024;
 constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
 
-constexpr size_t b3_fwd_smem() { return (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8; }
+constexpr size_t B3_FWD_LSE = (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8;   // [64][8] log-sum-exp of the chunk
+constexpr size_t b3_fwd_smem() { return B3_FWD_LSE + (size_t)64 * B3_H * 4; }
 
 // LayerNorm of one row piece into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns [8 sub, 8 sub + 8) = exactly
 // one 16-byte piece, handed over in two float4 (loaded by the caller, usually a whole chunk ahead); same arithmetic, in the same
@@ -1092,7 +1093,10 @@ struct B3RowFetchO {
             off[it] = (uint32_t)(ok ? tok : 0) * (uint32_t)(B3_I * 4) + 16u * (uint32_t)(e % W4);
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) v[it] = b3_ld4(src, off[it]);
+        for (int it = 0; it < NIT; ++it) {
+            // the saved O rows are read exactly once: non-temporal (same-box A/B in the step, round 4: attn_bwd3 L21 1290 -> 1267 us)
+            v[it] = rat_ld4_stream(reinterpret_cast<const float*>(reinterpret_cast<const char*>(src) + off[it]));
+        }
     }
     __device__ __forceinline__ void stash(float* tile, int ld) {
 #pragma unroll
@@ -1157,6 +1161,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
     const PlanesO op{smem + 3 * B3_XP + 64 * B3_LDQ * 4};                   // O planes (row operand of the output projection)
     int64_t* const rowtok0 = reinterpret_cast<int64_t*>(smem + 3 * B3_XP + 64 * B3_LDQ * 4 + 3 * B3_OP);
     float* ys = reinterpret_cast<float*>(smem);                             // [64][68] over the (then dead) x planes
+    float* const lse_s = reinterpret_cast<float*>(smem + B3_FWD_LSE);       // the chunk's log-sum-exp, saved as whole rows below
     constexpr int LDY = B3_D + 4;
     const int L = a.L;
 
@@ -1264,9 +1269,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             }
             const float inv = 1.0f / l;
             o.store(qp, B3_DH, inv);
-            const int64_t tok = rowtok[row_i];
-            if (a.o_save != nullptr) o.store(a.o_save + tok * B3_I + h * B3_DH, B3_DH, inv);
-            if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = m + rat_log2(l);
+            lse_s[row_i * B3_H + h] = m + rat_log2(l);
         }
         if (QSUB && nq < L) {                                    // the positions nobody asked for: O = 0, lse = 0 (defined, never used)
             for (int e = threadIdx.x; e < rows * B3_H; e += ATT_THREADS) {
@@ -1275,20 +1278,31 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
                 HV z;
                 z.zero();
                 z.store(qkv + (size_t)r * B3_LDQ + h * B3_DH, B3_DH, 1.0f);
-                const int64_t tok = rowtok[r];
-                if (a.o_save != nullptr) z.store(a.o_save + tok * B3_I + h * B3_DH, B3_DH, 1.0f);
-                if (a.lse_save != nullptr) a.lse_save[tok * B3_H + h] = 0.f;
+                lse_s[e] = 0.f;
             }
         }
         __syncthreads();
         RAT_PROF_MARK(2);
-        // O (the Q columns of the valid rows; padding rows are exact zeros) -> planes
+        // O (the Q columns of the valid rows; padding rows are exact zeros) -> planes, and -> o_save for the backward: whole 320-byte
+        // rows in 16-byte pieces with the non-temporal hint (round 4; before, every core lane stored its head's 40 bytes in five
+        // scattered 8-byte stores at the end of its key loop).  lse_save leaves the same way, from the LDS copy.
         for (int e = threadIdx.x; e < ATT_ROWS * (B3_I / 8); e += ATT_THREADS) {
             const int r = e / (B3_I / 8), o8 = e - r * (B3_I / 8);
             const float* src = qkv + (size_t)r * B3_LDQ + 8 * o8;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
             rat_u4 h, m, l;
-            rat_split8(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4), h, m, l);
+            rat_split8(v0, v1, h, m, l);
             op.store(r, o8, h, m, l);
+            const int64_t tok = rowtok[r];
+            if (a.o_save != nullptr && tok >= 0) {
+                rat_st4_stream(a.o_save + tok * B3_I + 8 * o8, v0);
+                rat_st4_stream(a.o_save + tok * B3_I + 8 * o8 + 4, v1);
+            }
+        }
+        if (a.lse_save != nullptr && (int)threadIdx.x < 2 * ATT_ROWS) {
+            const int r = threadIdx.x >> 1, part = threadIdx.x & 1;
+            const int64_t tok = rowtok[r];
+            if (tok >= 0) rat_st4_stream(a.lse_save + tok * B3_H + 4 * part, *reinterpret_cast<const float4*>(lse_s + r * B3_H + 4 * part));
         }
         __syncthreads();
         RAT_PROF_MARK(3);
@@ -1839,7 +1853,12 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             const uint32_t po = DPAD ? b3_piece_off_d(tok_own, dreal, colok) : b3_piece_off(tok_own);
             B3RowFetchO fo;
             float4 x0 = b3_ld4(a.x, po), x1 = b3_ld4(a.x, po + 16u);
+#ifdef RAT_ATTN_BWD_DY_NT
+            float4 d0 = rat_ld4_stream(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.dy) + po)),
+                   d1 = rat_ld4_stream(reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.dy) + po + 16u));
+#else
             float4 d0 = b3_ld4(a.dy, po), d1 = b3_ld4(a.dy, po + 16u);
+#endif
             fo.issue(a.o_save, rowtok);
             float lsen = b3_ld1(a.lse_save, (uint32_t)(tok_own >= 0 ? tok_own : 0) * (uint32_t)(B3_H * 4) + 4u * sub);
             RAT_SCHED_FENCE();                                               // every request is out before anything is consumed
@@ -2291,7 +2310,7 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() * per_cu ? a.nchunks : rat_max_blocks() * per_cu);
     RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
     if (dropout_p > 0.f && w_host->w_out != nullptr)              // Attention.to_out is Identity without a projection: no Dropout there
-        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p)};
+        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p), w_host->drop_seed_dev};
     const int fast = fast_dim(a, {x, y, res, o_save, lse_save});
     const bool plain = res == x && out_scale == 1.0f && a.drop.threshold == 0;
     const bool have_planes = w_host->planes != nullptr && aligned16(w_host->planes);
@@ -2389,7 +2408,7 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     a.add = add;
     RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
     if (dropout_p > 0.f && w_host->w_out != nullptr)
-        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p)};
+        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p), w_host->drop_seed_dev};
     a.add_lds = (add == dy && out_scale == 1.0f && a.drop.threshold == 0) ? 1 : 0;
     a.x = x;
     a.dy = dy;

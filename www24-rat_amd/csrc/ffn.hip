@@ -1194,6 +1194,271 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t3_kernel(FfnArgs a, Ffn3W
     }
 }
 
+// ---- round 4: the same backward with the WEIGHTS stationary.  In ffn_bwd_t3_kernel a wave owns a token tile and streams the weight
+// fragments of four hidden tiles from L2: every fragment is fetched by four waves, 576 KB per 64 tokens and work-group — at ~60 B per
+// clock and CU that stream alone is longer than the kernel's MFMAs (PMC round 3: MFMA busy 29 %, waves waiting 46 %).  Here a wave owns
+// a HIDDEN tile: its W1 / W2^T fragments (48 VGPRs) stay in registers for the whole launch and the token fragments come from the plane
+// images in LDS, which the weight-gradient GEMMs need there anyway:
+//   split   wave (tile tt, half): half 0 splits x of token tile tt into the x planes, half 1 dy into the dy planes        | barrier
+//   chain   wave w = hidden tile: for the four token tiles  h^T = W1 x^T + b1, dh^T = W2^T dy^T  (B fragments = 16-byte row reads of
+//           the planes), gelu / gelu' on the accumulators, gelu(h) and dh' split into their planes                          | barrier
+//   dx      wave (d tile w & 3, token tiles 2 (w >> 2), + 1): dx^T = W1^T dh'^T over all 128 hidden (A: W1^T fragments from L2, 12 KB
+//           per wave — a sixth of the old stream; B: the dh' planes in W1^T's permuted k order, 8-byte reads) + dy, stored from the
+//           accumulators: no partial sums to exchange, the 16 KB exchange tile and its traffic are gone
+//   dW      as before (transposed block reads of the four plane images)                                                     | barrier
+template <bool DPAD = false>
+__global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t4_kernel(FfnArgs a, Ffn3W W) {
+    constexpr int D = F3_D, H = F3_H, SL = 4;
+    const int dr = DPAD ? a.d : D, hid = DPAD ? a.hidden : H;                // DPAD: see ffn_fwd_t3_kernel
+    RAT_DYN_SMEM(smem);
+    const PlanesT64 xsp{smem};
+    const PlanesT64 dysp{smem + 3 * 64 * 128};
+    const PlanesT128 gsp{smem + 2 * 3 * 64 * 128};
+    const PlanesT128 dhsp{smem + 2 * 3 * 64 * 128 + 3 * 64 * 256};
+
+    const int l = rat_lane(), n = l & 15, g = l >> 4;
+    const int w = rat_wave(), tt = w & 3, half = w >> 2;
+    const int row = 16 * tt + n;                                             // the token whose x (half 0) / dy (half 1) this thread splits
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* const src = half == 0 ? a.x : a.dy;
+
+    f32x4 acc1[SL], acc2[SL];
+#pragma unroll
+    for (int i = 0; i < SL; ++i) acc1[i] = acc2[i] = rat_zero4();
+    f32x4 db1a = rat_zero4();                                                // hidden 16 w + 4 g + r, this lane's token columns
+    float4 db2f[4] = {zero4, zero4, zero4, zero4};                           // column sums of dy in fragment order (half 1 only)
+
+    // the stationary operands of the chain: hidden tile w of W1 and W2^T (two K steps each), and its bias quad
+    const RatB3 w1a = W.w1(w, 0), w1b = W.w1(w, 1), w2a = W.w2t(w, 0), w2b = W.w2t(w, 1);
+    const f32x4 b1v = (!DPAD || 16 * w + 4 * g < hid) ? as_v4(ld4(a.b1 + 16 * w + 4 * g)) : rat_zero4();
+
+    float4 tN[4];                                                            // [2 s + part]: src[token][32 s + 8 g + 4 part .. + 3]
+    int64_t chunk = blockIdx.x;
+    {
+        const int64_t tk = chunk * FB_TOK + row;
+        const bool ok = chunk < a.nchunks && tk < a.ntok;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+#ifdef RAT_FFN_BWD_NT                                             // (A/B knob: x and dy of this layer are read exactly once)
+            tN[q] = (ok && (!DPAD || c < dr)) ? rat_ld4_stream(src + tk * dr + c) : zero4;
+#else
+            tN[q] = (ok && (!DPAD || c < dr)) ? ld4(src + tk * dr + c) : zero4;
+#endif
+        }
+    }
+    RAT_PROF_DECL
+    for (; chunk < a.nchunks; chunk += gridDim.x) {
+        {
+            float4 tT[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tT[q] = rat_consume4(tN[q]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                rat_u4 h, m, lo;
+                rat_split8(tT[2 * s], tT[2 * s + 1], h, m, lo);
+                if (half == 0) xsp.store(row, 4 * s + g, h, m, lo);
+                else dysp.store(row, 4 * s + g, h, m, lo);
+            }
+            if (half == 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    db2f[q].x += tT[q].x; db2f[q].y += tT[q].y; db2f[q].z += tT[q].z; db2f[q].w += tT[q].w;
+                }
+        }
+        RAT_PROF_MARK(0);
+        __syncthreads();
+        RAT_PROF_MARK(1);
+        // ---- chain: hidden tile w against the four token tiles
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const RatB3 x0 = xsp.row_frag(t, 0), x1 = xsp.row_frag(t, 1), y0 = dysp.row_frag(t, 0), y1 = dysp.row_frag(t, 1);
+            f32x4 c0 = b1v, c1 = rat_zero4();
+            c0 = RAT_MFMA_BF16(w1a.l, x0.h, c0);
+            c1 = RAT_MFMA_BF16(w2a.l, y0.h, c1);
+            c0 = RAT_MFMA_BF16(w1a.h, x0.l, c0);
+            c1 = RAT_MFMA_BF16(w2a.h, y0.l, c1);
+            c0 = RAT_MFMA_BF16(w1a.m, x0.m, c0);
+            c1 = RAT_MFMA_BF16(w2a.m, y0.m, c1);
+            c0 = RAT_MFMA_BF16(w1a.m, x0.h, c0);
+            c1 = RAT_MFMA_BF16(w2a.m, y0.h, c1);
+            c0 = RAT_MFMA_BF16(w1a.h, x0.m, c0);
+            c1 = RAT_MFMA_BF16(w2a.h, y0.m, c1);
+            c0 = RAT_MFMA_BF16(w1a.h, x0.h, c0);
+            c1 = RAT_MFMA_BF16(w2a.h, y0.h, c1);
+            c0 = RAT_MFMA_BF16(w1b.l, x1.h, c0);
+            c1 = RAT_MFMA_BF16(w2b.l, y1.h, c1);
+            c0 = RAT_MFMA_BF16(w1b.h, x1.l, c0);
+            c1 = RAT_MFMA_BF16(w2b.h, y1.l, c1);
+            c0 = RAT_MFMA_BF16(w1b.m, x1.m, c0);
+            c1 = RAT_MFMA_BF16(w2b.m, y1.m, c1);
+            c0 = RAT_MFMA_BF16(w1b.m, x1.h, c0);
+            c1 = RAT_MFMA_BF16(w2b.m, y1.h, c1);
+            c0 = RAT_MFMA_BF16(w1b.h, x1.m, c0);
+            c1 = RAT_MFMA_BF16(w2b.h, y1.m, c1);
+            c0 = RAT_MFMA_BF16(w1b.h, x1.h, c0);
+            c1 = RAT_MFMA_BF16(w2b.h, y1.h, c1);
+            float4 gv, dp;
+            float dg;
+            rat_gelu_both(c0[0], gv.x, dg);
+            dp.x = c1[0] * dg;
+            rat_gelu_both(c0[1], gv.y, dg);
+            dp.y = c1[1] * dg;
+            rat_gelu_both(c0[2], gv.z, dg);
+            dp.z = c1[2] * dg;
+            rat_gelu_both(c0[3], gv.w, dg);
+            dp.w = c1[3] * dg;
+            const HalfPieces gp = f3_split4(gv);
+            const HalfPieces dq = f3_split4(dp);
+            gsp.store_half(16 * t + n, 4 * w + g, gp.h0, gp.h1, gp.m0, gp.m1, gp.l0, gp.l1);
+            dhsp.store_half(16 * t + n, 4 * w + g, dq.h0, dq.h1, dq.m0, dq.m1, dq.l0, dq.l1);
+            db1a[0] += dp.x;
+            db1a[1] += dp.y;
+            db1a[2] += dp.z;
+            db1a[3] += dp.w;
+        }
+        // the dx phase's A operand (W1^T, d tile w & 3, all four K steps: 12 KB per wave from L2) is requested HERE, in front of the
+        // barrier: the round trip runs while the wave waits for the slower chains (stamps, round 4: the barrier took 11 % of the
+        // iteration and the dx phase, with its fragments requested one step ahead inside the loop, 29 %)
+        RAT_SCHED_FENCE();                                           // (not earlier: inside the chain they would be 48 more live registers)
+        const RatB3 wt0 = W.w1t(w & 3, 0), wt1 = W.w1t(w & 3, 1), wt2 = W.w1t(w & 3, 2), wt3 = W.w1t(w & 3, 3);
+        RAT_SCHED_FENCE();
+        RAT_PROF_MARK(2);
+        __syncthreads();
+        RAT_PROF_MARK(3);
+        {   // next chunk's token fragments: in flight behind the dx and weight-gradient GEMMs
+            const int64_t tk = (chunk + gridDim.x) * FB_TOK + row;
+            const bool ok = chunk + gridDim.x < a.nchunks && tk < a.ntok;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+    #ifdef RAT_FFN_BWD_NT                                             // (A/B knob: x and dy of this layer are read exactly once)
+            tN[q] = (ok && (!DPAD || c < dr)) ? rat_ld4_stream(src + tk * dr + c) : zero4;
+#else
+            tN[q] = (ok && (!DPAD || c < dr)) ? ld4(src + tk * dr + c) : zero4;
+#endif
+            }
+        }
+        // ---- dx^T (d tile md, token tiles t0, t0 + 1) = W1^T dh'^T over the four K steps of the hidden dimension; W1^T's planes carry
+        // the hidden index in the stacked-accumulator order (k slot j of lane group g <-> hidden 32 s + 4 g + j | 32 s + 16 + 4 g + j - 4):
+        // the B fragment takes those two quads of a token's dh' row
+        {
+            const int md = w & 3, t0 = 2 * (w >> 2);
+            f32x4 dxa[2] = {rat_zero4(), rat_zero4()};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const RatB3& wa = s == 0 ? wt0 : (s == 1 ? wt1 : (s == 2 ? wt2 : wt3));
+                RatB3 db[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    unsigned ah0, ah1, am0, am1, al0, al1, bh0, bh1, bm0, bm1, bl0, bl1;      // (plain scalars: a struct here lands in scratch)
+                    dhsp.load_half(16 * (t0 + i) + n, 8 * s + g, ah0, ah1, am0, am1, al0, al1);
+                    dhsp.load_half(16 * (t0 + i) + n, 8 * s + 4 + g, bh0, bh1, bm0, bm1, bl0, bl1);
+                    rat_u4 sh, sm, sl;
+                    sh.x = ah0; sh.y = ah1; sh.z = bh0; sh.w = bh1;
+                    sm.x = am0; sm.y = am1; sm.z = bm0; sm.w = bm1;
+                    sl.x = al0; sl.y = al1; sl.z = bl0; sl.w = bl1;
+                    db[i] = RatB3{rat_as_bf16x8(sh), rat_as_bf16x8(sm), rat_as_bf16x8(sl)};
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dxa[i] = RAT_MFMA_BF16(wa.l, db[i].h, dxa[i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dxa[i] = RAT_MFMA_BF16(wa.h, db[i].l, dxa[i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dxa[i] = RAT_MFMA_BF16(wa.m, db[i].m, dxa[i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dxa[i] = RAT_MFMA_BF16(wa.m, db[i].h, dxa[i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dxa[i] = RAT_MFMA_BF16(wa.h, db[i].m, dxa[i]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dxa[i] = RAT_MFMA_BF16(wa.h, db[i].h, dxa[i]);
+                if (s == 1) RAT_SCHED_FENCE();                               // (all four steps' LDS reads hoisted to the top spill 9 VGPRs)
+            }
+            // + dy: rebuilt from the three planes of the dy tile (h + m + l IS the fp32 value), then out
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = 16 * (t0 + i) + n;
+                const int64_t tok = chunk * FB_TOK + r;
+                float4 rsd = zero4;
+                if (a.add_dy) {                                               // uniform
+                    unsigned h0, h1, m0, m1, l0, l1;
+                    dysp.load_half(r, 4 * md + g, h0, h1, m0, m1, l0, l1);
+                    rsd = make_float4(rat_join(h0, m0, l0, 0), rat_join(h0, m0, l0, 1), rat_join(h1, m1, l1, 0), rat_join(h1, m1, l1, 1));
+                }
+                const float4 o = make_float4(dxa[i][0] + rsd.x, dxa[i][1] + rsd.y, dxa[i][2] + rsd.z, dxa[i][3] + rsd.w);
+                if (tok < a.ntok && (!DPAD || 16 * md + 4 * g < dr)) st4(a.y + tok * dr + 16 * md + 4 * g, o);
+            }
+        }
+        RAT_PROF_MARK(4);
+        // ---- dW1 += dh'^T x (tiles: hidden (w >> 2) + 2 i  x  d (w & 3)) ; dW2 += dy^T gelu(h) (tiles: d (w & 3)  x  hidden (w >> 2) + 2 i)
+        {
+            const RatB3 xb0 = xsp.col_frag(w & 3, 0), xb1 = xsp.col_frag(w & 3, 1);
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int mt = (w >> 2) + 2 * i;
+                acc1[i] = rat_mfma3(dhsp.col_frag(mt, 0), xb0, acc1[i]);
+                acc1[i] = rat_mfma3(dhsp.col_frag(mt, 1), xb1, acc1[i]);
+            }
+            const RatB3 ya0 = dysp.col_frag(w & 3, 0), ya1 = dysp.col_frag(w & 3, 1);
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int nt = (w >> 2) + 2 * i;
+                acc2[i] = rat_mfma3(ya0, gsp.col_frag(nt, 0), acc2[i]);
+                acc2[i] = rat_mfma3(ya1, gsp.col_frag(nt, 1), acc2[i]);
+            }
+        }
+        RAT_PROF_MARK(5);
+        __syncthreads();
+        RAT_PROF_MARK(6);
+    }
+    RAT_PROF_FLUSH(a.prof, 72);
+
+    // slab: [dW1 (H x D) | dW2 (D x H) | db1 (H) | db2 (D)]
+    float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
+    float* s_w1 = slab;                                           // (the host's layout: [hidden][d], [d][hidden], [hidden], [d])
+    float* s_w2 = s_w1 + (int64_t)hid * dr;
+    float* s_b1 = s_w2 + (int64_t)dr * hid;
+    float* s_b2 = s_b1 + hid;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+        const int t2 = (w >> 2) + 2 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!DPAD || (rat_acc_row(t2, r) < hid && rat_acc_col(w & 3) < dr))
+                s_w1[(int64_t)rat_acc_row(t2, r) * dr + rat_acc_col(w & 3)] = acc1[i][r];
+            if (!DPAD || (rat_acc_row(w & 3, r) < dr && rat_acc_col(t2) < hid))
+                s_w2[(int64_t)rat_acc_row(w & 3, r) * hid + rat_acc_col(t2)] = acc2[i][r];
+        }
+    }
+    {   // bias gradients: db1 — 16 token-column partials per hidden unit; db2 — 64 token-row partials per column; fixed-order sums
+        constexpr int L1 = 17, L2 = FB_TOK + 1;
+        float* red1 = reinterpret_cast<float*>(smem);              // [H][L1]
+        float* red2 = red1 + H * L1;                               // [D][L2]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red1[(16 * w + 4 * g + r) * L1 + n] = db1a[r];
+        if (half == 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
+                red2[(c0 + 0) * L2 + row] = db2f[q].x;
+                red2[(c0 + 1) * L2 + row] = db2f[q].y;
+                red2[(c0 + 2) * L2 + row] = db2f[q].z;
+                red2[(c0 + 3) * L2 + row] = db2f[q].w;
+            }
+        __syncthreads();
+        for (int c = threadIdx.x; c < H + D; c += FB_THREADS) {
+            float sacc = 0.f;
+            if (c < H) {
+                for (int k = 0; k < 16; ++k) sacc += red1[c * L1 + k];
+                if (!DPAD || c < hid) s_b1[c] = sacc;
+            } else {
+                for (int k = 0; k < FB_TOK; ++k) sacc += red2[(c - H) * L2 + k];
+                if (!DPAD || c - H < dr) s_b2[c - H] = sacc;
+            }
+        }
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // the bf16x3 kernels also serve (d, 2 d) for d = 40 / 48 / 56 inside their (64, 128) tiles (DPAD; the shipped KKBox config is (40, 80))
@@ -1355,8 +1620,12 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
         W.w1 = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.w2t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + F3_WP), 2};
         W.w1t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + 2 * F3_WP), 4};
-        if (dpad) RAT_LAUNCH((ffn_bwd_t3_kernel<true>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
-        else RAT_LAUNCH((ffn_bwd_t3_kernel<false>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+        static const bool t3 = [] { const char* e = getenv("RAT_FFN_BWD"); return e != nullptr && e[0] == 't' && e[1] == '3'; }();
+        if (t3) {                                                 // the round-2/3 kernel (token-stationary), kept for A/Bs: RAT_FFN_BWD=t3
+            if (dpad) RAT_LAUNCH((ffn_bwd_t3_kernel<true>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+            else RAT_LAUNCH((ffn_bwd_t3_kernel<false>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+        } else if (dpad) RAT_LAUNCH((ffn_bwd_t4_kernel<true>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
+        else RAT_LAUNCH((ffn_bwd_t4_kernel<false>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
     } else
     if (fast) {
         float* w1t = workspace + (size_t)256 * a.slab_stride;

@@ -129,7 +129,7 @@ gather_fwd_rows64_kernel(const int32_t* __restrict__ idx, const int32_t* __restr
                 const float4 w = *(reinterpret_cast<const float4*>(tab[u] + (int64_t)i * d) + piece);
                 v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
             }
-#if defined(RAT_GATHER_NT) && !defined(RAT_EMU)
+#if !defined(RAT_GATHER_PLAIN) && !defined(RAT_EMU)     // non-temporal grid stores: see optim.hip (opt_ld4_stream)
             if (ok[u]) {
                 f32x4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
                 __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(grid) + (size_t)(r0 + u * nslots) * 16 + piece);

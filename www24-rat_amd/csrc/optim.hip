@@ -94,11 +94,22 @@ clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __re
 // next step's zero-fill made 4 (w, g -> g | g | g, w, m, v -> w, m, v | -> g).  Elements [0, n_split) carry lam_a (the
 // "embedding_layer" tensors, base_model.py:86), the rest lam_b (net_regularizer).
 __device__ __forceinline__ float4 opt_ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+// streamed-once data (the gradient, the moments): loads AND stores carry the non-temporal hint, so that the sweep leaves the caches
+// to W — which the next step's embedding gather reads at random.  Same-box A/B inside the training step (rocprofv3, round 4,
+// profiles/round4/r4_nt_ab.txt): rat_clip_adam_fused 377-416 -> 309-315 us, the rat_gather_fwd behind it 99-104 -> 86-91 us; the
+// stores alone (round 3's -DRAT_OPT_NT) or the gather's grid stores alone changed nothing.  -DRAT_OPT_PLAIN restores plain accesses.
+__device__ __forceinline__ float4 opt_ld4_stream(const float* p, int64_t i4) {
+#if !defined(RAT_OPT_PLAIN) && !defined(RAT_EMU)
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i4);
+    return make_float4(t[0], t[1], t[2], t[3]);
+#else
+    return reinterpret_cast<const float4*>(p)[i4];
+#endif
+}
 __device__ __forceinline__ void opt_st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
-// streaming store for data nothing reads before the next step's sweep (moments, the zeroed gradient): keeps them out of the caches the
-// embedding gather that follows wants for the table rows
+// streaming store for data nothing reads before the next step's sweep (moments, the zeroed gradient)
 __device__ __forceinline__ void opt_st4_stream(float* p, int64_t i4, float4 v) {
-#if defined(RAT_OPT_NT) && !defined(RAT_EMU)
+#if !defined(RAT_OPT_PLAIN) && !defined(RAT_EMU)
     f32x4 t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p) + i4);
 #else
@@ -119,7 +130,7 @@ sumsq_reg_kernel(const float* __restrict__ g, const float* __restrict__ w, int64
     if (vec) {
         const int64_t n4 = n >> 2, s4 = n_split >> 2;
         for (int64_t i = tid; i < n4; i += nthr) {
-            const float4 gv = opt_ld4(g, i), wv = opt_ld4(w, i);
+            const float4 gv = opt_ld4_stream(g, i), wv = opt_ld4(w, i);
             const bool a = i < s4;
             const float l = a ? la : lb;
             float t;
@@ -173,8 +184,8 @@ clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __re
     if (vec) {
         const int64_t n4 = n >> 2, s4 = n_split >> 2;
         for (int64_t i = tid; i < n4; i += nthr) {
-            float4 wv = opt_ld4(w, i), mv = opt_ld4(m, i), vv = opt_ld4(v, i);
-            const float4 gv = opt_ld4(g, i);
+            float4 wv = opt_ld4(w, i), mv = opt_ld4_stream(m, i), vv = opt_ld4_stream(v, i);
+            const float4 gv = opt_ld4_stream(g, i);
             const float l = i < s4 ? la : lb;
             opt_adam1(wv.x, gv.x, mv.x, vv.x, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
             opt_adam1(wv.y, gv.y, mv.y, vv.y, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
@@ -277,15 +288,43 @@ extern "C" int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64
 namespace {
 
 __global__ void __launch_bounds__(OPT_THREADS)
-dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint32_t threshold, float scale, uint64_t seed) {
+dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, uint32_t threshold, float scale, uint64_t seed,
+               const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev != nullptr) seed = *seed_dev;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = rat_hash32(seed, (uint64_t)i) >= threshold ? x[i] * scale : 0.f;
+}
+// one training step's seeds: counter += 1, seeds[i] = mix(base, counter, i) — the whole state of the step's dropout masks lives on
+// the device, so a captured step (graph.StepGraph) draws new masks on every replay without a host call
+__global__ void dropout_seeds_kernel(uint64_t* seeds, int n, uint64_t base, uint64_t* counter) {
+    const uint64_t c = counter[0] + 1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t hi = rat_hash32(base ^ (0xD1B54A32D192ED03ull * c), (uint64_t)(2 * i));
+        const uint64_t lo = rat_hash32(base + c, (uint64_t)(2 * i + 1));
+        seeds[i] = (hi << 32) | lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counter[0] = c;
 }
 }  // namespace
 
 extern "C" int rat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
     RAT_REQUIRE(n > 0 && x && y && p >= 0.f && p < 1.f, "bad args");
     const uint32_t threshold = (uint32_t)((double)p * 4294967296.0);
-    RAT_LAUNCH(dropout_kernel, opt_blocks(n), OPT_THREADS, 0, stream, x, y, n, threshold, 1.0f / (1.0f - p), seed);
+    RAT_LAUNCH(dropout_kernel, opt_blocks(n), OPT_THREADS, 0, stream, x, y, n, threshold, 1.0f / (1.0f - p), seed,
+               (const uint64_t*)nullptr);
     return rat_check_launch("rat_dropout");
+}
+
+extern "C" int rat_dropout_dev(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, void* stream) {
+    RAT_REQUIRE(n > 0 && x && y && seed_dev && p >= 0.f && p < 1.f, "bad args");
+    const uint32_t threshold = (uint32_t)((double)p * 4294967296.0);
+    RAT_LAUNCH(dropout_kernel, opt_blocks(n), OPT_THREADS, 0, stream, x, y, n, threshold, 1.0f / (1.0f - p), (uint64_t)0, seed_dev);
+    return rat_check_launch("rat_dropout_dev");
+}
+
+extern "C" int rat_dropout_seeds(uint64_t* seeds_dev, int n, uint64_t base_seed, uint64_t* counter_dev, void* stream) {
+    RAT_REQUIRE(seeds_dev && counter_dev && n >= 1, "bad args");
+    RAT_LAUNCH(dropout_seeds_kernel, 1, 64, 0, stream, seeds_dev, n, base_seed, counter_dev);
+    return rat_check_launch("rat_dropout_seeds");
 }

@@ -120,10 +120,32 @@ struct RatDrop {                     // threshold == 0: no dropout
     uint64_t seed;
     uint32_t threshold;
     float scale;                     // 1 / (1 - p)
+    const uint64_t* seed_dev;        // ABI v6: when set, the seed is read from device memory (rat_dropout_seeds refreshes it once per
+                                     // training step, so a captured step replays with a new mask every time); `seed` is ignored
+    __device__ __forceinline__ uint64_t the_seed() const { return seed_dev != nullptr ? *seed_dev : seed; }
     __device__ __forceinline__ float apply(float v, int64_t idx) const {
-        return threshold == 0 ? v : (rat_hash32(seed, (uint64_t)idx) >= threshold ? v * scale : 0.f);
+        return threshold == 0 ? v : (rat_hash32(the_seed(), (uint64_t)idx) >= threshold ? v * scale : 0.f);
     }
 };
+
+// 16-byte accesses with the non-temporal hint, for data that is written (read) once and not touched again for a long time — saved
+// activations, optimizer moments: they should not evict what the next kernel is about to re-read from L2 / Infinity Cache
+__device__ __forceinline__ void rat_st4_stream(float* p, const float4& v) {
+#ifdef RAT_EMU
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#endif
+}
+__device__ __forceinline__ float4 rat_ld4_stream(const float* p) {
+#ifdef RAT_EMU
+    return *reinterpret_cast<const float4*>(p);
+#else
+    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+#endif
+}
 
 __device__ __forceinline__ f32x4 rat_zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -531,10 +553,10 @@ __device__ __forceinline__ void rat_wave_gemm_ct(f32x4 (&acc)[SL], const AF& af,
 // ============================================================================================================================
 // bf16x3: fp32 GEMMs on the bf16 matrix instruction (v_mfma_f32_16x16x32_bf16, 16x the fp32 MFMA rate per FLOP).
 //
-//   x = h + m + l EXACTLY, with h, m, l the three 8-bit chunks of x's 24-bit significand as bf16 numbers (truncation split: h = x
-//   with the low 16 bits cleared, m = the same of x - h, l = x - h - m; every subtraction is exact).  A product a*b is evaluated
+//   x = h + m + l EXACTLY, with h, m, l bf16 numbers (h = x rounded to nearest bf16, m = x - h rounded to nearest, l = x - h - m;
+//   every subtraction is exact, rat_split2).  A product a*b is evaluated
 //   as the six cross terms of weight >= 2^-16:  al*bh + ah*bl + am*bm + am*bh + ah*bm + ah*bh  (each bf16 x bf16 product is exact
-//   in fp32; the MFMA accumulates in fp32).  Dropped: am*bl + al*bm + al*bl <= 2^-23 |a b| — the size of ONE fp32 rounding of the
+//   in fp32; the MFMA accumulates in fp32).  Dropped: am*bl + al*bm + al*bl <= 2^-25 |a b| — a quarter of ONE fp32 rounding of the
 //   product, so the result has fp32-class accuracy (measured: tools/probes/bf16x3_probe.hip) while costing 6 x 16 cycles per
 //   K = 32 step of a 16x16 tile instead of 8 x 32 cycles on v_mfma_f32_16x16x4_f32.
 // Lane maps (cdna_hip_programming.md §3): A: lane l holds A[row l & 15][k = 8 (l >> 4) + j], j = 0..7 (one 16-byte fragment);
@@ -562,15 +584,29 @@ __device__ __forceinline__ unsigned rat_fbits(float x) { return __builtin_bit_ca
 __device__ __forceinline__ float rat_bitsf(unsigned u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ bf16x8 rat_as_bf16x8(const rat_u4& v) { return __builtin_bit_cast(bf16x8, v); }
 
-// two floats -> their packed (low half = x0, high half = x1) bf16 chunks
+// two floats -> packed bf16 (low half = x0, high half = x1), ROUND TO NEAREST EVEN: v_cvt_pk_bf16_f32 on the device (one instruction
+// per pair), the integer formula on the host emulation (bit-identical for finite values)
+__device__ __forceinline__ unsigned rat_bf16_pair(float x0, float x1) {
+#ifdef RAT_EMU
+    const unsigned u0 = rat_fbits(x0), u1 = rat_fbits(x1);
+    return ((u0 + 0x7fffu + ((u0 >> 16) & 1u)) >> 16) | ((u1 + 0x7fffu + ((u1 >> 16) & 1u)) & 0xffff0000u);
+#else
+    typedef __bf16 rat_bf16x2 __attribute__((ext_vector_type(2)));
+    const rat_bf16x2 v = {(__bf16)x0, (__bf16)x1};
+    return __builtin_bit_cast(unsigned, v);
+#endif
+}
+// two floats -> their packed (low half = x0, high half = x1) bf16 chunks.  Round-to-nearest split (round 4; rounds 2-3 truncated):
+// h = rne(x), m = rne(x - h), l = x - h - m.  Every subtraction is exact and l needs at most 8 significant bits, so x = h + m + l
+// still holds EXACTLY; against the truncation split the remainders are half as large (|m| <= 2^-9 |x|, |l| <= 2^-17 |x|: the dropped
+// cross terms of rat_mfma3 shrink from 2^-23 to 2^-25 |a b|) and, unlike truncated remainders, carry no sign bias — a truncated m / l
+// always has the sign of x, so the dropped terms always had the sign of a b.  11 VALU instructions per pair instead of 14.
 __device__ __forceinline__ void rat_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned h0 = rat_fbits(x0) & 0xffff0000u, h1 = rat_fbits(x1) & 0xffff0000u;
-    const float r0 = x0 - rat_bitsf(h0), r1 = x1 - rat_bitsf(h1);
-    const unsigned m0 = rat_fbits(r0) & 0xffff0000u, m1 = rat_fbits(r1) & 0xffff0000u;
-    const float s0 = r0 - rat_bitsf(m0), s1 = r1 - rat_bitsf(m1);
-    h = (h0 >> 16) | h1;
-    m = (m0 >> 16) | m1;
-    l = (rat_fbits(s0) >> 16) | (rat_fbits(s1) & 0xffff0000u);
+    h = rat_bf16_pair(x0, x1);
+    const float r0 = x0 - rat_bitsf(h << 16), r1 = x1 - rat_bitsf(h & 0xffff0000u);
+    m = rat_bf16_pair(r0, r1);
+    const float s0 = r0 - rat_bitsf(m << 16), s1 = r1 - rat_bitsf(m & 0xffff0000u);
+    l = rat_bf16_pair(s0, s1);                           // exact: s0, s1 have no more than 8 significant bits
 }
 // eight floats (two float4: elements 0..3, 4..7) -> three 16-byte pieces
 __device__ __forceinline__ void rat_split8(const float4& a, const float4& b, rat_u4& h, rat_u4& m, rat_u4& l) {

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class RatField(Structure):
@@ -25,7 +25,7 @@ class RatSeqMap(Structure):
 
 class RatAttnParams(Structure):
     _fields_ = [("ln_g", c_void_p), ("ln_b", c_void_p), ("w_qkv", c_void_p), ("w_out", c_void_p), ("b_out", c_void_p),
-                ("planes", c_void_p)]
+                ("planes", c_void_p), ("drop_seed_dev", c_void_p)]
 
 
 class RatSplitJob(Structure):
@@ -103,6 +103,8 @@ _SIGNATURES = {
     "rat_check_ids": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "rat_sumsq": (c_int, [_P, c_int64, _P, _P]),
     "rat_dropout": (c_int, [_P, _P, c_int64, c_float, ctypes.c_uint64, _P]),
+    "rat_dropout_dev": (c_int, [_P, _P, c_int64, c_float, _P, _P]),
+    "rat_dropout_seeds": (c_int, [_P, c_int, ctypes.c_uint64, _P, _P]),
     "rat_clip_adam": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "rat_adam_tick": (c_int, [_P, _P, c_float, c_float, _P, _P]),
     "rat_sumsq_reg": (c_int, [_P, _P, c_int64, c_int64, c_float, c_float, _P, _P, _P, _P]),

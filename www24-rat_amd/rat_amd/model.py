@@ -172,7 +172,11 @@ class _RATFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, with_reg, *params):
-        y_pred, loss, reg, saved = model._run_forward(batch, save=True, with_reg=with_reg)
+        model._drop_private = True         # this forward's backward may run after ANOTHER forward: private copy of the seed words
+        try:
+            y_pred, loss, reg, saved = model._run_forward(batch, save=True, with_reg=with_reg)
+        finally:
+            model._drop_private = False
         ctx.model, ctx.saved_state, ctx.with_reg = model, saved, with_reg
         ctx.mark_non_differentiable(y_pred)
         return y_pred, loss, reg
@@ -332,9 +336,9 @@ class RAT_m2(BaseModel):
         c, lib = self._cfg, self._lib
         d, heads, dh = c["d"], c["heads"], c["dh"]
         mode, per = self._attn_mode(smap)
-        # Dropout behind the output projection (RAT_m2.py:186-189), training only; the seed comes from torch's CPU generator (so
-        # seed_everything governs it) and is kept for the backward, which re-derives the mask
-        drop = (c["attn_dropout"], int(torch.randint(0, 2 ** 62, (1,)))) if (self.training and c["attn_dropout"] > 0) else (0.0, 0)
+        # Dropout behind the output projection (RAT_m2.py:186-189), training only; the seed is one of this step's device words
+        # (_dropout_begin) and is kept for the backward, which re-derives the mask
+        drop = (c["attn_dropout"], self._dropout_word()) if (self.training and c["attn_dropout"] > 0) else (0.0, 0)
         if mode == "fused":
             y, o, l = ops.attn_fwd(x, desc[1], smap, d, heads, dh, save=save, out=out, arith=self.arith, dropout=drop, lib=lib)
             return y, (o, l, drop)
@@ -841,7 +845,8 @@ class RAT_m2(BaseModel):
         and the regulariser's value in one sweep) -> rat_clip_adam_fused (Adam on g + lambda W, leaves g = 0: the next zero_grad).
         Same arithmetic per element as the reference's sequence; p.grad is not populated (it would be None after zero_grad anyway).
         On a GPU the iteration is captured into a hipGraph after `graph_warmup` eager steps of the same batch shape and replayed
-        from then on (graph.StepGraph; `use_graph = False` or a positive dropout rate keep it eager)."""
+        from then on (graph.StepGraph; `use_graph = False` keeps it eager).  Dropout does not: its generator state lives on the
+        device (_dropout_begin), so every replay draws new masks."""
         batch = self._prepare_batch(inputs)
         self.batch_size = batch[0].shape[0]
         if not self.training:
@@ -917,8 +922,6 @@ class RAT_m2(BaseModel):
         if self._dp() and not self.graph_under_dp:
             return None
         c = self._cfg
-        if c["attn_dropout"] > 0 or c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers):
-            return None                                    # dropout seeds are drawn on the host per step: not replayable
         graphs = self.__dict__.setdefault("_step_graphs", {})
         group = self.optimizer.param_groups[0]
         key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens),
@@ -984,9 +987,12 @@ class RAT_m2(BaseModel):
             ops.check_ids(idx, labels, self._ftab, F, self._id_errors, B, T, L, lib=lib)
         x0 = ops.gather_fwd(idx, labels, self._ftab, F, self._p("label_embedding_layer.weight"), B, T, L, d, lib=lib)
         saved = {"batch": batch, "dims": (B, T, L, S), "blocks": [], "dnn": []}
-        # dropout seeds come from torch's CPU generator, so seed_everything() governs them (masks are re-derived in backward)
+        # dropout: the masks are counter-based functions of per-layer seed WORDS that live on the device and are refreshed once per
+        # training forward (rat_dropout_seeds) — no host draw per step, so a captured step replays with new masks; backward re-derives
         drop = training and (c["emb_dropout"] > 0 or any(p > 0 for _, _, p in self._dnn_layers))
-        seeds = torch.randint(0, 2 ** 62, (1 + len(self._dnn_layers),)).tolist() if drop else None
+        if training and (drop or c["attn_dropout"] > 0):
+            self._dropout_begin()
+        seeds = [self._dropout_word() for _ in range(1 + len(self._dnn_layers))] if drop else None
         saved["seeds"] = seeds
         # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
         dnn_out = None
@@ -1035,6 +1041,28 @@ class RAT_m2(BaseModel):
         if save:
             saved["x_final"], saved["cls_stride"], saved["y_pred"] = x, cls_stride, y_pred
         return y_pred, loss[0], reg, saved
+
+    _DROP_WORDS = 64
+
+    def _dropout_begin(self):
+        """Start of a training forward with a positive dropout rate: advance the device-side generator state (base seed drawn ONCE
+        from torch's CPU generator — so seed_everything governs it — plus a device counter) and hand out this step's seed words.
+        Under autograd (_RATFunction: another forward may run before this one's backward) the step works on a private copy of the
+        words; the fused / captured iteration reads the shared words directly."""
+        if self.__dict__.get("_drop_words") is None or self._drop_words.device != self._flat.device:
+            self._drop_base = int(torch.randint(0, 2 ** 62, (1,)))
+            self._drop_words = torch.zeros(self._DROP_WORDS, dtype=torch.int64, device=self._flat.device)
+            self._drop_counter = torch.zeros(1, dtype=torch.int64, device=self._flat.device)
+        ops.dropout_seeds(self._drop_words, self._drop_base, self._drop_counter, lib=self._lib)
+        self._drop_step_words = self._drop_words.clone() if self.__dict__.get("_drop_private") else self._drop_words
+        self._drop_cursor = 0
+
+    def _dropout_word(self):
+        i = self._drop_cursor
+        if i >= self._DROP_WORDS:
+            raise RuntimeError("more than %d dropout layers" % self._DROP_WORDS)
+        self._drop_cursor = i + 1
+        return self._drop_step_words[i:i + 1]
 
     def _workspace(self, key, nbytes):
         ws = self._ws.get(key)

@@ -307,8 +307,9 @@ def attn_fwd_ex(x, res, params, seqmap, d, heads, dim_head, softmax_scale=0.0, o
         o_save = torch.empty((ntok, heads * dim_head), dtype=torch.float32, device=x.device)
         lse = torch.empty((ntok, heads), dtype=torch.float32, device=x.device)
     ws = _attn_fwd_workspace(lib, d, heads, dim_head, x.device) if arith != "f32" else None
+    drop_p, drop_seed = _drop_args(params, dropout)
     lib.call("rat_attn_fwd_ex", _p(x), _p(res), _p(y), _p(o_save), _p(lse), ctypes.byref(params), ctypes.byref(seqmap), d, heads,
-             dim_head, float(softmax_scale), float(out_scale), eps, float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF, ARITH[arith],
+             dim_head, float(softmax_scale), float(out_scale), eps, drop_p, drop_seed, ARITH[arith],
              _p(ws), ws.numel() * 4 if ws is not None else 0, _stream(x))
     return y, o_save, lse
 
@@ -322,9 +323,10 @@ def attn_bwd_ex(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_he
     if workspace is None or workspace.numel() * 4 < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     dx = out if out is not None else torch.empty_like(x)
+    drop_p, drop_seed = _drop_args(params, dropout)
     lib.call("rat_attn_bwd_ex", _p(x), _p(dy), _p(add), _p(o_save), _p(lse), _p(dx), ctypes.byref(params), ctypes.byref(grads),
              _p(workspace), workspace.numel() * 4, ctypes.byref(seqmap), d, heads, dim_head, float(softmax_scale),
-             float(out_scale), eps, float(dropout[0]), int(dropout[1]) & 0xFFFFFFFFFFFFFFFF, ARITH[arith], _stream(x))
+             float(out_scale), eps, drop_p, drop_seed, ARITH[arith], _stream(x))
     return dx, workspace
 
 
@@ -559,11 +561,34 @@ def clip_adam(w, g, m, v, norm_sq, max_norm, lr, beta1, beta2, eps, step, lib=No
 
 
 def dropout(x, p, seed, out=None, lib=None):
+    """seed: an int (by value) or a one-element int64 DEVICE tensor — one of the words `dropout_seeds` refreshes per step"""
     lib = lib or get_lib()
     _chk(x, name="x")
     y = out if out is not None else torch.empty_like(x)
-    lib.call("rat_dropout", _p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(x))
+    if torch.is_tensor(seed):
+        _chk(seed, torch.int64, "seed word")
+        lib.call("rat_dropout_dev", _p(x), _p(y), x.numel(), float(p), _p(seed), _stream(x))
+    else:
+        lib.call("rat_dropout", _p(x), _p(y), x.numel(), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream(x))
     return y
+
+
+def dropout_seeds(words, base_seed, counter, lib=None):
+    """counter += 1; words[i] = mix(base_seed, counter, i): the dropout state of one training step, on the device"""
+    lib = lib or get_lib()
+    _chk(words, torch.int64, "seed words"), _chk(counter, torch.int64, "counter")
+    lib.call("rat_dropout_seeds", _p(words), words.numel(), int(base_seed) & 0xFFFFFFFFFFFFFFFF, _p(counter), _stream(words))
+
+
+def _drop_args(params, dropout):
+    """(p, seed) -> the by-value arguments; a tensor seed goes into the parameter struct (RatAttnParams.drop_seed_dev, ABI v6)"""
+    p, seed = dropout
+    if torch.is_tensor(seed):
+        _chk(seed, torch.int64, "seed word")
+        params.drop_seed_dev = seed.data_ptr()
+        return float(p), 0
+    params.drop_seed_dev = None
+    return float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
 # ----------------------------------------------------------------------------- ABI v4: two-sweep optimizer, device-side clock
