@@ -624,6 +624,15 @@ class RAT_m2(BaseModel):
                     j += 1
                 self._dnn_layers.append((lin, bn, pdrop))
             self._dnn_out = len(mods) - 1
+        # BatchNorm's num_batches_tracked (deep.py:128-132 -> nn.BatchNorm1d): one int64 tensor, every layer's buffer a 0-dim view of
+        # it, so that a training forward advances all of them with ONE launch (state_dict keys / values are unchanged)
+        bns = [self.dnn.dnn[bn] for _, bn, _ in self._dnn_layers if bn is not None] if self.dnn is not None else []
+        self._bn_counts = None
+        if bns:
+            counts = torch.stack([m.num_batches_tracked.detach().to(dev).reshape(()) for m in bns]).contiguous()
+            for i, m in enumerate(bns):
+                m._buffers["num_batches_tracked"] = counts[i]
+            self._bn_counts = counts
 
     def _grad_buffer(self):
         """-> (zeroed flat gradient buffer, its embedding / LR gradient field tables).  ONE persistent buffer is reused (so the
@@ -866,6 +875,10 @@ class RAT_m2(BaseModel):
         """the launches of one fused iteration on `batch` = (idx, label ids, y_true) device tensors -> total loss (device scalar)"""
         world = self._world_size()
         inv = self._inv_world()
+        # the step's accumulator scalars — BCE sum, clip norm^2, regulariser value — share one 4-float tensor: ONE fill per step
+        scal = self.optimizer.step_scalars()
+        scal.zero_()
+        self._step_loss = scal[0:1]
         _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
         if self._graph_test_splits:
             self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
@@ -874,9 +887,10 @@ class RAT_m2(BaseModel):
             self._collective(lambda: None)
         g = self._last_gflat
         self._exchange_gradients(g)
-        reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count)
+        reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count, zeroed=True)
         self._gbuf_clean = self._gbuf is not None and g is self._gbuf[0]
-        return (loss + reg[0]) * inv[0]
+        total = loss + reg[0]
+        return total if world == 1 else total * inv[0]
 
     def _row_lists_travel_lighter(self, idx_shape, world):
         """Table gradients under data parallelism in the dense modes: all-gather of (row ids, gradient rows) lists at capacity (every
@@ -996,6 +1010,8 @@ class RAT_m2(BaseModel):
         saved["seeds"] = seeds
         # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
         dnn_out = None
+        if training and self._bn_counts is not None:
+            self._bn_counts.add_(1)                                         # every BatchNorm layer's num_batches_tracked (shared storage)
         if self.dnn is not None:
             mods = self.dnn.dnn
             a_prev, lda, K = x0[:, 0, 1:, :], T * S * d, F * d
@@ -1013,8 +1029,6 @@ class RAT_m2(BaseModel):
                     else:
                         a, sm, sr = ops.bn_relu_fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
                                                     eps=m.eps, momentum=m.momentum, lib=lib)
-                    if training:
-                        m.num_batches_tracked += 1
                 else:
                     a, sm, sr = ops.bn_relu_fwd(z, None, None, None, None, training, False, lib=lib)
                 a_act = a
@@ -1034,10 +1048,12 @@ class RAT_m2(BaseModel):
             x = ops.dropout(x0, c["emb_dropout"], seeds[0], lib=lib)
         x, cls_stride = self._encoder_forward(x, x0, (B, T, L, S), save, saved)
         # ---- logit = fc(cls) + dnn + wide ; sigmoid ; BCE
-        loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
+        loss = self.__dict__.pop("_step_loss", None)                      # the fused iteration's zeroed scalar (one fill per step)
+        if loss is None:
+            loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
         y_pred = ops.logit_fwd(x, cls_stride, self.fc.weight.data, self.fc.bias.data, dnn_out, self._lr_ftab, F, idx, T * L,
                                y_true, loss, B, d, lib=lib)
-        reg = self._regularization_value() if with_reg else torch.zeros((), dtype=torch.float32, device=x0.device)
+        reg = self._regularization_value() if with_reg else None
         if save:
             saved["x_final"], saved["cls_stride"], saved["y_pred"] = x, cls_stride, y_pred
         return y_pred, loss[0], reg, saved

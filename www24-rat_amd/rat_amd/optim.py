@@ -71,9 +71,16 @@ class FusedClipAdam(torch.optim.Optimizer):
             self._step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
             self._lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.device)
             self._hyper = torch.zeros(4, dtype=torch.float32, device=flat.device)
-            self._reg_value = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            self._scal = torch.zeros(4, dtype=torch.float32, device=flat.device)     # [BCE sum | clip norm^2 | regulariser value | -]
+            self._reg_value = self._scal[2:3]
             self._clock_step, self._clock_lr = None, None
         return self._step_dev, self._lr_dev, self._hyper
+
+    def step_scalars(self):
+        """the 4-float tensor behind the fused step's accumulators; the caller zeroes it once per step and passes zeroed=True"""
+        self._clock()
+        self._buffers()
+        return self._scal
 
     def prepare_step(self):
         """host -> device synchronisation of the clock; cheap, and a no-op unless the learning rate changed (lr_decay) or the step
@@ -89,7 +96,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             self._clock_step = self._step
 
     @torch.no_grad()
-    def fused_step(self, grad, max_norm, count=True):
+    def fused_step(self, grad, max_norm, count=True, zeroed=False):
         """clip_grad_norm_(max_norm) + Adam + zero_grad over the flat buffers with the regulariser folded in (rat_sumsq_reg,
         rat_clip_adam_fused): `grad` is the flat gradient WITHOUT the lambda*W terms; afterwards it holds zeros.  Returns the
         regulariser's value (device scalar, (lambda/2)||W||^2 over the tensors the reference regularises).  Call prepare_step()
@@ -108,12 +115,15 @@ class FusedClipAdam(torch.optim.Optimizer):
         if count:
             self._step += 1
             self._clock_step = self._step
-        self._norm_sq.zero_()
-        self._reg_value.zero_()
-        ops.sumsq_reg(grad, model._flat[ns:], n_split, c["lam_emb"], c["lam_net"], self._norm_sq, reg_out=self._reg_value, lib=lib)
+        acc = self._scal[1:2] if zeroed else self._norm_sq           # zeroed: step_scalars() was cleared at the start of this step
+        if not zeroed:
+            self._norm_sq.zero_()
+            self._reg_value.zero_()
+        ops.sumsq_reg(grad, model._flat[ns:], n_split, c["lam_emb"], c["lam_net"], acc, reg_out=self._reg_value, lib=lib)
         for rows, g, cnt, width, _total, _base in sparse:
-            ops.sumsq_rows(g, cnt, rows.numel(), width, self._norm_sq, lib=lib)
-        norm_sq = self._norm_sq if max_norm is not None else None
+            ops.sumsq_rows(g, cnt, rows.numel(), width, acc, lib=lib)
+        self._last_norm_sq = acc
+        norm_sq = acc if max_norm is not None else None
         ops.clip_adam_fused(model._flat[ns:], grad, m[ns:], v[ns:], n_split, c["lam_emb"], c["lam_net"], norm_sq, max_norm or 0.0,
                             hyper, b1, b2, eps, zero_g=True, lib=lib)
         for rows, g, cnt, width, _total, base in sparse:
@@ -128,7 +138,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         return loss
 
     def last_grad_norm(self):
-        return float(torch.sqrt(self._norm_sq)[0]) if self._norm_sq is not None else None
+        t = getattr(self, "_last_norm_sq", None)
+        t = self._norm_sq if t is None else t
+        return float(torch.sqrt(t)[0]) if t is not None else None
 
     def state_dict(self):
         sd = super().state_dict()
