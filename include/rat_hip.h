@@ -391,6 +391,10 @@ int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64_t n, int64
  * row, base_model.py:79-94) runs unchanged after a row-list exchange. */
 int rat_scatter_rows(float* dense_base, const int32_t* rows, const float* grads, const int32_t* count_dev, int64_t max_rows,
                      int d, void* stream);
+/* ABI v6 — the same for `lists` lists of capacity `cap` each (rows [lists][cap], grads [lists][cap][d], counts_dev [lists]): what the
+ * owner-partitioned exchange of the table gradients leaves on every rank (one reduced list per owner rank, disjoint row ranges). */
+int rat_scatter_rows_lists(float* dense_base, const int32_t* rows, const float* grads, const int32_t* counts_dev, int64_t cap,
+                           int lists, int d, void* stream);
 int rat_adam_rows_dev(float* w_base, float* m_base, float* v_base, const int32_t* rows, const float* grads,
                       const int32_t* count_dev, int64_t max_rows, int d, const float* norm_sq, float max_norm,
                       const float* hyper_dev, float beta1, float beta2, float eps, void* stream);

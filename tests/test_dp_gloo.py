@@ -37,7 +37,7 @@ def _make(case_name, batch_norm=False):
     return case, model, mc.batch_of(case)
 
 
-def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, row_lists=True):
+def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, row_lists=True, owner=True):
     _setup_paths()
     import rat_amd._lib as L
     L._default = L.RatLib(emu_path)
@@ -57,19 +57,22 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, r
         return inner(part)
     model._merge_sparse = counting_merge
     model.row_list_exchange = row_lists       # (the traffic rule would pick the dense all-reduce for this toy vocabulary)
+    model.owner_exchange = owner              # all-to-all to the rows' owners (default) / all-gather at capacity + merge of the union
     assert model._cfg["lam_emb"] > 0 and model._grad_mode == "atomic"
     for _ in range(2):
         loss = model.train_step(shard)
     buffers = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k}
-    torch.save({"flat": model._flat.clone(), "loss": loss, "buffers": buffers, "merges": merges[0]},
+    torch.save({"flat": model._flat.clone(), "loss": loss, "buffers": buffers, "merges": merges[0],
+                "owner_stats": model.__dict__.get("_owner_stats")},
                os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch_norm,row_lists", [twin(False, True, id="bn_off"), pytest.param(True, True, id="sync_bn"),
-                                                  pytest.param(True, False, id="sync_bn_dense_tables")])
-def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists):
+@pytest.mark.parametrize("batch_norm,row_lists,owner", [twin(False, True, True, id="bn_off"), pytest.param(True, True, True, id="sync_bn"),
+                                                        pytest.param(True, True, False, id="sync_bn_gather_at_capacity"),
+                                                        pytest.param(True, False, True, id="sync_bn_dense_tables")])
+def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
     _setup_paths()
     import build_emu
     import rat_amd._lib as L
@@ -95,10 +98,15 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists):
         L._default = old
     port = 29500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, port, "tiny_seq_bn", emu_path, out_dir, batch_norm, row_lists), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, "tiny_seq_bn", emu_path, out_dir, batch_norm, row_lists, owner), nprocs=2, join=True)
         r0 = torch.load(os.path.join(out_dir, "rank0.pt"))
         r1 = torch.load(os.path.join(out_dir, "rank1.pt"))
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
+    if row_lists and owner:                          # the owner-partitioned exchange ran: every pair went to exactly one owner
+        s0, s1 = r0["owner_stats"], r1["owner_stats"]
+        assert s0 is not None and s1 is not None and s0["sent"] + s1["sent"] == s0["received"] + s1["received"] > 0
+    else:
+        assert r0["owner_stats"] is None
     # embedding_regularizer = 0.01 > 0 (dense semantics: lambda*W on every row) and yet the table gradients travelled as row lists
     # (SURVEY.md §8e C2): 2 steps x 2 table families (feature tables, LR tables) merged on every rank, no dense table all-reduce
     # — or, with row_lists off, as one dense all-reduce of the table block (what the traffic rule picks when every rank brings a full batch)

@@ -36,19 +36,21 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--B", type=int, default=4096)
     ap.add_argument("--arith", default="f32", choices=["f32", "bf16x3", "both"])
+    ap.add_argument("--gather-rows", type=int, default=50_000, help="gather: rows per field (2500000 with --gather-F 40 = configs[3]'s 25.6 GB table)")
+    ap.add_argument("--gather-F", type=int, default=20)
     args = ap.parse_args()
     dev = "cuda"
     B, T, S, d, heads, dh, H = args.B, 11, 21, 64, 8, 10, 128
     I = heads * dh
     tok = B * T * S
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn(B, T, S, d, generator=g).to(dev)
-    dy = torch.randn(B, T, S, d, generator=g).to(dev)
     rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
     if "gather" in args.which:
         from types import SimpleNamespace
-        F, vocab = 20, 50_000
-        table = torch.randn(F * vocab, d, generator=g).to(dev) * 0.01
+        F, vocab = args.gather_F, args.gather_rows
+        S = F + 1
+        dy = torch.randn(B, T, S, d, generator=g).to(dev)
+        table = torch.empty(F * vocab, d, device=dev).normal_(0.0, 0.01)
         fields = [SimpleNamespace(col=i, ncols=1, vocab=vocab, padding_idx=None) for i in range(F)]
         tabs = [table[i * vocab:(i + 1) * vocab] for i in range(F)]
         gtable = torch.zeros_like(table)
@@ -74,6 +76,10 @@ def main():
         ms = timeit(bwd, args.reps)
         nb = B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4)
         print("gather_bwd %.4f ms  %.0f GB/s  (%.1f %% of 8 TB/s)" % (ms, nb / ms / 1e6, 100 * nb / ms / 1e6 / 8000))
+        del table, gtable, dy
+        S = 21
+    x = torch.randn(B, T, S, d, generator=g).to(dev)
+    dy = torch.randn(B, T, S, d, generator=g).to(dev)
     if any(w.startswith("ffn") for w in args.which):
         w1, b1, w2, b2 = rn(H, d, sc=d ** -0.5), rn(H, sc=0.1), rn(d, H, sc=H ** -0.5), rn(d, sc=0.1)
         y = torch.empty_like(x)

@@ -88,6 +88,11 @@ gather_fwd_vec_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict
 // d = 64 and fewer than 2^31 grid rows: 32-bit index arithmetic (the path above spends two 64-bit divisions per 16-byte piece) and
 // branch-free fetches — the label row and the field rows go through the same unconditional id load and row load, so that all
 // GATHER_ITEMS rows of a lane are in flight together (a load inside a divergent branch is waited for inside the branch).
+// NT: the grid leaves with non-temporal stores.  Same-box A/Bs (round 4, profiles/round4/r4_nt_ab.txt): inside the N2 training step
+// (242 MB grid, behind the optimizer's sweep) 91-98 us with the hint against 103 us without; alone on the 25.6 GB table at B = 1024
+// (118 MB grid: it fits the 256 MB Infinity Cache, where plain stores are absorbed) 46 us without against 50 us with — so the
+// host asks for the hint only when the grid is larger than what the cache can take.
+template <bool NT>
 __global__ void __launch_bounds__(GATHER_THREADS)
 gather_fwd_rows64_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ label_ids,
                          const RatField* __restrict__ fields, const float* __restrict__ label_table,
@@ -129,14 +134,11 @@ gather_fwd_rows64_kernel(const int32_t* __restrict__ idx, const int32_t* __restr
                 const float4 w = *(reinterpret_cast<const float4*>(tab[u] + (int64_t)i * d) + piece);
                 v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w;
             }
-#if !defined(RAT_GATHER_PLAIN) && !defined(RAT_EMU)     // non-temporal grid stores: see optim.hip (opt_ld4_stream)
             if (ok[u]) {
-                f32x4 t = {v[u].x, v[u].y, v[u].z, v[u].w};
-                __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(grid) + (size_t)(r0 + u * nslots) * 16 + piece);
+                float* dst = grid + ((size_t)(r0 + u * nslots) * 16 + piece) * 4;
+                if (NT) rat_st4_stream(dst, v[u]);
+                else *reinterpret_cast<float4*>(dst) = v[u];
             }
-#else
-            if (ok[u]) reinterpret_cast<float4*>(grid)[(size_t)(r0 + u * nslots) * 16 + piece] = v[u];
-#endif
         }
     }
 }
@@ -337,8 +339,8 @@ check_ids_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ la
 int pick_blocks(int64_t nitems, int per_thread) {
     int64_t want = (nitems + (int64_t)GATHER_THREADS * per_thread - 1) / ((int64_t)GATHER_THREADS * per_thread);
     if (want < 1) want = 1;
-    if (want > 2048) want = 2048;                             // 256 CUs x 8 blocks, grid-stride the rest
-    return (int)want;
+    if (want > 2048) want = 2048;                             // 256 CUs x 8 blocks, grid-stride the rest.  (A grid that gives every thread
+    return (int)want;                                         //  the same number of trips — 1804 blocks instead of 2048 — measured 2-3 % slower.)
 }
 
 }  // namespace
@@ -351,10 +353,14 @@ extern "C" int rat_gather_fwd(const int32_t* idx, const int32_t* label_ids, cons
     const int64_t nrows = (int64_t)B * T * S;
     const bool vec = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(grid) | reinterpret_cast<uintptr_t>(label_table)) % 16 == 0);
     if (vec) {
-        if (d == 64 && nrows < (int64_t)0x7fffffff)
-            RAT_LAUNCH(gather_fwd_rows64_kernel, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
-                       label_ids, fields_dev, label_table, grid, (unsigned)nrows, (unsigned)S, L);
-        else
+        if (d == 64 && nrows < (int64_t)0x7fffffff) {
+            if (nrows * d * 4 > ((int64_t)160 << 20))
+                RAT_LAUNCH(gather_fwd_rows64_kernel<true>, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
+                           label_ids, fields_dev, label_table, grid, (unsigned)nrows, (unsigned)S, L);
+            else
+                RAT_LAUNCH(gather_fwd_rows64_kernel<false>, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
+                           label_ids, fields_dev, label_table, grid, (unsigned)nrows, (unsigned)S, L);
+        } else
             RAT_LAUNCH(gather_fwd_vec_kernel, pick_blocks(nrows * (d / 4), GATHER_ITEMS), GATHER_THREADS, 0, stream, idx,
                        label_ids, fields_dev, label_table, grid, nrows, S, L, d);
     } else {

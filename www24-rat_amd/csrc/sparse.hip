@@ -369,6 +369,22 @@ scatter_rows_kernel(float* __restrict__ dense, const int32_t* __restrict__ rows,
     }
 }
 
+// the same for `lists` lists of capacity `cap` each ([lists][cap] rows, [lists][cap][d] gradient rows, counts[lists]): what the
+// owner-partitioned exchange leaves on every rank — one reduced list per owner, disjoint row ranges
+__global__ void __launch_bounds__(SP_THREADS)
+scatter_rows_lists_kernel(float* __restrict__ dense, const int32_t* __restrict__ rows, const float* __restrict__ g,
+                          const int32_t* __restrict__ counts, int64_t cap, int lists, int d) {
+    for (int k = 0; k < lists; ++k) {
+        const int64_t n = (int64_t)counts[k] * d;
+        const int32_t* rk = rows + (int64_t)k * cap;
+        const float* gk = g + (int64_t)k * cap * d;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t s = i / d;
+            dense[(int64_t)rk[s] * d + (i - s * d)] = gk[i];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t rat_sparse_workspace(int64_t n) {
@@ -482,4 +498,13 @@ extern "C" int rat_scatter_rows(float* dense_base, const int32_t* rows, const fl
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     RAT_LAUNCH(scatter_rows_kernel, (unsigned)blocks, SP_THREADS, 0, stream, dense_base, rows, grads, count_dev, d);
     return rat_check_launch("rat_scatter_rows");
+}
+
+extern "C" int rat_scatter_rows_lists(float* dense_base, const int32_t* rows, const float* grads, const int32_t* counts_dev, int64_t cap,
+                                      int lists, int d, void* stream) {
+    RAT_REQUIRE(dense_base && rows && grads && counts_dev && d > 0 && cap > 0 && lists > 0, "bad args");
+    int64_t blocks = (cap * d + SP_THREADS * 4 - 1) / (SP_THREADS * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    RAT_LAUNCH(scatter_rows_lists_kernel, (unsigned)blocks, SP_THREADS, 0, stream, dense_base, rows, grads, counts_dev, cap, lists, d);
+    return rat_check_launch("rat_scatter_rows_lists");
 }

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "rat_clip_adam_fused": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, c_float, _P, _P, c_float, _P, c_float, c_float, c_float,
                                     c_int, _P]),
     "rat_scatter_rows": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
+    "rat_scatter_rows_lists": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "rat_adam_rows_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, _P, c_float, c_float, c_float, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

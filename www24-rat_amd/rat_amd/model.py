@@ -716,8 +716,7 @@ class RAT_m2(BaseModel):
             if pending is not None and pending[1] is g:            # the dense-net part is already on its way
                 if lists is not None:
                     for part in lists:
-                        rows, grads, count, width, _total, base = self._merge_sparse(part)
-                        ops.scatter_rows(g[base:], rows, grads, count, width, lib=self._lib)     # into the zeroed table block
+                        self._scatter_merged(g[part[5]:], self._merge_sparse(part), part[3])       # into the zeroed table block
                     if n0 > self._n_tab:
                         self._all_reduce_sum(g[self._n_tab:n0])    # the label table (3 x d floats)
                 elif n0 > 0:
@@ -736,10 +735,89 @@ class RAT_m2(BaseModel):
                     self._params[n].grad = self._gflat_view(g, n)
                 self._last_gflat = g
         if self._sparse is not None and not self._sparse_is_global:      # (a second call must not merge global lists again)
-            self._sparse = [self._merge_sparse(part) for part in self._sparse]
+            self._sparse = [rec for part in self._sparse for rec in self._merge_sparse(part)["records"]]
             self._sparse_is_global = True
 
+    # Owner-partitioned exchange of the table-gradient lists: rank k owns the rows [k R/N, (k+1) R/N) of a table
+    # family; every rank sends each owner ITS rows of the local (sorted, unique) list — an all-to-all of exactly the rows that exist
+    # — the owner sorts / reduces only what it received (1/N of the union instead of the whole union on every rank) and the reduced
+    # lists are all-gathered.  Same sums in the same (rank) order as the all-gather form, so the replicas stay bit-identical.  The
+    # split sizes have to be known on the host (one read-back of an N x N count matrix per family and step), which a captured step
+    # cannot do: while a StepGraph is recording, the all-gather-at-capacity form below is used.
+    owner_exchange = True
+    _OWNER_BUCKET = 4096                 # list capacities are rounded up to this many rows (few distinct plan sizes)
+
     def _merge_sparse(self, part):
+        """one family's local (rows, grads, count) -> {"records": the global list as one or more disjoint (rows, grads, count, width,
+        total_rows, base) records, "stacked": ([lists, cap] rows, [lists, cap, width] grads, [lists] counts) or None}"""
+        if self.owner_exchange and self._tape is None and self._world_size() > 1:
+            return self._merge_sparse_owner(part)
+        return {"records": [self._merge_sparse_gather(part)], "stacked": None}
+
+    def _scatter_merged(self, dense, merged, width):
+        if merged["stacked"] is not None:
+            rows, grads, counts = merged["stacked"]
+            ops.scatter_rows_lists(dense, rows, grads, counts, width, lib=self._lib)
+        else:
+            for rows, grads, count, _w, _t, _b in merged["records"]:
+                ops.scatter_rows(dense, rows, grads, count, width, lib=self._lib)
+
+    def _merge_sparse_owner(self, part):
+        import torch.distributed as dist
+        lib, world, rank = self._lib, self._world_size(), dist.get_rank()
+        rows, grads, count, width, total_rows, base_off = part
+        dev, cap = rows.device, rows.numel()
+        per = -(-int(total_rows) // world)                                    # owner k: rows [k per, (k + 1) per)
+        # (1) my rows per owner range: the list is sorted, so one binary search per range edge (the tail past `count` is masked)
+        pos = self._ws.get(("iota", cap))
+        if pos is None or pos.device != dev:
+            pos = self._ws[("iota", cap)] = torch.arange(cap, dtype=torch.int32, device=dev)
+        big = torch.iinfo(torch.int32).max
+        keyed = torch.where(pos < count, rows, torch.full_like(rows, big))
+        edges = torch.clamp(torch.arange(1, world + 1, dtype=torch.int64, device=dev) * per, max=big - 1).to(torch.int32)
+        ends = torch.searchsorted(keyed, edges)
+        send = torch.diff(ends, prepend=ends.new_zeros(1)).to(torch.int64)    # [world]
+        # (2) the N x N count matrix, on every host
+        mat = self._all_gather_flat(send).view(world, world)
+        S = mat.cpu()
+        in_splits, out_splits = [int(v) for v in S[rank]], [int(v) for v in S[:, rank]]
+        n_send, n_recv = sum(in_splits), sum(out_splits)
+        bucket = lambda n: max(self._OWNER_BUCKET, -(-n // self._OWNER_BUCKET) * self._OWNER_BUCKET)      # noqa: E731
+        cap2 = max(bucket(int(v)) for v in S.sum(0))                          # the same number on every rank
+        # (3) all-to-all of the (row, gradient row) pairs to their owners
+        recv_rows = torch.empty(cap2, dtype=torch.int32, device=dev)
+        recv_grads = torch.empty((cap2, width), dtype=torch.float32, device=dev)
+        self._all_to_all_rows(recv_rows[:n_recv], rows[:n_send], out_splits, in_splits)
+        self._all_to_all_rows(recv_grads[:n_recv], grads[:n_send], out_splits, in_splits)
+        n_recv_dev = mat[:, rank].sum().reshape(1).to(torch.int32)
+        # (4) the owner's merge: sort + fixed-order reduction of what it received (sources in rank order)
+        pkey = ("merge-owner", width, cap2)
+        plan = ops.sparse_plan_rows(recv_rows, n_recv_dev, cap2, 1, total_rows, plan=self._ws.get(pkey), lib=lib)
+        self._ws[pkey] = plan
+        out_rows = torch.empty(cap2, dtype=torch.int32, device=dev)
+        out_grads = torch.empty((cap2, width), dtype=torch.float32, device=dev)
+        ops.sparse_reduce_rows(plan, recv_grads, cap2, 1, width, out_rows, out_grads, lib=lib)
+        # (5) every rank gets every owner's reduced list
+        rows_all = self._all_gather_flat(out_rows).view(world, cap2)
+        grads_all = self._all_gather_flat(out_grads.reshape(-1)).view(world, cap2, width)
+        counts_all = self._all_gather_flat(plan.count)
+        records = [(rows_all[k], grads_all[k], counts_all[k:k + 1], width, total_rows, base_off) for k in range(world)]
+        self._owner_stats = dict(sent=n_send, received=n_recv, capacity=cap2, local_capacity=cap)
+        return {"records": records, "stacked": (rows_all, grads_all, counts_all)}
+
+    def _all_to_all_rows(self, out, inp, out_splits, in_splits):
+        """uneven all-to-all along dim 0 (RCCL on device tensors; gloo on host tensors, staged through the host for device tensors)"""
+        import torch.distributed as dist
+        if self._staged(inp):
+            def run():
+                ho = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_to_all_single(ho, inp.detach().cpu().contiguous(), out_splits, in_splits)
+                out.copy_(ho)
+            self._collective(run)
+        else:
+            self._collective(lambda: dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits))
+
+    def _merge_sparse_gather(self, part):
         """all-gather one family's (rows, grads, count) at capacity and reduce the union: -> the same record, global"""
         lib, world = self._lib, self._world_size()
         rows, grads, count, width, total_rows, base_off = part

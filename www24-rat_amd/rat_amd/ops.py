@@ -619,6 +619,13 @@ def adam_rows_dev(w_base, m_base, v_base, rows, grads, count, max_rows, d, norm_
              float(max_norm), _p(hyper), float(beta1), float(beta2), float(eps), _stream(grads))
 
 
+def scatter_rows_lists(dense_base, rows, grads, counts, d, lib=None):
+    """rows [lists, cap] int32, grads [lists, cap, d], counts [lists] int32 -> the zeroed dense gradient block"""
+    lib = lib or get_lib()
+    _chk(rows, torch.int32, "rows"), _chk(counts, torch.int32, "counts"), _chk(grads, name="grads")
+    lib.call("rat_scatter_rows_lists", _p(dense_base), _p(rows), _p(grads), _p(counts), rows.shape[1], rows.shape[0], int(d), _stream(grads))
+
+
 def scatter_rows(dense_base, rows, grads, count, d, lib=None):
     """merged (unique rows, gradient rows) lists -> the zeroed dense gradient block"""
     lib = lib or get_lib()
