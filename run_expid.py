@@ -74,18 +74,43 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
             pool = None if split == "train" else _find(data_dir, "train")
         else:
             pool = _find(data_dir, "retrieval_pool")
-        if rpath is None:
+        if shard[1] > 1:
+            # every rank takes the SAME branch: rank 0 looks and tells the others (a rank that starts later could otherwise see the file
+            # rank 0 is still writing, skip the wait and run into rank 0's barrier with its next collective)
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([1 if rpath is not None else 0], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                flag = flag.cuda()
+            dist.broadcast(flag, src=0)
+            have = bool(int(flag.cpu()[0]))
+        else:
+            have = rpath is not None
+        if not have:
             # stored next to the data in the data's own format: retrieval_{K}_{split}.h5 — the reference's file name and keys
             # (data_generator.py:106-113) — when the split is an HDF5 file, .npz otherwise
             rpath = os.path.join(data_dir, "retrieval_%d_%s%s" % (topk, split, ".h5" if dpath.endswith(".h5") else ".npz"))
-            if shard[0] == 0:                                   # one rank computes and writes the file, the others wait for it
+            if shard[0] == 0:                                   # one rank computes and writes the file (atomically), the others wait
                 precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
             if shard[1] > 1:
-                import torch.distributed as dist
-                dist.barrier()
+                _wait_for_file(rpath, leader=shard[0] == 0)
+        elif rpath is None:                                      # (this rank's listing was older than rank 0's)
+            rpath = _find(data_dir, "retrieval_%d_%s" % (topk, split))
         out.append(rat_data.batches_from_files(dpath, rpath, bs, pool_path=pool, shuffle=(split == "train") and params.get("shuffle", True),
                                                seed=params.get("seed", 0), shard=shard if split == "train" else (0, 1)))
     return out
+
+
+def _wait_for_file(path, leader, poll_s=2.0):
+    """The top-K pre-computation of a large split can take longer than a collective's timeout (10 minutes by default), so the other ranks
+    do not sit in a barrier: they poll for the finished file (written under a temporary name and renamed, so existence means complete)
+    and only then meet rank 0 in a barrier that returns at once."""
+    import time
+    import torch.distributed as dist
+    if not leader:
+        while not os.path.exists(path):
+            time.sleep(poll_s)
+    dist.barrier()
 
 
 def precompute_retrieval_file(data_path, pool_path, save_path, rcfg, feature_map, params):
@@ -102,11 +127,14 @@ def precompute_retrieval_file(data_path, pool_path, save_path, rcfg, feature_map
                  "self / %s" % rcfg.get("split_type") if pool is None else "%d rows" % len(pool))
     cols = retrieval.used_col_indices(feature_map, rcfg)
     indices, values, lens = retrieval.precompute_retrieval(data, rcfg, cols, pool_array=pool, device="cuda:%d" % params["gpu"])
+    root, ext = os.path.splitext(save_path)
+    tmp = "%s.tmp%d%s" % (root, os.getpid(), ext)                # same directory, same extension (np.savez appends .npz otherwise)
     if save_path.endswith(".h5"):
         from rat_amd import h5io
-        h5io.write_arrays(save_path, {"indices": np.asarray(indices), "values": np.asarray(values), "lens": np.asarray(lens)})
+        h5io.write_arrays(tmp, {"indices": np.asarray(indices), "values": np.asarray(values), "lens": np.asarray(lens)})
     else:
-        np.savez_compressed(save_path, indices=indices, values=values, lens=lens)
+        np.savez_compressed(tmp, indices=indices, values=values, lens=lens)
+    os.replace(tmp, save_path)                                   # atomic: a reader never sees a partial file
 
 
 def main(argv=None):

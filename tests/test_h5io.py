@@ -72,3 +72,16 @@ def test_batches_from_h5_files_equal_batches_from_npz_files(tmp_path):
     assert len(a) == len(b) == 3
     for x, y in zip(a, b):
         assert all(bool((u == v).all()) for u, v in zip(x, y))
+
+
+def test_unsigned_datasets_keep_their_values(tmp_path):
+    """unsigned ids used to be read through a signed native type of the same width, where the library clamps at the signed
+    maximum (200 -> 127 for a uint8 dataset).  They now come back unsigned, value for value."""
+    from rat_amd import h5io
+    path = str(tmp_path / "unsigned.h5")
+    want = {"u1": np.array([0, 127, 128, 200, 255], dtype=np.uint8), "u2": np.array([1, 40000, 65535], dtype=np.uint16),
+            "u4": np.array([7, 3_000_000_000, 4_294_967_295], dtype=np.uint32), "i4": np.array([-5, 5], dtype=np.int32)}
+    h5io.write_arrays(path, want)
+    got = h5io.read_arrays(path, list(want))
+    for k, v in want.items():
+        assert got[k].dtype == v.dtype and np.array_equal(got[k], v), k

@@ -80,6 +80,45 @@ def main():
         S = 21
     x = torch.randn(B, T, S, d, generator=g).to(dev)
     dy = torch.randn(B, T, S, d, generator=g).to(dev)
+    if "merge" in args.which:
+        # the table-gradient merge of a data-parallel step at the strong-scaling rank shape (8 ranks x 512 samples of N2): every rank sorts
+        # and reduces the union of all lists gathered at capacity (round 3) against the owner's share only (round 4, 1 / world of it)
+        world, Bl, F, rows_total = 8, 512, 20, 1_000_000
+        cap = min(Bl * T * F, rows_total)
+        per = -(-rows_total // world)
+
+        def one_list(seed):
+            gg = torch.Generator().manual_seed(seed)
+            r = torch.unique(torch.randint(0, rows_total, (Bl * T * F,), generator=gg)).to(torch.int32)
+            return r
+
+        lists = [one_list(100 + k) for k in range(world)]
+        # (a) all lists at capacity
+        rows_a = torch.zeros(world, cap, dtype=torch.int32)
+        counts_a = torch.tensor([len(r) for r in lists], dtype=torch.int32)
+        for k, r in enumerate(lists):
+            rows_a[k, :len(r)] = r
+        rows_a, counts_a = rows_a.to(dev), counts_a.to(dev)
+        grads_a = torch.randn(world * cap, d, device=dev)
+        # (b) what owner 0 receives: the rows of its range from every list, packed in rank order
+        recv = torch.cat([r[r < per] for r in lists])
+        cap_b = -(-len(recv) // 4096) * 4096
+        rows_b = torch.zeros(cap_b, dtype=torch.int32)
+        rows_b[:len(recv)] = recv
+        rows_b, count_b = rows_b.to(dev), torch.tensor([len(recv)], dtype=torch.int32, device=dev)
+        grads_b = torch.randn(cap_b, d, device=dev)
+        for label, rows, counts, c, w, grads in (("all-gather at capacity: union of %d lists" % world, rows_a, counts_a, cap, world, grads_a),
+                                                 ("owner-partitioned: one owner's share", rows_b, count_b, cap_b, 1, grads_b)):
+            n = c * w
+            out_rows = torch.empty(min(n, rows_total), dtype=torch.int32, device=dev)
+            out_grads = torch.empty((min(n, rows_total), d), device=dev)
+            plan = [None]
+
+            def run():
+                plan[0] = ops.sparse_plan_rows(rows.reshape(-1), counts, c, w, rows_total, plan=plan[0])
+                ops.sparse_reduce_rows(plan[0], grads, c, w, d, out_rows, out_grads)
+            ms = timeit(run, args.reps)
+            print("merge %-48s n = %7d pairs  %.4f ms per table family" % (label, n, ms))
     if any(w.startswith("ffn") for w in args.which):
         w1, b1, w2, b2 = rn(H, d, sc=d ** -0.5), rn(H, sc=0.1), rn(d, H, sc=H ** -0.5), rn(d, sc=0.1)
         y = torch.empty_like(x)

@@ -45,6 +45,12 @@ def library():
         lib.H5open.restype = herr_t
         if lib.H5open() < 0:
             continue
+        # hid_t is 64-bit from HDF5 1.10 on (a 32-bit int before): refuse an older library instead of passing it truncated handles
+        ver = (ctypes.c_uint * 3)()
+        lib.H5get_libversion.restype = herr_t
+        if lib.H5get_libversion(ctypes.byref(ver, 0), ctypes.byref(ver, 4), ctypes.byref(ver, 8)) < 0 or (ver[0], ver[1]) < (1, 10):
+            last = OSError("%s is HDF5 %d.%d.%d; 1.10 or newer is needed (64-bit hid_t)" % (name, ver[0], ver[1], ver[2]))
+            continue
         sig = {
             "H5Fopen": (hid_t, [ctypes.c_char_p, ctypes.c_uint, hid_t]),
             "H5Fcreate": (hid_t, [ctypes.c_char_p, ctypes.c_uint, hid_t, hid_t]),
@@ -62,6 +68,7 @@ def library():
             "H5Sclose": (herr_t, [hid_t]),
             "H5Tget_class": (ctypes.c_int, [hid_t]),
             "H5Tget_size": (ctypes.c_size_t, [hid_t]),
+            "H5Tget_sign": (ctypes.c_int, [hid_t]),
             "H5Tclose": (herr_t, [hid_t]),
             "H5Eset_auto2": (herr_t, [hid_t, ctypes.c_void_p, ctypes.c_void_p]),
         }
@@ -82,7 +89,7 @@ def _mem_type(lib, dtype):
     dtype = np.dtype(dtype)
     table = {"f8": "H5T_NATIVE_DOUBLE_g", "f4": "H5T_NATIVE_FLOAT_g", "i8": "H5T_NATIVE_INT64_g", "i4": "H5T_NATIVE_INT32_g",
              "i2": "H5T_NATIVE_INT16_g", "i1": "H5T_NATIVE_INT8_g", "u8": "H5T_NATIVE_UINT64_g", "u4": "H5T_NATIVE_UINT32_g",
-             "u1": "H5T_NATIVE_UINT8_g"}
+             "u2": "H5T_NATIVE_UINT16_g", "u1": "H5T_NATIVE_UINT8_g"}
     key = dtype.kind + str(dtype.itemsize)
     if key not in table:
         raise TypeError("HDF5 I/O here covers float / integer arrays, not %s" % dtype)
@@ -101,6 +108,7 @@ def read_arrays(path, keys):
             did = lib.H5Dopen2(fid, key.encode(), H5P_DEFAULT)
             if did < 0:
                 raise KeyError("%s has no dataset %r" % (path, key))
+            sid = tid = -1
             try:
                 sid, tid = lib.H5Dget_space(did), lib.H5Dget_type(did)
                 nd = lib.H5Sget_simple_extent_ndims(sid)
@@ -111,16 +119,22 @@ def read_arrays(path, keys):
                 if cls == H5T_FLOAT:
                     dtype = np.float64 if size >= 8 else np.float32
                 elif cls == H5T_INTEGER:
-                    dtype = {1: np.int8, 2: np.int16, 4: np.int32}.get(size, np.int64)
+                    # unsigned data keeps an unsigned type: read through a signed native type of the same width the library would
+                    # CLAMP values above the signed maximum (H5T_SGN_NONE = 0)
+                    unsigned = lib.H5Tget_sign(tid) == 0
+                    dtype = ({1: np.uint8, 2: np.uint16, 4: np.uint32}.get(size, np.uint64) if unsigned else
+                             {1: np.int8, 2: np.int16, 4: np.int32}.get(size, np.int64))
                 else:
                     raise TypeError("dataset %r of %s is neither float nor integer (HDF5 type class %d)" % (key, path, cls))
                 arr = np.empty(tuple(int(d) for d in dims[:nd]), dtype=dtype)
                 if lib.H5Dread(did, _mem_type(lib, dtype), H5S_ALL, H5S_ALL, H5P_DEFAULT, arr.ctypes.data_as(ctypes.c_void_p)) < 0:
                     raise OSError("H5Dread failed on %r of %s" % (key, path))
-                lib.H5Tclose(tid)
-                lib.H5Sclose(sid)
                 out[key] = arr
             finally:
+                if tid >= 0:
+                    lib.H5Tclose(tid)
+                if sid >= 0:
+                    lib.H5Sclose(sid)
                 lib.H5Dclose(did)
     finally:
         lib.H5Fclose(fid)
@@ -139,10 +153,15 @@ def write_arrays(path, arrays):
             tid = _mem_type(lib, arr.dtype)
             dims = (hsize_t * max(arr.ndim, 1))(*arr.shape)
             sid = lib.H5Screate_simple(arr.ndim, dims, None)
-            did = lib.H5Dcreate2(fid, key.encode(), tid, sid, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
-            if did < 0 or lib.H5Dwrite(did, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT, arr.ctypes.data_as(ctypes.c_void_p)) < 0:
-                raise OSError("writing dataset %r to %s failed" % (key, path))
-            lib.H5Dclose(did)
-            lib.H5Sclose(sid)
+            did = -1
+            try:
+                did = lib.H5Dcreate2(fid, key.encode(), tid, sid, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT)
+                if did < 0 or lib.H5Dwrite(did, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT, arr.ctypes.data_as(ctypes.c_void_p)) < 0:
+                    raise OSError("writing dataset %r to %s failed" % (key, path))
+            finally:
+                if did >= 0:
+                    lib.H5Dclose(did)
+                if sid >= 0:
+                    lib.H5Sclose(sid)
     finally:
         lib.H5Fclose(fid)
