@@ -352,8 +352,6 @@ class RAT_m2(BaseModel):
                                           arith=self.arith, dropout=drop, lib=lib)
                 kept.append((w_g, wo_g, params_g, zb, o, l, drop))
             return y, (kept if save else None)
-        if drop[0] > 0:
-            raise NotImplementedError("attention dropout > 0 on the composed path (sequences above 64 tokens) is not implemented")
         inner, ntok = heads * dh, x.numel() // d
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in desc[0]]
         if w_out is None:
@@ -363,9 +361,15 @@ class RAT_m2(BaseModel):
         qkv = torch.empty((ntok, 3 * inner), dtype=torch.float32, device=x.device)
         ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_qkv, d, qkv, 3 * inner, arith=self.gemm_arith, lib=lib)                     # to_qkv (no bias)
         o, lse = ops.attn_core_fwd_map(qkv, smap, heads, dh, save=True, lib=lib)
-        y = x.clone()                                                                                     # the residual, accumulated by beta = 1
-        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, arith=self.gemm_arith, lib=lib)      # to_out + x
-        return y, ((qkv, o, lse) if save else None)
+        if drop[0] > 0:                                              # y = x + Dropout(to_out(o)) (RAT_m0.py / RAT_m2.py Attention.to_out)
+            t = torch.empty((ntok, d), dtype=torch.float32, device=x.device)
+            ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, t, d, bias=b_out, arith=self.gemm_arith, lib=lib)
+            ops.dropout(t, drop[0], drop[1], out=t, lib=lib)
+            y = torch.add(x.reshape(ntok, d), t).view_as(x)
+        else:
+            y = x.clone()                                                                                 # the residual, accumulated by beta = 1
+            ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, arith=self.gemm_arith, lib=lib)  # to_out + x
+        return y, ((qkv, o, lse, drop) if save else None)
 
     def _attn_layer_backward(self, desc, x_in, dy, att, smap, G, out=None):
         c, lib = self._cfg, self._lib
@@ -401,13 +405,14 @@ class RAT_m2(BaseModel):
             return dx
         inner, ntok = heads * dh, x_in.numel() // d
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
-        qkv, o, lse = att
+        qkv, o, lse, drop = att
         dev = dy.device
         xn = ops.layernorm_fwd(x_in, d, ntok, ln_g, ln_b, d, lib=lib)                                     # recomputed, not stored
         do = torch.empty((ntok, inner), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, inner, d, dy, d, w_out, inner, do, inner, arith=self.gemm_arith, lib=lib)                          # dO = dy W_out
-        ops.sgemm(1, 0, d, inner, ntok, dy, d, o, inner, G(names[3]), inner, arith=self.gemm_arith, lib=lib)                     # dW_out = dy^T O
-        ops.colsum(dy, d, G(names[4]), ntok, d, lib=lib)
+        dyp = dy if drop[0] == 0 else ops.dropout(dy.reshape(ntok, d), drop[0], drop[1], lib=lib)         # through the projection's Dropout
+        ops.sgemm(0, 0, ntok, inner, d, dyp, d, w_out, inner, do, inner, arith=self.gemm_arith, lib=lib)                         # dO = dy W_out
+        ops.sgemm(1, 0, d, inner, ntok, dyp, d, o, inner, G(names[3]), inner, arith=self.gemm_arith, lib=lib)                    # dW_out = dy^T O
+        ops.colsum(dyp, d, G(names[4]), ntok, d, lib=lib)
         dqkv = ops.attn_core_bwd_map(qkv, o, lse, do, smap, heads, dh, lib=lib)
         dxn = torch.empty((ntok, d), dtype=torch.float32, device=dev)
         ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_qkv, d, dxn, d, arith=self.gemm_arith, lib=lib)                   # d(norm(x)) = dQKV W_qkv
@@ -1415,8 +1420,6 @@ class RAT_m3(RAT_m2):
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
         if num_heads < 2:
             raise ValueError("RAT_m3 splits the projections into num_heads/2 heads (RAT_m3.py:181): num_heads must be >= 2")
-        if dropout and dropout > 0:
-            raise NotImplementedError("attention dropout > 0 is wired for RAT_m2 / m1 / m0 only (every shipped config uses 0)")
         self.encoder = _EncoderM3(d, num_heads, dim_head, dropout, depth, hidden)
 
     def _build_encoder_descriptors(self):
@@ -1457,27 +1460,31 @@ class RAT_m3(RAT_m2):
             torch.cat([wq, wkt, wvt], dim=0, out=blk["w_t"])
             ps = self._m3_params(blk, "intra", blk["w_s"], self._p)
             pt = self._m3_params(blk, "cross", blk["w_t"], self._p)
+            # each of the two attentions has its own nn.Dropout behind to_out (RAT_m3.py:186-189 via Attention): y = 0.5 * Dropout(..)
+            drop_on = self.training and c["attn_dropout"] > 0
+            dr_s = (c["attn_dropout"], self._dropout_word()) if drop_on and blk["intra"][2] else (0.0, 0)
+            dr_t = (c["attn_dropout"], self._dropout_word()) if drop_on and blk["cross"][2] else (0.0, 0)
             if bi == last and self.prune_dead_tokens:
                 # Dead-token pruning (RAT_m2._encoder_forward): the head reads x[:, 0][:, 0] only (RAT_m3.py:128-129), and in
                 # the LAST block that token needs the intra-sample attention of the target sample's sequence and the cross-sample
                 # attention of token position 0's sequence — B sequences each instead of B T and B S — and the MLP on one token.
                 im0, cm0 = ops.intra_map_target_sample(B, T, S), ops.cross_map_label_token(B, T, S)
-                out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, im0, d, h, dh, sc, 0.5, save=save, lib=lib)
-                out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cm0, d, h, dh, sc, 0.5, save=save, out=out, lib=lib)
+                out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, im0, d, h, dh, sc, 0.5, save=save, dropout=dr_s, lib=lib)
+                out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cm0, d, h, dh, sc, 0.5, save=save, out=out, dropout=dr_t, lib=lib)
                 out_cls = out.view(B, T, S, d)[:, 0, 0, :].contiguous()
                 x_cls = x.view(B, T, S, d)[:, 0, 0, :].contiguous()
                 w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
                 xc = ops.ffn_fwd_res(out_cls, x_cls, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)
                 if save:
-                    saved["blocks"].append((x, o_s, l_s, o_t, l_t, out_cls))
+                    saved["blocks"].append((x, o_s, l_s, o_t, l_t, out_cls, dr_s, dr_t))
                     saved["pruned"] = True
                 return xc, d
-            out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, imap, d, h, dh, sc, 0.5, save=save, lib=lib)             # 0.5 * intra(x)
-            out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cmap, d, h, dh, sc, 0.5, save=save, out=out, lib=lib)     # += 0.5 * cross(x)
+            out, o_s, l_s = ops.attn_fwd_ex(x, None, ps, imap, d, h, dh, sc, 0.5, save=save, dropout=dr_s, lib=lib)             # 0.5 * intra(x)
+            out, o_t, l_t = ops.attn_fwd_ex(x, out, pt, cmap, d, h, dh, sc, 0.5, save=save, out=out, dropout=dr_t, lib=lib)     # += 0.5 * cross(x)
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             xn = ops.ffn_fwd_res(out, x, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)                         # mlp(out) + x
             if save:
-                saved["blocks"].append((x, o_s, l_s, o_t, l_t, out))
+                saved["blocks"].append((x, o_s, l_s, o_t, l_t, out, dr_s, dr_t))
             x = xn
         return x, T * S * d
 
@@ -1493,7 +1500,7 @@ class RAT_m3(RAT_m2):
         g_s = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
         g_t = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
         pruned = bool(saved.get("pruned"))
-        for bi, (blk, (x_in, o_s, l_s, o_t, l_t, out)) in enumerate(zip(reversed(self._blocks), reversed(saved["blocks"]))):
+        for bi, (blk, (x_in, o_s, l_s, o_t, l_t, out, dr_s, dr_t)) in enumerate(zip(reversed(self._blocks), reversed(saved["blocks"]))):
             w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
             gw = [G(n) for n in blk["ffn"]]
             dout, _ = ops.ffn_bwd_res(out, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
@@ -1511,11 +1518,13 @@ class RAT_m3(RAT_m2):
                 dx, dout = dgrid, dog
                 amap, bmap = ops.cross_map_label_token(B, T, S), ops.intra_map_target_sample(B, T, S)
                 # in place: the rows of the two B-sequence maps receive their gradient, every other row stays zero
-                dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, amap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dx, lib=lib)
+                dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, amap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dx, dropout=dr_t,
+                                         lib=lib)
             else:
                 # dx = dy (the MLP residual) + cross backward + intra backward, accumulated in place
-                dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, amap, d, h, dh, sc, 0.5, workspace=ws_attn, lib=lib)
-            dxn, _ = ops.attn_bwd_ex(x_in, dout, dxn, o_s, l_s, ps, gs, bmap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dxn, lib=lib)
+                dxn, _ = ops.attn_bwd_ex(x_in, dout, dx, o_t, l_t, pt, gt, amap, d, h, dh, sc, 0.5, workspace=ws_attn, dropout=dr_t, lib=lib)
+            dxn, _ = ops.attn_bwd_ex(x_in, dout, dxn, o_s, l_s, ps, gs, bmap, d, h, dh, sc, 0.5, workspace=ws_attn, out=dxn, dropout=dr_s,
+                                     lib=lib)
             gq, gks, gvs, gkt, gvt = [G(n) for n in blk["proj"]]
             torch.add(g_s[:inner], g_t[:inner], out=gq)                    # W_q is used by both attentions
             gks.copy_(g_s[inner:2 * inner])
