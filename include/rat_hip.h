@@ -268,16 +268,24 @@ int rat_sgemm_arith(int trans_a, int trans_b, int M, int N, int K, const float* 
                     int arith, void* stream);
 
 /* BatchNorm1d (train: batch stats, biased var; running stats momentum update with unbiased var; eval:
- * running stats) followed by ReLU — deep.py:128-132.  use_bn=0 -> ReLU only.  z,a [M][N].
- * workspace: rat_bn_workspace(N) bytes (per-row-split partial sums; needed when use_bn && training, and by bwd). */
+ * running stats) followed by the hidden layer's activation — deep.py:128-132.  use_bn=0 -> activation only.  z,a [M][N].
+ * workspace: rat_bn_workspace(N) bytes (per-row-split partial sums; needed when use_bn && training, and by bwd).
+ * act (ABI v6; every rat_bn_* entry point below takes it): the activation MLP_Layer puts behind the layer (deep.py:121-123,
+ * torch_utils.get_activation, torch_utils.py:83-94) — the names stay "bn_relu" because ReLU is what every shipped config uses. */
+#define RAT_ACT_RELU 0
+#define RAT_ACT_NONE 1        /* no activation module (hidden_activations entry None / "") or nn.Identity */
+#define RAT_ACT_SIGMOID 2
+#define RAT_ACT_TANH 3
+#define RAT_ACT_LEAKY_RELU 4  /* nn.LeakyReLU(): negative_slope 0.01 */
+#define RAT_ACT_ELU 5         /* nn.ELU(): alpha 1.0 */
 size_t rat_bn_workspace(int N);
 int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* save_mean, float* save_rstd, float* workspace, int M, int N,
-                    int training, int use_bn, float eps, float momentum, void* stream);
-/* a = the forward output (its sign is the ReLU mask); dgamma/dbeta overwritten */
+                    int training, int use_bn, float eps, float momentum, int act, void* stream);
+/* a = the forward output (the derivative of every supported activation is a function of it); dgamma/dbeta overwritten */
 int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* workspace,
-                    int M, int N, int use_bn, void* stream);
+                    int M, int N, int use_bn, int act, void* stream);
 /* SyncBN for data parallelism (deep.py:128-132 evaluated over the GLOBAL batch, i.e. exactly what the
  * reference's single-device BatchNorm1d sees).  The collectives between the calls belong to the caller (RCCL):
  *   fwd:  rat_bn_local_stats -> all_gather(stats, 2N+1 floats per rank) -> rat_bn_relu_fwd_sync
@@ -289,12 +297,12 @@ int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, 
 int rat_bn_local_stats(const float* z, float* stats, float* workspace, int M, int N, void* stream);
 int rat_bn_relu_fwd_sync(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
                          float* running_var, float* save_mean, float* save_rstd, const float* all_stats, int world,
-                         int M, int N, float eps, float momentum, void* stream);
+                         int M, int N, float eps, float momentum, int act, void* stream);
 int rat_bn_bwd_local_sums(const float* z, const float* a, const float* da, const float* save_mean, const float* save_rstd,
-                          float* sums, float* workspace, int M, int N, void* stream);
+                          float* sums, float* workspace, int M, int N, int act, void* stream);
 int rat_bn_relu_bwd_sync(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                          const float* save_mean, const float* save_rstd, const float* local_sums, const float* global_sums,
-                         float* dgamma, float* dbeta, const float* all_stats, int world, int M, int N, void* stream);
+                         float* dgamma, float* dbeta, const float* all_stats, int world, int M, int N, int act, void* stream);
 /* column sums of a [M][N] matrix (bias gradients); workspace: rat_colsum_workspace(M, N) bytes (= rat_bn_workspace(N) up to
  * M = 65536 rows; more row splits beyond, for the token-sized matrices of the composed attention path) */
 size_t rat_colsum_workspace(int M, int N);
@@ -303,18 +311,22 @@ int rat_colsum(const float* a, int lda, float* out, float* workspace, int M, int
 /* logit = fc(cls) + dnn_out + sum_f lr_table_f[idx] ; y_pred = sigmoid(logit)  (RAT_m2.py:138-150,
  * shallow.py:36-45); loss_sum += sum_b BCE(y_pred, y_true)/B with torch's log clamp at -100
  * (torch_utils.py:51-63, base_model.py:74-77).  cls rows are read at cls + b*cls_stride (floats); idx rows of
- * the TARGET sample at idx + b*idx_stride.  dnn_out / lr_fields_dev / loss_sum / y_true may be NULL. */
+ * the TARGET sample at idx + b*idx_stride.  dnn_out / lr_fields_dev / loss_sum / y_true may be NULL.
+ * head (ABI v6): RAT_HEAD_BINARY — the above; RAT_HEAD_REGRESSION — task = "regression" (base_model.py:286-292: no output
+ * activation) with loss = "mse_loss": y_pred = logit, loss_sum += sum_b (y_pred - y_true)^2 / B. */
+#define RAT_HEAD_BINARY 0
+#define RAT_HEAD_REGRESSION 1
 int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* fc_w, const float* fc_b,
                   const float* dnn_out, const RatField* lr_fields_dev, int nfields, const int32_t* idx,
                   int64_t idx_stride, const float* y_true, float* y_pred, float* loss_sum, int B, int d,
-                  void* stream);
-/* dlogit[b] = gscale * (gscale_dev ? *gscale_dev : 1) * (y_pred - y_true)/B ; dcls row b (written at
+                  int head, void* stream);
+/* dlogit[b] = gscale * (gscale_dev ? *gscale_dev : 1) * (y_pred - y_true)/B (x 2 for RAT_HEAD_REGRESSION) ; dcls row b (written at
  * dcls + b*dcls_stride) = dlogit*fc_w ; dfc_w, dfc_b and the LR grad tables are ACCUMULATED into (caller zeroes them).
  * gscale_dev (nullable): a DEVICE scalar — autograd's incoming loss gradient — so that backward needs no host read-back. */
 int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride,
                   const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
                   float* dfc_b, const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx,
-                  int64_t idx_stride, float gscale, const float* gscale_dev, int B, int d, void* stream);
+                  int64_t idx_stride, float gscale, const float* gscale_dev, int B, int d, int head, void* stream);
 
 /* ---- K1s: row-sparse / deterministic embedding gradients (BASELINE.json configs[3]; SURVEY.md §2a rows H/I, §7 hard parts 3, 7)
  * replaces, for tables too large for dense semantics, embedding_dense_backward + the dense clip/Adam pass over the tables
@@ -386,6 +398,21 @@ int rat_sumsq_reg(const float* g, const float* w, int64_t n, int64_t n_split, fl
 int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64_t n, int64_t n_split, float lam_a, float lam_b,
                         const float* lam_scale_dev, const float* norm_sq, float max_norm, const float* hyper_dev,
                         float beta1, float beta2, float eps, int zero_g, void* stream);
+/* ABI v6 — the optimizers torch_utils.get_optimizer (torch_utils.py:41-49) builds besides Adam: getattr(torch.optim, name)(params,
+ * lr=lr), i.e. torch's default hyper-parameters.  kind: RAT_OPT_SGD  w -= lr g;  RAT_OPT_ADAGRAD  s += g g, w -= lr g / (sqrt(s) + eps)
+ * (eps 1e-10);  RAT_OPT_RMSPROP  s = p0 s + (1 - p0) g g, w -= lr g / (sqrt(s) + eps) (p0 = alpha 0.99, eps 1e-8).  `state` is the one
+ * fp32 buffer of the parameters' shape these keep (NULL for SGD).  rat_clip_opt is the counterpart of rat_clip_adam (gradient already
+ * holds the regulariser term), rat_clip_opt_fused of rat_clip_adam_fused (g + lambda w formed in registers, g left zero; lr read from
+ * hyper_dev[2], which rat_adam_tick keeps current). */
+#define RAT_OPT_ADAM 0
+#define RAT_OPT_SGD 1
+#define RAT_OPT_ADAGRAD 2
+#define RAT_OPT_RMSPROP 3
+int rat_clip_opt(float* w, const float* g, float* state, int64_t n, const float* norm_sq, float max_norm, float lr, int kind,
+                 float p0, float eps, void* stream);
+int rat_clip_opt_fused(float* w, float* g, float* state, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                       const float* lam_scale_dev, const float* norm_sq, float max_norm, const float* hyper_dev, int kind,
+                       float p0, float eps, int zero_g, void* stream);
 /* rat_scatter_rows: dense_base[rows[s]*d + c] = grads[s*d + c] for s < *count_dev — the merged (unique rows, gradient rows)
  * lists of all ranks written into the (zeroed) dense gradient block, so that the dense-semantics optimizer (regulariser on every
  * row, base_model.py:79-94) runs unchanged after a row-list exchange. */

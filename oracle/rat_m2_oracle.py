@@ -68,6 +68,9 @@ class Config:
     bn_eps: float = 1e-5
     bn_momentum: float = 0.1
     ln_eps: float = 1e-5
+    dnn_activations: object = "relu"    # str or per-layer list (MLP_Layer hidden_activations, deep.py:108-141; torch_utils.get_activation)
+    optimizer: str = "adam"             # torch_utils.get_optimizer (torch_utils.py:41-49): "adam" or a torch.optim class name
+    task: str = "binary_classification"   # "regression": no output activation (base_model.py:286-292), loss F.mse_loss
     variant: str = "m2"       # "m2": cross/intra encoder blocks (RAT_m2.py); "m1": cascaded transformers (RAT_m1.py);
                               # "m0": ONE transformer over all T*S tokens of a sample (RAT_m0.py);
                               # "m3": parallel intra/cross attention with a shared query projection, mean fusion (RAT_m3.py)
@@ -171,6 +174,7 @@ def parameter_shapes(cfg: Config) -> "OrderedDict[str, Tuple[int, ...]]":
     if cfg.dnn_hidden_units:
         widths = [d * nf] + list(cfg.dnn_hidden_units)
         pos = 0
+        acts = activation_names(cfg)
         for j in range(len(widths) - 1):
             shapes["dnn.dnn.%d.weight" % pos] = (widths[j + 1], widths[j])
             shapes["dnn.dnn.%d.bias" % pos] = (widths[j + 1],)
@@ -179,7 +183,8 @@ def parameter_shapes(cfg: Config) -> "OrderedDict[str, Tuple[int, ...]]":
                 shapes["dnn.dnn.%d.weight" % pos] = (widths[j + 1],)
                 shapes["dnn.dnn.%d.bias" % pos] = (widths[j + 1],)
                 pos += 1
-            pos += 1                                   # the activation module (deep.py:131-132)
+            if acts[j] is not None:
+                pos += 1                               # the activation module (deep.py:121-123: only when the entry is truthy)
         shapes["dnn.dnn.%d.weight" % pos] = (1, widths[-1])
         shapes["dnn.dnn.%d.bias" % pos] = (1,)
     shapes["fc.weight"] = (1, d)
@@ -198,18 +203,44 @@ def count_parameters(cfg: Config) -> int:
     return total
 
 
+def activation_names(cfg: Config) -> List[Optional[str]]:
+    """per hidden layer: None (no activation module) or the lower-cased activation name"""
+    acts = cfg.dnn_activations
+    acts = list(acts) if isinstance(acts, (list, tuple)) else [acts] * len(cfg.dnn_hidden_units)
+    return [(a.lower() if isinstance(a, str) and a else None) for a in acts]
+
+
+def apply_activation(z: Tensor, name: Optional[str]) -> Tensor:
+    """torch_utils.get_activation (torch_utils.py:83-94) -> the nn module's function (default hyper-parameters)"""
+    if name is None or name == "identity":
+        return z
+    if name == "relu":
+        return torch.relu(z)
+    if name == "sigmoid":
+        return torch.sigmoid(z)
+    if name == "tanh":
+        return torch.tanh(z)
+    if name == "leakyrelu":
+        return torch.nn.functional.leaky_relu(z, 0.01)
+    if name == "elu":
+        return torch.nn.functional.elu(z, 1.0)
+    raise NotImplementedError(name)
+
+
 def dnn_layout(cfg: Config):
-    """Indices inside ``dnn.dnn`` of (linear, bn or None) per hidden layer, plus the output linear."""
+    """Indices inside ``dnn.dnn`` of (linear, bn or None) per hidden layer, plus the output linear (MLP_Layer appends
+    Linear, [BatchNorm1d], [activation module], [Dropout: p = 0 here] per layer, deep.py:117-125)."""
     layers = []
     pos = 0
-    for _ in cfg.dnn_hidden_units:
+    for act in activation_names(cfg):
         lin = pos
         pos += 1
         bn = None
         if cfg.batch_norm:
             bn = pos
             pos += 1
-        pos += 1
+        if act is not None:
+            pos += 1
         layers.append((lin, bn))
     return layers, pos
 
@@ -345,8 +376,9 @@ def dnn_head(flat: Tensor, w: Dict[str, Tensor], cfg: Config, training: bool,
     running stats.  ``bn_state`` (if given) receives the updated buffers.
     """
     layers, out_pos = dnn_layout(cfg)
+    acts = activation_names(cfg)
     z = flat
-    for lin, bn in layers:
+    for (lin, bn), act in zip(layers, acts):
         z = z @ w["dnn.dnn.%d.weight" % lin].t() + w["dnn.dnn.%d.bias" % lin]
         if bn is not None:
             g, bta = w["dnn.dnn.%d.weight" % bn], w["dnn.dnn.%d.bias" % bn]
@@ -367,7 +399,7 @@ def dnn_head(flat: Tensor, w: Dict[str, Tensor], cfg: Config, training: bool,
                 mu = w["dnn.dnn.%d.running_mean" % bn]
                 var = w["dnn.dnn.%d.running_var" % bn]
             z = (z - mu) / torch.sqrt(var + cfg.bn_eps) * g + bta
-        z = torch.relu(z)
+        z = apply_activation(z, act)
     return z @ w["dnn.dnn.%d.weight" % out_pos].t() + w["dnn.dnn.%d.bias" % out_pos]
 
 
@@ -415,7 +447,7 @@ def forward(w: Dict[str, Tensor], X: Tensor, y: Tensor, cfg: Config, training: b
         # dim 1 is over a singleton because X is passed as [B, 1, F] (RAT_m2.py:119,148).
         lr = embed_fields(X[:, :1].long(), cfg, w, prefix=LR).sum(dim=-2).mean(dim=1)
         logit = logit + lr
-    if return_logit:
+    if return_logit or cfg.task == "regression":            # get_output_activation: None for regression (base_model.py:286-292)
         return logit
     return torch.sigmoid(logit)
 
@@ -445,7 +477,8 @@ def total_loss(w: Dict[str, Tensor], X: Tensor, y: Tensor, cfg: Config, training
     y_pred = forward(w, X, y, cfg, training=training, bn_state=bn_state)
     y_true = y[:, :1].to(y_pred.dtype)
     names = list(parameter_shapes(cfg).keys())
-    return bce_mean(y_pred, y_true) + regularization(w, cfg, names), y_pred
+    data_loss = ((y_pred - y_true) ** 2).mean() if cfg.task == "regression" else bce_mean(y_pred, y_true)     # F.mse_loss / BCE
+    return data_loss + regularization(w, cfg, names), y_pred
 
 
 # --------------------------------------------------------------------------- backward / optimizer
@@ -488,13 +521,36 @@ def adam_step(w: Dict[str, Tensor], grads: Dict[str, Tensor], state: Dict[str, D
     return new_w
 
 
+def other_optimizer_step(w: Dict[str, Tensor], grads: Dict[str, Tensor], state: Dict[str, Dict[str, Tensor]], lr: float, kind: str):
+    """torch.optim.SGD / Adagrad / RMSprop as get_optimizer builds them — getattr(torch.optim, name)(params, lr=lr), torch_utils.py:41-49:
+    torch's defaults (SGD without momentum; Adagrad lr_decay 0, eps 1e-10; RMSprop alpha 0.99, eps 1e-8, no momentum, not centered)."""
+    new_w = dict(w)
+    for name, g in grads.items():
+        if kind == "SGD":
+            new_w[name] = w[name] - lr * g
+            continue
+        st = state.setdefault(name, {"s": torch.zeros_like(g)})
+        if kind == "Adagrad":
+            st["s"] = st["s"] + g * g
+            new_w[name] = w[name] - lr * g / (torch.sqrt(st["s"]) + 1e-10)
+        elif kind == "RMSprop":
+            st["s"] = 0.99 * st["s"] + (1 - 0.99) * g * g
+            new_w[name] = w[name] - lr * g / (torch.sqrt(st["s"]) + 1e-8)
+        else:
+            raise NotImplementedError(kind)
+    return new_w
+
+
 def train_step(w: Dict[str, Tensor], X: Tensor, y: Tensor, cfg: Config, state: Dict, step: int):
     """One iteration of BaseModel.train_one_epoch (base_model.py:220-226).
 
     Returns (new weights incl. updated BN buffers, loss, y_pred, raw grads, grad norm)."""
     loss, y_pred, grads, bn_state = loss_and_grads(w, X, y, cfg, training=True)
     clipped, gnorm = clip_grad_norm(grads, cfg.max_gradient_norm)
-    new_w = adam_step(w, clipped, state, cfg.learning_rate, step)
+    if cfg.optimizer.lower() == "adam":
+        new_w = adam_step(w, clipped, state, cfg.learning_rate, step)
+    else:
+        new_w = other_optimizer_step(w, clipped, state, cfg.learning_rate, cfg.optimizer)
     new_w.update(bn_state)
     return new_w, loss, y_pred, grads, gnorm
 

@@ -103,6 +103,8 @@ def run_case(case, models, FeatureMap, seed_everything):
     with torch.no_grad():
         ev = model.forward(batch)
     out["eval_after/y_pred"] = ev["y_pred"].numpy().astype(np.float32)
+    if case.get("task", "binary_classification") != "binary_classification":
+        return out                                            # (AUC / logloss are classification metrics)
     from sklearn.metrics import roc_auc_score, log_loss
     yt = out["eval/y_true"].reshape(-1).astype(np.float64)
     yp = np.clip(out["eval/y_pred"].reshape(-1).astype(np.float64), 1e-7, 1 - 1e-7)

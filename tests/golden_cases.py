@@ -111,6 +111,31 @@ CASES += [
 ]
 
 # The three shipped experiments (exps/RAT_m2/*/*.log "Total number of parameters").
+# Round 4: the constructor options the shipped configs never vary — hidden activations other than ReLU (per-layer list, with and
+# without BatchNorm, a layer WITHOUT an activation module: the Sequential's indices shift), the other optimizers get_optimizer can
+# build (torch defaults), task = "regression" with F.mse_loss (no output activation).
+_OPT_FIELDS = [_cat("a", 7), _cat("b", 5), _seq("c", 6), _cat("e", 9, padding_idx=8)]
+CASES += [
+    dict(name="act_tanh_sigmoid_leaky_bn", batch=6, topk=3, init_seed=2021, data_seed=211, weight_seed=212, full_limit=1 << 20,
+         fields=_OPT_FIELDS, embedding_dim=8, num_heads=2, dim_head=4, depth=1, scale_dim=2, dnn_hidden_units=[16, 8, 8],
+         dnn_activations=["Tanh", "sigmoid", "LeakyReLU"], batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="act_elu_none_relu", batch=6, topk=3, init_seed=2021, data_seed=221, weight_seed=222, full_limit=1 << 20,
+         fields=_OPT_FIELDS, embedding_dim=8, num_heads=2, dim_head=4, depth=1, scale_dim=2, dnn_hidden_units=[16, 8, 8],
+         dnn_activations=["ELU", None, "relu"], batch_norm=False, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="opt_sgd", batch=6, topk=3, init_seed=2021, data_seed=231, weight_seed=232, full_limit=1 << 20, optimizer="SGD",
+         learning_rate=0.05, fields=_OPT_FIELDS, embedding_dim=8, num_heads=2, dim_head=4, depth=1, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="opt_adagrad", batch=6, topk=3, init_seed=2021, data_seed=241, weight_seed=242, full_limit=1 << 20, optimizer="Adagrad",
+         learning_rate=0.01, fields=_OPT_FIELDS, embedding_dim=8, num_heads=2, dim_head=4, depth=1, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="opt_rmsprop", batch=6, topk=3, init_seed=2021, data_seed=251, weight_seed=252, full_limit=1 << 20, optimizer="RMSprop",
+         learning_rate=0.001, fields=_OPT_FIELDS, embedding_dim=8, num_heads=2, dim_head=4, depth=1, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=False, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+    dict(name="regression_mse", batch=6, topk=3, init_seed=2021, data_seed=261, weight_seed=262, full_limit=1 << 20, task="regression",
+         loss="mse_loss", fields=_OPT_FIELDS, embedding_dim=8, num_heads=2, dim_head=4, depth=1, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+]
+
 KNOWN_COUNT_CASES = [
     dict(name="count_mltag", expected_params=1337241, topk=5,
          fields=[_cat("user_id", 90239 - 2000 - 1000), _cat("item_id", 2000), _cat("tag_id", 1000)],
@@ -164,15 +189,16 @@ def input_length(case):
 
 def model_kwargs(case):
     """The flattened params dict run_expid.py would splat into the constructor."""
-    return dict(model_id=case.get("model", "RAT_m2") + "_" + case["name"], gpu=-1, task="binary_classification", learning_rate=1e-3,
+    return dict(model_id=case.get("model", "RAT_m2") + "_" + case["name"], gpu=-1, task=case.get("task", "binary_classification"),
+                learning_rate=case.get("learning_rate", 1e-3),
                 embedding_dim=case["embedding_dim"], dnn_hidden_units=list(case["dnn_hidden_units"]),
-                dnn_activations="relu", num_heads=case["num_heads"], dim_head=case["dim_head"],
+                dnn_activations=case.get("dnn_activations", "relu"), num_heads=case["num_heads"], dim_head=case["dim_head"],
                 depth=case["depth"], scale_dim=case["scale_dim"], dropout=0.0, emb_dropout=0.0, net_dropout=0,
                 batch_norm=case["batch_norm"], use_wide=case["use_wide"],
                 embedding_regularizer=case["embedding_regularizer"], net_regularizer=case["net_regularizer"],
                 retrieval_augmented=True, retrieval_configs={"topK": case["topk"], "label_wise": False},
-                model_root="./_golden_models/", metrics=["AUC", "logloss"], verbose=0, optimizer="adam",
-                loss="binary_crossentropy", monitor="AUC", monitor_mode="max", patience=2, every_x_epochs=1,
+                model_root="./_golden_models/", metrics=["AUC", "logloss"], verbose=0, optimizer=case.get("optimizer", "adam"),
+                loss=case.get("loss", "binary_crossentropy"), monitor="AUC", monitor_mode="max", patience=2, every_x_epochs=1,
                 save_best_only=True, layer_norm=True, use_scale=True, use_residual=True, pool="cls", seed=2021)
 
 

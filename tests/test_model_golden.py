@@ -54,6 +54,23 @@ def test_reference_written_checkpoint_loads_and_round_trips(name, tmp_path):
     mc.check_checkpoint(name, gpu=-1, tmpdir=tmp_path)
 
 
+# round 4: hidden activations other than ReLU (incl. a layer without an activation module), SGD / Adagrad / RMSprop, the regression head —
+# golden vectors from the real reference built with those constructor options
+OPTION_CASES = ["act_tanh_sigmoid_leaky_bn", "act_elu_none_relu", "opt_sgd", "opt_adagrad", "opt_rmsprop", "regression_mse"]
+
+
+@pytest.mark.parametrize("name", OPTION_CASES)
+def test_constructor_options_init_eval_and_training(name):
+    mc.check_init(name, gpu=-1)
+    mc.check_eval(name, gpu=-1)
+    mc.check_training(name, gpu=-1)
+
+
+@pytest.mark.parametrize("name", ["act_tanh_sigmoid_leaky_bn", "opt_sgd", "opt_adagrad", "opt_rmsprop", twin("regression_mse")])
+def test_constructor_options_through_the_fused_step(name):
+    mc.check_train_step_api(name, gpu=-1)
+
+
 # (RAT_m0 shares RAT_m1's transformer-stack code; its long-sequence composed path is exercised by
 # test_m2_composed_attention_path here and by the m0_northstar_shape golden case on the GPU)
 # one case per variant on the emulator (35-40 s each); the GPU suite runs every case of golden_cases.CASES

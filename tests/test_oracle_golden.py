@@ -17,7 +17,9 @@ def oracle_config(case):
                       dim_head=case["dim_head"], depth=case["depth"], scale_dim=case["scale_dim"],
                       dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=case["batch_norm"],
                       use_wide=case["use_wide"], embedding_regularizer=float(case["embedding_regularizer"] or 0.0),
-                      net_regularizer=float(case["net_regularizer"] or 0.0),
+                      net_regularizer=float(case["net_regularizer"] or 0.0), learning_rate=case.get("learning_rate", 1e-3),
+                      dnn_activations=case.get("dnn_activations", "relu"), optimizer=case.get("optimizer", "adam"),
+                      task=case.get("task", "binary_classification"),
                       variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3", "RAT_m0": "m0"}[case.get("model", "RAT_m2")])
 
 
@@ -85,7 +87,8 @@ def test_eval_forward(name):
         yp = orc.forward(w, X, y, cfg, training=False).numpy()
     np.testing.assert_allclose(yp, gold["eval/y_pred"], rtol=0, atol=1e-6)
     np.testing.assert_array_equal(y[:, :1].numpy().astype(np.float32), gold["eval/y_true"])
-    assert abs(orc.logloss(gold["eval/y_true"], yp) - float(gold["eval/logloss"])) < 1e-9 + 1e-6
+    if "eval/logloss" in gold.files:                     # (classification cases only)
+        assert abs(orc.logloss(gold["eval/y_true"], yp) - float(gold["eval/logloss"])) < 1e-9 + 1e-6
     if "eval/auc" in gold.files:
         assert abs(orc.auc(gold["eval/y_true"], gold["eval/y_pred"]) - float(gold["eval/auc"])) < 1e-12
 
@@ -120,7 +123,8 @@ def test_two_training_steps(name):
     with torch.no_grad():
         yp = orc.forward(w, X, y, cfg, training=False).numpy()
     # with BN the eval output sees (bias walk - running_mean walk): up to ~2 steps * lr of logit noise per unit
-    np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=2e-3 if cfg.batch_norm else 2e-6)
+    # (BatchNorm: the biases in front of it step by +-lr on rounding noise, and the running mean follows them: the bound scales with lr)
+    np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=2e-3 * (cfg.learning_rate / 1e-3) * (4.0 if cfg.task == "regression" else 1.0) if cfg.batch_norm else 2e-6)   # (a raw logit: no sigmoid's <= 1/4 slope)
 
 
 def test_float64_oracle_agrees_with_float32():

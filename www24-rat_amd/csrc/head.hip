@@ -53,10 +53,34 @@ bn_stats_kernel(const float* __restrict__ z, float* __restrict__ ws, int M, int 
     }
 }
 
+// Hidden-layer activation of the DNN head (MLP_Layer, deep.py:108-141; torch_utils.get_activation, torch_utils.py:83-94).  `act` is one
+// of RAT_ACT_* (include/rat_hip.h): 0 ReLU, 1 none, 2 Sigmoid, 3 Tanh, 4 LeakyReLU(0.01), 5 ELU(1.0).  The derivative is written in
+// terms of the activation's OUTPUT a (saved by the forward), so the backward needs nothing but a and the incoming gradient.
+__device__ __forceinline__ float head_act(float y, int act) {
+    switch (act) {
+        case 1: return y;
+        case 2: return 1.0f / (1.0f + expf(-y));
+        case 3: return tanhf(y);
+        case 4: return y > 0.f ? y : 0.01f * y;
+        case 5: return y > 0.f ? y : expm1f(y);
+        default: return y > 0.f ? y : 0.f;
+    }
+}
+__device__ __forceinline__ float head_act_bwd(float a, float da, int act) {
+    switch (act) {
+        case 1: return da;
+        case 2: return da * a * (1.0f - a);
+        case 3: return da * (1.0f - a * a);
+        case 4: return a > 0.f ? da : 0.01f * da;
+        case 5: return a > 0.f ? da : da * (a + 1.0f);
+        default: return a > 0.f ? da : 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(HD_THREADS)
 bn_relu_apply_kernel(const float* __restrict__ z, float* __restrict__ a, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, float* save_mean, float* save_rstd, const float* ws, int M,
-                     int N, int training, int use_bn, float eps, float momentum) {
+                     int N, int training, int use_bn, float eps, float momentum, int act) {
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
     const int nblk = (N + HD_COLS - 1) / HD_COLS;
     const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
@@ -92,13 +116,13 @@ bn_relu_apply_kernel(const float* __restrict__ z, float* __restrict__ a, const f
     const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
     for (int m = r0 + rg; m < r1; m += HD_RG) {
         const float y = (z[(size_t)m * N + col] - mean) * rstd * gam + bet;
-        a[(size_t)m * N + col] = y > 0.f ? y : 0.f;
+        a[(size_t)m * N + col] = head_act(y, act);
     }
 }
 
 __global__ void __launch_bounds__(HD_THREADS)
 bn_bwd_stats_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
-                    const float* save_mean, const float* save_rstd, float* __restrict__ ws, int M, int N) {
+                    const float* save_mean, const float* save_rstd, float* __restrict__ ws, int M, int N, int act) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
@@ -111,7 +135,7 @@ bn_bwd_stats_kernel(const float* __restrict__ z, const float* __restrict__ a, co
         const float mean = save_mean[col], rstd = save_rstd[col];
         for (int m = r0 + rg; m < r1; m += HD_RG) {
             const size_t o = (size_t)m * N + col;
-            const float g = a[o] > 0.f ? da[o] : 0.f;
+            const float g = head_act_bwd(a[o], da[o], act);
             s1 += g;
             s2 = fmaf(g, (z[o] - mean) * rstd, s2);
         }
@@ -127,7 +151,7 @@ bn_bwd_stats_kernel(const float* __restrict__ z, const float* __restrict__ a, co
 __global__ void __launch_bounds__(HD_THREADS)
 bn_relu_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
                          float* __restrict__ dz, const float* gamma, const float* save_mean, const float* save_rstd,
-                         float* dgamma, float* dbeta, const float* ws, int M, int N, int use_bn) {
+                         float* dgamma, float* dbeta, const float* ws, int M, int N, int use_bn, int act) {
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
     const int nblk = (N + HD_COLS - 1) / HD_COLS;
     const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
@@ -137,7 +161,7 @@ bn_relu_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ 
     if (!use_bn) {
         for (int m = r0 + rg; m < r1; m += HD_RG) {
             const size_t o = (size_t)m * N + col;
-            dz[o] = a[o] > 0.f ? da[o] : 0.f;
+            dz[o] = head_act_bwd(a[o], da[o], act);
         }
         return;
     }
@@ -155,7 +179,7 @@ bn_relu_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ 
     for (int m = r0 + rg; m < r1; m += HD_RG) {
         const size_t o = (size_t)m * N + col;
         const float xh = (z[o] - mean) * rstd;
-        const float g = a[o] > 0.f ? da[o] : 0.f;
+        const float g = head_act_bwd(a[o], da[o], act);
         dz[o] = gam * rstd * (g - m1 - xh * m2);
     }
 }
@@ -183,7 +207,7 @@ bn_local_finalize_kernel(const float* __restrict__ z, const float* __restrict__ 
 __global__ void __launch_bounds__(HD_THREADS)
 bn_relu_apply_sync_kernel(const float* __restrict__ z, float* __restrict__ a, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float* save_mean, float* save_rstd,
-                          const float* __restrict__ all_stats, int world, int M, int N, float eps, float momentum) {
+                          const float* __restrict__ all_stats, int world, int M, int N, float eps, float momentum, int act) {
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
     const int nblk = (N + HD_COLS - 1) / HD_COLS;
     const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
@@ -214,7 +238,7 @@ bn_relu_apply_sync_kernel(const float* __restrict__ z, float* __restrict__ a, co
     const int r0 = split * per, r1 = r0 + per < M ? r0 + per : M;
     for (int m = r0 + rg; m < r1; m += HD_RG) {
         const float y = (z[(size_t)m * N + col] - mean) * rstd * gam + bet;
-        a[(size_t)m * N + col] = y > 0.f ? y : 0.f;
+        a[(size_t)m * N + col] = head_act(y, act);
     }
 }
 
@@ -235,7 +259,7 @@ __global__ void __launch_bounds__(HD_THREADS)
 bn_relu_bwd_apply_sync_kernel(const float* __restrict__ z, const float* __restrict__ a, const float* __restrict__ da,
                               float* __restrict__ dz, const float* gamma, const float* save_mean, const float* save_rstd,
                               const float* local_sums, const float* global_sums, float* dgamma, float* dbeta,
-                              const float* __restrict__ all_stats, int world, int M, int N) {
+                              const float* __restrict__ all_stats, int world, int M, int N, int act) {
     const int cg = threadIdx.x % HD_COLS, rg = threadIdx.x / HD_COLS;
     const int nblk = (N + HD_COLS - 1) / HD_COLS;
     const int col = (blockIdx.x % nblk) * HD_COLS + cg, split = blockIdx.x / nblk;
@@ -253,7 +277,7 @@ bn_relu_bwd_apply_sync_kernel(const float* __restrict__ z, const float* __restri
     for (int m = r0 + rg; m < r1; m += HD_RG) {
         const size_t o = (size_t)m * N + col;
         const float xh = (z[o] - mean) * rstd;
-        const float g = a[o] > 0.f ? da[o] : 0.f;
+        const float g = head_act_bwd(a[o], da[o], act);
         dz[o] = gam * rstd * (g - m1 - xh * m2);
     }
 }
@@ -295,7 +319,7 @@ __device__ __forceinline__ float block_sum(float v, float* scratch) {   // 256 t
 __global__ void __launch_bounds__(HD_THREADS)
 logit_fwd_kernel(const float* __restrict__ cls, int64_t cls_stride, const float* fc_w, const float* fc_b,
                  const float* dnn_out, const RatField* lr_fields, int nfields, const int32_t* idx, int64_t idx_stride,
-                 const float* y_true, float* y_pred, float* loss_sum, int B, int d) {
+                 const float* y_true, float* y_pred, float* loss_sum, int B, int d, int head) {
     RAT_DYN_SMEM(smem);
     float* scratch = reinterpret_cast<float*>(smem);
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,12 +342,20 @@ logit_fwd_kernel(const float* __restrict__ cls, int64_t cls_stride, const float*
             }
             zl += lr;
         }
-        const float p = 1.0f / (1.0f + expf(-zl));
-        y_pred[b] = p;
-        if (y_true != nullptr) {
-            const float t = y_true[b];
-            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
-            loss = -(t * lp + (1.0f - t) * l1p) / (float)B;
+        if (head == 1) {                                         // task = "regression": no output activation, mean squared error
+            y_pred[b] = zl;
+            if (y_true != nullptr) {
+                const float e = zl - y_true[b];
+                loss = e * e / (float)B;
+            }
+        } else {
+            const float p = 1.0f / (1.0f + expf(-zl));
+            y_pred[b] = p;
+            if (y_true != nullptr) {
+                const float t = y_true[b];
+                const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.0f - p), -100.f);
+                loss = -(t * lp + (1.0f - t) * l1p) / (float)B;
+            }
         }
     }
     if (loss_sum != nullptr) {
@@ -336,7 +368,7 @@ __global__ void __launch_bounds__(HD_THREADS)
 logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_true, const float* __restrict__ cls,
                  int64_t cls_stride, const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
                  float* dfc_b, const RatField* lr_grad_fields, int nfields, const int32_t* idx, int64_t idx_stride,
-                 float gscale, const float* gscale_dev, int B, int d) {
+                 float gscale, const float* gscale_dev, int B, int d, int head) {
     // One block = LB_SAMPLES samples.  Phase 1: one thread per sample (dlogit, LR-table atomics, dfc_b partial).  Phase 2:
     // thread = (column k, sample group): dcls rows and the dfc_w partial sums are produced column-parallel — no LDS atomics
     // (the first version issued d LDS atomics per sample onto the same d addresses and ran on B/256 CUs only).
@@ -351,7 +383,7 @@ logit_bwd_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_t
         float dl = 0.f;
         if ((int)threadIdx.x < nb) {
             const int b = b0 + threadIdx.x;
-            dl = gscale * (y_pred[b] - y_true[b]) / (float)B;
+            dl = gscale * (head == 1 ? 2.0f : 1.0f) * (y_pred[b] - y_true[b]) / (float)B;    // d BCE(sigmoid z) / dz = p - t; d MSE / dz = 2 (z - t)
             dlogit[b] = dl;
             if (lr_grad_fields != nullptr)
                 for (int f = 0; f < nfields; ++f) {
@@ -395,8 +427,8 @@ extern "C" size_t rat_bn_workspace(int N) { return (size_t)2 * BN_SPLITS * (size
 
 extern "C" int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float* save_mean, float* save_rstd, float* workspace, int M, int N,
-                               int training, int use_bn, float eps, float momentum, void* stream) {
-    RAT_REQUIRE(M > 0 && N > 0 && z && a, "bad args");
+                               int training, int use_bn, float eps, float momentum, int act, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && a && act >= 0 && act <= 5, "bad args");
     const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
     if (use_bn) {
         RAT_REQUIRE(gamma && beta && running_mean && running_var, "null BN pointer");
@@ -406,7 +438,7 @@ extern "C" int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, con
         }
     }
     RAT_LAUNCH(bn_relu_apply_kernel, blocks, HD_THREADS, 0, stream, z, a, gamma, beta, running_mean, running_var, save_mean,
-               save_rstd, workspace, M, N, training, use_bn, eps, momentum);
+               save_rstd, workspace, M, N, training, use_bn, eps, momentum, act);
     return rat_check_launch("rat_bn_relu_fwd");
 }
 
@@ -438,39 +470,39 @@ extern "C" int rat_colsum(const float* a, int lda, float* out, float* workspace,
 
 extern "C" int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* fc_w, const float* fc_b, const float* dnn_out,
                              const RatField* lr_fields_dev, int nfields, const int32_t* idx, int64_t idx_stride,
-                             const float* y_true, float* y_pred, float* loss_sum, int B, int d, void* stream) {
-    RAT_REQUIRE(B > 0 && d > 0 && cls && fc_w && fc_b && y_pred, "bad args");
+                             const float* y_true, float* y_pred, float* loss_sum, int B, int d, int head, void* stream) {
+    RAT_REQUIRE(B > 0 && d > 0 && cls && fc_w && fc_b && y_pred && (head == 0 || head == 1), "bad args");
     RAT_REQUIRE(lr_fields_dev == nullptr || idx != nullptr, "LR term needs idx");
     RAT_LAUNCH(logit_fwd_kernel, (B + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 16 * sizeof(float), stream, cls, cls_stride,
-               fc_w, fc_b, dnn_out, lr_fields_dev, nfields, idx, idx_stride, y_true, y_pred, loss_sum, B, d);
+               fc_w, fc_b, dnn_out, lr_fields_dev, nfields, idx, idx_stride, y_true, y_pred, loss_sum, B, d, head);
     return rat_check_launch("rat_logit_fwd");
 }
 
 extern "C" int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride,
                              const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w, float* dfc_b,
                              const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx, int64_t idx_stride,
-                             float gscale, const float* gscale_dev, int B, int d, void* stream) {
-    RAT_REQUIRE(B > 0 && d > 0 && y_pred && y_true && cls && fc_w && dlogit && dcls && dfc_w && dfc_b, "bad args");
+                             float gscale, const float* gscale_dev, int B, int d, int head, void* stream) {
+    RAT_REQUIRE(B > 0 && d > 0 && y_pred && y_true && cls && fc_w && dlogit && dcls && dfc_w && dfc_b && (head == 0 || head == 1), "bad args");
     RAT_REQUIRE(lr_grad_fields_dev == nullptr || idx != nullptr, "LR term needs idx");
     RAT_REQUIRE(d <= HD_THREADS, "embedding_dim above the block size");
     RAT_LAUNCH(logit_bwd_kernel, (B + LB_SAMPLES - 1) / LB_SAMPLES, HD_THREADS, (size_t)(LB_SAMPLES + HD_THREADS) * sizeof(float), stream,
                y_pred, y_true, cls, cls_stride, fc_w, dlogit, dcls, dcls_stride, dfc_w, dfc_b, lr_grad_fields_dev, nfields,
-               idx, idx_stride, gscale, gscale_dev, B, d);
+               idx, idx_stride, gscale, gscale_dev, B, d, head);
     return rat_check_launch("rat_logit_bwd");
 }
 
 extern "C" int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                                const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
-                               float* workspace, int M, int N, int use_bn, void* stream) {
-    RAT_REQUIRE(M > 0 && N > 0 && z && a && da && dz, "bad args");
+                               float* workspace, int M, int N, int use_bn, int act, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && a && da && dz && act >= 0 && act <= 5, "bad args");
     const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
     if (use_bn) {
         RAT_REQUIRE(gamma && save_mean && save_rstd && dgamma && dbeta && workspace, "null BN pointer");
         RAT_LAUNCH(bn_bwd_stats_kernel, blocks, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, da, save_mean, save_rstd,
-                   workspace, M, N);
+                   workspace, M, N, act);
     }
     RAT_LAUNCH(bn_relu_bwd_apply_kernel, blocks, HD_THREADS, 0, stream, z, a, da, dz, gamma, save_mean, save_rstd, dgamma,
-               dbeta, workspace, M, N, use_bn);
+               dbeta, workspace, M, N, use_bn, act);
     return rat_check_launch("rat_bn_relu_bwd");
 }
 
@@ -485,21 +517,21 @@ extern "C" int rat_bn_local_stats(const float* z, float* stats, float* workspace
 
 extern "C" int rat_bn_relu_fwd_sync(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
                                     float* running_var, float* save_mean, float* save_rstd, const float* all_stats, int world,
-                                    int M, int N, float eps, float momentum, void* stream) {
+                                    int M, int N, float eps, float momentum, int act, void* stream) {
     RAT_REQUIRE(M > 0 && N > 0 && world >= 1 && z && a && gamma && beta && running_mean && running_var && save_mean && save_rstd &&
-                all_stats, "bad args");
+                all_stats && act >= 0 && act <= 5, "bad args");
     const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
     RAT_LAUNCH(bn_relu_apply_sync_kernel, blocks, HD_THREADS, 0, stream, z, a, gamma, beta, running_mean, running_var, save_mean,
-               save_rstd, all_stats, world, M, N, eps, momentum);
+               save_rstd, all_stats, world, M, N, eps, momentum, act);
     return rat_check_launch("rat_bn_relu_fwd_sync");
 }
 
 extern "C" int rat_bn_bwd_local_sums(const float* z, const float* a, const float* da, const float* save_mean,
-                                     const float* save_rstd, float* sums, float* workspace, int M, int N, void* stream) {
-    RAT_REQUIRE(M > 0 && N > 0 && z && a && da && save_mean && save_rstd && sums && workspace, "bad args");
+                                     const float* save_rstd, float* sums, float* workspace, int M, int N, int act, void* stream) {
+    RAT_REQUIRE(M > 0 && N > 0 && z && a && da && save_mean && save_rstd && sums && workspace && act >= 0 && act <= 5, "bad args");
     const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
     RAT_LAUNCH(bn_bwd_stats_kernel, blocks, HD_THREADS, HD_THREADS * sizeof(float), stream, z, a, da, save_mean, save_rstd,
-               workspace, M, N);
+               workspace, M, N, act);
     RAT_LAUNCH(bn_bwd_sums_final_kernel, (N + HD_THREADS - 1) / HD_THREADS, HD_THREADS, 0, stream, workspace, sums, N);
     return rat_check_launch("rat_bn_bwd_local_sums");
 }
@@ -507,11 +539,11 @@ extern "C" int rat_bn_bwd_local_sums(const float* z, const float* a, const float
 extern "C" int rat_bn_relu_bwd_sync(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                                     const float* save_mean, const float* save_rstd, const float* local_sums,
                                     const float* global_sums, float* dgamma, float* dbeta, const float* all_stats, int world,
-                                    int M, int N, void* stream) {
+                                    int M, int N, int act, void* stream) {
     RAT_REQUIRE(M > 0 && N > 0 && world >= 1 && z && a && da && dz && gamma && save_mean && save_rstd && local_sums &&
-                global_sums && dgamma && dbeta && all_stats, "bad args");
+                global_sums && dgamma && dbeta && all_stats && act >= 0 && act <= 5, "bad args");
     const int blocks = ((N + HD_COLS - 1) / HD_COLS) * BN_SPLITS;
     RAT_LAUNCH(bn_relu_bwd_apply_sync_kernel, blocks, HD_THREADS, 0, stream, z, a, da, dz, gamma, save_mean, save_rstd, local_sums,
-               global_sums, dgamma, dbeta, all_stats, world, M, N);
+               global_sums, dgamma, dbeta, all_stats, world, M, N, act);
     return rat_check_launch("rat_bn_relu_bwd_sync");
 }

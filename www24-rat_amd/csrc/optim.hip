@@ -68,6 +68,42 @@ sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
+// torch.optim's other optimizers as get_optimizer builds them — getattr(torch.optim, name)(params, lr=lr), torch_utils.py:41-49 — i.e.
+// with torch's DEFAULT hyper-parameters: SGD (no momentum), Adagrad (lr_decay 0, initial accumulator 0, eps 1e-10), RMSprop (alpha 0.99,
+// eps 1e-8, no momentum, not centered).  Operation order as in torch's single-tensor implementations (addcmul_ / addcdiv_):
+//   kind 1 SGD      w -= lr g
+//   kind 2 Adagrad  s += g g ;            w -= lr g / (sqrt(s) + eps)
+//   kind 3 RMSprop  s = alpha s + ((1 - alpha) g) g ;  w -= lr g / (sqrt(s) + eps)
+// (kind 0 = Adam keeps its own code below.)  `v` is the one state buffer these use; `m` is untouched.
+__device__ __forceinline__ void opt_other1(int kind, float& w, float gv, float& s, float lr, float p0, float eps) {
+    if (kind == 1) {
+        w -= lr * gv;
+    } else if (kind == 2) {
+        s = s + gv * gv;
+        w -= lr * gv / (sqrtf(s) + eps);
+    } else {
+        s = p0 * s;
+        s = s + (1.0f - p0) * gv * gv;
+        w -= lr * gv / (sqrtf(s) + eps);
+    }
+}
+
+__global__ void __launch_bounds__(OPT_THREADS)
+clip_other_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v, int64_t n, const float* norm_sq,
+                  float max_norm, float lr, int kind, float p0, float eps) {
+    float coef = 1.0f;
+    if (norm_sq != nullptr) {
+        coef = max_norm / (sqrtf(*norm_sq) + 1e-6f);
+        coef = coef < 1.0f ? coef : 1.0f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float wv = w[i], sv = kind == 1 ? 0.f : v[i];
+        opt_other1(kind, wv, g[i] * coef, sv, lr, p0, eps);
+        w[i] = wv;
+        if (kind != 1) v[i] = sv;
+    }
+}
+
 __global__ void __launch_bounds__(OPT_THREADS)
 clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                  const float* norm_sq, float max_norm, float step_size, float beta1, float beta2, float eps,
@@ -170,7 +206,7 @@ __device__ __forceinline__ float opt_adam1(float& w, float g, float& m, float& v
 __global__ void __launch_bounds__(OPT_THREADS)
 clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                        int64_t n_split, float lam_a, float lam_b, const float* lam_scale_dev, const float* norm_sq, float max_norm,
-                       const float* __restrict__ hyper, float beta1, float beta2, float eps, int zero_g, int vec) {
+                       const float* __restrict__ hyper, float beta1, float beta2, float eps, int zero_g, int vec, int kind) {
     float coef = 1.0f;
     if (norm_sq != nullptr) {
         coef = max_norm / (sqrtf(*norm_sq) + 1e-6f);
@@ -181,6 +217,17 @@ clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __re
     const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1];
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
     int64_t head = 0;
+    if (kind != 0) {                                              // SGD / Adagrad / RMSprop (opt_other1): beta1 carries alpha, hyper[2] = lr
+        const float lr = hyper[2];
+        for (int64_t i = tid; i < n; i += nthr) {
+            float wv = w[i], sv = kind == 1 ? 0.f : v[i];
+            opt_other1(kind, wv, fmaf(i < n_split ? la : lb, wv, g[i]) * coef, sv, lr, beta1, eps);
+            w[i] = wv;
+            if (kind != 1) v[i] = sv;
+            if (zero_g) g[i] = 0.f;
+        }
+        return;
+    }
     if (vec) {
         const int64_t n4 = n >> 2, s4 = n_split >> 2;
         for (int64_t i = tid; i < n4; i += nthr) {
@@ -277,8 +324,24 @@ extern "C" int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64
     RAT_REQUIRE(n > 0 && w && g && m && v && hyper_dev && n_split >= 0 && n_split <= n, "bad args");
     const int vec = opt_vec_ok({w, g, m, v}, n_split) ? 1 : 0;
     RAT_LAUNCH(clip_adam_fused_kernel, opt_blocks(n), OPT_THREADS, 0, stream, w, g, m, v, n, n_split, lam_a, lam_b, lam_scale_dev,
-               norm_sq, max_norm, hyper_dev, beta1, beta2, eps, zero_g, vec);
+               norm_sq, max_norm, hyper_dev, beta1, beta2, eps, zero_g, vec, 0);
     return rat_check_launch("rat_clip_adam_fused");
+}
+
+extern "C" int rat_clip_opt_fused(float* w, float* g, float* state, int64_t n, int64_t n_split, float lam_a, float lam_b,
+                                  const float* lam_scale_dev, const float* norm_sq, float max_norm, const float* hyper_dev, int kind,
+                                  float p0, float eps, int zero_g, void* stream) {
+    RAT_REQUIRE(n > 0 && w && g && hyper_dev && n_split >= 0 && n_split <= n && kind >= 1 && kind <= 3 && (kind == 1 || state), "bad args");
+    RAT_LAUNCH(clip_adam_fused_kernel, opt_blocks(n), OPT_THREADS, 0, stream, w, g, (float*)nullptr, state, n, n_split, lam_a, lam_b,
+               lam_scale_dev, norm_sq, max_norm, hyper_dev, p0, 0.f, eps, zero_g, 0, kind);
+    return rat_check_launch("rat_clip_opt_fused");
+}
+
+extern "C" int rat_clip_opt(float* w, const float* g, float* state, int64_t n, const float* norm_sq, float max_norm, float lr, int kind,
+                            float p0, float eps, void* stream) {
+    RAT_REQUIRE(n > 0 && w && g && kind >= 1 && kind <= 3 && (kind == 1 || state), "bad args");
+    RAT_LAUNCH(clip_other_kernel, opt_blocks(n), OPT_THREADS, 0, stream, w, g, state, n, norm_sq, max_norm, lr, kind, p0, eps);
+    return rat_check_launch("rat_clip_opt");
 }
 
 // ---- inverted dropout with a counter-based generator (nn.Dropout of RAT_m2.py:83,135 `emb_dropout` and deep.py:133-134

@@ -79,16 +79,16 @@ _SIGNATURES = {
     "rat_sgemm_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P, c_size_t, _P]),
     "rat_sgemm_arith": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P, c_size_t, c_int, _P]),
     "rat_bn_workspace": (c_size_t, [c_int]),
-    "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, _P]),
-    "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
+    "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "rat_colsum": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P]),
     "rat_bn_local_stats": (c_int, [_P, _P, _P, c_int, c_int, _P]),
-    "rat_bn_relu_fwd_sync": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P]),
-    "rat_bn_bwd_local_sums": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
-    "rat_bn_relu_bwd_sync": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
-    "rat_logit_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, _P, _P, _P, c_int, c_int, _P]),
+    "rat_bn_relu_fwd_sync": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
+    "rat_bn_bwd_local_sums": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "rat_bn_relu_bwd_sync": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "rat_logit_fwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, _P, _P, _P, c_int, c_int, c_int, _P]),
     "rat_logit_bwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, c_int, _P, c_int64, c_float, _P, c_int,
-                              c_int, _P]),
+                              c_int, c_int, _P]),
     "rat_l2_reg": (c_int, [_P, _P, c_int64, c_float, _P, _P, _P]),
     "rat_label_grad_workspace": (c_size_t, [c_int]),
     "rat_label_grad": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
@@ -110,6 +110,8 @@ _SIGNATURES = {
     "rat_sumsq_reg": (c_int, [_P, _P, c_int64, c_int64, c_float, c_float, _P, _P, _P, _P]),
     "rat_clip_adam_fused": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, c_float, _P, _P, c_float, _P, c_float, c_float, c_float,
                                     c_int, _P]),
+    "rat_clip_opt": (c_int, [_P, _P, _P, c_int64, _P, c_float, c_float, c_int, c_float, c_float, _P]),
+    "rat_clip_opt_fused": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, c_float, _P, _P, c_float, _P, c_int, c_float, c_float, c_int, _P]),
     "rat_scatter_rows": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "rat_scatter_rows_lists": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     "rat_adam_rows_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, _P, c_float, c_float, c_float, _P]),

@@ -83,14 +83,27 @@ class BaseModel(nn.Module):
 
     # ---- compile / loss ------------------------------------------------------------------------------
     def compile(self, optimizer, loss, lr):
-        """base_model.py:70-72.  "adam" selects the fused HIP clip+Adam; the loss must be BCE."""
-        from .optim import FusedClipAdam
-        if not (isinstance(optimizer, str) and optimizer.lower() == "adam"):
-            raise NotImplementedError("optimizer=%r: the HIP path implements Adam (every shipped config)" % (optimizer,))
-        if loss not in ("bce", "binary_crossentropy", "binary_cross_entropy"):
-            raise NotImplementedError("loss=%r: the HIP path implements binary cross-entropy" % (loss,))
-        self.optimizer = FusedClipAdam(self, lr=lr)
-        self.loss_fn = "binary_cross_entropy"
+        """base_model.py:70-72 (torch_utils.get_optimizer / get_loss_fn): "adam" in any case, or a torch.optim class name — Adam, SGD,
+        Adagrad, RMSprop have kernels (clip + update over the flat buffers); the loss / task pairs the head kernels fuse: see below."""
+        from .optim import KINDS, FusedClipAdam
+        if not isinstance(optimizer, str):
+            raise NotImplementedError("optimizer=%r: pass a name" % (optimizer,))
+        if optimizer.lower() == "adam":
+            optimizer = "Adam"
+        if optimizer not in KINDS:
+            raise NotImplementedError("optimizer=%r is not supported on the HIP path (have %s)" % (optimizer, ", ".join(KINDS)))
+        # the head kernels (rat_logit_fwd / rat_logit_bwd) fuse output activation and loss: Sigmoid + binary cross-entropy for
+        # task = "binary_classification" (every shipped config), no activation + F.mse_loss for task = "regression"
+        # (base_model.py:286-292, torch_utils.get_loss_fn: torch_utils.py:51-63)
+        task = getattr(self, "_task", "binary_classification")
+        if loss in ("bce", "binary_crossentropy", "binary_cross_entropy") and task == "binary_classification":
+            self.loss_fn, self._head = "binary_cross_entropy", 0
+        elif loss in ("mse_loss", "mse") and task == "regression":
+            self.loss_fn, self._head = "mse_loss", 1
+        else:
+            raise NotImplementedError("task=%r with loss=%r: the HIP head implements binary_classification + binary cross-entropy and "
+                                      "regression + mse_loss" % (task, loss))
+        self.optimizer = FusedClipAdam(self, lr=lr, kind=optimizer)
 
     def add_loss(self, inputs, reduction="mean"):
         """base_model.py:74-77."""
@@ -324,8 +337,12 @@ class BaseModel(nn.Module):
         self.load_state_dict(state)          # copies in place: the flat parameter buffer stays intact
 
     def get_output_activation(self, task="binary_classification"):
+        """base_model.py:286-292"""
+        self._task = task
         if task == "binary_classification":
             return nn.Sigmoid()
+        if task == "regression":
+            return None
         raise NotImplementedError("task={} is not supported.".format(task))
 
     def count_parameters(self, count_embedding=True):

@@ -144,21 +144,59 @@ class _Transformer(nn.Module):
                                               _PreNorm(dim, _FeedForward(dim, hidden))]))
 
 
+def _activation_module(name):
+    """torch_utils.get_activation (torch_utils.py:83-94): "relu" / "sigmoid" / "tanh" in any case, otherwise the torch.nn class of that
+    name; a module (or None) passes through"""
+    if isinstance(name, str):
+        low = name.lower()
+        if low == "relu":
+            return nn.ReLU()
+        if low == "sigmoid":
+            return nn.Sigmoid()
+        if low == "tanh":
+            return nn.Tanh()
+        return getattr(nn, name)()
+    return name
+
+
+def _activation_code(mod):
+    """the RAT_ACT_* code (include/rat_hip.h) of a hidden-layer activation module, or NotImplementedError"""
+    if isinstance(mod, nn.ReLU):
+        return 0
+    if isinstance(mod, nn.Identity):
+        return 1
+    if isinstance(mod, nn.Sigmoid):
+        return 2
+    if isinstance(mod, nn.Tanh):
+        return 3
+    if isinstance(mod, nn.LeakyReLU) and mod.negative_slope == 0.01:
+        return 4
+    if isinstance(mod, nn.ELU) and mod.alpha == 1.0:
+        return 5
+    raise NotImplementedError("dnn_activations: %r has no kernel on the HIP path (have ReLU, Sigmoid, Tanh, LeakyReLU(0.01), ELU(1.0), "
+                              "Identity / None)" % (mod,))
+
+
 class _MLP(nn.Module):
-    """MLP_Layer's module list (deep.py:108-139): [Linear, (BatchNorm1d), act, (Dropout)]* + Linear(.,1)."""
+    """MLP_Layer's module list (deep.py:108-139): [Linear, (BatchNorm1d), (activation), (Dropout)]* + Linear(.,1) — the same modules
+    in the same order, hence the same state_dict keys whatever the activations are."""
 
     def __init__(self, input_dim, hidden_units, activation, dropout, batch_norm):
         super().__init__()
-        if not isinstance(activation, str) or activation.lower() != "relu":
-            raise NotImplementedError("dnn_activations=%r: the HIP head fuses ReLU (every shipped config)" % (activation,))
         rates = dropout if isinstance(dropout, list) else [dropout] * len(hidden_units)
+        acts = activation if isinstance(activation, list) else [activation] * len(hidden_units)
+        acts = [_activation_module(a) for a in acts]
+        for a in acts:
+            if a:
+                _activation_code(a)                          # refuse what the kernels do not have at construction time
         mods = []
         widths = [input_dim] + list(hidden_units)
         for j in range(len(widths) - 1):
             mods.append(nn.Linear(widths[j], widths[j + 1], bias=True))
             if batch_norm:
                 mods.append(nn.BatchNorm1d(widths[j + 1]))
-            mods.append(nn.ReLU())
+            if acts[j]:
+                mods.append(acts[j])
             if rates[j] > 0:
                 mods.append(nn.Dropout(p=rates[j]))
         mods.append(nn.Linear(widths[-1], 1, bias=True))
@@ -613,22 +651,25 @@ class RAT_m2(BaseModel):
         self._col2field = None                                  # built on first use (needs the batch's column count)
         self._build_encoder_descriptors()
         # DNN head layout: [(linear_idx, bn_idx or None, dropout_p)], out linear idx
-        self._dnn_layers, self._dnn_out = [], None
+        self._dnn_layers, self._dnn_acts, self._dnn_out = [], [], None
         if self.dnn is not None:
             mods = list(self.dnn.dnn)
-            j = 0
-            while j < len(mods) - 1:
-                lin, bn, pdrop = j, None, 0.0
+            j, last = 0, len(mods) - 1
+            while j < last:
+                lin, bn, pdrop, act = j, None, 0.0, 1            # (act 1 = RAT_ACT_NONE: no activation module behind this layer)
                 j += 1
-                if isinstance(mods[j], nn.BatchNorm1d):
+                if j < last and isinstance(mods[j], nn.BatchNorm1d):
                     bn = j
                     j += 1
-                j += 1                                        # ReLU
-                if j < len(mods) and isinstance(mods[j], nn.Dropout):
+                if j < last and not isinstance(mods[j], (nn.Linear, nn.Dropout)):
+                    act = _activation_code(mods[j])
+                    j += 1
+                if j < last and isinstance(mods[j], nn.Dropout):
                     pdrop = mods[j].p
                     j += 1
                 self._dnn_layers.append((lin, bn, pdrop))
-            self._dnn_out = len(mods) - 1
+                self._dnn_acts.append(act)
+            self._dnn_out = last
         # BatchNorm's num_batches_tracked (deep.py:128-132 -> nn.BatchNorm1d): one int64 tensor, every layer's buffer a 0-dim view of
         # it, so that a training forward advances all of them with ONE launch (state_dict keys / values are unchanged)
         bns = [self.dnn.dnn[bn] for _, bn, _ in self._dnn_layers if bn is not None] if self.dnn is not None else []
@@ -1023,7 +1064,8 @@ class RAT_m2(BaseModel):
         group = self.optimizer.param_groups[0]
         key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens),
                # kernel arguments and control flow the recorded launches carry: a change of any of them takes a new capture
-               self._max_gradient_norm, tuple(group["betas"]), group["eps"], c["lam_emb"], c["lam_net"], self._grad_mode,
+               self._max_gradient_norm, self.optimizer.kind, tuple(group.get("betas", ())), group.get("eps"), group.get("alpha"),
+               c["lam_emb"], c["lam_net"], self._grad_mode,
                self.row_list_exchange, bool(self._graph_test_splits), bool(self._validate_ids))
         entry = graphs.get(key)
         if entry is None:
@@ -1107,13 +1149,14 @@ class RAT_m2(BaseModel):
                     m = mods[bn]
                     if training and self._sync_bn and self._dp():                     # SyncBN: statistics of the GLOBAL batch
                         a, sm, sr, gstats = ops.bn_relu_fwd_sync(z, m.weight.data, m.bias.data, m.running_mean, m.running_var,
-                                                                 self._all_gather_flat, eps=m.eps, momentum=m.momentum, lib=lib)
+                                                                 self._all_gather_flat, eps=m.eps, momentum=m.momentum,
+                                                                 act=self._dnn_acts[li], lib=lib)
                         sm = (sm, gstats)
                     else:
                         a, sm, sr = ops.bn_relu_fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
-                                                    eps=m.eps, momentum=m.momentum, lib=lib)
+                                                    eps=m.eps, momentum=m.momentum, act=self._dnn_acts[li], lib=lib)
                 else:
-                    a, sm, sr = ops.bn_relu_fwd(z, None, None, None, None, training, False, lib=lib)
+                    a, sm, sr = ops.bn_relu_fwd(z, None, None, None, None, training, False, act=self._dnn_acts[li], lib=lib)
                 a_act = a
                 if drop and pdrop > 0:                                      # net_dropout (deep.py:133-134)
                     a = ops.dropout(a_act, pdrop, seeds[1 + li], lib=lib)
@@ -1135,7 +1178,7 @@ class RAT_m2(BaseModel):
         if loss is None:
             loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
         y_pred = ops.logit_fwd(x, cls_stride, self.fc.weight.data, self.fc.bias.data, dnn_out, self._lr_ftab, F, idx, T * L,
-                               y_true, loss, B, d, lib=lib)
+                               y_true, loss, B, d, head=self._head, lib=lib)
         reg = self._regularization_value() if with_reg else None
         if save:
             saved["x_final"], saved["cls_stride"], saved["y_pred"] = x, cls_stride, y_pred
@@ -1199,7 +1242,7 @@ class RAT_m2(BaseModel):
         dx = torch.zeros_like(x_final)
         cs = saved["cls_stride"]
         dlogit = ops.logit_bwd(y_pred, y_true, x_final, cs, self.fc.weight.data, dx, cs, G("fc.weight"),
-                               G("fc.bias"), lr_gftab, F, idx, T * L, 1.0, B, d, gscale_dev=g_loss, lib=lib)
+                               G("fc.bias"), lr_gftab, F, idx, T * L, 1.0, B, d, gscale_dev=g_loss, head=self._head, lib=lib)
         dflat = None
         if self.dnn is not None:
             mods = self.dnn.dnn
@@ -1218,13 +1261,13 @@ class RAT_m2(BaseModel):
                 if bn is not None and isinstance(sm, tuple):                       # SyncBN (see _run_forward)
                     m = mods[bn]
                     dz = ops.bn_relu_bwd_sync(z, a, da, m.weight.data, sm[0], sr, G("dnn.dnn.%d.weight" % bn),
-                                              G("dnn.dnn.%d.bias" % bn), self._all_reduce_sum, sm[1], lib=lib)
+                                              G("dnn.dnn.%d.bias" % bn), self._all_reduce_sum, sm[1], act=self._dnn_acts[li], lib=lib)
                 elif bn is not None:
                     m = mods[bn]
                     dz = ops.bn_relu_bwd(z, a, da, m.weight.data, sm, sr, G("dnn.dnn.%d.weight" % bn), G("dnn.dnn.%d.bias" % bn),
-                                         True, lib=lib)
+                                         True, act=self._dnn_acts[li], lib=lib)
                 else:
-                    dz = ops.bn_relu_bwd(z, a, da, None, None, None, None, None, False, lib=lib)
+                    dz = ops.bn_relu_bwd(z, a, da, None, None, None, None, None, False, act=self._dnn_acts[li], lib=lib)
                 pre = "dnn.dnn.%d." % lin
                 ops.sgemm(1, 0, N, K_in, B, dz, N, a_in, lda_in, G(pre + "weight"), K_in, arith=self.gemm_arith, lib=lib)  # dW = dz^T a_in
                 ops.colsum(dz, N, G(pre + "bias"), B, N, lib=lib)

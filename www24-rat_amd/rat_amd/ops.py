@@ -460,7 +460,11 @@ def _bn_ws(N, device, lib):
     return torch.empty((lib.size("rat_bn_workspace", N) + 3) // 4, dtype=torch.float32, device=device)
 
 
-def bn_relu_fwd(z, gamma, beta, running_mean, running_var, training, use_bn, eps=1e-5, momentum=0.1, lib=None):
+ACT = {"relu": 0, "none": 1, "identity": 1, "sigmoid": 2, "tanh": 3, "leakyrelu": 4, "elu": 5}     # RAT_ACT_* (include/rat_hip.h)
+
+
+def bn_relu_fwd(z, gamma, beta, running_mean, running_var, training, use_bn, eps=1e-5, momentum=0.1, act=0, lib=None):
+    """[BatchNorm1d] + activation (act: a RAT_ACT_* code, 0 = ReLU)"""
     lib = lib or get_lib()
     _chk(z, name="z")
     M, N = z.shape
@@ -471,21 +475,21 @@ def bn_relu_fwd(z, gamma, beta, running_mean, running_var, training, use_bn, eps
         save_rstd = torch.empty(N, dtype=torch.float32, device=z.device)
         ws = _bn_ws(N, z.device, lib)
     lib.call("rat_bn_relu_fwd", _p(z), _p(a), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(save_mean),
-             _p(save_rstd), _p(ws), M, N, int(training), int(use_bn), eps, momentum, _stream(z))
+             _p(save_rstd), _p(ws), M, N, int(training), int(use_bn), eps, momentum, int(act), _stream(z))
     return a, save_mean, save_rstd
 
 
-def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, lib=None):
+def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, act=0, lib=None):
     lib = lib or get_lib()
     M, N = z.shape
     dz = torch.empty_like(z)
     ws = _bn_ws(N, z.device, lib) if use_bn else None
     lib.call("rat_bn_relu_bwd", _p(z), _p(a), _p(da), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd), _p(dgamma), _p(dbeta),
-             _p(ws), M, N, int(use_bn), _stream(z))
+             _p(ws), M, N, int(use_bn), int(act), _stream(z))
     return dz
 
 
-def bn_relu_fwd_sync(z, gamma, beta, running_mean, running_var, all_gather, eps=1e-5, momentum=0.1, lib=None):
+def bn_relu_fwd_sync(z, gamma, beta, running_mean, running_var, all_gather, eps=1e-5, momentum=0.1, act=0, lib=None):
     """SyncBN training forward: local (mean, M2, count) -> `all_gather(stats) -> [world, 2N+1]` (the caller's
     collective: torch.distributed over RCCL / gloo) -> normalise with the GLOBAL batch statistics + ReLU."""
     lib = lib or get_lib()
@@ -501,21 +505,21 @@ def bn_relu_fwd_sync(z, gamma, beta, running_mean, running_var, all_gather, eps=
     save_mean = torch.empty(N, dtype=torch.float32, device=z.device)
     save_rstd = torch.empty(N, dtype=torch.float32, device=z.device)
     lib.call("rat_bn_relu_fwd_sync", _p(z), _p(a), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(save_mean),
-             _p(save_rstd), _p(all_stats), world, M, N, eps, momentum, _stream(z))
+             _p(save_rstd), _p(all_stats), world, M, N, eps, momentum, int(act), _stream(z))
     return a, save_mean, save_rstd, all_stats
 
 
-def bn_relu_bwd_sync(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, all_reduce_sum, all_stats, lib=None):
+def bn_relu_bwd_sync(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, all_reduce_sum, all_stats, act=0, lib=None):
     """SyncBN backward: local (sum g, sum g*xhat) -> `all_reduce_sum(copy)` (caller's collective) -> dz; dgamma/dbeta = LOCAL sums."""
     lib = lib or get_lib()
     M, N = z.shape
     local = torch.empty(2 * N, dtype=torch.float32, device=z.device)
     ws = _bn_ws(N, z.device, lib)
-    lib.call("rat_bn_bwd_local_sums", _p(z), _p(a), _p(da), _p(save_mean), _p(save_rstd), _p(local), _p(ws), M, N, _stream(z))
+    lib.call("rat_bn_bwd_local_sums", _p(z), _p(a), _p(da), _p(save_mean), _p(save_rstd), _p(local), _p(ws), M, N, int(act), _stream(z))
     glob = all_reduce_sum(local.clone())
     dz = torch.empty_like(z)
     lib.call("rat_bn_relu_bwd_sync", _p(z), _p(a), _p(da), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd), _p(local), _p(glob),
-             _p(dgamma), _p(dbeta), _p(all_stats), all_stats.numel() // (2 * N + 1), M, N, _stream(z))
+             _p(dgamma), _p(dbeta), _p(all_stats), all_stats.numel() // (2 * N + 1), M, N, int(act), _stream(z))
     return dz
 
 
@@ -525,21 +529,23 @@ def colsum(a, lda, out, M, N, lib=None):
     lib.call("rat_colsum", _p(a), lda, _p(out), _p(ws), M, N, _stream(out))
 
 
-def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_stride, y_true, loss_sum, B, d, lib=None):
+def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_stride, y_true, loss_sum, B, d, head=0, lib=None):
+    """head: 0 = sigmoid + binary cross-entropy, 1 = no output activation + mean squared error (task "regression")"""
     lib = lib or get_lib()
     y_pred = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
     lib.call("rat_logit_fwd", _p(cls), cls_stride, _p(fc_w), _p(fc_b), _p(dnn_out), _p(lr_ftab), nfields, _p(idx),
-             idx_stride, _p(y_true), _p(y_pred), _p(loss_sum), B, d, _stream(fc_w))
+             idx_stride, _p(y_true), _p(y_pred), _p(loss_sum), B, d, int(head), _stream(fc_w))
     return y_pred
 
 
 def logit_bwd(y_pred, y_true, cls, cls_stride, fc_w, dcls, dcls_stride, dfc_w, dfc_b, lr_gftab, nfields, idx, idx_stride,
-              gscale, B, d, gscale_dev=None, lib=None):
+              gscale, B, d, gscale_dev=None, head=0, lib=None):
     """gscale: host factor; gscale_dev: optional DEVICE scalar multiplied in by the kernel (autograd's incoming gradient)."""
     lib = lib or get_lib()
     dlogit = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
     lib.call("rat_logit_bwd", _p(y_pred), _p(y_true), _p(cls), cls_stride, _p(fc_w), _p(dlogit), _p(dcls), dcls_stride,
-             _p(dfc_w), _p(dfc_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), _p(gscale_dev), B, d, _stream(fc_w))
+             _p(dfc_w), _p(dfc_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), _p(gscale_dev), B, d, int(head),
+             _stream(fc_w))
     return dlogit
 
 
@@ -558,6 +564,19 @@ def clip_adam(w, g, m, v, norm_sq, max_norm, lr, beta1, beta2, eps, step, lib=No
     lib = lib or get_lib()
     lib.call("rat_clip_adam", _p(w), _p(g), _p(m), _p(v), w.numel(), _p(norm_sq), float(max_norm), float(lr), float(beta1),
              float(beta2), float(eps), int(step), _stream(w))
+
+
+def clip_opt(w, g, state, norm_sq, max_norm, lr, kind, p0, eps, lib=None):
+    """SGD / Adagrad / RMSprop (kind 1 / 2 / 3) on a flat buffer, after the clip factor derived from norm_sq"""
+    lib = lib or get_lib()
+    lib.call("rat_clip_opt", _p(w), _p(g), _p(state), w.numel(), _p(norm_sq), float(max_norm), float(lr), int(kind), float(p0), float(eps),
+             _stream(w))
+
+
+def clip_opt_fused(w, g, state, n_split, lam_a, lam_b, norm_sq, max_norm, hyper, kind, p0, eps, zero_g=True, lib=None):
+    lib = lib or get_lib()
+    lib.call("rat_clip_opt_fused", _p(w), _p(g), _p(state), w.numel(), int(n_split), float(lam_a), float(lam_b), None, _p(norm_sq),
+             float(max_norm), _p(hyper), int(kind), float(p0), float(eps), int(bool(zero_g)), _stream(w))
 
 
 def dropout(x, p, seed, out=None, lib=None):

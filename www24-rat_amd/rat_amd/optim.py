@@ -10,10 +10,21 @@ import torch
 from . import ops
 
 
+KINDS = {"Adam": 0, "SGD": 1, "Adagrad": 2, "RMSprop": 3}          # RAT_OPT_* (include/rat_hip.h)
+
+
 class FusedClipAdam(torch.optim.Optimizer):
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """kind: "Adam" (every shipped config) or one of the other optimizers torch_utils.get_optimizer can name — "SGD", "Adagrad",
+    "RMSprop" — built like the reference builds them, `getattr(torch.optim, name)(params, lr=lr)`: torch's default hyper-parameters."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, kind="Adam"):
         params = [p for p in model.parameters() if p.requires_grad]
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if kind not in KINDS:
+            raise NotImplementedError("optimizer=%r: the HIP path implements %s" % (kind, ", ".join(KINDS)))
+        defaults = {"Adam": dict(lr=lr, betas=betas, eps=eps), "SGD": dict(lr=lr), "Adagrad": dict(lr=lr, eps=1e-10),
+                    "RMSprop": dict(lr=lr, alpha=0.99, eps=1e-8)}[kind]
+        super().__init__(params, defaults)
+        self.kind, self._kind = kind, KINDS[kind]
         self._model = model
         self._step = 0
         self._m = None
@@ -22,9 +33,9 @@ class FusedClipAdam(torch.optim.Optimizer):
 
     def _buffers(self):
         flat = self._model._flat
-        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
-            self._m = torch.zeros_like(flat)
-            self._v = torch.zeros_like(flat)
+        if self._norm_sq is None or self._norm_sq.device != flat.device or (self._v is not None and self._v.numel() != flat.numel()):
+            self._m = torch.zeros_like(flat) if self._kind == 0 else None          # first moment: Adam only
+            self._v = torch.zeros_like(flat) if self._kind != 1 else None          # second moment / accumulator: all but SGD
             self._norm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
         return self._m, self._v
 
@@ -37,10 +48,12 @@ class FusedClipAdam(torch.optim.Optimizer):
             return None
         m, v = self._buffers()
         group = self.param_groups[0]
-        lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
+        lr, (b1, b2), eps = group["lr"], group.get("betas", (0.0, 0.0)), group.get("eps", 0.0)
         self._step += 1
         self._clock_step = None
         ns = getattr(model, "_n_sparse", 0)
+        if self._kind != 0 and sparse:
+            raise NotImplementedError("row-sparse table gradients are wired for Adam only")
         norm_sq = None
         if max_norm is not None:                         # ONE global norm over dense gradients and sparse row lists alike
             self._norm_sq.zero_()
@@ -49,7 +62,10 @@ class FusedClipAdam(torch.optim.Optimizer):
             for rows, g, count, width, _total, _base in sparse:
                 ops.sumsq_rows(g, count, rows.numel(), width, self._norm_sq, lib=model._lib)
             norm_sq = self._norm_sq
-        if grad is not None:
+        if grad is not None and self._kind != 0:
+            ops.clip_opt(model._flat[ns:], grad, v[ns:] if v is not None else None, norm_sq, max_norm or 0.0, lr, self._kind,
+                         group.get("alpha", 0.0), eps, lib=model._lib)
+        elif grad is not None:
             ops.clip_adam(model._flat[ns:], grad, m[ns:], v[ns:], norm_sq, max_norm or 0.0, lr, b1, b2, eps, self._step, lib=model._lib)
         for rows, g, count, width, _total, base in sparse:   # lazy Adam on the touched table rows (rat_adam_rows)
             ops.adam_rows(model._flat[base:], m[base:], v[base:], rows, g, count, rows.numel(), width, norm_sq, max_norm or 0.0,
@@ -107,10 +123,12 @@ class FusedClipAdam(torch.optim.Optimizer):
         m, v = self._buffers()
         step_dev, lr_dev, hyper = self._clock()
         group = self.param_groups[0]
-        (b1, b2), eps = group["betas"], group["eps"]
+        (b1, b2), eps = group.get("betas", (0.9, 0.999)), group.get("eps", 0.0)
         ns = getattr(model, "_n_sparse", 0)
         n_split = model._n_emb - ns
         lib = model._lib
+        if self._kind != 0 and sparse:
+            raise NotImplementedError("row-sparse table gradients are wired for Adam only")
         ops.adam_tick(step_dev, lr_dev, b1, b2, hyper, lib=lib)
         if count:
             self._step += 1
@@ -124,8 +142,12 @@ class FusedClipAdam(torch.optim.Optimizer):
             ops.sumsq_rows(g, cnt, rows.numel(), width, acc, lib=lib)
         self._last_norm_sq = acc
         norm_sq = acc if max_norm is not None else None
-        ops.clip_adam_fused(model._flat[ns:], grad, m[ns:], v[ns:], n_split, c["lam_emb"], c["lam_net"], norm_sq, max_norm or 0.0,
-                            hyper, b1, b2, eps, zero_g=True, lib=lib)
+        if self._kind != 0:
+            ops.clip_opt_fused(model._flat[ns:], grad, v[ns:] if v is not None else None, n_split, c["lam_emb"], c["lam_net"], norm_sq,
+                               max_norm or 0.0, hyper, self._kind, group.get("alpha", 0.0), eps, zero_g=True, lib=lib)
+        else:
+            ops.clip_adam_fused(model._flat[ns:], grad, m[ns:], v[ns:], n_split, c["lam_emb"], c["lam_net"], norm_sq, max_norm or 0.0,
+                                hyper, b1, b2, eps, zero_g=True, lib=lib)
         for rows, g, cnt, width, _total, base in sparse:
             ops.adam_rows_dev(model._flat[base:], m[base:], v[base:], rows, g, cnt, rows.numel(), width, norm_sq, max_norm or 0.0,
                               hyper, b1, b2, eps, lib=lib)
@@ -155,7 +177,8 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._clock_step = None                          # the device clock is re-synchronised by the next prepare_step()
         m, v = state_dict.pop("rat_m", None), state_dict.pop("rat_v", None)
         super().load_state_dict(state_dict)
-        if m is not None:
-            mm, vv = self._buffers()
+        mm, vv = self._buffers()
+        if m is not None and mm is not None:
             mm.copy_(m)
+        if v is not None and vv is not None:
             vv.copy_(v)
