@@ -434,6 +434,15 @@ int rat_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, voi
  * counter_dev[0] += 1; seeds_dev[i] = mix(base_seed, counter, i), i < n.  nn.Dropout draws from torch's generator on every call
  * (RAT_m2.py:135,186-189, deep.py:133-134); here the generator's state is (base_seed, counter) on the device, so forward and backward
  * of a step agree on the masks (backward reads the same words) and a captured step needs no host-drawn seed. */
+/* ABI v6 — FeedForward WITH its two nn.Dropout layers (RAT_m1.py:151-161, RAT_m0.py:150-160: Linear, GELU, Dropout, Linear, Dropout),
+ * training mode: y = Dropout2(W2 Dropout1(gelu(W1 x + b1)) + b2) + res, and its backward (dx = [dy +] chain; the residual takes the
+ * unmasked dy).  p: the rate both layers share; seed1_dev / seed2_dev: their seed words (rat_dropout_seeds).  Arguments otherwise as
+ * rat_ffn_fwd_res / rat_ffn_bwd_res; exact fp32 on the generic kernels (RAT_m2 / RAT_m3 build FeedForward without dropout). */
+int rat_ffn_fwd_drop(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
+                     int64_t ntok, int d, int hidden, float p, const uint64_t* seed1_dev, const uint64_t* seed2_dev, void* stream);
+int rat_ffn_bwd_drop(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2, const float* b2,
+                     float* dw1, float* db1, float* dw2, float* db2, float* workspace, size_t workspace_bytes, int64_t ntok, int d,
+                     int hidden, int add_dy, float p, const uint64_t* seed1_dev, const uint64_t* seed2_dev, void* stream);
 int rat_dropout_dev(const float* x, float* y, int64_t n, float p, const uint64_t* seed_dev, void* stream);
 int rat_dropout_seeds(uint64_t* seeds_dev, int n, uint64_t base_seed, uint64_t* counter_dev, void* stream);
 

@@ -377,6 +377,38 @@ def check_ffn_res(lib, dev, ntok, d, hidden, with_res, arith="f32"):
         close(g, w.grad, 1e-4, 1e-4 * scale)
 
 
+def check_ffn_dropout(lib, dev, ntok, d, hidden, with_res, add_dy, p=0.3):
+    """FeedForward with its two Dropout layers (rat_ffn_fwd_drop / rat_ffn_bwd_drop) against the float64 reference under the SAME masks:
+    the masks are counter-based functions of (seed word, element index) — the generator of rat_dropout — so the reference takes them
+    from rat_dropout on ones."""
+    rs = np.random.RandomState(23)
+    x, res = rnd(rs, ntok, d), rnd(rs, ntok, d)
+    ws = (rnd(rs, hidden, d, scale=d ** -0.5), 0.1 * rnd(rs, hidden), rnd(rs, d, hidden, scale=hidden ** -0.5), 0.1 * rnd(rs, d))
+    dy = rnd(rs, ntok, d)
+    words = torch.tensor([0x1234567890ABCDE, 0x0FEDCBA987654321 & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64).to(dev)
+    m1 = ops.dropout(torch.ones(ntok, hidden).to(dev), p, words[0:1], lib=lib).cpu().double()
+    m2 = ops.dropout(torch.ones(ntok, d).to(dev), p, words[1:2], lib=lib).cpu().double()
+    assert 0.5 < float((m1 != 0).double().mean()) < 0.9 and not torch.equal(m1[:, :d] != 0, m2 != 0)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    hdn = xr @ wr[0].t() + wr[1]
+    ref = ((0.5 * hdn * (1.0 + torch.erf(hdn / 2.0 ** 0.5))) * m1 @ wr[2].t() + wr[3]) * m2
+    if with_res:
+        ref = ref + (xr if add_dy else res.double())
+    ref.backward(dy.double())
+    xd, dyd = x.to(dev), dy.to(dev)
+    wd = [w.to(dev) for w in ws]
+    drop = (p, words[0:1], words[1:2])
+    y = ops.ffn_fwd_res(xd, (xd if add_dy else res.to(dev)) if with_res else None, *wd, d, hidden, dropout=drop, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    gs = [torch.zeros_like(w) for w in wd]
+    dx, _ = ops.ffn_bwd_res(xd, dyd, *wd, gs[0], gs[1], gs[2], gs[3], d, hidden, add_dy=bool(with_res and add_dy), dropout=drop, lib=lib)
+    scale = max(1.0, ntok ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    for g, w in zip(gs, wr):
+        close(g, w.grad, 1e-4, 1e-4 * scale)
+
+
 def check_layernorm(lib, dev, nrows, d, stride_mul, with_add):
     """rat_layernorm_fwd / bwd on strided rows against torch's float64 layer_norm."""
     rs = np.random.RandomState(14)

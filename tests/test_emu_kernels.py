@@ -189,3 +189,8 @@ def test_logit_fwd_bwd(emu, with_dnn, with_lr):
 
 def test_l2_sumsq_clip_adam(emu):
     kc.check_optim(emu, "cpu", 777)
+
+
+@pytest.mark.parametrize("ntok,d,hidden,with_res,add_dy", [(150, 16, 32, True, False), (77, 10, 20, True, True), twin(200, 64, 128, False, False)])
+def test_feed_forward_with_its_dropout_layers(emu, ntok, d, hidden, with_res, add_dy):
+    kc.check_ffn_dropout(emu, "cpu", ntok, d, hidden, with_res, add_dy)

@@ -190,3 +190,9 @@ def test_colsum_long_matrices(lib, M, N):
     ops.colsum(a, N, out, M, N, lib=lib)
     ref = a.double().sum(0)
     assert float((out.double() - ref).abs().max()) < 1e-4 * max(1.0, M ** 0.5)
+
+
+@pytest.mark.parametrize("ntok,d,hidden,with_res,add_dy", [(1500, 16, 32, True, False), (777, 10, 20, True, True), (2000, 64, 128, False, False),
+                                                            (3000, 40, 80, True, False)])
+def test_feed_forward_with_its_dropout_layers(lib, ntok, d, hidden, with_res, add_dy):
+    kc.check_ffn_dropout(lib, "cuda", ntok, d, hidden, with_res, add_dy)

@@ -202,3 +202,10 @@ def test_attention_dropout_on_the_composed_path(monkeypatch):
     from rat_amd import models
     monkeypatch.setattr(models.RAT_m2, "FUSED_MAX_L", 3)
     _dropout_gradient_probe("tiny_seq_bn", dict(dropout=0.3))
+
+
+@pytest.mark.parametrize("name", ["m1_tiny_seq", "m0_tiny_seq"])
+def test_feed_forward_dropout_of_the_transformer_variants(name):
+    """RAT_m1 / RAT_m0 hand `dropout` to FeedForward too (two Dropout layers per layer, behind GELU and behind the second Linear):
+    rat_ffn_fwd_drop / rat_ffn_bwd_drop (missing until round 4)"""
+    _dropout_gradient_probe(name, dict(dropout=0.25))

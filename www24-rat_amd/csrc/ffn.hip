@@ -38,6 +38,8 @@ struct FfnArgs {
     int d, hidden;
     int vec_x, vec_w1, vec_w2;
     unsigned long long* prof;
+    RatDrop drop1, drop2;  // FeedForward's two nn.Dropout (RAT_m1.py:151-161, RAT_m0.py:150-160): behind GELU (index token * H + unit) and
+                           // behind the second Linear, in front of the residual (index token * D + column); generic kernels only
 };
 
 struct FfnGeom {
@@ -95,7 +97,7 @@ __device__ __forceinline__ void ffn_zero_cols(float* tile, int ld, int c0) {
 // hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- gelu'(h), gs <- gelu(h))
 template <int TD, int MODE>
 __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
-                                           int mt_valid, int rows) {
+                                           int mt_valid, int rows, int64_t tok0 = 0) {
     constexpr bool FAST = TD > 0;
     const RatLdsRows A{xs, g.ldx};
     const RatGlobalWnkT<!FAST> Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
@@ -109,18 +111,20 @@ __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, c
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {                      // two activations per packed-math evaluation
                 const size_t o0 = (size_t)rat_acc_row(mt, r) * g.ldh + col, o1 = (size_t)rat_acc_row(mt, r + 1) * g.ldh + col;
+                // Dropout behind GELU (drop1; threshold 0 = none): g <- keep ? g / (1 - p) : 0, and the same factor on gelu'(h)
+                const int64_t i0 = (tok0 + rat_acc_row(mt, r)) * g.H + col, i1 = (tok0 + rat_acc_row(mt, r + 1)) * g.H + col;
                 if (MODE == 0) {
                     const rat_f2 gv = rat_gelu2(rat_f2_make(h[r], h[r + 1]));
-                    hs[o0] = gv.x;
-                    hs[o1] = gv.y;
+                    hs[o0] = a.drop1.apply(gv.x, i0);
+                    hs[o1] = a.drop1.apply(gv.y, i1);
                 } else {                                         // backward: hs <- gelu'(h) (h itself is not needed again);
                     float g0, d0, g1, d1;                        // scalar form: the packed one measured 3 % slower here
                     rat_gelu_both(h[r], g0, d0);
                     rat_gelu_both(h[r + 1], g1, d1);
-                    hs[o0] = d0;
-                    hs[o1] = d1;
-                    gs[o0] = g0;
-                    gs[o1] = g1;
+                    hs[o0] = a.drop1.apply(d0, i0);
+                    hs[o1] = a.drop1.apply(d1, i1);
+                    gs[o0] = a.drop1.apply(g0, i0);
+                    gs[o1] = a.drop1.apply(g1, i1);
                 }
             }
         }
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, FAST || a.vec_x != 0);
         __syncthreads();
         RAT_PROF_MARK(0);
-        ffn_hidden<TD, 0>(a, g, xs, hs, nullptr, mt_valid, rows);
+        ffn_hidden<TD, 0>(a, g, xs, hs, nullptr, mt_valid, rows, tok0);
         __syncthreads();
         float pf = 0.f;
         {   // touch one dword per 128-byte line of the NEXT chunk's x rows: they travel HBM -> L2 behind the second GEMM
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
                         float rv = 0.f;
                         if (a.res == a.x) rv = xs[o];
                         else if (a.res != nullptr && row < rows) rv = a.res[(tok0 + row) * g.D + col];
-                        ys[o] = acc[r] + bias + rv;
+                        ys[o] = a.drop2.apply(acc[r] + bias, (tok0 + row) * g.D + col) + rv;
                     }
                 }
             });
@@ -218,9 +222,16 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         const int mt_valid = (rows + 15) / 16;
         ffn_load(xs, g.ldx, a.x, tok0, rows, D, FAST || a.vec_x != 0);
         ffn_load(dys, g.ldx, a.dy, tok0, rows, D, FAST || a.vec_x != 0);
+        if (a.drop2.threshold != 0) {                           // dy through the output Dropout: every product below takes the masked dy
+            __syncthreads();
+            for (int e = threadIdx.x; e < rows * D; e += FFN_THREADS) {
+                const int r = e / D, c = e - r * D;
+                dys[(size_t)r * g.ldx + c] = a.drop2.apply(dys[(size_t)r * g.ldx + c], (tok0 + r) * D + c);
+            }
+        }
         __syncthreads();
         RAT_PROF_MARK(0);
-        ffn_hidden<TD, 1>(a, g, xs, hs, gs, mt_valid, rows);
+        ffn_hidden<TD, 1>(a, g, xs, hs, gs, mt_valid, rows, tok0);
         __syncthreads();
         RAT_PROF_MARK(1);
         // dW2 += dy^T gelu(h) ; db2 += colsum(dy)
@@ -276,8 +287,11 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
                 if (FAST || col < D)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                                                   // dx tile, in place
-                        const size_t o = (size_t)rat_acc_row(mt, r) * g.ldx + col;
-                        dys[o] = a.add_dy ? dys[o] + acc[r] : acc[r];
+                        const int row = rat_acc_row(mt, r);
+                        const size_t o = (size_t)row * g.ldx + col;
+                        float rsd = a.add_dy ? dys[o] : 0.f;
+                        if (a.add_dy && a.drop2.threshold != 0) rsd = row < rows ? a.dy[(tok0 + row) * D + col] : 0.f;   // the residual takes the UNmasked dy
+                        dys[o] = rsd + acc[r];
                     }
             };
             if (FAST) {
@@ -1494,6 +1508,84 @@ int ffn_check(int64_t ntok, int d, int hidden, bool backward) {
 extern "C" int rat_ffn_fwd(const float* x, float* y, const float* w1, const float* b1, const float* w2, const float* b2,
                            int64_t ntok, int d, int hidden, void* stream) {
     return rat_ffn_fwd_res(x, x, y, w1, b1, w2, b2, ntok, d, hidden, RAT_ARITH_F32, stream);
+}
+
+static RatDrop ffn_drop(float p, const uint64_t* seed_dev) {
+    RatDrop dr{};
+    if (p > 0.f) dr = RatDrop{0, (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p), seed_dev};
+    return dr;
+}
+
+// FeedForward WITH its two Dropout layers (RAT_m1.py:151-161, RAT_m0.py:150-160: Linear, GELU, Dropout, Linear, Dropout), training mode:
+// y = Dropout2(W2 Dropout1(gelu(W1 x + b1)) + b2) + res.  The masks are the counter-based ones of rat_dropout on (seed word, element
+// index), seeds read from device memory (rat_dropout_seeds).  Exact fp32 on the generic LDS-staged kernels (no shipped config trains
+// with this dropout; the fast kernels carry no mask).
+extern "C" int rat_ffn_fwd_drop(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2,
+                                const float* b2, int64_t ntok, int d, int hidden, float p, const uint64_t* seed1_dev,
+                                const uint64_t* seed2_dev, void* stream) {
+    if (ffn_check(ntok, d, hidden, false)) return -1;
+    RAT_REQUIRE(x && y && w1 && b1 && w2 && b2 && p >= 0.f && p < 1.f && (p == 0.f || (seed1_dev && seed2_dev)), "bad args");
+    FfnArgs a{};
+    a.x = x;
+    a.res = res;
+    a.y = y;
+    a.w1 = w1;
+    a.b1 = b1;
+    a.w2 = w2;
+    a.b2 = b2;
+    a.ntok = ntok;
+    a.nchunks = (ntok + FFN_ROWS - 1) / FFN_ROWS;
+    a.d = d;
+    a.hidden = hidden;
+    a.vec_x = (d % 4 == 0) && aligned16(x) && aligned16(y);
+    a.vec_w1 = (d % 4 == 0) && aligned16(w1);
+    a.vec_w2 = (hidden % 4 == 0) && aligned16(w2);
+    a.prof = rat_prof_buffer();
+    a.drop1 = ffn_drop(p, seed1_dev);
+    a.drop2 = ffn_drop(p, seed2_dev);
+    const FfnGeom g(d, hidden);
+    const int64_t blocks = a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks();
+    RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, g.fwd_smem(), stream, a);
+    return rat_check_launch("rat_ffn_fwd_drop");
+}
+
+extern "C" int rat_ffn_bwd_drop(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                                const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                                size_t workspace_bytes, int64_t ntok, int d, int hidden, int add_dy, float p,
+                                const uint64_t* seed1_dev, const uint64_t* seed2_dev, void* stream) {
+    if (ffn_check(ntok, d, hidden, true)) return -1;
+    RAT_REQUIRE(x && dy && dx && w1 && b1 && w2 && b2 && dw1 && db1 && dw2 && db2 && workspace, "null pointer");
+    RAT_REQUIRE(workspace_bytes >= rat_ffn_bwd_workspace(d, hidden), "workspace too small");
+    RAT_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || (seed1_dev && seed2_dev)), "bad dropout arguments");
+    FfnArgs a{};
+    a.x = x;
+    a.dy = dy;
+    a.y = dx;
+    a.add_dy = add_dy;
+    a.w1 = w1;
+    a.b1 = b1;
+    a.w2 = w2;
+    a.b2 = b2;
+    a.ntok = ntok;
+    a.nchunks = (ntok + FFN_ROWS - 1) / FFN_ROWS;
+    a.d = d;
+    a.hidden = hidden;
+    a.vec_x = (d % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx);
+    a.vec_w1 = (d % 4 == 0) && aligned16(w1);
+    a.vec_w2 = (hidden % 4 == 0) && aligned16(w2);
+    a.prof = rat_prof_buffer();
+    a.drop1 = ffn_drop(p, seed1_dev);
+    a.drop2 = ffn_drop(p, seed2_dev);
+    const FfnGeom g(d, hidden);
+    a.slabs = workspace;
+    a.slab_stride = g.slab_floats();
+    const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
+    RAT_LAUNCH(ffn_bwd_kernel, blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+    if (rat_check_launch("rat_ffn_bwd_drop")) return -1;
+    float* outs[4] = {dw1, dw2, db1, db2};
+    const int64_t sizes[4] = {(int64_t)hidden * d, (int64_t)d * hidden, hidden, d};
+    const int64_t offs[4] = {0, (int64_t)hidden * d, 2 * (int64_t)hidden * d, 2 * (int64_t)hidden * d + hidden};
+    return rat_launch_reduce_slabs(workspace, blocks, a.slab_stride, outs, offs, sizes, 4, stream);
 }
 
 extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const float* w1, const float* b1, const float* w2,

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "rat_bm25_topk_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_ffn_fwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
     "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "rat_ffn_fwd_drop": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, _P]),
+    "rat_ffn_bwd_drop": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "rat_attn_planes_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rat_attn_split_jobs": (c_int, [POINTER(RatAttnParams), c_int, c_int, c_int, _P, POINTER(RatSplitJob)]),
     "rat_ffn_planes_bytes": (c_size_t, [c_int, c_int]),

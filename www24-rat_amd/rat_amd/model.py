@@ -1372,18 +1372,7 @@ class RAT_m1(RAT_m2):
     def __init__(self, feature_map, model_id="RAT_m1", **kwargs):
         super().__init__(feature_map, model_id=model_id, **kwargs)
 
-    @staticmethod
-    def _no_ffn_dropout(dropout, which):
-        """The reference's RAT_m1 / RAT_m0 hand `dropout` to FeedForward as well (two nn.Dropout per layer: RAT_m1.py:157,159,202;
-        RAT_m0.py:156,158,201); only the Dropout behind the attention output projection exists on the HIP path, so a positive rate
-        would silently train with a different regularisation — refuse it (every shipped config uses 0)."""
-        if dropout and dropout > 0:
-            raise NotImplementedError("%s with dropout > 0: the reference also applies it inside FeedForward (after GELU and after the "
-                                      "second Linear); the HIP feed-forward kernels carry no dropout mask — only RAT_m2's attention-"
-                                      "output Dropout is implemented" % which)
-
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
-        self._no_ffn_dropout(dropout, "RAT_m1")
         self.intra_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:71
         self.cross_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:72
 
@@ -1408,9 +1397,11 @@ class RAT_m1(RAT_m2):
             xa, att = self._attn_layer_forward(lay["attn"], x, smap, save)                            # attn(norm(x)) + x
             xn = ops.layernorm_fwd(xa, d, ntok, self._p(lay["ln"][0]), self._p(lay["ln"][1]), d, lib=lib)
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
-            xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)             # ff(norm(x)) + x
+            # FeedForward(dim, mlp_dim, dropout) carries two Dropout layers of the same rate (RAT_m1.py:151-161,202; RAT_m0.py:150-160,201)
+            fdrop = (c["attn_dropout"], self._dropout_word(), self._dropout_word()) if (self.training and c["attn_dropout"] > 0) else None
+            xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, arith=self.arith, dropout=fdrop, lib=lib)   # ff(norm(x)) + x
             if save:
-                rec.append((x, att, xa, xn))
+                rec.append((x, att, xa, xn, fdrop))
             x = xb
         out = ops.layernorm_fwd(x, cls_stride, ncls, self._p(norm[0]), self._p(norm[1]), d, lib=lib)
         if save:
@@ -1425,11 +1416,11 @@ class RAT_m1(RAT_m2):
         ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
         dx = torch.zeros(shape, dtype=torch.float32, device=dcls.device)          # only the class-token rows get a gradient
         ops.layernorm_bwd(x_last, cls_stride, dcls, self._p(norm[0]), dx, cls_stride, G(norm[0]), G(norm[1]), d, lib=lib)
-        for lay, (x_in, att, xa, xn) in zip(reversed(layers), reversed(rec)):
+        for lay, (x_in, att, xa, xn, fdrop) in zip(reversed(layers), reversed(rec)):
             w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
             gw = [G(n) for n in lay["ffn"]]
             dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
-                                     arith=self.arith, lib=lib)
+                                     arith=self.arith, dropout=fdrop, lib=lib)
             dxa = ops.layernorm_bwd(xa, d, dxn, self._p(lay["ln"][0]), dxn, d, G(lay["ln"][0]), G(lay["ln"][1]), d, add=dx, lib=lib)
             dx = self._attn_layer_backward(lay["attn"], x_in, dxa, att, smap, G)
         return dx
@@ -1588,7 +1579,6 @@ class RAT_m0(RAT_m1):
         super().__init__(feature_map, model_id=model_id, **kwargs)
 
     def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
-        self._no_ffn_dropout(dropout, "RAT_m0")
         self.encoder = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)               # RAT_m0.py:70
 
     def _build_encoder_descriptors(self):

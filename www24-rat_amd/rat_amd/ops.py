@@ -401,25 +401,37 @@ def ffn_bwd(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None
     return dx, workspace
 
 
-def ffn_fwd_res(x, res, w1, b1, w2, b2, d, hidden, out=None, arith="f32", lib=None):
-    """y = FFN(x) + res (res None: no residual) — rat_ffn_fwd_res."""
+def ffn_fwd_res(x, res, w1, b1, w2, b2, d, hidden, out=None, arith="f32", dropout=None, lib=None):
+    """y = FFN(x) + res (res None: no residual) — rat_ffn_fwd_res.  dropout = (p, word1, word2): FeedForward's two Dropout layers in
+    training mode (rat_ffn_fwd_drop; exact fp32, generic kernels)."""
     lib = lib or get_lib()
     _chk(x, name="x")
     if res is not None:
         _chk(res, name="res")
     y = out if out is not None else torch.empty_like(x)
+    if dropout is not None and dropout[0] > 0:
+        _chk(dropout[1], torch.int64, "seed word"), _chk(dropout[2], torch.int64, "seed word")
+        lib.call("rat_ffn_fwd_drop", _p(x), _p(res), _p(y), _p(w1), _p(b1), _p(w2), _p(b2), x.numel() // d, d, hidden, float(dropout[0]),
+                 _p(dropout[1]), _p(dropout[2]), _stream(x))
+        return y
     lib.call("rat_ffn_fwd_res", _p(x), _p(res), _p(y), _p(w1), _p(b1), _p(w2), _p(b2), x.numel() // d, d, hidden, ARITH[arith],
              _stream(x))
     return y
 
 
-def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, arith="f32", planes=None, lib=None):
+def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, workspace=None, arith="f32", planes=None, dropout=None,
+                lib=None):
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(dy, name="dy")
     need = lib.size("rat_ffn_bwd_workspace", d, hidden)
     if workspace is None or workspace.numel() * 4 < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
+    if dropout is not None and dropout[0] > 0:
+        lib.call("rat_ffn_bwd_drop", _p(x), _p(dy), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2), _p(db2),
+                 _p(workspace), workspace.numel() * 4, x.numel() // d, d, hidden, int(bool(add_dy)), float(dropout[0]), _p(dropout[1]),
+                 _p(dropout[2]), _stream(x))
+        return dx, workspace
     lib.call("rat_ffn_bwd_res", _p(x), _p(dy), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2), _p(db2),
              _p(workspace), workspace.numel() * 4, _p(planes), x.numel() // d, d, hidden, int(bool(add_dy)), ARITH[arith], _stream(x))
     return dx, workspace
