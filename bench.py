@@ -40,7 +40,8 @@ ROCPROF_NOTE = "profiles/round4/r4_bench_kernel_stats.csv (in the step), r4_gath
 NBATCH = 4                        # distinct batches rotated through the timed loop
 # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected with rocprofv3 in
 # separate runs (bench.py cannot host the profiler) and committed next to the kernel stats; valid for the north-star shapes only
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "round3", "r3_traffic_pmc.json"),
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "round4", "r4_traffic_pmc.json"),
+                 os.path.join(ROOT, "profiles", "round3", "r3_traffic_pmc.json"),
                  os.path.join(ROOT, "profiles", "round2", "r2_traffic_pmc.json"),
                  os.path.join(ROOT, "profiles", "round1", "r1_traffic_pmc.json")]
 
