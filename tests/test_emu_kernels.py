@@ -194,3 +194,9 @@ def test_l2_sumsq_clip_adam(emu):
 @pytest.mark.parametrize("ntok,d,hidden,with_res,add_dy", [(150, 16, 32, True, False), (77, 10, 20, True, True), twin(200, 64, 128, False, False)])
 def test_feed_forward_with_its_dropout_layers(emu, ntok, d, hidden, with_res, add_dy):
     kc.check_ffn_dropout(emu, "cpu", ntok, d, hidden, with_res, add_dy)
+
+
+@pytest.mark.parametrize("case", [(2, 3, 4, 10, 2, 10, True), twin((2, 4, 9, 10, 8, 10, True))], ids=str)
+def test_attn_generic_kernel_with_one_column_tile(emu, two_blocks, case):
+    kc.check_attn(emu, "cpu", case, "intra")
+    kc.check_attn(emu, "cpu", case, "cross")

@@ -196,3 +196,11 @@ def test_colsum_long_matrices(lib, M, N):
                                                             (3000, 40, 80, True, False)])
 def test_feed_forward_with_its_dropout_layers(lib, ntok, d, hidden, with_res, add_dy):
     kc.check_ffn_dropout(lib, "cuda", ntok, d, hidden, with_res, add_dy)
+
+
+@pytest.mark.parametrize("case", [(60, 6, 4, 10, 2, 10, True), (40, 6, 10, 10, 8, 10, True), (33, 5, 3, 16, 4, 10, True), (21, 3, 4, 12, 8, 10, True)], ids=str)
+@pytest.mark.parametrize("mode", ["intra", "cross"])
+def test_attn_generic_kernel_with_one_column_tile(lib, case, mode):
+    """embedding_dim <= 16 on the generic kernel (the shipped MovieLens / Tmall geometries, d = 10): the d(LayerNorm out) GEMM has one
+    column tile and splits its contraction over the waves (round 4), LayerNorm backward adds the four partial tiles"""
+    kc.check_attn(lib, "cuda", case, mode)

@@ -554,6 +554,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     float* dlt = lses + (size_t)ATT_ROWS * H;                   // [64][H]   rowsum(dO * O)
     int64_t* rowtok = reinterpret_cast<int64_t*>(dlt + (size_t)ATT_ROWS * H);
     const bool has_out = a.w_out != nullptr;
+    const bool ksplit = !FAST && g.D16 == 16 && ldt >= 32;       // one column tile: the dXn GEMM splits its contraction (phase 5)
 
     // persistent parameter-gradient accumulators
     f32x4 accq[QSLOTS], acco[OSLOTS];
@@ -798,6 +799,21 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 for (int i = 0; i < ATT_MT; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) part[(size_t)rat_acc_row(i, r) * ldt + col] = acc[i][r];
+            } else if (ksplit) {
+                // embedding_dim <= 16 (the shipped MovieLens / Tmall geometries: d = 10): ONE column tile — as (row-tile pair x column
+                // tile) tasks that is 2 tasks for 8 waves, each a chain over all 3 I / 16 k-blocks (stamps at the Tmall shape, round 4:
+                // 18 % of the kernel).  Split the contraction four ways instead: wave = (row-tile pair w & 1, K part w >> 1); the four
+                // partial tiles land side by side in dob / ob (free since dQ moved into qkv) and LayerNorm backward adds them.
+                const int w = rat_wave(), mb = w & 1, part = w >> 1;
+                const int kbt = g.Q16 / 16, k0 = part * kbt / 4, k1 = (part + 1) * kbt / 4;
+                f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+                if (k1 > k0) rat_wave_gemm_col<2, 0>(acc, A, Bw, 2 * mb, 0, k1, k0);
+                float* pt = (part < 2 ? dob : ob) + 16 * (part & 1);
+                const int col = rat_acc_col(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[(size_t)rat_acc_row(2 * mb + i, r) * ldt + col] = acc[i][r];
             } else {
                 rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
                     const int col = rat_acc_col(nt);
@@ -863,6 +879,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                     const int c = c0 + k;
                     xh[k] = (c < D && valid) ? a.x[tok * D + c] : 0.f;
                     gg[k] = (c < D && valid) ? dob[(size_t)r * ldt + c] : 0.f;
+                    if (ksplit && c < D && valid)                   // the other three K parts of the split dXn GEMM
+                        gg[k] += dob[(size_t)r * ldt + 16 + c] + (ob[(size_t)r * ldt + c] + ob[(size_t)r * ldt + 16 + c]);
                 }
             }
 #pragma unroll
@@ -1011,7 +1029,20 @@ constexpr size_t B3_W_QKV = (size_t)15 * 2 * 3 * 1024, B3_W_OUT = (size_t)4 * 3 
 constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
 
 constexpr size_t B3_FWD_LSE = (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8;   // [64][8] log-sum-exp of the chunk
-constexpr size_t b3_fwd_smem() { return B3_FWD_LSE + (size_t)64 * B3_H * 4; }
+constexpr size_t B3_FWD_WOUT = B3_FWD_LSE + (size_t)64 * B3_H * 4;      // the output projection's fragment planes, LDS-resident (36 KB)
+constexpr size_t b3_fwd_smem() { return B3_FWD_WOUT + B3_W_OUT; }
+static_assert(b3_fwd_smem() <= 160 * 1024, "LDS budget (forward)");
+// weight fragment planes held in LDS (same [n tile][K step][plane][lane] x 16 B layout as RatWPlanes): a fragment is three 16-byte
+// LDS reads instead of a round trip to L2.  The forward kernel has 41 KB of LDS to spare, W_out's planes are 36 KB.
+struct RatWPlanesLds {
+    const char* base;
+    int steps;
+    __device__ __forceinline__ RatB3 operator()(int nt, int s) const {
+        const char* p = base + ((size_t)(nt * steps + s) * 3) * 1024 + 16 * rat_lane();
+        return RatB3{rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(p)), rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(p + 1024)),
+                     rat_as_bf16x8(*reinterpret_cast<const rat_u4*>(p + 2048))};
+    }
+};
 
 // LayerNorm of one row piece into planes: thread (row = tid / 8, sub = tid % 8) owns the 8 columns [8 sub, 8 sub + 8) = exactly
 // one 16-byte piece, handed over in two float4 (loaded by the caller, usually a whole chunk ahead); same arithmetic, in the same
@@ -1125,8 +1156,8 @@ __device__ __forceinline__ void b3_load_piece(const float* src, const int64_t* r
 // 4 k + 3 and 4 k + 1 column tiles (Q|K|V: 15, dO: 5) give every wave the same number of tiles in total.
 // Same-box A/B of the alternatives (tools/ab_attn.sh, tools/experiments/): a whole column tile of B in flight: +5 % (registers);
 // all four row tiles on one wave (half the L2 traffic, A re-read per column tile): +50 %; REV: -2 %.
-template <int KS, bool REV = false, class PA, class Epi>
-__device__ __forceinline__ void b3_gemm_rows(const PA& A, const RatWPlanes& Bw, int n_tiles, const Epi& epi) {
+template <int KS, bool REV = false, class PA, class BW, class Epi>
+__device__ __forceinline__ void b3_gemm_rows(const PA& A, const BW& Bw, int n_tiles, const Epi& epi) {
     const int w = rat_wave(), mt0 = 2 * (w >> 2);
     int nt = REV ? 3 - (w & 3) : (w & 3);
     if (nt >= n_tiles) return;
@@ -1164,6 +1195,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
     float* const lse_s = reinterpret_cast<float*>(smem + B3_FWD_LSE);       // the chunk's log-sum-exp, saved as whole rows below
     constexpr int LDY = B3_D + 4;
     const int L = a.L;
+    // W_out's fragment planes: global -> LDS once per work-group (every chunk's output projection then reads them from LDS)
+    for (int e = threadIdx.x; e < (int)(B3_W_OUT / 16); e += ATT_THREADS)
+        reinterpret_cast<rat_u4*>(smem + B3_FWD_WOUT)[e] = W.out.base[e];
+    const RatWPlanesLds wout_lds{smem + B3_FWD_WOUT, 3};
 
     for (int e = threadIdx.x; e < 3 * B3_OP / 4; e += ATT_THREADS) reinterpret_cast<float*>(op.base)[e] = 0.f;   // incl. the slack
     for (int e = threadIdx.x; e < 64 * (B3_LDQ - B3_Q3); e += ATT_THREADS) qkv[(e >> 2) * B3_LDQ + B3_Q3 + (e & 3)] = 0.f;
@@ -1307,7 +1342,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         __syncthreads();
         RAT_PROF_MARK(3);
         // y = O W_out^T + b_out (+ residual), staged through LDS for whole-row stores
+#ifdef RAT_FWD_WOUT_L2                                           // (A/B knob: round 3's form, fragments from L2)
         b3_gemm_rows<3>(op, W.out, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
+#else
+        b3_gemm_rows<3>(op, wout_lds, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
+#endif
             const int col = rat_acc_col(nt);
             const float bias = (!DPAD || col < dreal) ? a.b_out[col] : 0.f;
 #pragma unroll
