@@ -362,13 +362,17 @@ __device__ __forceinline__ float head_dot(const V& a, const V& b) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // EX = false: the plain PreNorm(Attention)(x) + x layer (residual = x, output scale 1) — the _ex constants fold away
-template <int TD, int TDH, bool EX = true>
+// GC: columns per lane of the 8-lanes-per-row phases in the generic (TD = 0) kernels — 16 serves embedding_dim <= 128; the instantiations
+// with GC = 2 serve embedding_dim <= 16 (the shipped MovieLens / Tmall geometries, d = 10) with an eighth of the per-lane column state
+// GH: head count of a generic instantiation as a compile-time constant (0 = run-time): every LDS stride of the head side folds
+// GD: likewise the embedding dimension of a generic instantiation (0 = run-time; unlike TD it promises no 16-byte alignment)
+template <int TD, int TDH, bool EX = true, int GC = 16, int GH = 0, int GD = 0>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
-    constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
+    constexpr int COLS = FAST ? (TD + 7) / 8 : GC;
     RAT_DYN_SMEM(smem);
-    const int heads_c = FAST ? fast_heads(TDH) : a.heads;
-    const AttnGeom g(FAST ? TD : a.d, heads_c, TDH > 0 ? TDH : a.dh);
+    const int heads_c = FAST ? fast_heads(TDH) : (GH > 0 ? GH : a.heads);
+    const AttnGeom g(FAST ? TD : (GD > 0 ? GD : a.d), heads_c, TDH > 0 ? TDH : a.dh);
     float* xs = reinterpret_cast<float*>(smem);
     float* qkv = xs + (size_t)ATT_ROWS * g.ldx;
     int64_t* rowtok = reinterpret_cast<int64_t*>(qkv + (size_t)ATT_ROWS * g.ldq);
@@ -535,13 +539,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- backward
-template <int TD, int TDH, bool EX = true>
+template <int TD, int TDH, bool EX = true, int GC = 16, int GH = 0, int GD = 0>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     constexpr bool FAST = TD > 0;
-    constexpr int COLS = FAST ? (TD + 7) / 8 : 16;
+    constexpr int COLS = FAST ? (TD + 7) / 8 : GC;
     RAT_DYN_SMEM(smem);
-    const AttnGeom g(FAST ? TD : a.d, FAST ? fast_heads(TDH) : a.heads, TDH > 0 ? TDH : a.dh);
-    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = FAST ? fast_heads(TDH) : a.heads;
+    const AttnGeom g(FAST ? TD : (GD > 0 ? GD : a.d), FAST ? fast_heads(TDH) : (GH > 0 ? GH : a.heads), TDH > 0 ? TDH : a.dh);
+    const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh, H = FAST ? fast_heads(TDH) : (GH > 0 ? GH : a.heads);
     const int ldx = g.ldx, ldq = g.ldq, ldt = g.ldt;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx]  LayerNorm(x)
     float* dys = xs + (size_t)ATT_ROWS * ldx;                   // [64][ldx]  dL/dy
@@ -554,7 +558,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     float* dlt = lses + (size_t)ATT_ROWS * H;                   // [64][H]   rowsum(dO * O)
     int64_t* rowtok = reinterpret_cast<int64_t*>(dlt + (size_t)ATT_ROWS * H);
     const bool has_out = a.w_out != nullptr;
-    const bool ksplit = !FAST && g.D16 == 16 && ldt >= 32;       // one column tile: the dXn GEMM splits its contraction (phase 5)
 
     // persistent parameter-gradient accumulators
     f32x4 accq[QSLOTS], acco[OSLOTS];
@@ -799,21 +802,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 for (int i = 0; i < ATT_MT; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) part[(size_t)rat_acc_row(i, r) * ldt + col] = acc[i][r];
-            } else if (ksplit) {
-                // embedding_dim <= 16 (the shipped MovieLens / Tmall geometries: d = 10): ONE column tile — as (row-tile pair x column
-                // tile) tasks that is 2 tasks for 8 waves, each a chain over all 3 I / 16 k-blocks (stamps at the Tmall shape, round 4:
-                // 18 % of the kernel).  Split the contraction four ways instead: wave = (row-tile pair w & 1, K part w >> 1); the four
-                // partial tiles land side by side in dob / ob (free since dQ moved into qkv) and LayerNorm backward adds them.
-                const int w = rat_wave(), mb = w & 1, part = w >> 1;
-                const int kbt = g.Q16 / 16, k0 = part * kbt / 4, k1 = (part + 1) * kbt / 4;
-                f32x4 acc[2] = {rat_zero4(), rat_zero4()};
-                if (k1 > k0) rat_wave_gemm_col<2, 0>(acc, A, Bw, 2 * mb, 0, k1, k0);
-                float* pt = (part < 2 ? dob : ob) + 16 * (part & 1);
-                const int col = rat_acc_col(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pt[(size_t)rat_acc_row(2 * mb + i, r) * ldt + col] = acc[i][r];
             } else {
                 rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
                     const int col = rat_acc_col(nt);
@@ -879,8 +867,6 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                     const int c = c0 + k;
                     xh[k] = (c < D && valid) ? a.x[tok * D + c] : 0.f;
                     gg[k] = (c < D && valid) ? dob[(size_t)r * ldt + c] : 0.f;
-                    if (ksplit && c < D && valid)                   // the other three K parts of the split dXn GEMM
-                        gg[k] += dob[(size_t)r * ldt + 16 + c] + (ob[(size_t)r * ldt + c] + ob[(size_t)r * ldt + 16 + c]);
                 }
             }
 #pragma unroll
@@ -2399,6 +2385,9 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
+    else if (dim_head == 10 && d == 10 && heads == 8) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2, 8, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped Tmall (groups of 8 heads)
+    else if (dim_head == 10 && d == 10 && heads == 2) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2, 2, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped MovieLens
+    else if (dim_head == 10 && d <= 16) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<0, 10>), blocks, ATT_THREADS, smem, stream, a);   // e.g. the shipped KKBox d = 40
     else RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
     return rat_check_launch("rat_attn_fwd");
@@ -2496,6 +2485,9 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     else if (fast == 16 && dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<16, 10>), blocks, ATT_THREADS, smem, stream, a);
     else if (fast == 64 && dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<64, 20>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
+    else if (dim_head == 10 && d == 10 && heads == 8) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2, 8, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped Tmall (groups of 8 heads)
+    else if (dim_head == 10 && d == 10 && heads == 2) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2, 2, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped MovieLens
+    else if (dim_head == 10 && d <= 16) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<0, 10>), blocks, ATT_THREADS, smem, stream, a);   // e.g. the shipped KKBox d = 40
     else RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
     if (rat_check_launch("rat_attn_bwd")) return -1;
