@@ -200,3 +200,8 @@ def test_feed_forward_with_its_dropout_layers(emu, ntok, d, hidden, with_res, ad
 def test_attn_generic_kernel_with_one_column_tile(emu, two_blocks, case):
     kc.check_attn(emu, "cpu", case, "intra")
     kc.check_attn(emu, "cpu", case, "cross")
+
+
+@pytest.mark.parametrize("d,hidden", [(10, 40), twin(10, 20)])
+def test_ffn_compile_time_geometry_of_the_shipped_d10_configs(emu, d, hidden):
+    kc.check_ffn(emu, "cpu", 150, d, hidden)

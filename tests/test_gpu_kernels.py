@@ -198,9 +198,17 @@ def test_feed_forward_with_its_dropout_layers(lib, ntok, d, hidden, with_res, ad
     kc.check_ffn_dropout(lib, "cuda", ntok, d, hidden, with_res, add_dy)
 
 
-@pytest.mark.parametrize("case", [(60, 6, 4, 10, 2, 10, True), (40, 6, 10, 10, 8, 10, True), (33, 5, 3, 16, 4, 10, True), (21, 3, 4, 12, 8, 10, True)], ids=str)
+@pytest.mark.parametrize("case", [(60, 6, 4, 10, 2, 10, True), (40, 6, 10, 10, 8, 10, True), (33, 5, 3, 16, 4, 10, True), (21, 3, 4, 12, 8, 10, True),
+                                  (50, 11, 4, 16, 2, 10, True)], ids=str)
 @pytest.mark.parametrize("mode", ["intra", "cross"])
 def test_attn_generic_kernel_with_one_column_tile(lib, case, mode):
-    """embedding_dim <= 16 on the generic kernel (the shipped MovieLens / Tmall geometries, d = 10): the d(LayerNorm out) GEMM has one
-    column tile and splits its contraction over the waves (round 4), LayerNorm backward adds the four partial tiles"""
+    """embedding_dim <= 16 on the generic kernels: the instantiations with two columns per lane, and — for the shipped MovieLens / Tmall
+    geometries (d = 10; 2 or 8 heads) and BASELINE configs[0] (d = 16, 2 heads) — compile-time geometry, where the d(LayerNorm out) GEMM
+    (one column tile) splits its contraction over the waves and LayerNorm backward adds the four partial tiles (round 4)"""
     kc.check_attn(lib, "cuda", case, mode)
+
+
+@pytest.mark.parametrize("ntok,d,hidden", [(3000, 10, 40), (3000, 10, 20), (130, 10, 40)])
+def test_ffn_compile_time_geometry_of_the_shipped_d10_configs(lib, ntok, d, hidden):
+    kc.check_ffn(lib, "cuda", ntok, d, hidden)
+    kc.check_ffn_res(lib, "cuda", ntok, d, hidden, True)

@@ -558,6 +558,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     float* dlt = lses + (size_t)ATT_ROWS * H;                   // [64][H]   rowsum(dO * O)
     int64_t* rowtok = reinterpret_cast<int64_t*>(dlt + (size_t)ATT_ROWS * H);
     const bool has_out = a.w_out != nullptr;
+    // compile-time d <= 16 (one column tile): the d(LayerNorm out) GEMM splits its CONTRACTION over the waves (phase 5)
+    constexpr bool KSPLIT = !FAST && GD > 0 && GD <= 16 && GH > 0 && ((GH * (TDH > 0 ? TDH : 16) + 15) / 16 * 16) >= 32;
 
     // persistent parameter-gradient accumulators
     f32x4 accq[QSLOTS], acco[OSLOTS];
@@ -802,6 +804,21 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 for (int i = 0; i < ATT_MT; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) part[(size_t)rat_acc_row(i, r) * ldt + col] = acc[i][r];
+            } else if (KSPLIT) {
+                // ONE column tile: as (row-tile pair x column tile) tasks that is 2 tasks for 8 waves, each a chain over all 3 I / 16
+                // k-blocks (stamps at the Tmall shape: 18 % of the kernel).  Four-way split of the contraction instead: wave = (row-tile
+                // pair w & 1, K part w >> 1); the partial tiles land side by side in dob / ob (free since dQ moved into qkv), LayerNorm
+                // backward adds them.  (Only with compile-time geometry: in the run-time-dimension kernel the extra live state spilled.)
+                const int w = rat_wave(), mb = w & 1, part = w >> 1;
+                const int kbt = g.Q16 / 16, k0 = part * kbt / 4, k1 = (part + 1) * kbt / 4;
+                f32x4 acc[2] = {rat_zero4(), rat_zero4()};
+                if (k1 > k0) rat_wave_gemm_col<2, 0>(acc, A, Bw, 2 * mb, 0, k1, k0);
+                float* pt = (part < 2 ? dob : ob) + 16 * (part & 1);
+                const int col = rat_acc_col(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pt[(size_t)rat_acc_row(2 * mb + i, r) * ldt + col] = acc[i][r];
             } else {
                 rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.Q16 / 16, [&](int mt, int nt, const f32x4& acc) {
                     const int col = rat_acc_col(nt);
@@ -867,6 +884,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                     const int c = c0 + k;
                     xh[k] = (c < D && valid) ? a.x[tok * D + c] : 0.f;
                     gg[k] = (c < D && valid) ? dob[(size_t)r * ldt + c] : 0.f;
+                    if (KSPLIT && c < D && valid)                   // the other three K parts of the split dXn GEMM
+                        gg[k] += dob[(size_t)r * ldt + 16 + c] + (ob[(size_t)r * ldt + c] + ob[(size_t)r * ldt + 16 + c]);
                 }
             }
 #pragma unroll
@@ -2387,6 +2406,7 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     else if (dim_head == 20) RAT_LAUNCH((attn_fwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 10 && d == 10 && heads == 8) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2, 8, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped Tmall (groups of 8 heads)
     else if (dim_head == 10 && d == 10 && heads == 2) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2, 2, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped MovieLens
+    else if (dim_head == 10 && d == 16 && heads == 2) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2, 2, 16>), blocks, ATT_THREADS, smem, stream, a);   // BASELINE configs[0]
     else if (dim_head == 10 && d <= 16) RAT_LAUNCH((attn_fwd_kernel<0, 10, true, 2>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<0, 10>), blocks, ATT_THREADS, smem, stream, a);   // e.g. the shipped KKBox d = 40
     else RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
@@ -2487,6 +2507,7 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     else if (dim_head == 20) RAT_LAUNCH((attn_bwd_kernel<0, 20>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 10 && d == 10 && heads == 8) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2, 8, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped Tmall (groups of 8 heads)
     else if (dim_head == 10 && d == 10 && heads == 2) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2, 2, 10>), blocks, ATT_THREADS, smem, stream, a);   // shipped MovieLens
+    else if (dim_head == 10 && d == 16 && heads == 2) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2, 2, 16>), blocks, ATT_THREADS, smem, stream, a);   // BASELINE configs[0]
     else if (dim_head == 10 && d <= 16) RAT_LAUNCH((attn_bwd_kernel<0, 10, true, 2>), blocks, ATT_THREADS, smem, stream, a);
     else if (dim_head == 10) RAT_LAUNCH((attn_bwd_kernel<0, 10>), blocks, ATT_THREADS, smem, stream, a);   // e.g. the shipped KKBox d = 40
     else RAT_LAUNCH((attn_bwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);

@@ -131,11 +131,13 @@ __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, c
     });
 }
 
-template <int TD>
+// GD / GHID: embedding_dim / hidden width of a generic (TD = 0) instantiation as compile-time constants (0 = run-time): the shipped
+// d = 10 configs (MovieLens hidden 40, Tmall hidden 20) — every LDS stride and loop bound folds, the SGPR spills of the run-time form go
+template <int TD, int GD = 0, int GHID = 0>
 __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
     constexpr bool FAST = TD > 0;
     RAT_DYN_SMEM(smem);
-    const FfnGeom g(FAST ? TD : a.d, a.hidden);
+    const FfnGeom g(FAST ? TD : (GD > 0 ? GD : a.d), GHID > 0 ? GHID : a.hidden);
     float* xs = reinterpret_cast<float*>(smem);
     float* hs = xs + (size_t)FFN_ROWS * g.ldx;
     float* ys = hs + (size_t)FFN_ROWS * g.ldh;                  // [64][ldx] output staging (whole-row coalesced stores)
@@ -191,11 +193,12 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
 
 // generic shapes (any d, hidden up to the LDS tile): LDS-staged, weights streamed from L2 with guarded fragment loads.  The
 // compiled fast shapes (d, 2d) = (64, 128), (16, 32) run ffn_bwd_t_kernel below.
+template <int GD = 0, int GHID = 0>
 __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
     constexpr bool FAST = false;
     constexpr int TD = 0;
     RAT_DYN_SMEM(smem);
-    const FfnGeom g(a.d, a.hidden);
+    const FfnGeom g(GD > 0 ? GD : a.d, GHID > 0 ? GHID : a.hidden);
     const int D = g.D, H = g.H;
     float* xs = reinterpret_cast<float*>(smem);                 // [64][ldx] x
     float* dys = xs + (size_t)FFN_ROWS * g.ldx;                 // [64][ldx] dL/dy
@@ -1580,7 +1583,7 @@ extern "C" int rat_ffn_bwd_drop(const float* x, const float* dy, float* dx, cons
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-    RAT_LAUNCH(ffn_bwd_kernel, blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+    RAT_LAUNCH((ffn_bwd_kernel<>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     if (rat_check_launch("rat_ffn_bwd_drop")) return -1;
     float* outs[4] = {dw1, dw2, db1, db2};
     const int64_t sizes[4] = {(int64_t)hidden * d, (int64_t)d * hidden, hidden, d};
@@ -1630,6 +1633,10 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
     } else if (fast == 16 && hidden == 32) {
         if (xres) RAT_LAUNCH((ffn_fwd_t_kernel<16, 32, true>), tgrid, FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
         else RAT_LAUNCH((ffn_fwd_t_kernel<16, 32, false>), tgrid, FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
+    } else if (d == 10 && hidden == 40) {                       // shipped MovieLens geometry
+        RAT_LAUNCH((ffn_fwd_kernel<0, 10, 40>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
+    } else if (d == 10 && hidden == 20) {                       // shipped Tmall geometry
+        RAT_LAUNCH((ffn_fwd_kernel<0, 10, 20>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     } else {
         RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     }
@@ -1732,8 +1739,12 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
         RAT_LAUNCH((ffn_bwd_t_kernel<64, 128>), blocks, FB_THREADS, (FfnBTGeom<64, 128>::smem), stream, a);
     } else if (fast == 16 && hidden == 32) {
         RAT_LAUNCH((ffn_bwd_t_kernel<16, 32>), blocks, FB_THREADS, (FfnBTGeom<16, 32>::smem), stream, a);
+    } else if (d == 10 && hidden == 40) {
+        RAT_LAUNCH((ffn_bwd_kernel<10, 40>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+    } else if (d == 10 && hidden == 20) {
+        RAT_LAUNCH((ffn_bwd_kernel<10, 20>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     } else {
-        RAT_LAUNCH(ffn_bwd_kernel, blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+        RAT_LAUNCH((ffn_bwd_kernel<>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     }
     if (rat_check_launch("rat_ffn_bwd")) return -1;
     float* outs[4] = {dw1, dw2, db1, db2};
