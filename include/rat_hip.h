@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 6
+#define RAT_ABI_VERSION 7
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -217,6 +217,17 @@ int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1,
                     size_t workspace_bytes, const void* planes /* of rat_ffn_split_jobs, or NULL */, int64_t ntok, int d,
                     int hidden, int add_dy, int arith, void* stream);
 
+/* ABI v7: rat_ffn_bwd_res for an incoming gradient that is zero except on the token rows t = k * dy_period (k = 0, 1, ...): dy_rows
+ * [ceil(ntok / dy_period)][d] holds those rows compactly, the zero rows are neither stored nor read.  The last encoder block's case:
+ * the head reads one class token per sample (RAT_m2.py:138-140), so d loss / d x is zero on every other token of the [B][T][S] grid and
+ * the [ntok][d] zero fill in front of the backward disappears.  Only where rat_ffn_bwd_rows_supported says 1 (the bf16x3
+ * weight-stationary kernel: d = 64 or 40 / 48 / 56 with hidden = 2 d, RAT_ARITH_BF16X3); ntok, dy_period < 2^31. */
+int rat_ffn_bwd_rows_supported(int d, int hidden, int arith);
+int rat_ffn_bwd_res_rows(const float* x, const float* dy_rows, int64_t dy_period, float* dx, const float* w1, const float* b1,
+                         const float* w2, const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                         size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
+                         void* stream);
+
 /* ---- K2c: stand-alone nn.LayerNorm(d) (biased variance, affine) over selected token rows — RAT_m1's PreNorm in front of
  * FeedForward and the final `self.norm` of each Transformer (RAT_m1.py:137-141,198,209), of which only token 0 of every
  * sequence is read (RAT_m1.py:125,128).  Row r is read at x + r * x_stride; y is a compact [nrows][d]. */
@@ -266,7 +277,6 @@ int rat_sgemm_ws(int trans_a, int trans_b, int M, int N, int K, const float* A, 
 int rat_sgemm_arith(int trans_a, int trans_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                     float* C, int ldc, const float* bias, float beta, float* workspace, size_t workspace_bytes,
                     int arith, void* stream);
-
 /* BatchNorm1d (train: batch stats, biased var; running stats momentum update with unbiased var; eval:
  * running stats) followed by the hidden layer's activation — deep.py:128-132.  use_bn=0 -> activation only.  z,a [M][N].
  * workspace: rat_bn_workspace(N) bytes (per-row-split partial sums; needed when use_bn && training, and by bwd).
@@ -286,6 +296,24 @@ int rat_bn_relu_fwd(const float* z, float* a, const float* gamma, const float* b
 int rat_bn_relu_bwd(const float* z, const float* a, const float* da, float* dz, const float* gamma,
                     const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* workspace,
                     int M, int N, int use_bn, int act, void* stream);
+/* ABI v7 — column-strip forms of the two calls above: ONE launch per layer and direction, no workspace, sums in a fixed order
+ * (deterministic).  A work-group owns 8 columns for all M rows: batch statistics and their use share the launch, and the backward
+ * also returns dbias_lin[N] = column sums of dz — the bias gradient of the nn.Linear in front (deep.py:126-127), i.e. rat_colsum of
+ * its own output (nullptr = not wanted).  Need rat_bn_strip_ok(M, N) (N % 4 == 0) and 16-byte aligned pointers; same arithmetic
+ * per element as rat_bn_relu_fwd / rat_bn_relu_bwd, batch sums in another (fixed) order. */
+int rat_bn_strip_ok(int M, int N);
+int rat_bn_act_fwd_strip(const float* z, float* a, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float* save_mean, float* save_rstd, int M, int N, int training, int use_bn,
+                         float eps, float momentum, int act, void* stream);
+int rat_bn_act_bwd_strip(const float* z, const float* a, const float* da, float* dz, const float* gamma,
+                         const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, float* dbias_lin,
+                         int M, int N, int use_bn, int act, void* stream);
+/* The LAST hidden layer in front of the DNN's one-output Linear (deep.py:135-137): its incoming gradient is the outer product
+ * da[r][c] = dl[r] * w[c] (dl = dlogit [M], w = that Linear's weight [N]) — formed inside the kernel — and dw[c] = sum_r dl[r] a[r][c]
+ * (the Linear's weight gradient) comes back with it: replaces two rat_sgemm launches and the da matrix. */
+int rat_bn_act_bwd_strip_outer(const float* z, const float* a, const float* dl, const float* w, float* dw, float* dz,
+                               const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                               float* dbias_lin, int M, int N, int use_bn, int act, void* stream);
 /* SyncBN for data parallelism (deep.py:128-132 evaluated over the GLOBAL batch, i.e. exactly what the
  * reference's single-device BatchNorm1d sees).  The collectives between the calls belong to the caller (RCCL):
  *   fwd:  rat_bn_local_stats -> all_gather(stats, 2N+1 floats per rank) -> rat_bn_relu_fwd_sync
@@ -320,6 +348,12 @@ int rat_logit_fwd(const float* cls, int64_t cls_stride, const float* fc_w, const
                   const float* dnn_out, const RatField* lr_fields_dev, int nfields, const int32_t* idx,
                   int64_t idx_stride, const float* y_true, float* y_pred, float* loss_sum, int B, int d,
                   int head, void* stream);
+/* ABI v7: the same with the DNN's one-output Linear evaluated inside: logit = fc(cls) + (dnn_in[b] . dnn_w + dnn_b) + LR — dnn_in
+ * [B][dnn_k] with leading dimension dnn_ld is the last hidden layer's output (formerly an N = 1 rat_sgemm launch into dnn_out). */
+int rat_logit_fwd_dnn(const float* cls, int64_t cls_stride, const float* fc_w, const float* fc_b, const float* dnn_in,
+                      int64_t dnn_ld, const float* dnn_w, const float* dnn_b, int dnn_k, const RatField* lr_fields_dev,
+                      int nfields, const int32_t* idx, int64_t idx_stride, const float* y_true, float* y_pred,
+                      float* loss_sum, int B, int d, int head, void* stream);
 /* dlogit[b] = gscale * (gscale_dev ? *gscale_dev : 1) * (y_pred - y_true)/B (x 2 for RAT_HEAD_REGRESSION) ; dcls row b (written at
  * dcls + b*dcls_stride) = dlogit*fc_w ; dfc_w, dfc_b and the LR grad tables are ACCUMULATED into (caller zeroes them).
  * gscale_dev (nullable): a DEVICE scalar — autograd's incoming loss gradient — so that backward needs no host read-back. */
@@ -327,6 +361,11 @@ int rat_logit_bwd(const float* y_pred, const float* y_true, const float* cls, in
                   const float* fc_w, float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w,
                   float* dfc_b, const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx,
                   int64_t idx_stride, float gscale, const float* gscale_dev, int B, int d, int head, void* stream);
+/* ABI v7: rat_logit_bwd that also ACCUMULATES sum_b dlogit[b] into ddnn_b (the bias gradient of the DNN's one-output Linear) */
+int rat_logit_bwd_dnn(const float* y_pred, const float* y_true, const float* cls, int64_t cls_stride, const float* fc_w,
+                      float* dlogit, float* dcls, int64_t dcls_stride, float* dfc_w, float* dfc_b, float* ddnn_b,
+                      const RatField* lr_grad_fields_dev, int nfields, const int32_t* idx, int64_t idx_stride, float gscale,
+                      const float* gscale_dev, int B, int d, int head, void* stream);
 
 /* ---- K1s: row-sparse / deterministic embedding gradients (BASELINE.json configs[3]; SURVEY.md §2a rows H/I, §7 hard parts 3, 7)
  * replaces, for tables too large for dense semantics, embedding_dense_backward + the dense clip/Adam pass over the tables

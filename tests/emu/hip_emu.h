@@ -115,6 +115,7 @@ static inline float atomicAdd(float* p, float v) {
     while (!r.compare_exchange_weak(old, old + v)) {}
     return old;
 }
+static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline int atomicAdd(int* p, int v) { return std::atomic_ref<int>(*p).fetch_add(v); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return std::atomic_ref<unsigned>(*p).fetch_add(v); }
 static inline unsigned atomicMax(unsigned* p, unsigned v) {

@@ -377,6 +377,28 @@ def check_ffn_res(lib, dev, ntok, d, hidden, with_res, arith="f32"):
         close(g, w.grad, 1e-4, 1e-4 * scale)
 
 
+def check_ffn_rows(lib, dev, ntok, d, hidden, period):
+    """rat_ffn_bwd_res_rows (dy given as the compact rows k * period, zero elsewhere) == rat_ffn_bwd_res on the dense dy, BIT FOR BIT:
+    the same kernel, zeros substituted instead of loaded"""
+    rs = np.random.RandomState(31)
+    x = rnd(rs, ntok, d)
+    ws = (rnd(rs, hidden, d, scale=d ** -0.5), 0.1 * rnd(rs, hidden), rnd(rs, d, hidden, scale=hidden ** -0.5), 0.1 * rnd(rs, d))
+    nrows = (ntok + period - 1) // period
+    rows = rnd(rs, nrows, d)
+    dy = torch.zeros(ntok, d)
+    dy[::period] = rows
+    assert ops.ffn_bwd_rows_supported(d, hidden, "bf16x3", lib)
+    xd, wd = x.to(dev), [w.to(dev) for w in ws]
+    g1 = [torch.zeros_like(w) for w in wd]
+    dx1, _ = ops.ffn_bwd_res(xd, dy.to(dev), *wd, g1[0], g1[1], g1[2], g1[3], d, hidden, add_dy=True, arith="bf16x3", lib=lib)
+    g2 = [torch.zeros_like(w) for w in wd]
+    dx2, _ = ops.ffn_bwd_rows(xd, rows.to(dev), period, *wd, g2[0], g2[1], g2[2], g2[3], d, hidden, arith="bf16x3", lib=lib)
+    assert torch.equal(dx1.cpu(), dx2.cpu()), "dx"
+    for a, b in zip(g1, g2):
+        assert torch.equal(a.cpu(), b.cpu()), "weight gradients"
+    assert float(dx1.abs().sum()) > 0
+
+
 def check_ffn_dropout(lib, dev, ntok, d, hidden, with_res, add_dy, p=0.3):
     """FeedForward with its two Dropout layers (rat_ffn_fwd_drop / rat_ffn_bwd_drop) against the float64 reference under the SAME masks:
     the masks are counter-based functions of (seed word, element index) — the generator of rat_dropout — so the reference takes them
@@ -472,6 +494,49 @@ def check_bn_relu(lib, dev, M, N, use_bn):
     close(out, z.double().sum(0), 1e-5, 1e-4, "colsum")
 
 
+def check_bn_strip(lib, dev, M, N, use_bn, act="relu"):
+    """column-strip forms (one launch per direction, Linear bias gradient included) against float64 autograd"""
+    rs = np.random.RandomState(14)
+    z = rnd(rs, M, N) + 3.0 * rnd(rs, N)                       # column means far from zero: the pivot form must not cancel
+    gamma, beta = 1 + 0.1 * rnd(rs, N), 0.1 * rnd(rs, N)
+    rm, rv = 0.1 * rnd(rs, N), 1 + 0.1 * rnd(rs, N).abs()
+    da = rnd(rs, M, N)
+    fn = {"relu": torch.relu, "tanh": torch.tanh, "none": lambda t: t}[act]
+    zr = z.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm_ref, rv_ref = rm.double().clone(), rv.double().clone()
+    pre = torch.nn.functional.batch_norm(zr, rm_ref, rv_ref, gr, br, training=True, momentum=0.1, eps=1e-5) if use_bn else zr
+    yr = fn(pre)
+    yr.backward(da.double())
+    zd, rmd, rvd, gd, bd = z.to(dev), rm.to(dev), rv.to(dev), gamma.to(dev), beta.to(dev)
+    code = ops.ACT[act]
+    if use_bn:
+        a, sm, sr = ops.bn_act_fwd_strip(zd, gd, bd, rmd, rvd, True, True, act=code, lib=lib)
+    else:
+        a, sm, sr = ops.bn_act_fwd_strip(zd, None, None, None, None, True, False, act=code, lib=lib)
+    close(a, yr, 1e-5, 1e-5, "strip fwd")
+    dg, db, dbl = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.full((N,), 7.0, device=dev)
+    dz = ops.bn_act_bwd_strip(zd, a, da.to(dev), gd if use_bn else None, sm, sr, dg if use_bn else None, db if use_bn else None, dbl,
+                              use_bn, act=code, lib=lib)
+    close(dz, zr.grad, 1e-4, 1e-5, "strip dz")
+    close(dbl, dz.double().sum(0), 1e-5, 1e-4 * max(1.0, M ** 0.5) * 1e-1, "strip Linear bias gradient")
+    if use_bn:
+        close(rmd, rm_ref, 1e-5, 1e-6, "running_mean")
+        close(rvd, rv_ref, 1e-5, 1e-6, "running_var")
+        scale = max(1.0, M ** 0.5)
+        close(dg, gr.grad, 1e-4, 1e-5 * scale, "dgamma")
+        close(db, br.grad, 1e-4, 1e-5 * scale, "dbeta")
+        a2, _, _ = ops.bn_act_fwd_strip(zd, gd, bd, rmd, rvd, False, True, act=code, lib=lib)
+        ye = fn(torch.nn.functional.batch_norm(z.double(), rm_ref, rv_ref, gamma.double(), beta.double(), training=False, eps=1e-5))
+        close(a2, ye, 1e-5, 1e-5, "strip eval")
+        # and against the two-launch kernels: same per-element arithmetic, batch sums in another order
+        rm2, rv2 = rm.to(dev), rv.to(dev)
+        a3, sm3, sr3 = ops.bn_relu_fwd(zd, gd, bd, rm2, rv2, True, True, act=code, lib=lib)
+        close(a, a3, 1e-5, 1e-5, "strip vs two-launch fwd")
+        close(sm, sm3, 1e-6, 1e-6, "save_mean")
+        close(sr, sr3, 1e-5, 1e-6, "save_rstd")
+
+
 def check_logit(lib, dev, B, d, with_dnn=True, with_lr=True):
     rs = np.random.RandomState(5)
     T, S, L = 3, 4, 5
@@ -518,6 +583,54 @@ def check_logit(lib, dev, B, d, with_dnn=True, with_lr=True):
     if with_lr:
         for g, t in zip(glt, lt):
             close(g, t.grad, 1e-4, 1e-7, "lr grad")
+    if with_dnn:
+        # the DNN's one-output Linear evaluated inside the launches (rat_logit_fwd_dnn / rat_logit_bwd_dnn): K = 52 (vector path) and
+        # K = 7 with an odd leading dimension (scalar path)
+        for K, ld in ((52, 52), (7, 9)):
+            a = rnd(rs, B, ld)
+            w_o, b_o = rnd(rs, 1, K, scale=K ** -0.5), 0.1 * rnd(rs, 1)
+            dn = (a[:, :K].double() @ w_o.double().t() + b_o.double())
+            z2 = grid.double()[:, 0, 0] @ fc_w.double().t() + fc_b.double() + dn
+            if with_lr:
+                z2 = z2 + lr.detach()
+            p2 = torch.sigmoid(z2)
+            loss2 = torch.nn.functional.binary_cross_entropy(p2, y.double().unsqueeze(-1))
+            ls2 = torch.zeros(1, device=dev)
+            yp2 = ops.logit_fwd(gd, T * S * d, fwd, fbd, None, ftab, 3, idxd, T * L, yd, ls2, B, d,
+                                dnn_last=(a.to(dev), ld, K, w_o.to(dev), b_o.to(dev)), lib=lib)
+            close(yp2, p2, 1e-5, 1e-6, "y_pred (DNN output layer inside)")
+            close(ls2, loss2.reshape(1), 1e-5, 1e-6, "loss (DNN output layer inside)")
+        dgrid2, dfw2, dfb2, dob = torch.zeros_like(gd), torch.zeros_like(fwd), torch.zeros_like(fbd), torch.full((1,), 0.5, device=dev)
+        dl2 = ops.logit_bwd(yp, yd, gd, T * S * d, fwd, dgrid2, T * S * d, dfw2, dfb2, None, 3, idxd, T * L, 1.0, B, d, ddnn_b=dob, lib=lib)
+        close(dl2, dlogit, 1e-6, 1e-9, "dlogit (dnn variant)")
+        close(dob - 0.5, dfb2.reshape(1), 1e-4, 1e-6, "ddnn_b accumulates the sum dfc_b gets")
+
+
+def check_bn_strip_outer(lib, dev, M, N, use_bn):
+    """last hidden layer + the one-output Linear behind it: da = dl (x) w formed inside the launch, dw returned"""
+    rs = np.random.RandomState(15)
+    z = rnd(rs, M, N)
+    gamma, beta = (1 + 0.1 * rnd(rs, N)).to(dev), (0.1 * rnd(rs, N)).to(dev)
+    rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    dl, w = rnd(rs, M, 1), rnd(rs, 1, N)
+    zd, dld, wd = z.to(dev), dl.to(dev), w.to(dev)
+    if use_bn:
+        a, sm, sr = ops.bn_act_fwd_strip(zd, gamma, beta, rm, rv, True, True, lib=lib)
+    else:
+        a, sm, sr = ops.bn_act_fwd_strip(zd, None, None, None, None, True, False, lib=lib)
+    da = (dl.double() @ w.double()).float().to(dev)
+    dg, db, dbl = (torch.zeros(N, device=dev) for _ in range(3))
+    ref = ops.bn_act_bwd_strip(zd, a, da, gamma if use_bn else None, sm, sr, dg if use_bn else None, db if use_bn else None, dbl, use_bn, lib=lib)
+    dg2, db2, dbl2, dw = (torch.zeros(N, device=dev) for _ in range(4))
+    dz = ops.bn_act_bwd_strip_outer(zd, a, dld, wd, dw, gamma if use_bn else None, sm, sr, dg2 if use_bn else None, db2 if use_bn else None,
+                                    dbl2, use_bn, lib=lib)
+    scale = max(1.0, M ** 0.5)
+    close(dz, ref, 1e-5, 1e-6, "outer dz")
+    close(dbl2, dbl, 1e-4, 1e-5 * scale, "outer dbias")
+    close(dw, (dl.double().t() @ a.double().cpu()).reshape(-1), 1e-5, 1e-5 * scale, "dw = dl^T a")
+    if use_bn:
+        close(dg2, dg, 1e-4, 1e-5 * scale, "outer dgamma")
+        close(db2, db, 1e-4, 1e-5 * scale, "outer dbeta")
 
 
 def check_optim(lib, dev, n):

@@ -161,6 +161,12 @@ def test_ffn_bf16x3_narrower_layer(emu, two_blocks):
     kc.check_ffn_res(emu, "cpu", 77, 40, 80, True, arith="bf16x3")
 
 
+def test_ffn_backward_from_compact_gradient_rows(emu, two_blocks):
+    """the last block's feed-forward backward: only one token row per sample carries a gradient (rat_ffn_bwd_res_rows)"""
+    kc.check_ffn_rows(emu, "cpu", 231, 64, 128, 21)            # 11 rows of 231 tokens; several chunks per work-group
+    kc.check_ffn_rows(emu, "cpu", 150, 40, 80, 7)
+
+
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (77, 64, 128), (45, 16, 32)])
 def test_ffn_fwd_bwd(emu, ntok, d, hidden):
     kc.check_ffn(emu, "cpu", ntok, d, hidden)
@@ -180,6 +186,14 @@ def test_layernorm_fwd_bwd(emu, nrows, d, stride_mul, with_add):
 def test_bn_relu_colsum(emu, use_bn):
     kc.check_bn_relu(emu, "cpu", 37, 40, use_bn)
     kc.check_bn_relu(emu, "cpu", 9, 5, use_bn)
+
+
+@pytest.mark.parametrize("use_bn,act", [(True, "relu"), (False, "relu"), (True, "tanh")])
+def test_bn_act_column_strips(emu, use_bn, act):
+    kc.check_bn_strip(emu, "cpu", 37, 40, use_bn, act)         # one row per thread at most, 5 column groups on 8 "XCDs"
+    kc.check_bn_strip(emu, "cpu", 600, 12, use_bn, act)        # three rows per thread (RPT 4), a half-filled last column group
+    if act == "relu":
+        kc.check_bn_strip_outer(emu, "cpu", 300, 20, use_bn)
 
 
 @pytest.mark.parametrize("with_dnn,with_lr", [(True, True), (False, False)])

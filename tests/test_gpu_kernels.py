@@ -160,6 +160,11 @@ def test_ffn_separate_residual(lib, ntok, d, hidden, with_res):
     kc.check_ffn_res(lib, "cuda", ntok, d, hidden, with_res)
 
 
+@pytest.mark.parametrize("ntok,d,hidden,period", [(4096 * 231, 64, 128, 231), (1000 * 66, 40, 80, 66), (70000, 64, 128, 7), (100, 64, 128, 231)])
+def test_ffn_backward_from_compact_gradient_rows(lib, ntok, d, hidden, period):
+    kc.check_ffn_rows(lib, "cuda", ntok, d, hidden, period)
+
+
 @pytest.mark.parametrize("nrows,d,stride_mul,with_add", [(37, 8, 1, False), (100000, 64, 1, True), (8192, 64, 21, False), (4096, 64, 11, True), (1000, 10, 3, True), (300, 400, 2, False)])
 def test_layernorm_fwd_bwd(lib, nrows, d, stride_mul, with_add):
     kc.check_layernorm(lib, "cuda", nrows, d, stride_mul, with_add)
@@ -169,6 +174,15 @@ def test_layernorm_fwd_bwd(lib, nrows, d, stride_mul, with_add):
 def test_bn_relu_colsum(lib, use_bn):
     kc.check_bn_relu(lib, "cuda", 4096, 400, use_bn)
     kc.check_bn_relu(lib, "cuda", 9, 5, use_bn)
+
+
+@pytest.mark.parametrize("use_bn,act", [(True, "relu"), (False, "relu"), (True, "tanh"), (False, "none")])
+@pytest.mark.parametrize("M,N", [(4096, 400), (512, 400), (256, 400), (37, 12), (1500, 64), (5000, 40), (9000, 400)])
+def test_bn_act_column_strips(lib, use_bn, act, M, N):
+    """every rows-per-thread instantiation (2 / 4 / 8 / 16 and the streaming form above 4096 rows)"""
+    kc.check_bn_strip(lib, "cuda", M, N, use_bn, act)
+    if act == "relu":
+        kc.check_bn_strip_outer(lib, "cuda", M, N, use_bn)
 
 
 @pytest.mark.parametrize("with_dnn,with_lr", [(True, True), (False, False)])

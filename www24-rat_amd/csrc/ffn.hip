@@ -38,6 +38,9 @@ struct FfnArgs {
     int d, hidden;
     int vec_x, vec_w1, vec_w2;
     unsigned long long* prof;
+    int dy_period;       // ffn_bwd_t4 only: 0 = dy is [ntok][d]; P > 0 = only tokens t with t % P == 0 have a gradient row, stored compactly at
+                         // dy[(t / P)][d] — every other row of dy is zero by contract and is neither stored nor read (the last encoder block:
+                         // the head reads the class token of each sample only, RAT_m2.py:138-140)
     RatDrop drop1, drop2;  // FeedForward's two nn.Dropout (RAT_m1.py:151-161, RAT_m0.py:150-160): behind GELU (index token * H + unit) and
                            // behind the second Linear, in front of the residual (index token * D + column); generic kernels only
 };
@@ -1251,9 +1254,15 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t4_kernel(FfnArgs a, Ffn3W
 
     float4 tN[4];                                                            // [2 s + part]: src[token][32 s + 8 g + 4 part .. + 3]
     int64_t chunk = blockIdx.x;
+    const unsigned period = half == 1 ? (unsigned)a.dy_period : 0u;          // (wave-uniform)
     {
-        const int64_t tk = chunk * FB_TOK + row;
-        const bool ok = chunk < a.nchunks && tk < a.ntok;
+        int64_t tk = chunk * FB_TOK + row;
+        bool ok = chunk < a.nchunks && tk < a.ntok;
+        if (period != 0) {                                                   // sparse dy: the row exists for tokens t = k P only, at row k
+            const unsigned k = (unsigned)tk / period;
+            ok = ok && k * period == (unsigned)tk;
+            tk = k;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
@@ -1344,8 +1353,13 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t4_kernel(FfnArgs a, Ffn3W
         __syncthreads();
         RAT_PROF_MARK(3);
         {   // next chunk's token fragments: in flight behind the dx and weight-gradient GEMMs
-            const int64_t tk = (chunk + gridDim.x) * FB_TOK + row;
-            const bool ok = chunk + gridDim.x < a.nchunks && tk < a.ntok;
+            int64_t tk = (chunk + gridDim.x) * FB_TOK + row;
+            bool ok = chunk + gridDim.x < a.nchunks && tk < a.ntok;
+            if (period != 0) {
+                const unsigned k = (unsigned)tk / period;
+                ok = ok && k * period == (unsigned)tk;
+                tk = k;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
@@ -1637,6 +1651,8 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
         RAT_LAUNCH((ffn_fwd_kernel<0, 10, 40>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     } else if (d == 10 && hidden == 20) {                       // shipped Tmall geometry
         RAT_LAUNCH((ffn_fwd_kernel<0, 10, 20>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
+    } else if (d == 16 && hidden == 64) {                       // BASELINE configs[0] (d = 16, scale_dim 4)
+        RAT_LAUNCH((ffn_fwd_kernel<0, 16, 64>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     } else {
         RAT_LAUNCH((ffn_fwd_kernel<0>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     }
@@ -1671,10 +1687,42 @@ extern "C" int rat_ffn_bwd(const float* x, const float* dy, float* dx, const flo
                            stream);
 }
 
+static int ffn_bwd_res_launch(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                              const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                              size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
+                              int64_t dy_period, void* stream);
+
 extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
                                const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
                                size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
                                void* stream) {
+    return ffn_bwd_res_launch(x, dy, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, planes, ntok, d, hidden, add_dy,
+                              arith, 0, stream);
+}
+
+// 1 if rat_ffn_bwd_res_rows accepts this layer (the bf16x3 weight-stationary kernel: d = 64 or 40 / 48 / 56, hidden = 2 d)
+extern "C" int rat_ffn_bwd_rows_supported(int d, int hidden, int arith) {
+    static const bool t3 = [] { const char* e = getenv("RAT_FFN_BWD"); return e != nullptr && e[0] == 't' && e[1] == '3'; }();
+    if (t3 || arith != RAT_ARITH_BF16X3) return 0;
+    return (d == F3_D && hidden == F3_H) || ((d == 40 || d == 48 || d == 56) && hidden == 2 * d);
+}
+
+// rat_ffn_bwd_res for a gradient that is zero except on the rows t = k * dy_period: dy_rows [ceil(ntok / dy_period)][d] holds those rows
+// compactly; the zero rows are neither stored nor read (no [ntok][d] zero fill in front of the last block's backward).
+extern "C" int rat_ffn_bwd_res_rows(const float* x, const float* dy_rows, int64_t dy_period, float* dx, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                                    size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
+                                    void* stream) {
+    RAT_REQUIRE(dy_period > 0 && dy_period < ((int64_t)1 << 31) && ntok < ((int64_t)1 << 31), "bad dy_period");
+    RAT_REQUIRE(rat_ffn_bwd_rows_supported(d, hidden, arith), "rat_ffn_bwd_res_rows: geometry without the bf16x3 weight-stationary kernel");
+    return ffn_bwd_res_launch(x, dy_rows, dx, w1, b1, w2, b2, dw1, db1, dw2, db2, workspace, workspace_bytes, planes, ntok, d, hidden,
+                              add_dy, arith, dy_period, stream);
+}
+
+static int ffn_bwd_res_launch(const float* x, const float* dy, float* dx, const float* w1, const float* b1, const float* w2,
+                              const float* b2, float* dw1, float* db1, float* dw2, float* db2, float* workspace,
+                              size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
+                              int64_t dy_period, void* stream) {
     if (ffn_check(ntok, d, hidden, true)) return -1;
     RAT_REQUIRE(x && dy && dx && w1 && b1 && w2 && b2 && dw1 && db1 && dw2 && db2 && workspace, "null pointer");
     RAT_REQUIRE(workspace_bytes >= rat_ffn_bwd_workspace(d, hidden), "workspace too small");
@@ -1702,6 +1750,8 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
     const int fast = ffn_fast_dim(a, {x, dy, dx, b1});
     const bool dpad = arith == RAT_ARITH_BF16X3 && f3_dpad(a, {x, dy, dx, b1});
     const bool b3 = dpad || (fast == F3_D && hidden == F3_H && arith == RAT_ARITH_BF16X3);
+    a.dy_period = (int)dy_period;
+    RAT_REQUIRE(dy_period == 0 || b3, "sparse dy rows: the pointers do not allow the bf16x3 kernel");
     if (b3) {
         const char* ws;
         if (planes != nullptr && aligned16(planes)) {            // split once per step by the caller (rat_split_weights_batch)
@@ -1743,6 +1793,8 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
         RAT_LAUNCH((ffn_bwd_kernel<10, 40>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     } else if (d == 10 && hidden == 20) {
         RAT_LAUNCH((ffn_bwd_kernel<10, 20>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+    } else if (d == 16 && hidden == 64) {
+        RAT_LAUNCH((ffn_bwd_kernel<16, 64>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     } else {
         RAT_LAUNCH((ffn_bwd_kernel<>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     }

@@ -4,6 +4,7 @@
 // (2x2 MFMA tiles); the next k-tile is fetched into registers with 16-byte loads while the current one feeds the
 // MFMAs (register-staged software pipeline: one barrier pair per 32-deep step).
 #include "rat_device.h"
+#include <stdlib.h>
 #include "../../include/rat_hip.h"
 
 namespace {
@@ -267,7 +268,8 @@ void plan_split(int M, int N, int K, int& slices, int& kper) {
     slices = 1;
     kper = (K + GM_K - 1) / GM_K * GM_K;
     if (tiles >= 512 || K < 8 * GM_K) return;
-    int want = (1024 + tiles - 1) / tiles;
+    static const int target = [] { const char* e = getenv("RAT_SGEMM_SPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();   // (A/B knob)
+    int want = (target + tiles - 1) / tiles;
     const int max_slices = K / (2 * GM_K);
     if (want > max_slices) want = max_slices;
     if (want <= 1) return;

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class RatField(Structure):
@@ -64,6 +64,8 @@ _SIGNATURES = {
     "rat_bm25_topk_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_ffn_fwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
     "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "rat_ffn_bwd_rows_supported": (c_int, [c_int, c_int, c_int]),
+    "rat_ffn_bwd_res_rows": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
     "rat_ffn_fwd_drop": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, _P]),
     "rat_ffn_bwd_drop": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "rat_attn_planes_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -80,6 +82,13 @@ _SIGNATURES = {
     "rat_sgemm_workspace": (c_size_t, [c_int, c_int, c_int]),
     "rat_sgemm_ws": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P, c_size_t, _P]),
     "rat_sgemm_arith": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_float, _P, c_size_t, c_int, _P]),
+    "rat_bn_strip_ok": (c_int, [c_int, c_int]),
+    "rat_bn_act_fwd_strip": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
+    "rat_bn_act_bwd_strip": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "rat_bn_act_bwd_strip_outer": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "rat_logit_fwd_dnn": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int, _P, c_int, _P, c_int64, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "rat_logit_bwd_dnn": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int, _P, c_int64, c_float, _P, c_int,
+                                  c_int, c_int, _P]),
     "rat_bn_workspace": (c_size_t, [c_int]),
     "rat_bn_relu_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, c_int, _P]),
     "rat_bn_relu_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

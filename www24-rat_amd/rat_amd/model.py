@@ -549,8 +549,9 @@ class RAT_m2(BaseModel):
             x = xc
         return x, T * S * d
 
-    def _encoder_backward(self, saved, dx, G):
-        """dx: gradient of the tensor _encoder_forward returned -> gradient of the [B,T,S,d] grid."""
+    def _encoder_backward(self, saved, dx, G, dy_period=0):
+        """dx: gradient of the tensor _encoder_forward returned -> gradient of the [B,T,S,d] grid.
+        dy_period > 0: dx holds only the rows k * dy_period of that gradient ([B, d]: the class tokens'), every other row is zero."""
         c, lib = self._cfg, self._lib
         B, T, L, S = saved["dims"]
         d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
@@ -574,8 +575,12 @@ class RAT_m2(BaseModel):
                 dx = self._attn_layer_backward(blk["cross"], xa, dgrid, a2, cm0, G, out=dxg)
                 dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, ops.intra_map(B, T, S, queries=1), G)
                 continue
-            dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
-                                planes=blk["ffn_planes"], lib=lib)
+            if bi == 0 and dy_period:
+                dx, _ = ops.ffn_bwd_rows(xb, dx, dy_period, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn,
+                                         arith=self.arith, planes=blk["ffn_planes"], lib=lib)
+            else:
+                dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
+                                    planes=blk["ffn_planes"], lib=lib)
             dx = self._attn_layer_backward(blk["cross"], xa, dx, a2, cmap, G)
             dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G)
         return dx
@@ -1134,7 +1139,7 @@ class RAT_m2(BaseModel):
         seeds = [self._dropout_word() for _ in range(1 + len(self._dnn_layers))] if drop else None
         saved["seeds"] = seeds
         # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
-        dnn_out = None
+        dnn_out = dnn_last = None
         if training and self._bn_counts is not None:
             self._bn_counts.add_(1)                                         # every BatchNorm layer's num_batches_tracked (shared storage)
         if self.dnn is not None:
@@ -1153,10 +1158,12 @@ class RAT_m2(BaseModel):
                                                                  act=self._dnn_acts[li], lib=lib)
                         sm = (sm, gstats)
                     else:
-                        a, sm, sr = ops.bn_relu_fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
-                                                    eps=m.eps, momentum=m.momentum, act=self._dnn_acts[li], lib=lib)
+                        fwd = ops.bn_act_fwd_strip if self._head_strips and B <= self._strip_fwd_rows and ops.bn_strip_ok(B, N, lib) else ops.bn_relu_fwd
+                        a, sm, sr = fwd(z, m.weight.data, m.bias.data, m.running_mean, m.running_var, training, True,
+                                        eps=m.eps, momentum=m.momentum, act=self._dnn_acts[li], lib=lib)
                 else:
-                    a, sm, sr = ops.bn_relu_fwd(z, None, None, None, None, training, False, act=self._dnn_acts[li], lib=lib)
+                    fwd = ops.bn_act_fwd_strip if self._head_strips and B <= self._strip_fwd_rows and ops.bn_strip_ok(B, N, lib) else ops.bn_relu_fwd
+                    a, sm, sr = fwd(z, None, None, None, None, training, False, act=self._dnn_acts[li], lib=lib)
                 a_act = a
                 if drop and pdrop > 0:                                      # net_dropout (deep.py:133-134)
                     a = ops.dropout(a_act, pdrop, seeds[1 + li], lib=lib)
@@ -1164,8 +1171,11 @@ class RAT_m2(BaseModel):
                     saved["dnn"].append((a_prev, lda, K, z, a_act, sm, sr))
                 a_prev, lda, K = a, N, N
             W, bvec = mods[self._dnn_out].weight.data, mods[self._dnn_out].bias.data
-            dnn_out = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
-            ops.sgemm(0, 1, B, 1, K, a_prev, lda, W, K, dnn_out, 1, bias=bvec, arith=self.gemm_arith, lib=lib)
+            if self._head_strips:                                           # the one-output Linear is evaluated inside rat_logit_fwd_dnn
+                dnn_last = (a_prev, lda, K, W, bvec)
+            else:
+                dnn_out = torch.empty((B, 1), dtype=torch.float32, device=x0.device)
+                ops.sgemm(0, 1, B, 1, K, a_prev, lda, W, K, dnn_out, 1, bias=bvec, arith=self.gemm_arith, lib=lib)
             if save:
                 saved["dnn_last"] = (a_prev, lda, K)
         # ---- encoder on the token grid
@@ -1178,7 +1188,7 @@ class RAT_m2(BaseModel):
         if loss is None:
             loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
         y_pred = ops.logit_fwd(x, cls_stride, self.fc.weight.data, self.fc.bias.data, dnn_out, self._lr_ftab, F, idx, T * L,
-                               y_true, loss, B, d, head=self._head, lib=lib)
+                               y_true, loss, B, d, head=self._head, dnn_last=dnn_last, lib=lib)
         reg = self._regularization_value() if with_reg else None
         if save:
             saved["x_final"], saved["cls_stride"], saved["y_pred"] = x, cls_stride, y_pred
@@ -1205,6 +1215,15 @@ class RAT_m2(BaseModel):
             raise RuntimeError("more than %d dropout layers" % self._DROP_WORDS)
         self._drop_cursor = i + 1
         return self._drop_step_words[i:i + 1]
+
+    # column-strip BatchNorm / activation launches (rat_bn_act_*_strip: one launch per layer and direction, the Linear's bias gradient and —
+    # last hidden layer — the one-output Linear's gradients included).  A strip work-group walks ALL rows of its 8 columns, so its time grows
+    # with the batch while the row-split two-launch forms spread a tall matrix over the chip: measured on MI355X (rocprofv3, N = 400) the
+    # forward strip wins up to 2048 rows (B = 512: 7.9 against 10.7 us; B = 4096: 25.4 against 17.6), the backward strip — which also
+    # replaces the two column-sum launches — up to 4096 (B = 4096: 29.2 against 39.8 us).  False = always the older forms.
+    _head_strips = True
+    _strip_fwd_rows = 2048
+    _strip_bwd_rows = 4096
 
     def _workspace(self, key, nbytes):
         ws = self._ws.get(key)
@@ -1239,43 +1258,79 @@ class RAT_m2(BaseModel):
         x_final, y_pred = saved["x_final"], saved["y_pred"]
         g_loss = g_loss.reshape(1).to(torch.float32).contiguous()
         # ---- head
-        dx = torch.zeros_like(x_final)
         cs = saved["cls_stride"]
-        dlogit = ops.logit_bwd(y_pred, y_true, x_final, cs, self.fc.weight.data, dx, cs, G("fc.weight"),
-                               G("fc.bias"), lr_gftab, F, idx, T * L, 1.0, B, d, gscale_dev=g_loss, head=self._head, lib=lib)
+        # the head's gradient lives on ONE token row per sample.  Where the last block's feed-forward backward can take it as compact
+        # rows (rat_ffn_bwd_res_rows) the [B][T][S][d] zero grid that used to carry it is never filled nor read.
+        dy_period = 0
+        if (not saved.get("pruned") and cs == T * S * d and len(saved["blocks"]) > 0 and self._head_strips
+                and type(self)._encoder_backward is RAT_m2._encoder_backward and ops.ffn_bwd_rows_supported(d, H, self.arith, lib)):
+            dy_period = T * S
+            dx = torch.empty((B, d), dtype=torch.float32, device=dev)
+        else:
+            dx = torch.zeros_like(x_final)
+        dcs = d if dy_period else cs
+        # the DNN's one-output Linear (deep.py:135-137) rides along with its neighbours when the last hidden layer runs as a column
+        # strip and has no Dropout behind it: bias gradient from rat_logit_bwd_dnn, weight gradient and the outer product da = dlogit W
+        # inside the last hidden layer's strip launch (rat_bn_act_bwd_strip_outer)
+        seeds = saved["seeds"]
+        fold = False
+        if self.dnn is not None and self._head_strips and saved["dnn"]:
+            (_, bn_l, pdrop_l), (_, _, _, z_l, _, sm_l, _) = self._dnn_layers[-1], saved["dnn"][-1]
+            fold = (not (seeds is not None and pdrop_l > 0) and not (bn_l is not None and isinstance(sm_l, tuple))
+                    and B <= self._strip_bwd_rows and ops.bn_strip_ok(B, z_l.shape[1], lib))
+        pre_out = "dnn.dnn.%d." % self._dnn_out if self.dnn is not None else None
+        dlogit = ops.logit_bwd(y_pred, y_true, x_final, cs, self.fc.weight.data, dx, dcs, G("fc.weight"),
+                               G("fc.bias"), lr_gftab, F, idx, T * L, 1.0, B, d, gscale_dev=g_loss, head=self._head,
+                               ddnn_b=G(pre_out + "bias") if fold else None, lib=lib)
         dflat = None
         if self.dnn is not None:
             mods = self.dnn.dnn
-            pre = "dnn.dnn.%d." % self._dnn_out
+            pre = pre_out
             a_prev, lda, K = saved["dnn_last"]
             W = mods[self._dnn_out].weight.data
-            ops.sgemm(1, 0, 1, K, B, dlogit, 1, a_prev, lda, G(pre + "weight"), K, arith=self.gemm_arith, lib=lib)       # dW = dlogit^T a
-            ops.colsum(dlogit, 1, G(pre + "bias"), B, 1, lib=lib)
-            da = torch.empty((B, K), dtype=torch.float32, device=dev)
-            ops.sgemm(0, 0, B, K, 1, dlogit, 1, W, K, da, K, arith=self.gemm_arith, lib=lib)                             # da = dlogit W
-            seeds = saved["seeds"]
+            da = None
+            if not fold:
+                ops.sgemm(1, 0, 1, K, B, dlogit, 1, a_prev, lda, G(pre + "weight"), K, arith=self.gemm_arith, lib=lib)       # dW = dlogit^T a
+                ops.colsum(dlogit, 1, G(pre + "bias"), B, 1, lib=lib)
+                da = torch.empty((B, K), dtype=torch.float32, device=dev)
+                ops.sgemm(0, 0, B, K, 1, dlogit, 1, W, K, da, K, arith=self.gemm_arith, lib=lib)                             # da = dlogit W
             for li, ((lin, bn, pdrop), (a_in, lda_in, K_in, z, a, sm, sr)) in reversed(list(enumerate(zip(self._dnn_layers, saved["dnn"])))):
                 N = z.shape[1]
                 if seeds is not None and pdrop > 0:
                     da = ops.dropout(da, pdrop, seeds[1 + li], out=da, lib=lib)
-                if bn is not None and isinstance(sm, tuple):                       # SyncBN (see _run_forward)
+                pre = "dnn.dnn.%d." % lin
+                strip = (self._head_strips and B <= self._strip_bwd_rows and not (bn is not None and isinstance(sm, tuple))
+                         and ops.bn_strip_ok(B, N, lib))
+                if da is None:                              # fold: the last hidden layer
+                    m = mods[bn] if bn is not None else None
+                    dz = ops.bn_act_bwd_strip_outer(z, a, dlogit, W, G(pre_out + "weight"), m.weight.data if m is not None else None,
+                                                    sm, sr, G("dnn.dnn.%d.weight" % bn) if m is not None else None,
+                                                    G("dnn.dnn.%d.bias" % bn) if m is not None else None, G(pre + "bias"),
+                                                    m is not None, act=self._dnn_acts[li], lib=lib)
+                elif bn is not None and isinstance(sm, tuple):                       # SyncBN (see _run_forward)
                     m = mods[bn]
                     dz = ops.bn_relu_bwd_sync(z, a, da, m.weight.data, sm[0], sr, G("dnn.dnn.%d.weight" % bn),
                                               G("dnn.dnn.%d.bias" % bn), self._all_reduce_sum, sm[1], act=self._dnn_acts[li], lib=lib)
+                elif strip:                                 # one launch: [BatchNorm backward +] activation backward + the Linear's bias gradient
+                    m = mods[bn] if bn is not None else None
+                    dz = ops.bn_act_bwd_strip(z, a, da, m.weight.data if m is not None else None, sm, sr,
+                                              G("dnn.dnn.%d.weight" % bn) if m is not None else None,
+                                              G("dnn.dnn.%d.bias" % bn) if m is not None else None, G(pre + "bias"), m is not None,
+                                              act=self._dnn_acts[li], lib=lib)
                 elif bn is not None:
                     m = mods[bn]
                     dz = ops.bn_relu_bwd(z, a, da, m.weight.data, sm, sr, G("dnn.dnn.%d.weight" % bn), G("dnn.dnn.%d.bias" % bn),
                                          True, act=self._dnn_acts[li], lib=lib)
                 else:
                     dz = ops.bn_relu_bwd(z, a, da, None, None, None, None, None, False, act=self._dnn_acts[li], lib=lib)
-                pre = "dnn.dnn.%d." % lin
                 ops.sgemm(1, 0, N, K_in, B, dz, N, a_in, lda_in, G(pre + "weight"), K_in, arith=self.gemm_arith, lib=lib)  # dW = dz^T a_in
-                ops.colsum(dz, N, G(pre + "bias"), B, N, lib=lib)
+                if not strip:
+                    ops.colsum(dz, N, G(pre + "bias"), B, N, lib=lib)
                 da = torch.empty((B, K_in), dtype=torch.float32, device=dev)
                 ops.sgemm(0, 0, B, K_in, N, dz, N, mods[lin].weight.data, K_in, da, K_in, arith=self.gemm_arith, lib=lib)   # da_in = dz W
             dflat = da                                                                             # [B, F*d]
         # ---- encoder, reversed
-        dx = self._encoder_backward(saved, dx, G)
+        dx = self._encoder_backward(saved, dx, G, dy_period=dy_period) if dy_period else self._encoder_backward(saved, dx, G)
         # every dense-net gradient (encoder, DNN, fc) is final now: add its regulariser term and, under data parallelism, start
         # its all-reduce — it travels over xGMI while the embedding-table gradients below are still being produced
         n_dense0 = self._n_emb - self._n_sparse

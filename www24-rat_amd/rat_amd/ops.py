@@ -437,6 +437,25 @@ def ffn_bwd_res(x, dy, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, add_dy, wo
     return dx, workspace
 
 
+def ffn_bwd_rows_supported(d, hidden, arith, lib=None):
+    return bool((lib or get_lib()).cdll.rat_ffn_bwd_rows_supported(int(d), int(hidden), ARITH[arith]))
+
+
+def ffn_bwd_rows(x, dy_rows, period, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidden, workspace=None, arith="bf16x3", planes=None, lib=None):
+    """ffn_bwd (residual from x itself) where dy is zero except on the token rows k * period, held compactly in dy_rows [*, d]"""
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy_rows, name="dy_rows")
+    ntok = x.numel() // d
+    assert dy_rows.numel() == (ntok + period - 1) // period * d, (tuple(dy_rows.shape), ntok, period)
+    need = lib.size("rat_ffn_bwd_workspace", d, hidden)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    lib.call("rat_ffn_bwd_res_rows", _p(x), _p(dy_rows), int(period), _p(dx), _p(w1), _p(b1), _p(w2), _p(b2), _p(dw1), _p(db1), _p(dw2),
+             _p(db2), _p(workspace), workspace.numel() * 4, _p(planes), ntok, d, hidden, 1, ARITH[arith], _stream(x))
+    return dx, workspace
+
+
 # ----------------------------------------------------------------------------- K2c
 def layernorm_fwd(x, x_stride, nrows, gamma, beta, d, eps=1e-5, lib=None):
     """LayerNorm of rows x[r * x_stride : r * x_stride + d] -> compact [nrows, d]."""
@@ -491,6 +510,45 @@ def bn_relu_fwd(z, gamma, beta, running_mean, running_var, training, use_bn, eps
     return a, save_mean, save_rstd
 
 
+def bn_strip_ok(M, N, lib=None):
+    return bool((lib or get_lib()).cdll.rat_bn_strip_ok(int(M), int(N)))
+
+
+def bn_act_fwd_strip(z, gamma, beta, running_mean, running_var, training, use_bn, eps=1e-5, momentum=0.1, act=0, lib=None):
+    """bn_relu_fwd in one launch (column strips; N % 4 == 0)"""
+    lib = lib or get_lib()
+    _chk(z, name="z")
+    M, N = z.shape
+    a = torch.empty_like(z)
+    save_mean = save_rstd = None
+    if use_bn and training:
+        save = torch.empty((2, (N + 3) // 4 * 4), dtype=torch.float32, device=z.device)
+        save_mean, save_rstd = save[0, :N], save[1, :N]
+    lib.call("rat_bn_act_fwd_strip", _p(z), _p(a), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(save_mean),
+             _p(save_rstd), M, N, int(training), int(use_bn), eps, momentum, int(act), _stream(z))
+    return a, save_mean, save_rstd
+
+
+def bn_act_bwd_strip(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, dbias_lin, use_bn, act=0, lib=None):
+    """bn_relu_bwd + colsum(dz) -> dbias_lin in one launch"""
+    lib = lib or get_lib()
+    M, N = z.shape
+    dz = torch.empty_like(z)
+    lib.call("rat_bn_act_bwd_strip", _p(z), _p(a), _p(da), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd), _p(dgamma), _p(dbeta),
+             _p(dbias_lin), M, N, int(use_bn), int(act), _stream(z))
+    return dz
+
+
+def bn_act_bwd_strip_outer(z, a, dl, w, dw, gamma, save_mean, save_rstd, dgamma, dbeta, dbias_lin, use_bn, act=0, lib=None):
+    """bn_act_bwd_strip of the last hidden layer with da = dl (x) w formed in the kernel; dw <- sum_r dl[r] a[r][:]"""
+    lib = lib or get_lib()
+    M, N = z.shape
+    dz = torch.empty_like(z)
+    lib.call("rat_bn_act_bwd_strip_outer", _p(z), _p(a), _p(dl), _p(w), _p(dw), _p(dz), _p(gamma), _p(save_mean), _p(save_rstd),
+             _p(dgamma), _p(dbeta), _p(dbias_lin), M, N, int(use_bn), int(act), _stream(z))
+    return dz
+
+
 def bn_relu_bwd(z, a, da, gamma, save_mean, save_rstd, dgamma, dbeta, use_bn, act=0, lib=None):
     lib = lib or get_lib()
     M, N = z.shape
@@ -541,20 +599,34 @@ def colsum(a, lda, out, M, N, lib=None):
     lib.call("rat_colsum", _p(a), lda, _p(out), _p(ws), M, N, _stream(out))
 
 
-def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_stride, y_true, loss_sum, B, d, head=0, lib=None):
-    """head: 0 = sigmoid + binary cross-entropy, 1 = no output activation + mean squared error (task "regression")"""
+def logit_fwd(cls, cls_stride, fc_w, fc_b, dnn_out, lr_ftab, nfields, idx, idx_stride, y_true, loss_sum, B, d, head=0, dnn_last=None,
+              lib=None):
+    """head: 0 = sigmoid + binary cross-entropy, 1 = no output activation + mean squared error (task "regression")
+    dnn_last = (a [B][K], lda, K, w [1][K], b [1]): the DNN's one-output Linear is evaluated inside the launch (dnn_out must be None)"""
     lib = lib or get_lib()
     y_pred = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
+    if dnn_last is not None:
+        assert dnn_out is None
+        a, lda, K, w, b = dnn_last
+        lib.call("rat_logit_fwd_dnn", _p(cls), cls_stride, _p(fc_w), _p(fc_b), _p(a), lda, _p(w), _p(b), K, _p(lr_ftab), nfields,
+                 _p(idx), idx_stride, _p(y_true), _p(y_pred), _p(loss_sum), B, d, int(head), _stream(fc_w))
+        return y_pred
     lib.call("rat_logit_fwd", _p(cls), cls_stride, _p(fc_w), _p(fc_b), _p(dnn_out), _p(lr_ftab), nfields, _p(idx),
              idx_stride, _p(y_true), _p(y_pred), _p(loss_sum), B, d, int(head), _stream(fc_w))
     return y_pred
 
 
 def logit_bwd(y_pred, y_true, cls, cls_stride, fc_w, dcls, dcls_stride, dfc_w, dfc_b, lr_gftab, nfields, idx, idx_stride,
-              gscale, B, d, gscale_dev=None, head=0, lib=None):
-    """gscale: host factor; gscale_dev: optional DEVICE scalar multiplied in by the kernel (autograd's incoming gradient)."""
+              gscale, B, d, gscale_dev=None, head=0, ddnn_b=None, lib=None):
+    """gscale: host factor; gscale_dev: optional DEVICE scalar multiplied in by the kernel (autograd's incoming gradient).
+    ddnn_b: also accumulate sum_b dlogit[b] there (bias gradient of the DNN's one-output Linear)"""
     lib = lib or get_lib()
     dlogit = torch.empty((B, 1), dtype=torch.float32, device=fc_w.device)
+    if ddnn_b is not None:
+        lib.call("rat_logit_bwd_dnn", _p(y_pred), _p(y_true), _p(cls), cls_stride, _p(fc_w), _p(dlogit), _p(dcls), dcls_stride,
+                 _p(dfc_w), _p(dfc_b), _p(ddnn_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), _p(gscale_dev), B, d,
+                 int(head), _stream(fc_w))
+        return dlogit
     lib.call("rat_logit_bwd", _p(y_pred), _p(y_true), _p(cls), cls_stride, _p(fc_w), _p(dlogit), _p(dcls), dcls_stride,
              _p(dfc_w), _p(dfc_b), _p(lr_gftab), nfields, _p(idx), idx_stride, float(gscale), _p(gscale_dev), B, d, int(head),
              _stream(fc_w))
