@@ -432,6 +432,11 @@ int rat_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const
  *                      kernel arguments.
  * rat_adam_rows_dev  : rat_adam_rows with the two step scalars read from hyper_dev. */
 int rat_adam_tick(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_out, void* stream);
+/* ABI v7 — what a fused training iteration starts with, in one launch: rat_adam_tick, scalars[0 .. nscalars) = 0 (the step's
+ * accumulators: BCE sum, clip norm^2, regulariser value) and counters[i] += 1 for i < ncounters (nn.BatchNorm1d.num_batches_tracked of
+ * every BatchNorm layer, int64).  Either list may be empty. */
+int rat_step_begin(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_out, float* scalars, int nscalars,
+                   int64_t* counters, int ncounters, void* stream);
 int rat_sumsq_reg(const float* g, const float* w, int64_t n, int64_t n_split, float lam_a, float lam_b,
                   const float* lam_scale_dev, float* norm_sq_out, float* reg_out, void* stream);
 int rat_clip_adam_fused(float* w, float* g, float* m, float* v, int64_t n, int64_t n_split, float lam_a, float lam_b,

@@ -657,3 +657,20 @@ def check_optim(lib, dev, n):
     close(md, mr, 1e-5, 1e-7, "m")
     close(vd, vr, 1e-5, 1e-8, "v")
     close(wd, wr, 1e-5, 1e-6, "w")
+
+
+def check_step_begin(lib, dev):
+    """rat_step_begin == rat_adam_tick + cleared accumulator scalars + advanced BatchNorm counters"""
+    lr = torch.tensor([3e-3], device=dev)
+    s1, s2 = torch.tensor([4], dtype=torch.int32, device=dev), torch.tensor([4], dtype=torch.int32, device=dev)
+    h1, h2 = torch.zeros(4, device=dev), torch.zeros(4, device=dev)
+    scal = torch.tensor([1.0, 2.0, 3.0, 4.0], device=dev)
+    counts = torch.tensor([7, 7, 9], dtype=torch.int64, device=dev)
+    ops.adam_tick(s1, lr, 0.9, 0.999, h1, lib=lib)
+    ops.step_begin(s2, lr, 0.9, 0.999, h2, scal, counts, lib=lib)
+    assert int(s1) == int(s2) == 5 and torch.equal(h1.cpu(), h2.cpu())
+    assert float(scal.abs().sum()) == 0.0 and counts.tolist() == [8, 8, 10]
+    ops.step_begin(s2, lr, 0.9, 0.999, h2, scal, None, lib=lib)
+    assert int(s2) == 6
+    want = 3e-3 / (1 - 0.9 ** 6)
+    assert abs(float(h2[0]) - want) < 1e-6 * want and abs(float(h2[1]) - (1 - 0.999 ** 6) ** -0.5) < 1e-4, h2

@@ -201,6 +201,10 @@ def test_logit_fwd_bwd(emu, with_dnn, with_lr):
     kc.check_logit(emu, "cpu", 9, 8, with_dnn, with_lr)
 
 
+def test_step_begin(emu):
+    kc.check_step_begin(emu, "cpu")
+
+
 def test_l2_sumsq_clip_adam(emu):
     kc.check_optim(emu, "cpu", 777)
 

@@ -190,6 +190,10 @@ def test_logit_fwd_bwd(lib, with_dnn, with_lr):
     kc.check_logit(lib, "cuda", 1000, 64, with_dnn, with_lr)
 
 
+def test_step_begin(lib):
+    kc.check_step_begin(lib, "cuda")
+
+
 def test_l2_sumsq_clip_adam(lib):
     kc.check_optim(lib, "cuda", 1000003)
 

@@ -21,3 +21,4 @@ for f in sorted(glob.glob("$out/bench_*.json")):
         d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], d["value"], d["ms_per_step"])
     except Exception as e: print(f, "ERR", e)
 PY
+rocprofv3 --kernel-trace --stats -d $out/prof_mltag -o r --output-format csv -- python3 bench.py --workload mltag_like_K10_d16_B256 --steps 50 --warmup 3 --no-cpu-baseline --no-extras > $out/bench_mltag_under_rocprof.json 2>> $out/rocprof.err

@@ -248,25 +248,53 @@ gather_bwd_fields64_kernel(const float* __restrict__ dgrid, const float* __restr
     }
 }
 
-// label-token rows: only 3 destination rows -> reduce inside the block first (LDS), then 3*d atomics per block
+// label-token rows: only 3 destination rows.  Thread = (column, row group) keeps its three label rows in registers over the block's slice
+// of the (sample, target / retrieved) rows (four rows in flight), row groups meet in LDS, then 3 d atomics per block.  (The first
+// version added every element to LDS with an atomic: 28 us at the north-star shape, all of it contention on 3 d addresses.)
 __global__ void __launch_bounds__(GATHER_THREADS)
 gather_bwd_label_kernel(const float* __restrict__ dgrid, const int32_t* __restrict__ label_ids,
                         float* __restrict__ dlabel, int64_t nbt, int S, int d) {
     RAT_DYN_SMEM(smem);
-    float* part = reinterpret_cast<float*>(smem);            // [3][d]
-    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) part[i] = 0.f;
-    __syncthreads();
-    const int64_t nitems = nbt * d;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nitems; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % d);
-        const int64_t bt = e / d;
-        int lab = label_ids[bt];
-        lab = lab < 0 ? 0 : (lab > 2 ? 2 : lab);
-        atomicAdd(&part[lab * d + c], dgrid[(bt * S) * d + c]);
+    float* red = reinterpret_cast<float*>(smem);             // [groups][3][d]
+    const int groups = GATHER_THREADS / d;                   // d <= GATHER_THREADS (checked on the host)
+    const int c = threadIdx.x % d, rg = threadIdx.x / d;
+    const int64_t per = (nbt + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < nbt ? r0 + per : nbt;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (rg < groups) {
+        int64_t bt = r0 + rg;
+        for (; bt + 3 * groups < r1; bt += 4 * groups) {
+            float g[4];
+            int lab[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = dgrid[((bt + (int64_t)u * groups) * S) * d + c];
+                lab[u] = label_ids[bt + (int64_t)u * groups];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0 += lab[u] <= 0 ? g[u] : 0.f;
+                a1 += lab[u] == 1 ? g[u] : 0.f;
+                a2 += lab[u] >= 2 ? g[u] : 0.f;
+            }
+        }
+        for (; bt < r1; bt += groups) {
+            const float g = dgrid[(bt * S) * d + c];
+            const int lab = label_ids[bt];
+            a0 += lab <= 0 ? g : 0.f;
+            a1 += lab == 1 ? g : 0.f;
+            a2 += lab >= 2 ? g : 0.f;
+        }
+        red[(rg * 3 + 0) * d + c] = a0;
+        red[(rg * 3 + 1) * d + c] = a1;
+        red[(rg * 3 + 2) * d + c] = a2;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x)
-        if (part[i] != 0.f) atomicAdd(&dlabel[i], part[i]);
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < groups; ++k) s += red[k * 3 * d + i];
+        if (s != 0.f) atomicAdd(&dlabel[i], s);
+    }
 }
 
 // deterministic variant of the label-row gradient: every block owns a fixed slice of the (sample, target/retrieved) rows, thread =
@@ -387,10 +415,11 @@ extern "C" int rat_gather_bwd(const float* dgrid, const float* dflat, const int3
                        idx, grad_fields_dev, nbt, T, S, L, d);
     }
     if (dlabel_table) {
-        int blocks = pick_blocks(nbt * d, 16);
+        RAT_REQUIRE(d <= GATHER_THREADS, "embedding_dim above the block size");
+        int64_t blocks = (nbt + 15) / 16;                      // at least 16 rows per work-group
         if (blocks > 256) blocks = 256;
-        RAT_LAUNCH(gather_bwd_label_kernel, blocks, GATHER_THREADS, (size_t)3 * d * sizeof(float), stream, dgrid,
-                   label_ids, dlabel_table, nbt, S, d);
+        RAT_LAUNCH(gather_bwd_label_kernel, (unsigned)blocks, GATHER_THREADS, (size_t)(GATHER_THREADS / d) * 3 * d * sizeof(float), stream,
+                   dgrid, label_ids, dlabel_table, nbt, S, d);
     }
     return rat_check_launch("rat_gather_bwd");
 }

@@ -265,6 +265,23 @@ __global__ void adam_tick_kernel(int32_t* step, const float* lr, float beta1, fl
     hyper[2] = *lr;
 }
 
+// the bookkeeping a training iteration starts with, in ONE launch: the clock tick above, the step's accumulator scalars cleared
+// (BCE sum | clip norm^2 | regulariser value | spare) and every BatchNorm layer's num_batches_tracked advanced
+__global__ void step_begin_kernel(int32_t* step, const float* lr, float beta1, float beta2, float* hyper, float* scalars, int nscalars,
+                                  int64_t* counters, int ncounters) {
+    if (blockIdx.x != 0) return;
+    for (int i = threadIdx.x; i < nscalars; i += blockDim.x) scalars[i] = 0.f;
+    for (int i = threadIdx.x; i < ncounters; i += blockDim.x) counters[i] += 1;
+    if (threadIdx.x != 0) return;
+    const int s = *step + 1;
+    *step = s;
+    const double bc1 = 1.0 - pow((double)beta1, (double)s);
+    const double bc2 = 1.0 - pow((double)beta2, (double)s);
+    hyper[0] = (float)((double)*lr / bc1);
+    hyper[1] = (float)(1.0 / sqrt(bc2));
+    hyper[2] = *lr;
+}
+
 int opt_blocks(int64_t n) {
     int64_t b = (n + OPT_THREADS * 4 - 1) / (OPT_THREADS * 4);
     if (b < 1) b = 1;
@@ -307,6 +324,14 @@ extern "C" int rat_adam_tick(int32_t* step_dev, const float* lr_dev, float beta1
     RAT_REQUIRE(step_dev && lr_dev && hyper_out, "bad args");
     RAT_LAUNCH(adam_tick_kernel, 1, 64, 0, stream, step_dev, lr_dev, beta1, beta2, hyper_out);
     return rat_check_launch("rat_adam_tick");
+}
+
+extern "C" int rat_step_begin(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_out, float* scalars,
+                              int nscalars, int64_t* counters, int ncounters, void* stream) {
+    RAT_REQUIRE(step_dev && lr_dev && hyper_out && nscalars >= 0 && ncounters >= 0 && (scalars || nscalars == 0) && (counters || ncounters == 0),
+                "bad args");
+    RAT_LAUNCH(step_begin_kernel, 1, 64, 0, stream, step_dev, lr_dev, beta1, beta2, hyper_out, scalars, nscalars, counters, ncounters);
+    return rat_check_launch("rat_step_begin");
 }
 
 extern "C" int rat_sumsq_reg(const float* g, const float* w, int64_t n, int64_t n_split, float lam_a, float lam_b,

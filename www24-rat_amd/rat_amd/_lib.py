@@ -118,6 +118,7 @@ _SIGNATURES = {
     "rat_dropout_seeds": (c_int, [_P, c_int, ctypes.c_uint64, _P, _P]),
     "rat_clip_adam": (c_int, [_P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
     "rat_adam_tick": (c_int, [_P, _P, c_float, c_float, _P, _P]),
+    "rat_step_begin": (c_int, [_P, _P, c_float, c_float, _P, _P, c_int, _P, c_int, _P]),
     "rat_sumsq_reg": (c_int, [_P, _P, c_int64, c_int64, c_float, c_float, _P, _P, _P, _P]),
     "rat_clip_adam_fused": (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_float, c_float, _P, _P, c_float, _P, c_float, c_float, c_float,
                                     c_int, _P]),

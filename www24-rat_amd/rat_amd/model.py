@@ -1005,9 +1005,11 @@ class RAT_m2(BaseModel):
         world = self._world_size()
         inv = self._inv_world()
         # the step's accumulator scalars — BCE sum, clip norm^2, regulariser value — share one 4-float tensor: ONE fill per step
-        scal = self.optimizer.step_scalars()
-        scal.zero_()
+        # (rat_step_begin: that fill, the optimizer's clock tick and the BatchNorm layers' num_batches_tracked in one launch)
+        counts = self._bn_counts if self.training else None
+        scal = self.optimizer.begin_step(counts, count=count)
         self._step_loss = scal[0:1]
+        self._bn_counted = counts is not None
         _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
         if self._graph_test_splits:
             self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
@@ -1016,7 +1018,7 @@ class RAT_m2(BaseModel):
             self._collective(lambda: None)
         g = self._last_gflat
         self._exchange_gradients(g)
-        reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count, zeroed=True)
+        reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count, zeroed=True, ticked=True)
         self._gbuf_clean = self._gbuf is not None and g is self._gbuf[0]
         total = loss + reg[0]
         return total if world == 1 else total * inv[0]
@@ -1140,7 +1142,7 @@ class RAT_m2(BaseModel):
         saved["seeds"] = seeds
         # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
         dnn_out = dnn_last = None
-        if training and self._bn_counts is not None:
+        if training and self._bn_counts is not None and not self.__dict__.pop("_bn_counted", False):
             self._bn_counts.add_(1)                                         # every BatchNorm layer's num_batches_tracked (shared storage)
         if self.dnn is not None:
             mods = self.dnn.dnn

@@ -702,6 +702,16 @@ def adam_tick(step_dev, lr_dev, beta1, beta2, hyper, lib=None):
     lib.call("rat_adam_tick", _p(step_dev), _p(lr_dev), float(beta1), float(beta2), _p(hyper), _stream(hyper))
 
 
+def step_begin(step_dev, lr_dev, beta1, beta2, hyper, scalars, counters=None, lib=None):
+    """adam_tick + scalars[:] = 0 + counters[:] += 1 (int64) in one launch"""
+    lib = lib or get_lib()
+    _chk(step_dev, torch.int32, "step_dev"), _chk(lr_dev, name="lr_dev"), _chk(hyper, name="hyper"), _chk(scalars, name="scalars")
+    if counters is not None:
+        _chk(counters, torch.int64, "counters")
+    lib.call("rat_step_begin", _p(step_dev), _p(lr_dev), float(beta1), float(beta2), _p(hyper), _p(scalars), scalars.numel(),
+             _p(counters), counters.numel() if counters is not None else 0, _stream(hyper))
+
+
 def sumsq_reg(g, w, n_split, lam_a, lam_b, norm_sq_out, reg_out=None, lam_scale_dev=None, lib=None):
     lib = lib or get_lib()
     assert g.numel() == w.numel()

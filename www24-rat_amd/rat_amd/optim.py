@@ -98,6 +98,19 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._buffers()
         return self._scal
 
+    def begin_step(self, counters=None, count=True):
+        """first launch of a fused iteration (rat_step_begin): clock tick, accumulator scalars cleared, `counters` (int64, the BatchNorm
+        layers' num_batches_tracked; None = none) advanced — fused_step(..., zeroed=True, ticked=True) follows at the end of the step"""
+        step_dev, lr_dev, hyper = self._clock()
+        self._buffers()
+        group = self.param_groups[0]
+        b1, b2 = group.get("betas", (0.9, 0.999))
+        ops.step_begin(step_dev, lr_dev, b1, b2, hyper, self._scal, counters, lib=self._model._lib)
+        if count:
+            self._step += 1
+            self._clock_step = self._step
+        return self._scal
+
     def prepare_step(self):
         """host -> device synchronisation of the clock; cheap, and a no-op unless the learning rate changed (lr_decay) or the step
         count was set from outside (load_state_dict).  Never called while a graph is being captured."""
@@ -112,7 +125,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             self._clock_step = self._step
 
     @torch.no_grad()
-    def fused_step(self, grad, max_norm, count=True, zeroed=False):
+    def fused_step(self, grad, max_norm, count=True, zeroed=False, ticked=False):
         """clip_grad_norm_(max_norm) + Adam + zero_grad over the flat buffers with the regulariser folded in (rat_sumsq_reg,
         rat_clip_adam_fused): `grad` is the flat gradient WITHOUT the lambda*W terms; afterwards it holds zeros.  Returns the
         regulariser's value (device scalar, (lambda/2)||W||^2 over the tensors the reference regularises).  Call prepare_step()
@@ -129,10 +142,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         lib = model._lib
         if self._kind != 0 and sparse:
             raise NotImplementedError("row-sparse table gradients are wired for Adam only")
-        ops.adam_tick(step_dev, lr_dev, b1, b2, hyper, lib=lib)
-        if count:
-            self._step += 1
-            self._clock_step = self._step
+        if not ticked:                                               # ticked: begin_step() advanced the clock at the start of this iteration
+            ops.adam_tick(step_dev, lr_dev, b1, b2, hyper, lib=lib)
+            if count:
+                self._step += 1
+                self._clock_step = self._step
         acc = self._scal[1:2] if zeroed else self._norm_sq           # zeroed: step_scalars() was cleared at the start of this step
         if not zeroed:
             self._norm_sq.zero_()
