@@ -228,6 +228,14 @@ int rat_ffn_bwd_res_rows(const float* x, const float* dy_rows, int64_t dy_period
                          size_t workspace_bytes, const void* planes, int64_t ntok, int d, int hidden, int add_dy, int arith,
                          void* stream);
 
+/* ABI v7 — one reduction launch for a whole backward pass.  rat_attn_bwd* / rat_ffn_bwd* / rat_layernorm_bwd each end with a launch
+ * that sums their per-work-group gradient slabs (in `workspace`) into the weight gradients.  Between rat_reduce_defer_begin() and
+ * rat_reduce_defer_end(stream, 1) of the SAME host thread those launches are recorded instead and run together at the end (one launch
+ * per 80 outputs; same sums in the same order).  Contract: every call in between gets a `workspace` of its own that stays untouched
+ * until the end call, and nothing reads the weight gradients before it.  run = 0 drops the record (error unwinding). */
+int rat_reduce_defer_begin(void);
+int rat_reduce_defer_end(void* stream, int run);
+
 /* ---- K2c: stand-alone nn.LayerNorm(d) (biased variance, affine) over selected token rows — RAT_m1's PreNorm in front of
  * FeedForward and the final `self.norm` of each Transformer (RAT_m1.py:137-141,198,209), of which only token 0 of every
  * sequence is read (RAT_m1.py:125,128).  Row r is read at x + r * x_stride; y is a compact [nrows][d]. */

@@ -674,3 +674,35 @@ def check_step_begin(lib, dev):
     assert int(s2) == 6
     want = 3e-3 / (1 - 0.9 ** 6)
     assert abs(float(h2[0]) - want) < 1e-6 * want and abs(float(h2[1]) - (1 - 0.999 ** 6) ** -0.5) < 1e-4, h2
+
+
+def check_deferred_reductions(lib, dev, arith="f32"):
+    """three backward calls (two feed-forward layers, one attention layer) with their slab reductions recorded and run as ONE launch
+    (rat_reduce_defer_begin / _end) == the same calls with their own reduction launches, bit for bit"""
+    rs = np.random.RandomState(41)
+    d, hidden, ntok = 64, 128, 300
+    x, dy = rnd(rs, ntok, d).to(dev), rnd(rs, ntok, d).to(dev)
+    ws = [w.to(dev) for w in (rnd(rs, hidden, d, scale=d ** -0.5), 0.1 * rnd(rs, hidden), rnd(rs, d, hidden, scale=hidden ** -0.5), 0.1 * rnd(rs, d))]
+    B, T, S, heads, dh = 3, 4, 5, 8, 10
+    xa, dya = rnd(rs, B, T, S, d).to(dev), rnd(rs, B, T, S, d).to(dev)
+    aw = [t.to(dev) if t is not None else None for t in attn_weights(rs, d, heads, dh, True)]
+    params = ops.attn_params(*aw)
+    smap = ops.intra_map(B, T, S)
+    y, o, lse = ops.attn_fwd(xa, params, smap, d, heads, dh, save=True, arith=arith, lib=lib)
+
+    def run(defer):
+        g1 = [torch.zeros_like(w) for w in ws]
+        g2 = [torch.zeros_like(w) for w in ws]
+        ga = [torch.zeros_like(t) for t in aw]
+        with ops.deferred_reductions(x, lib, enabled=defer):
+            dx1, w1 = ops.ffn_bwd_res(x, dy, *ws, g1[0], g1[1], g1[2], g1[3], d, hidden, add_dy=True, arith=arith, lib=lib)
+            dx2, w2 = ops.ffn_bwd_res(x, dx1, *ws, g2[0], g2[1], g2[2], g2[3], d, hidden, add_dy=False, arith=arith, lib=lib)
+            dxa, w3 = ops.attn_bwd(xa, dya, o, lse, params, ops.attn_params(*ga), smap, d, heads, dh, arith=arith, lib=lib)
+            if defer:
+                assert float(g1[0].abs().sum()) == 0.0 or dev == "cuda"     # (the launches are asynchronous on the GPU; on the emulator nothing ran yet)
+        return [dx1, dx2, dxa] + g1 + g2 + ga
+
+    a, b = run(False), run(True)
+    for u, v in zip(a, b):
+        assert torch.equal(u.cpu(), v.cpu())
+    assert float(b[3].abs().sum()) > 0 and float(b[-1].abs().sum()) > 0

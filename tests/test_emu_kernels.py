@@ -201,6 +201,10 @@ def test_logit_fwd_bwd(emu, with_dnn, with_lr):
     kc.check_logit(emu, "cpu", 9, 8, with_dnn, with_lr)
 
 
+def test_slab_reductions_of_several_layers_in_one_launch(emu, two_blocks):
+    kc.check_deferred_reductions(emu, "cpu")
+
+
 def test_step_begin(emu):
     kc.check_step_begin(emu, "cpu")
 

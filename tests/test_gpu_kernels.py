@@ -190,6 +190,11 @@ def test_logit_fwd_bwd(lib, with_dnn, with_lr):
     kc.check_logit(lib, "cuda", 1000, 64, with_dnn, with_lr)
 
 
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_slab_reductions_of_several_layers_in_one_launch(lib, arith):
+    kc.check_deferred_reductions(lib, "cuda", arith)
+
+
 def test_step_begin(lib):
     kc.check_step_begin(lib, "cuda")
 

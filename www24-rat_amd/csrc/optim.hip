@@ -289,18 +289,29 @@ int opt_blocks(int64_t n) {
     return (int)b;
 }
 
+// grids of the reducing sweeps: every work-group ends with one or two atomic adds onto ONE address, which the L2 serialises (~10 ns
+// each).  2048 work-groups hide that behind a 0.5 GB stream; on a small model (BASELINE configs[0]: 2.4 M parameters) they WERE the kernel
+// — 50 us for a 10 MB read.  Below 16 M elements a work-group takes at least 8192 of them.
+int red_blocks(int64_t n) {
+    if (n >= ((int64_t)16 << 20)) return opt_blocks(n);
+    int64_t b = (n + 8191) / 8192;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
 }  // namespace
 
 extern "C" int rat_l2_reg(const float* w, float* g, int64_t n, float lambda, const float* lambda_scale_dev, float* reg_out,
                           void* stream) {
     RAT_REQUIRE(n > 0 && w && g, "bad args");
-    RAT_LAUNCH(l2_reg_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, w, g, n, lambda, lambda_scale_dev, reg_out);
+    RAT_LAUNCH(l2_reg_kernel, red_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, w, g, n, lambda, lambda_scale_dev, reg_out);
     return rat_check_launch("rat_l2_reg");
 }
 
 extern "C" int rat_sumsq(const float* g, int64_t n, float* norm_sq_out, void* stream) {
     RAT_REQUIRE(n > 0 && g && norm_sq_out, "bad args");
-    RAT_LAUNCH(sumsq_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, g, n, norm_sq_out);
+    RAT_LAUNCH(sumsq_kernel, red_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, g, n, norm_sq_out);
     return rat_check_launch("rat_sumsq");
 }
 
@@ -338,7 +349,7 @@ extern "C" int rat_sumsq_reg(const float* g, const float* w, int64_t n, int64_t 
                              const float* lam_scale_dev, float* norm_sq_out, float* reg_out, void* stream) {
     RAT_REQUIRE(n > 0 && g && w && norm_sq_out && n_split >= 0 && n_split <= n, "bad args");
     const int vec = opt_vec_ok({g, w}, n_split) ? 1 : 0;
-    RAT_LAUNCH(sumsq_reg_kernel, opt_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, g, w, n, n_split, lam_a, lam_b, lam_scale_dev,
+    RAT_LAUNCH(sumsq_reg_kernel, red_blocks(n), OPT_THREADS, 16 * sizeof(float), stream, g, w, n, n_split, lam_a, lam_b, lam_scale_dev,
                norm_sq_out, reg_out, vec);
     return rat_check_launch("rat_sumsq_reg");
 }

@@ -1,6 +1,7 @@
 // rat_common.hip — error reporting, ABI version, slab reduction shared by the backward kernels.
 #include "rat_device.h"
 #include <stdlib.h>
+#include <vector>
 #include "../../include/rat_hip.h"
 
 static thread_local std::string g_last_error;
@@ -76,8 +77,99 @@ __global__ void __launch_bounds__(256) rat_reduce_slabs_kernel(RatReduceArgs r) 
     if (quarter == 0 && p < r.size[o]) r.out[o][p] = ((part[lane_p] + part[64 + lane_p]) + part[128 + lane_p]) + part[192 + lane_p];
 }
 
+// ---- deferred slab reductions (ABI v7: rat_reduce_defer_begin / rat_reduce_defer_end).  Every backward kernel of an encoder layer ends
+// with a slab reduction of its own — twelve launches of ~6 us per step at depth 4, a tenth of the step at BASELINE configs[0].  Nothing
+// reads those gradients before the optimizer, so a caller that gives every layer its OWN slab workspace may record the reductions
+// instead and run them all in one launch.  The record is per host thread; the sums and their order are those of the single launches.
+struct RatReduceEntry {
+    const float* src;           // slabs + offset of this output
+    float* out;
+    int64_t size, stride;
+    int nslabs, first_block;
+};
+constexpr int RAT_REDUCE_BATCH = 80;                  // 80 x 40 bytes of kernel arguments
+struct RatReduceTable {
+    RatReduceEntry e[RAT_REDUCE_BATCH];
+    int n, blocks;
+};
+static thread_local bool g_defer = false;
+static thread_local std::vector<RatReduceEntry> g_deferred;
+
+__global__ void __launch_bounds__(256) rat_reduce_slabs_batch_kernel(RatReduceTable t) {
+    __shared__ float part[256];
+    int o = 0;
+    while (o + 1 < t.n && (int)blockIdx.x >= t.e[o + 1].first_block) ++o;
+    const RatReduceEntry& r = t.e[o];
+    const int lane_p = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int64_t p = ((int64_t)blockIdx.x - r.first_block) * 64 + lane_p;
+    float s = 0.f;
+    if (p < r.size) {                                  // the arithmetic of rat_reduce_slabs_kernel, summand for summand
+        const int per = (r.nslabs + 3) / 4;
+        const int w0 = quarter * per, w1 = (w0 + per < r.nslabs) ? w0 + per : r.nslabs;
+        const float* src = r.src + p;
+        int w = w0;
+        for (; w + 8 <= w1; w += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(int64_t)(w + k) * r.stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; w < w1; ++w) s += src[(int64_t)w * r.stride];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (quarter == 0 && p < r.size) r.out[p] = ((part[lane_p] + part[64 + lane_p]) + part[128 + lane_p]) + part[192 + lane_p];
+}
+
+static int rat_flush_deferred(void* stream) {
+    size_t i = 0;
+    while (i < g_deferred.size()) {
+        RatReduceTable t{};
+        int blocks = 0;
+        while (i < g_deferred.size() && t.n < RAT_REDUCE_BATCH) {
+            RatReduceEntry e = g_deferred[i++];
+            e.first_block = blocks;
+            blocks += (int)((e.size + 63) / 64);
+            t.e[t.n++] = e;
+        }
+        t.blocks = blocks;
+        RAT_LAUNCH(rat_reduce_slabs_batch_kernel, (unsigned)blocks, 256, 0, stream, t);
+        if (rat_check_launch("rat_reduce_slabs (batch)")) {
+            g_deferred.clear();
+            return -1;
+        }
+    }
+    g_deferred.clear();
+    return 0;
+}
+
+extern "C" int rat_reduce_defer_begin(void) {
+    RAT_REQUIRE(!g_defer, "rat_reduce_defer_begin: already recording");
+    g_defer = true;
+    g_deferred.clear();
+    return 0;
+}
+
+extern "C" int rat_reduce_defer_end(void* stream, int run) {
+    RAT_REQUIRE(g_defer, "rat_reduce_defer_end without rat_reduce_defer_begin");
+    g_defer = false;
+    if (!run) {                                         // the caller is unwinding from an error: drop the record
+        g_deferred.clear();
+        return 0;
+    }
+    return rat_flush_deferred(stream);
+}
+
 int rat_launch_reduce_slabs(const float* slabs, int nslabs, int64_t stride, float* const* outs_host,
                             const int64_t* offsets, const int64_t* sizes, int nouts, void* stream) {
+    if (g_defer) {
+        for (int i = 0; i < nouts; ++i) {
+            if (!outs_host[i] || sizes[i] <= 0) continue;
+            g_deferred.push_back(RatReduceEntry{slabs + offsets[i], outs_host[i], sizes[i], stride, nslabs, 0});
+        }
+        return 0;
+    }
     RatReduceArgs r{};
     r.slabs = slabs;
     r.nslabs = nslabs;

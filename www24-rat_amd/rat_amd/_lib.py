@@ -64,6 +64,8 @@ _SIGNATURES = {
     "rat_bm25_topk_grouped": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, _P]),
     "rat_ffn_fwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P]),
     "rat_ffn_bwd_res": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
+    "rat_reduce_defer_begin": (c_int, []),
+    "rat_reduce_defer_end": (c_int, [_P, c_int]),
     "rat_ffn_bwd_rows_supported": (c_int, [c_int, c_int, c_int]),
     "rat_ffn_bwd_res_rows": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P, c_int64, c_int, c_int, c_int, c_int, _P]),
     "rat_ffn_fwd_drop": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, _P]),

@@ -409,13 +409,13 @@ class RAT_m2(BaseModel):
             ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, y, d, bias=b_out, beta=1.0, arith=self.gemm_arith, lib=lib)  # to_out + x
         return y, ((qkv, o, lse, drop) if save else None)
 
-    def _attn_layer_backward(self, desc, x_in, dy, att, smap, G, out=None):
+    def _attn_layer_backward(self, desc, x_in, dy, att, smap, G, out=None, ws_key="attn"):
         c, lib = self._cfg, self._lib
         d, heads, dh = c["d"], c["heads"], c["dh"]
         names = desc[0]
         mode, per = self._attn_mode(smap)
         if mode == "fused":
-            ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, heads, dh))
+            ws = self._workspace(ws_key, lib.size("rat_attn_bwd_workspace", d, heads, dh))
             grads = ops.attn_params(*[G(n) if n else None for n in names])
             dx, _ = ops.attn_bwd(x_in, dy, att[0], att[1], desc[1], grads, smap, d, heads, dh, workspace=ws, arith=self.arith,
                                  dropout=att[2], out=out, lib=lib)
@@ -556,33 +556,41 @@ class RAT_m2(BaseModel):
         B, T, L, S = saved["dims"]
         d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
-        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
         pruned = bool(saved.get("pruned"))
-        for bi, (blk, (x_in, a1, xa, a2, xb)) in enumerate(zip(reversed(self._blocks), reversed(saved["blocks"]))):
-            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            gw = [G(n) for n in blk["ffn"]]
-            if bi == 0 and pruned:                       # the last block (see _encoder_forward): dx is [B, d], the class tokens' gradient
-                dcls, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
-                                      planes=blk["ffn_planes"], lib=lib)
-                dgrid = torch.zeros((B, T, S, d), dtype=torch.float32, device=dx.device)
-                dgrid[:, 0, 0, :] = dcls
-                # cross-sample attention backward over the B sequences of token position 0, IN PLACE: their rows of dgrid become dx,
-                # every other row stays zero — exactly the gradient the intra-sample layer below would have been handed
-                # (both layers with ONE query position per sequence — RatSeqMap.queries —: the gradient rows of the others are zero)
-                cm0 = ops.cross_map_label_token(B, T, S, queries=1)
-                # (wide heads run in groups and every group reads dy again: there the result goes to a second zero grid)
-                dxg = dgrid if self._attn_is_fused(cm0) else torch.zeros_like(dgrid)
-                dx = self._attn_layer_backward(blk["cross"], xa, dgrid, a2, cm0, G, out=dxg)
-                dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, ops.intra_map(B, T, S, queries=1), G)
-                continue
-            if bi == 0 and dy_period:
-                dx, _ = ops.ffn_bwd_rows(xb, dx, dy_period, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn,
-                                         arith=self.arith, planes=blk["ffn_planes"], lib=lib)
-            else:
-                dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
-                                    planes=blk["ffn_planes"], lib=lib)
-            dx = self._attn_layer_backward(blk["cross"], xa, dx, a2, cmap, G)
-            dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G)
+        # Every backward kernel ends with a reduction of its per-work-group gradient slabs.  With one slab workspace PER LAYER the
+        # 3 x depth reductions run as one launch behind the last kernel (ops.deferred_reductions); wide heads (grouped launches) read
+        # their weight gradients back between the groups and keep the immediate form.
+        defer = (self.defer_slab_reductions and self._attn_mode(imap)[0] == "fused" and self._attn_mode(cmap)[0] == "fused"
+                 and (not pruned or self._attn_is_fused(ops.cross_map_label_token(B, T, S, queries=1))))
+        n_ffn = lib.size("rat_ffn_bwd_workspace", d, H)
+        with ops.deferred_reductions(dx, lib, enabled=defer):
+            for bi, (blk, (x_in, a1, xa, a2, xb)) in enumerate(zip(reversed(self._blocks), reversed(saved["blocks"]))):
+                w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
+                gw = [G(n) for n in blk["ffn"]]
+                ws_ffn = self._workspace(("ffn", bi) if defer else "ffn", n_ffn)
+                kc, ki = (("attn", bi, "cross"), ("attn", bi, "intra")) if defer else ("attn", "attn")
+                if bi == 0 and pruned:                       # the last block (see _encoder_forward): dx is [B, d], the class tokens' gradient
+                    dcls, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
+                                          planes=blk["ffn_planes"], lib=lib)
+                    dgrid = torch.zeros((B, T, S, d), dtype=torch.float32, device=dx.device)
+                    dgrid[:, 0, 0, :] = dcls
+                    # cross-sample attention backward over the B sequences of token position 0, IN PLACE: their rows of dgrid become dx,
+                    # every other row stays zero — exactly the gradient the intra-sample layer below would have been handed
+                    # (both layers with ONE query position per sequence — RatSeqMap.queries —: the gradient rows of the others are zero)
+                    cm0 = ops.cross_map_label_token(B, T, S, queries=1)
+                    # (wide heads run in groups and every group reads dy again: there the result goes to a second zero grid)
+                    dxg = dgrid if self._attn_is_fused(cm0) else torch.zeros_like(dgrid)
+                    dx = self._attn_layer_backward(blk["cross"], xa, dgrid, a2, cm0, G, out=dxg, ws_key=kc)
+                    dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, ops.intra_map(B, T, S, queries=1), G, ws_key=ki)
+                    continue
+                if bi == 0 and dy_period:
+                    dx, _ = ops.ffn_bwd_rows(xb, dx, dy_period, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn,
+                                             arith=self.arith, planes=blk["ffn_planes"], lib=lib)
+                else:
+                    dx, _ = ops.ffn_bwd(xb, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, workspace=ws_ffn, arith=self.arith,
+                                        planes=blk["ffn_planes"], lib=lib)
+                dx = self._attn_layer_backward(blk["cross"], xa, dx, a2, cmap, G, ws_key=kc)
+                dx = self._attn_layer_backward(blk["intra"], x_in, dx, a1, imap, G, ws_key=ki)
         return dx
 
     # ------------------------------------------------------------------------------ flat parameter buffer
@@ -1073,7 +1081,8 @@ class RAT_m2(BaseModel):
                # kernel arguments and control flow the recorded launches carry: a change of any of them takes a new capture
                self._max_gradient_norm, self.optimizer.kind, tuple(group.get("betas", ())), group.get("eps"), group.get("alpha"),
                c["lam_emb"], c["lam_net"], self._grad_mode,
-               self.row_list_exchange, bool(self._graph_test_splits), bool(self._validate_ids))
+               self.row_list_exchange, bool(self._graph_test_splits), bool(self._validate_ids), bool(self._head_strips),
+               bool(self.defer_slab_reductions))
         entry = graphs.get(key)
         if entry is None:
             if len(graphs) >= self.graph_shapes:
@@ -1224,6 +1233,7 @@ class RAT_m2(BaseModel):
     # forward strip wins up to 2048 rows (B = 512: 7.9 against 10.7 us; B = 4096: 25.4 against 17.6), the backward strip — which also
     # replaces the two column-sum launches — up to 4096 (B = 4096: 29.2 against 39.8 us).  False = always the older forms.
     _head_strips = True
+    defer_slab_reductions = True     # RAT_m2's encoder backward: one slab-reduction launch per step instead of one per layer (see _encoder_backward)
     _strip_fwd_rows = 2048
     _strip_bwd_rows = 4096
 

@@ -456,6 +456,24 @@ def ffn_bwd_rows(x, dy_rows, period, w1, b1, w2, b2, dw1, db1, dw2, db2, d, hidd
     return dx, workspace
 
 
+class deferred_reductions:
+    """with deferred_reductions(tensor_on_the_stream, lib): ... — the gradient-slab reductions of the attention / feed-forward backward
+    calls inside run as ONE launch at the end (rat_reduce_defer_begin / _end).  Every call inside needs a workspace of its own."""
+
+    def __init__(self, like, lib=None, enabled=True):
+        self.lib, self.like, self.enabled = lib or get_lib(), like, enabled
+
+    def __enter__(self):
+        if self.enabled:
+            self.lib.call("rat_reduce_defer_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.enabled:
+            self.lib.call("rat_reduce_defer_end", _stream(self.like), 0 if exc_type is not None else 1)
+        return False
+
+
 # ----------------------------------------------------------------------------- K2c
 def layernorm_fwd(x, x_stride, nrows, gamma, beta, d, eps=1e-5, lib=None):
     """LayerNorm of rows x[r * x_stride : r * x_stride + d] -> compact [nrows, d]."""
