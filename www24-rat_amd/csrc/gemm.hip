@@ -228,22 +228,16 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm3_kernel(GemmArgs g) {
     const TileLoader lb{g.B, g.N, g.K, g.ldb, n0, KB, g.vecb != 0};
     f32x4 acc[2][2];
     acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = rat_zero4();
-    // operand tiles travel TWO k-steps ahead of the MFMAs (two register sets, each refilled right after it was stashed): one step of
-    // 24 MFMAs per wave is shorter than a round trip to L2 / HBM, which a single set in flight left exposed (RAT_SGEMM_PF1: the old loop)
-    float4 ra0[GM_VEC], rb0[GM_VEC], ra1[GM_VEC], rb1[GM_VEC];
-    la.fetch(kbeg, ra0);
-    lb.fetch(kbeg, rb0);
-    if (kbeg + GM_K < kend) {
-        la.fetch(kbeg + GM_K, ra1);
-        lb.fetch(kbeg + GM_K, rb1);
-    }
-    auto step = [&](float4 (&ra)[GM_VEC], float4 (&rb)[GM_VEC], int k0) {
+    float4 ra[GM_VEC], rb[GM_VEC];
+    la.fetch(kbeg, ra);
+    lb.fetch(kbeg, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GM_K) {
         At.stash(ra);
         Bt.stash(rb);
         __syncthreads();
-        if (k0 + 2 * GM_K < kend) {                        // the tile two steps ahead flies while this one and the next are multiplied
-            la.fetch(k0 + 2 * GM_K, ra);
-            lb.fetch(k0 + 2 * GM_K, rb);
+        if (k0 + GM_K < kend) {                            // next tile's loads fly while this one is multiplied
+            la.fetch(k0 + GM_K, ra);
+            lb.fetch(k0 + GM_K, rb);
         }
         const RatB3 a0 = At.frag(wm), a1 = At.frag(wm + 1), b0 = Bt.frag(wn), b1 = Bt.frag(wn + 1);
         {
@@ -261,10 +255,6 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm3_kernel(GemmArgs g) {
             acc[1][1] = c[1];
         }
         __syncthreads();
-    };
-    for (int k0 = kbeg; k0 < kend; k0 += 2 * GM_K) {
-        step(ra0, rb0, k0);
-        if (k0 + GM_K < kend) step(ra1, rb1, k0 + GM_K);
     }
     sgemm_epilogue(g, acc, m0, n0, wm, wn, slice);
 }
