@@ -166,7 +166,7 @@ if __name__ == "__main__" and "sgemm" not in sys.argv:
 def sgemm_bench(reps=10, arith="f32"):
     """DNN-head GEMM shapes of the north-star config (B=4096, 1280 -> 400 -> 400 -> 400 -> 1)."""
     dev = "cuda"
-    B = 4096
+    B = int(os.environ.get("KBENCH_B", "4096"))
     shapes = []
     dims = [1280, 400, 400, 400]
     for li in range(3):

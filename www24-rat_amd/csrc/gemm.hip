@@ -263,12 +263,16 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // split-K plan: enough work-groups to cover the HBM latency of the k-loop by occupancy (the weight-gradient GEMMs of the
 // head have 7..140 output tiles and k = batch = 4096)
-void plan_split(int M, int N, int K, int& slices, int& kper) {
+// `target` work-groups: 1024 for the weight gradients (k = batch: long, few tiles), 512 for the forward / input-gradient products
+// (tools/kbench.py sgemm, MI355X: at 448 tiles two slices beat three — 32 against 38 us at K = 400, 70 against 86 us at K = 1280 —
+// while the weight gradients lose 20-40 % with fewer slices); RAT_SGEMM_SPLIT_TARGET overrides both (A/B knob)
+void plan_split(int M, int N, int K, int& slices, int& kper, int target = 1024) {
     const int tiles = ((M + GM_TILE - 1) / GM_TILE) * ((N + GM_TILE - 1) / GM_TILE);
     slices = 1;
     kper = (K + GM_K - 1) / GM_K * GM_K;
     if (tiles >= 512 || K < 8 * GM_K) return;
-    static const int target = [] { const char* e = getenv("RAT_SGEMM_SPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();   // (A/B knob)
+    static const int forced = [] { const char* e = getenv("RAT_SGEMM_SPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    if (forced) target = forced;
     int want = (target + tiles - 1) / tiles;
     const int max_slices = K / (2 * GM_K);
     if (want > max_slices) want = max_slices;
@@ -293,7 +297,7 @@ static int sgemm_launch(int trans_a, int trans_b, int M, int N, int K, const flo
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, trans_a, trans_b, 0, 0, beta, 1, 0, nullptr};
     g.veca = (lda % 4 == 0) && aligned16(A);
     g.vecb = (ldb % 4 == 0) && aligned16(B);
-    plan_split(M, N, K, g.slices, g.kper);
+    plan_split(M, N, K, g.slices, g.kper, trans_a ? 1024 : 512);       // (never more slices than rat_sgemm_workspace's plan: its target is 1024)
     if (g.slices > 1 && (workspace == nullptr || workspace_bytes < (size_t)g.slices * M * N * sizeof(float))) {
         g.slices = 1;                                       // no (or too small a) workspace: single pass over k
         g.kper = (K + GM_K - 1) / GM_K * GM_K;
