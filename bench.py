@@ -136,7 +136,7 @@ class KernelTimer:
     """HIP-event timing of C-ABI launches on torch's current stream (the stream the kernels are launched on)."""
 
     HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
-             "rat_ffn_bwd_res", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map",
+             "rat_ffn_bwd_res", "rat_ffn_bwd_res_rows", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map",
              "rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted")
     ATTN_ARGS = {"rat_attn_fwd": (5, 7), "rat_attn_bwd": (9, 11), "rat_attn_fwd_ex": (6, 8), "rat_attn_bwd_ex": (10, 12)}   # (map, heads)
 
@@ -172,6 +172,8 @@ class KernelTimer:
         s.record()
         self.inner(name, *args)
         e.record()
+        if name == "rat_ffn_bwd_res_rows":                               # the last block's backward (head gradient as compact rows): the same
+            name, args = "rat_ffn_bwd_res", tuple(args[:2]) + tuple(args[3:])   # kernel, same algorithmic work: counted with its siblings
         self.records.append((name, self._tag(name, args), s, e))
 
     @staticmethod
