@@ -1018,7 +1018,11 @@ class RAT_m2(BaseModel):
         scal = self.optimizer.begin_step(counts, count=count)
         self._step_loss = scal[0:1]
         self._bn_counted = counts is not None
-        _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
+        try:
+            _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
+        finally:
+            self.__dict__.pop("_bn_counted", None)
+            self.__dict__.pop("_step_loss", None)
         if self._graph_test_splits:
             self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
         self._run_backward(saved, inv, None, table_lists=self._dp() and self._row_lists_travel_lighter(batch[0].shape, world))
@@ -1151,7 +1155,7 @@ class RAT_m2(BaseModel):
         saved["seeds"] = seeds
         # ---- DNN branch on the target sample's raw field embeddings (RAT_m2.py:145-146; deep.py:126-141)
         dnn_out = dnn_last = None
-        if training and self._bn_counts is not None and not self.__dict__.pop("_bn_counted", False):
+        if training and self._bn_counts is not None and not self.__dict__.get("_bn_counted", False):
             self._bn_counts.add_(1)                                         # every BatchNorm layer's num_batches_tracked (shared storage)
         if self.dnn is not None:
             mods = self.dnn.dnn
