@@ -359,13 +359,13 @@ class RAT_m2(BaseModel):
         d, dh, groups = c["d"], c["dh"], c["heads"] // per
         ig = per * dh
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
-        wq = w_qkv.view(3, groups, ig, d)
-        wo = w_out.view(d, groups, ig)
+        # one permuting copy per tensor (not one per group): [groups][Q|K|V][ig][d] and [groups][d][ig], group g a contiguous slice
+        wq = w_qkv.view(3, groups, ig, d).permute(1, 0, 2, 3).contiguous()
+        wo = w_out.view(d, groups, ig).permute(1, 0, 2).contiguous()
         zero_bias = torch.zeros_like(b_out)
         out = []
         for g in range(groups):
-            w_g = wq[:, g].reshape(3 * ig, d).contiguous()
-            wo_g = wo[:, g].contiguous()
+            w_g, wo_g = wq[g].view(3 * ig, d), wo[g]
             out.append((w_g, wo_g, ops.attn_params(ln_g, ln_b, w_g, wo_g, b_out if g == 0 else zero_bias), zero_bias))
         return out
 
@@ -426,20 +426,22 @@ class RAT_m2(BaseModel):
             ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, per, dh))
             g_lng, g_lnb, g_wqkv, g_wout, g_bout = [G(n) for n in names]
             gq, go = g_wqkv.view(3, groups, ig, d), g_wout.view(d, groups, ig)
-            t_lng, t_lnb, t_b = torch.empty_like(g_lng), torch.empty_like(g_lnb), torch.empty_like(g_bout)
-            t_w = torch.empty((3 * ig, d), dtype=torch.float32, device=dy.device)
-            t_wo = torch.empty((d, ig), dtype=torch.float32, device=dy.device)
+            # every group writes its gradients into its own slice of group-major buffers; ONE permuting copy per weight tensor and one
+            # sum per LayerNorm vector move them into the gradient bucket afterwards (not two copies and two adds per group)
+            t_ln = torch.empty((2, groups, g_lng.numel()), dtype=torch.float32, device=dy.device)
+            t_b = torch.empty_like(g_bout)
+            t_w = torch.empty((groups, 3 * ig, d), dtype=torch.float32, device=dy.device)
+            t_wo = torch.empty((groups, d, ig), dtype=torch.float32, device=dy.device)
             dx = out                                     # (a caller's grid: must NOT be dy itself — every group reads dy)
             for g, (w_g, wo_g, params_g, zb, o, l, drop) in enumerate(att):
                 first = g == 0
-                grads_g = ops.attn_params(g_lng if first else t_lng, g_lnb if first else t_lnb, t_w, t_wo, g_bout if first else t_b)
+                grads_g = ops.attn_params(t_ln[0, g], t_ln[1, g], t_w[g], t_wo[g], g_bout if first else t_b)
                 dx, _ = ops.attn_bwd_ex(x_in, dy, dy if first else dx, o, l, params_g, grads_g, smap, d, per, dh, 0.0, 1.0,
                                         workspace=ws, out=dx, arith=self.arith, dropout=drop, lib=lib)   # dx = dy + sum over groups, in place
-                gq[:, g].copy_(t_w.view(3, ig, d))
-                go[:, g].copy_(t_wo)
-                if not first:                                                              # LayerNorm sees every group's gradient
-                    g_lng.add_(t_lng)
-                    g_lnb.add_(t_lnb)
+            gq.copy_(t_w.view(groups, 3, ig, d).permute(1, 0, 2, 3))
+            go.copy_(t_wo.permute(1, 0, 2))
+            torch.sum(t_ln[0], 0, out=g_lng)                                               # LayerNorm sees every group's gradient
+            torch.sum(t_ln[1], 0, out=g_lnb)
             return dx
         inner, ntok = heads * dh, x_in.numel() // d
         ln_g, ln_b, w_qkv, w_out, b_out = [self._p(n) if n else None for n in names]
