@@ -160,7 +160,7 @@ def test_ffn_separate_residual(lib, ntok, d, hidden, with_res):
     kc.check_ffn_res(lib, "cuda", ntok, d, hidden, with_res)
 
 
-@pytest.mark.parametrize("ntok,d,hidden,period", [(4096 * 231, 64, 128, 231), (1000 * 66, 40, 80, 66), (70000, 64, 128, 7), (100, 64, 128, 231)])
+@pytest.mark.parametrize("ntok,d,hidden,period", [(4096 * 231, 64, 128, 231), (1000 * 66, 40, 80, 66), (70001, 64, 128, 7), (100, 64, 128, 231), (5, 64, 128, 1)])
 def test_ffn_backward_from_compact_gradient_rows(lib, ntok, d, hidden, period):
     kc.check_ffn_rows(lib, "cuda", ntok, d, hidden, period)
 
@@ -177,7 +177,7 @@ def test_bn_relu_colsum(lib, use_bn):
 
 
 @pytest.mark.parametrize("use_bn,act", [(True, "relu"), (False, "relu"), (True, "tanh"), (False, "none")])
-@pytest.mark.parametrize("M,N", [(4096, 400), (512, 400), (256, 400), (37, 12), (1500, 64), (5000, 40), (9000, 400)])
+@pytest.mark.parametrize("M,N", [(4096, 400), (512, 400), (256, 400), (37, 12), (1500, 64), (5000, 40), (9000, 400), (8, 4)])
 def test_bn_act_column_strips(lib, use_bn, act, M, N):
     """every rows-per-thread instantiation (2 / 4 / 8 / 16 and the streaming form above 4096 rows)"""
     kc.check_bn_strip(lib, "cuda", M, N, use_bn, act)
