@@ -94,6 +94,13 @@ def parse(argv=None):
                     help="HIP-event timing around EVERY C-ABI launch (adds ~2 events x 60 launches of host work per step); "
                          "default: the encoder kernels (attention / FFN forward and backward, >90 %% of the step) and the "
                          "embedding gather / scatter")
+    ap.add_argument("--log-dir", default=None, help="--gpus N self-launch: directory for every rank's stdout / stderr (default: a new temp dir)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="--gpus N self-launch: seconds after which the whole job is ended")
+    ap.add_argument("--init-timeout", type=float, default=300.0,
+                    help="N > 1: bound (s) on the process-group rendezvous and on every collective's completion (RCCL watchdog / gloo)")
+    ap.add_argument("--fault", default=None,
+                    help="test hook RANK:WHERE — that rank exits with code 17 at `init` (before the rendezvous), `barrier` (after the "
+                         "first barrier) or `step` (inside the timed region): the launcher must notice and end the job")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo process group, the host-emulation build of the kernels (tests/emu), "
                          "workload `dryrun`; the printed numbers mean nothing")
@@ -103,22 +110,75 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------------------- self-launch
 def self_launch(args):
     """`python bench.py --gpus N` on its own: start N workers (this file, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
-    environment) as CHILD processes — before anything in this process has touched the GPU — wait for them, relay rank 0's
-    JSON line, exit with the worst return code."""
+    environment) as CHILD processes — before anything in this process has touched the GPU; nothing is exec'ed — and WATCH them:
+      * every rank's stderr goes to its own file (`--log-dir`, default a fresh directory under the system's temp dir); rank 0's
+        stdout (the one JSON line) is relayed at the end, the other ranks' stdout goes to their log too;
+      * all children are polled: the first non-zero exit ends the others (by PID: terminate, then kill) and this process exits
+        non-zero at once instead of leaving rank 0 inside a collective until RCCL's own timeout;
+      * `--launch-timeout` seconds bound the whole job the same way.
+    Exit code: 0 only when every rank returned 0; otherwise the first failing rank's code (or 124 on the deadline), after the tail
+    of every rank's log has been copied to stderr."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    log_dir = args.log_dir or tempfile.mkdtemp(prefix="rat_bench_")
+    os.makedirs(log_dir, exist_ok=True)
+    procs, logs, outs = [], [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
-    sys.stdout.flush()
-    return max(abs(c) for c in codes)
+        err = open(os.path.join(log_dir, "rank%d.err" % r), "w")
+        out = open(os.path.join(log_dir, "rank%d.out" % r), "w+")
+        logs.append(err)
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+    print("bench.py: %d ranks started, logs in %s" % (args.gpus, log_dir), file=sys.stderr)
+    deadline = time.monotonic() + args.launch_timeout
+    failed = None                                   # (rank, return code) of the first rank seen failing
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = (-1, 124)
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:                             # exactly the PIDs started above
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for f in logs:
+        f.close()
+    outs[0].seek(0)
+    text = outs[0].read()
+    for f in outs:
+        f.close()
+    if failed is None:
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        return 0
+    who = "the %d s launch timeout" % args.launch_timeout if failed[0] < 0 else "rank %d (exit code %d)" % failed
+    print("bench.py: %s ended the job; the other ranks were stopped.  Log tails:" % who, file=sys.stderr)
+    for r in range(args.gpus):
+        try:
+            with open(os.path.join(log_dir, "rank%d.err" % r)) as f:
+                tail = f.read()[-1500:]
+        except OSError:
+            tail = "(no log)"
+        print("---- rank %d (rc %s) ----\n%s" % (r, procs[r].returncode, tail), file=sys.stderr)
+    return abs(failed[1]) or 1
 
 
 # ------------------------------------------------------------------------------------------------- timing
@@ -390,6 +450,13 @@ def worker(args):
     # of the model (dp_single_rank: every collective of the step is issued), the barriers and the max-over-ranks reduction of this
     # file, the weak AND the strong region.  It is the only way to put the N > 1 bench on the one GPU of a gpurun box.
     dp = world > 1 or args.dp_rehearsal
+    first_barrier_s = None
+
+    def fault(where):
+        if args.fault and args.fault == "%d:%s" % (rank, where):
+            print("bench.py: --fault %s: rank %d exits" % (args.fault, rank), file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(17)
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -399,10 +466,19 @@ def worker(args):
         keep_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)
+            import datetime
+            fault("init")
+            # bounded: a rank that never arrives fails the rendezvous of the others after --init-timeout instead of the 10 / 30 min
+            # defaults; the same bound is what RCCL's watchdog / gloo apply to every later collective (a dead peer mid-run)
+            dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=args.init_timeout),
+                                    **({} if dry else {"device_id": torch.device("cuda", local_rank)}))
+            t_b = time.perf_counter()
+            dist.barrier()
             if not dry:
-                dist.barrier()
                 torch.cuda.synchronize()
+            first_barrier_s = time.perf_counter() - t_b
+            fault("barrier")
         finally:
             sys.stdout.flush()
             os.dup2(keep_fd, 1)
@@ -485,6 +561,8 @@ def worker(args):
             if args.step_times:
                 stamps.append(time.perf_counter())
             model.train_step(batches[i % nb])
+            if i == 0:
+                fault("step")
         sync()
         elapsed = time.perf_counter() - t0
         timer.enabled = False

@@ -5,6 +5,7 @@ nothing, the plumbing (self-launch, rank environment, SyncBN collectives, batch 
 import json
 import os
 import subprocess
+import pytest
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,3 +31,34 @@ def test_bench_gpus2_self_launch_dry_run():
     assert {"rat_gather_fwd", "cross_attention"} <= set(out["targets"])
     assert out["step_mode"]["graph"] is False             # hipGraph capture needs a GPU
     assert "cpu_baseline" not in out                      # N = 1 only (and never in a dry run)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+
+
+@pytest.mark.parametrize("where", ["init", "barrier", "step"])
+def test_bench_launcher_ends_the_job_when_one_rank_dies(where, tmp_path):
+    """a rank that dies (before the rendezvous, after the first barrier, inside the timed region) must not leave
+    rank 0 waiting in a collective: the launcher sees the exit code, stops the other rank and returns non-zero — within a minute."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "1",
+                        "--fault", "1:" + where, "--log-dir", str(tmp_path), "--init-timeout", "600"],
+                       capture_output=True, text=True, timeout=600, env=_clean_env())
+    took = time.monotonic() - t0
+    assert r.returncode == 17, (r.returncode, r.stderr[-2000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no result line from a job that lost a rank"
+    assert "rank 1 (exit code 17)" in r.stderr and "---- rank 0" in r.stderr
+    assert os.path.exists(os.path.join(str(tmp_path), "rank1.err"))
+    # `init` / `barrier` die before any kernel is built or run: the launcher's reaction time is what is measured
+    if where != "step":
+        assert took < 60.0, took
+
+
+def test_bench_launcher_deadline(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1",
+                        "--launch-timeout", "1", "--log-dir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert "launch timeout" in r.stderr
