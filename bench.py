@@ -82,9 +82,9 @@ def parse(argv=None):
     ap.add_argument("--dp-rehearsal", action="store_true",
                     help="with one rank: run the N > 1 code path anyway (RCCL process group of one rank, the model's data-parallel "
                          "path with every collective issued, barriers, weak and strong regions) — the 1-GPU rehearsal of the scaling job")
-    ap.add_argument("--graph-dp", action="store_true",
-                    help="N > 1: replay the step as graph segments with the collectives between them (default at N > 1: eager launches; the "
-                         "segmented path is proven with two gloo ranks on one GPU, tests/test_gpu_dp.py, but has not met RCCL yet)")
+    ap.add_argument("--graph-dp", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--no-graph-dp", action="store_true",
+                    help="N > 1: eager launches instead of graph segments with the collectives between them (the default)")
     ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the default N = 1 line (exact-fp32 run, per-rank B/8 shape, 100 M-row gather)")
@@ -256,6 +256,49 @@ class KernelTimer:
             d[0] += 1
             d[1] += s.elapsed_time(e)
         return {k: dict(launches_per_step=v[0] / steps, avg_ms=v[1] / v[0], ms_per_step=v[1] / steps) for k, v in out.items()}
+
+    def reset(self):
+        self.records = []
+
+
+class PhaseTimer:
+    """HIP-event pairs (on torch's current stream — the stream the launches and the collectives' waits are issued on) around the
+    communication phases and the optimizer of a data-parallel step: the gradient exchange (`_exchange_gradients`: table lists or the
+    dense all-reduce + the wait for the dense-net all-reduce started inside backward), the start-of-step count exchange of the owner
+    form, SyncBN's forward / backward launches with their collectives, and the two-sweep optimizer.  Active only in the eager
+    instrumented pass (a graph replay cannot host events)."""
+
+    def __init__(self, model, host_events=False):
+        from rat_amd import ops
+        self.enabled, self.records, self.host_events = False, [], host_events
+        self._wrap(model, "_exchange_gradients", "exchange")
+        if hasattr(model, "_owner_prepare"):
+            self._wrap(model, "_owner_prepare", "exchange_counts")
+        self._wrap(model.optimizer, "fused_step", "optimizer")
+        self._wrap(ops, "bn_relu_fwd_sync", "sync_bn")
+        self._wrap(ops, "bn_relu_bwd_sync", "sync_bn")
+
+    def _wrap(self, owner, name, tag):
+        inner = getattr(owner, name)
+
+        def timed(*a, **k):
+            if not self.enabled:
+                return inner(*a, **k)
+            import torch
+            s, e = (_HostEvent(), _HostEvent()) if self.host_events else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            s.record()
+            try:
+                return inner(*a, **k)
+            finally:
+                e.record()
+                self.records.append((tag, s, e))
+        setattr(owner, name, timed)
+
+    def summary(self, steps):
+        out = {}
+        for tag, s, e in self.records:
+            out[tag] = out.get(tag, 0.0) + s.elapsed_time(e)
+        return {k: round(v / steps, 4) for k, v in out.items()}
 
     def reset(self):
         self.records = []
@@ -451,6 +494,14 @@ def worker(args):
     # file, the weak AND the strong region.  It is the only way to put the N > 1 bench on the one GPU of a gpurun box.
     dp = world > 1 or args.dp_rehearsal
     first_barrier_s = None
+    result_fd = None
+
+    def emit(line):
+        if result_fd is None:
+            print(line)
+            sys.stdout.flush()
+        else:
+            os.write(result_fd, (line + "\n").encode())
 
     def fault(where):
         if args.fault and args.fault == "%d:%s" % (rank, where):
@@ -460,29 +511,25 @@ def worker(args):
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout must carry the one JSON line only, so
-        # file descriptor 1 points at stderr until the first collective is through
+        # RCCL prints a version banner on STDOUT when a communicator comes up (with eager initialisation: whenever its helper threads
+        # get to it); stdout must carry the one JSON line only.  So for the whole life of a data-parallel worker file descriptor 1
+        # points at stderr, and the result line is written to a private duplicate of the original stdout (`emit`).
         sys.stdout.flush()
-        keep_fd = os.dup(1)
+        result_fd = os.dup(1)
         os.dup2(2, 1)
-        try:
-            import datetime
-            fault("init")
-            # bounded: a rank that never arrives fails the rendezvous of the others after --init-timeout instead of the 10 / 30 min
-            # defaults; the same bound is what RCCL's watchdog / gloo apply to every later collective (a dead peer mid-run)
-            dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world,
-                                    timeout=datetime.timedelta(seconds=args.init_timeout),
-                                    **({} if dry else {"device_id": torch.device("cuda", local_rank)}))
-            t_b = time.perf_counter()
-            dist.barrier()
-            if not dry:
-                torch.cuda.synchronize()
-            first_barrier_s = time.perf_counter() - t_b
-            fault("barrier")
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep_fd, 1)
-            os.close(keep_fd)
+        import datetime
+        fault("init")
+        # bounded: a rank that never arrives fails the rendezvous of the others after --init-timeout instead of the 10 / 30 min
+        # defaults; the same bound is what RCCL's watchdog / gloo apply to every later collective (a dead peer mid-run)
+        dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=args.init_timeout),
+                                **({} if dry else {"device_id": torch.device("cuda", local_rank)}))
+        t_b = time.perf_counter()
+        dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+        first_barrier_s = time.perf_counter() - t_b
+        fault("barrier")
 
     spec = synthetic.WORKLOADS[args.workload]
     if args.batch:
@@ -504,6 +551,7 @@ def worker(args):
     dev = model.device if not dry else None
     model.train()
     timer = KernelTimer(model._lib, everything=args.time_all_kernels, host_events=dry)
+    phases = PhaseTimer(model, host_events=dry) if dp else None
 
     def sync():
         if dp:
@@ -521,9 +569,9 @@ def worker(args):
     can_prune = hasattr(model, "prune_dead_tokens") and args.model in ("RAT_m2", "RAT_m3")
     if can_prune:
         model.prune_dead_tokens = bool(args.prune)
-    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or args.graph_dp)
+    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or not args.no_graph_dp)
     model.use_graph = graph_mode
-    model.graph_under_dp = bool(args.graph_dp)
+    model.graph_under_dp = not args.no_graph_dp
     model.graph_shapes = 8                       # weak / strong / per-rank shapes and both arithmetics each get their own graph
     region_info = {}
 
@@ -555,6 +603,9 @@ def worker(args):
             model.train_step(batches[(warmup - 1) % nb])
         sync()
         timer.enabled = not graph_mode
+        if phases is not None:
+            phases.reset()
+            phases.enabled = not graph_mode
         t0 = time.perf_counter()
         stamps = []
         for i in range(steps):
@@ -566,6 +617,8 @@ def worker(args):
         sync()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
+        if phases is not None:
+            phases.enabled = False
         if args.step_times:                # diagnostic: host-side issue time of every step (stderr), e.g. to spot interpreter stalls
             stamps.append(time.perf_counter())
             print("%s step issue times (ms): %s" % (label, " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(stamps, stamps[1:]))),
@@ -584,14 +637,31 @@ def worker(args):
             model.train_step(batches[1 % nb])
             sync()
             timer.enabled = True
+            if phases is not None:
+                phases.enabled = True
             t1 = time.perf_counter()
             for i in range(steps):
                 model.train_step(batches[i % nb])
             sync()
             info["eager_instrumented_ms_per_step"] = round((time.perf_counter() - t1) / steps * 1e3, 3)
             timer.enabled = False
+            if phases is not None:
+                phases.enabled = False
             model.use_graph = True
         model.check_id_errors()
+        if phases is not None and (kernel_pass or not graph_mode):
+            # HIP-event times per step of the communication phases and the optimizer (eager instrumented pass of the same steps),
+            # the exchange form the model chose for this region's batch shape and what it put on the links
+            ex = dict(model.__dict__.get("_exchange_info") or {})
+            own = model.__dict__.get("_owner_stats") if str(ex.get("form", "")).startswith("owner") else None
+            info["communication"] = dict(world=dist.get_world_size(), backend=dist.get_backend(), phases_ms_per_step=phases.summary(steps),
+                                         exchange_form=ex.get("form"), table_bytes_sent_per_rank=ex.get("table_bytes"),
+                                         dense_net_bytes_sent_per_rank=ex.get("dense_net_bytes"),
+                                         owner_lists=dict(pairs_sent=own["sent"], pairs_received=own["received"], capacity=list(own["capacity"]),
+                                                          collectives_per_step=own["collectives"]) if own else None,
+                                         note="bytes: all-reduce priced as 2 (N-1)/N of its size; owner form: chunks for the other owners + the "
+                                              "reduced list to every peer; phases: HIP events on the launch stream, `exchange` includes the wait "
+                                              "for the dense-net all-reduce started inside backward")
         region_info[label] = info
         return elapsed, (timer.summary(steps) if (kernel_pass or not graph_mode) else {})
 
@@ -740,6 +810,10 @@ def worker(args):
                                   embedding_regularizer=model._cfg["lam_emb"], sync_batch_norm=bool(dp and spec["batch_norm"]),
                                   parallelism="dp%d" % world),
                       roofline=roofline, targets=targets, kernels=kernels)
+        if dp:
+            result["world"] = dist.get_world_size()
+            result["first_barrier_s"] = round(first_barrier_s, 3) if first_barrier_s is not None else None
+            result["communication"] = {k: v.get("communication") for k, v in region_info.items() if v.get("communication")}
         if strong is not None and weak is not None:
             el, _ = strong
             result["strong_scaling"] = dict(value=round(B * args.steps / el, 1), unit="samples/s", ms_per_step=round(el / args.steps * 1e3, 3),
@@ -768,8 +842,7 @@ def worker(args):
         if not dp and not args.no_cpu_baseline and not dry:
             result["cpu_baseline"] = cpu_baseline(args.workload, spec, args.cpu_batch or B, seed=1000, model=args.model,
                                                   timed_steps=args.cpu_steps)
-        print(json.dumps(result))
-        sys.stdout.flush()
+        emit(json.dumps(result))
     if dp:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 7
+#define RAT_ABI_VERSION 8
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -477,6 +477,31 @@ int rat_scatter_rows_lists(float* dense_base, const int32_t* rows, const float* 
 int rat_adam_rows_dev(float* w_base, float* m_base, float* v_base, const int32_t* rows, const float* grads,
                       const int32_t* count_dev, int64_t max_rows, int d, const float* norm_sq, float max_norm,
                       const float* hyper_dev, float beta1, float beta2, float eps, void* stream);
+
+/* ABI v8 — the owner-partitioned exchange of the table-gradient row lists under data parallelism (the reference
+ * has no counterpart — its DataParallel-less loop, base_model.py:213-230, runs on one device; this is the exchange step the sharded
+ * path adds).  Rank k owns the rows [k per, (k + 1) per) of a table family.
+ *   rat_owner_counts : counts_out[k] = unique rows of a rat_sparse_plan_* plan (workspace, count_dev, n as given to the plan) inside
+ *                      owner k's range.  A function of the batch's IDS alone: it runs at the start of the step, the N x N matrix of
+ *                      all ranks' counts is all-gathered and copied to the host while the forward runs.
+ *   rat_owner_pack   : this rank's sorted lists (A: rows_a / grads_a [.][d]; B, nullable: rows_b / vals_b, width 1) -> `wire`, one
+ *                      chunk per owner: [rows A pad 4][gradient rows A][rows B pad 4][values B pad 4] (32-bit words).
+ *                      mat_dev: int32 [world][2][world], mat[s][f][k] = rows of family f rank s holds for owner k.
+ *   rat_owner_unpack : the chunks received from ranks 0 .. world-1 -> contiguous (rows, gradient rows) pairs in rank order,
+ *                      totals[0..1] = pairs received per family; n_extra floats are copied from extra_src to extra_dst.
+ *   rat_owner_scatter: `world` all-gathered lists, `stride` words apart, each [count A, count B, -, -][n_extra floats pad 4]
+ *                      [rows A: cap_a][gradient rows A: cap_a x d][rows B: cap_b][values B: cap_b] -> dense_a[row * d + c],
+ *                      dense_b[row] (plain stores: the owners' ranges are disjoint); extra_out[i] = sum over the lists, in order.
+ * max_pairs only sizes the grid. */
+int rat_owner_counts(const void* workspace, const int32_t* count_dev, int64_t n, int64_t rows_per_owner, int world,
+                     int32_t* counts_out, void* stream);
+int rat_owner_pack(const int32_t* mat_dev, int world, int rank, int d, const int32_t* rows_a, const float* grads_a,
+                   const int32_t* rows_b, const float* vals_b, int64_t max_pairs, float* wire, void* stream);
+int rat_owner_unpack(const int32_t* mat_dev, int world, int rank, int d, const float* wire, int64_t max_pairs, int32_t* rows_a,
+                     float* grads_a, int32_t* rows_b, float* vals_b, int32_t* totals, const float* extra_src, float* extra_dst,
+                     int n_extra, void* stream);
+int rat_owner_scatter(float* dense_a, float* dense_b, float* extra_out, const float* lists, int64_t stride, int world,
+                      int64_t cap_a, int64_t cap_b, int d, int n_extra, void* stream);
 
 /* Inverted dropout (nn.Dropout; RAT_m2.py:83,135 emb_dropout, deep.py:133-134 net_dropout): y = keep(seed,i) ? x/(1-p) : 0
  * with a counter-based mask, so the backward pass calls the same function on the gradient with the same seed.

@@ -50,12 +50,17 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, r
     if world == 1:
         model.dp_single_rank = True           # one rank through the data-parallel path (what tests/test_gpu_rccl.py does with RCCL)
         assert model._dp()
-    merges, inner = [0], model._merge_sparse
+    merges, inner, inner_owner = [0], model._merge_sparse, model._exchange_lists_owner
 
-    def counting_merge(part):
+    def counting_merge(part):                 # the all-gather form: one merge per table family
         merges[0] += 1
         return inner(part)
+
+    def counting_owner(g, lists):             # the owner form: both families in one exchange
+        merges[0] += len(lists)
+        return inner_owner(g, lists)
     model._merge_sparse = counting_merge
+    model._exchange_lists_owner = counting_owner
     model.row_list_exchange = row_lists       # (the traffic rule would pick the dense all-reduce for this toy vocabulary)
     model.owner_exchange = owner              # all-to-all to the rows' owners (default) / all-gather at capacity + merge of the union
     assert model._cfg["lam_emb"] > 0 and model._grad_mode == "atomic"
@@ -105,6 +110,7 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
     if row_lists and owner:                          # the owner-partitioned exchange ran: every pair went to exactly one owner
         s0, s1 = r0["owner_stats"], r1["owner_stats"]
         assert s0 is not None and s1 is not None and s0["sent"] + s1["sent"] == s0["received"] + s1["received"] > 0
+        assert s0["collectives"] == 3             # one all-to-all + one all-gather behind the count matrix's all-gather
     else:
         assert r0["owner_stats"] is None
     # embedding_regularizer = 0.01 > 0 (dense semantics: lambda*W on every row) and yet the table gradients travelled as row lists

@@ -107,28 +107,51 @@ def _owner_worker(rank, world, port, emu_path, out_dir):
     L._default = L.RatLib(emu_path)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _case, model, _batch = sc2._model("tiny_seq_bn", -1, "sparse", embedding_regularizer=0.0, batch_norm=False)
-    total_rows, width, cap = 41, 4, 16
+    _case, model, _batch = sc2._model("tiny_seq_bn", -1, "atomic", batch_norm=False)
+    d = model._cfg["d"]
+    assert d % 4 == 0 and model._cfg["use_wide"]
+    rows_a_total, rows_b_total = model._n_feat // d, model._n_tab - model._n_feat
+    per_a, per_b = -(-rows_a_total // world), -(-rows_b_total // world)
+    last_a, last_b, cap = rows_a_total - 1, rows_b_total - 1, 16
     # hand-made local lists (sorted, unique) that stress the partition: (0) every pair in owner 0's range, rank 1 holds nothing;
-    # (1) the same rows on both ranks; (2) ragged, rows on both sides of the range edge, the last row of the table included
-    lists = {0: ([0, 3, 7, 20], []), 1: ([2, 5, 25, 40], [2, 5, 25, 40]), 2: ([1, 19, 20, 21, 39], [0, 20, 40])}
+    # (1) the same rows on both ranks, the last row of each family included; (2) ragged, rows on both sides of the range edge
+    lists = {0: (([0, 1, per_a - 1], []), ([0, per_b - 1], [])),
+             1: (([2, 5, per_a, last_a], [2, 5, per_a, last_a]), ([1, last_b], [1, last_b])),
+             2: (([1, per_a - 1, per_a, per_a + 1, last_a], [0, per_a, last_a]), ([per_b - 1, per_b], [0, per_b, last_b]))}
     out = {}
-    for key, per_rank in lists.items():
-        mine = per_rank[rank]
+
+    def make(mine, width, seed):
         rows = torch.full((cap,), 12345, dtype=torch.int32)          # garbage behind `count`
         rows[:len(mine)] = torch.tensor(mine, dtype=torch.int32)
-        g = torch.Generator().manual_seed(100 * key + rank)
-        grads = torch.randn(cap, width, generator=g)
-        count = torch.tensor([len(mine)], dtype=torch.int32)
+        grads = torch.randn(cap, width, generator=torch.Generator().manual_seed(seed))
+        return rows, grads, torch.tensor([len(mine)], dtype=torch.int32)
+    n_grad = model._flat.numel()
+    for key, (fam_a, fam_b) in lists.items():
+        ra, ga, ca = make(fam_a[rank], d, 100 * key + rank)
+        rb, gb, cb = make(fam_b[rank], 1, 100 * key + rank + 50)
+        parts = [(ra, ga, ca, d, rows_a_total, 0), (rb, gb, cb, 1, rows_b_total, model._n_feat)]
+        label = torch.randn(model._n_emb - model._n_tab, generator=torch.Generator().manual_seed(7 * key + rank))
         dense = {}
         for owner in (True, False):
-            model.owner_exchange = owner
-            merged = model._merge_sparse((rows, grads, count, width, total_rows, 0))
-            d = torch.zeros(total_rows * width)
-            model._scatter_merged(d, merged, width)
-            dense[owner] = d
-            n = sum(int(r[2]) for r in merged["records"])
-            assert n == len(set(per_rank[0]) | set(per_rank[1])), (key, owner, n)
+            g = torch.zeros(n_grad)
+            g[model._n_tab:model._n_emb] = label
+            if owner:
+                # what _owner_prepare publishes from the batch's plans, from the hand-made lists here
+                cnt = torch.zeros(2 * world, dtype=torch.int32)
+                for f, (mine, per) in enumerate(((fam_a[rank], per_a), (fam_b[rank], per_b))):
+                    for r_ in mine:
+                        cnt[f * world + min(r_ // per, world - 1)] += 1
+                model._owner_publish(cnt, (None, None), (per_a, per_b))
+                assert model._exchange_lists_owner(g, parts) is None
+                stats = model._owner_stats
+                assert stats["sent"] == len(fam_a[rank]) + len(fam_b[rank]) and stats["collectives"] == 3
+            else:
+                for part in parts:
+                    rows, grads, count, width, _t, base = model._merge_sparse(part)
+                    ops.scatter_rows(g[base:], rows, grads, count, width, lib=model._lib)
+                    assert int(count) == len(set(lists[key][0 if width == d else 1][0]) | set(lists[key][0 if width == d else 1][1]))
+                dist.all_reduce(g[model._n_tab:model._n_emb])
+            dense[owner] = g
         assert torch.equal(dense[True], dense[False]), key           # same sums in the same (rank) order: bit-identical
         out[key] = dense[True]
     torch.save(out, os.path.join(out_dir, "owner%d.pt" % rank))
@@ -137,8 +160,10 @@ def _owner_worker(rank, world, port, emu_path, out_dir):
 
 
 def test_owner_partitioned_exchange_on_ragged_lists(emu_default):
-    """the all-to-all form of the row-list exchange (round 4) against the all-gather form on hand-made lists: an owner that receives
-    nothing, a rank that sends nothing, rows on the range edge, garbage behind `count` — both forms must give the same bits on both ranks"""
+    """the owner form of the row-list exchange (count matrix -> one packed all-to-all -> owner merge -> one packed all-gather ->
+    rat_owner_scatter, both table families and the label table's partial gradient in the same buffers) against the all-gather form on
+    hand-made lists: an owner that receives nothing, a rank that sends nothing, rows on the range edge, the last row of a family,
+    garbage behind `count` — both forms must give the same bits on both ranks"""
     import build_emu
     port = 31500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as out_dir:

@@ -385,6 +385,129 @@ scatter_rows_lists_kernel(float* __restrict__ dense, const int32_t* __restrict__
     }
 }
 
+
+// ---- owner-partitioned exchange of the row lists (data parallelism, ABI v8) -----------------------------------------------------
+// Rank k owns the rows [k per, (k + 1) per) of a table family.  The per-owner counts of a rank's list are a function of the batch's
+// IDS alone (the plan), so they are produced — and exchanged, and read back by the host — at the START of the step, while the
+// forward runs; when the gradients exist the host already knows the exact split sizes: no host stall in the step, exact traffic.
+
+// counts[k] = unique rows of the plan inside owner k's range (the plan's segments are sorted by row: a binary search per range edge)
+__global__ void __launch_bounds__(SP_THREADS)
+owner_counts_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ seg_start, const int32_t* __restrict__ count,
+                    int64_t per, int world, int32_t* __restrict__ counts) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= world) return;
+    const int64_t nseg = *count;
+    auto below = [&](int64_t edge) {                 // segments whose row is < edge
+        int64_t lo = 0, hi = nseg;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)keys[seg_start[mid]] < edge) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int64_t a = k == 0 ? 0 : below((int64_t)k * per);
+    const int64_t b = k == world - 1 ? nseg : below((int64_t)(k + 1) * per);
+    counts[k] = (int32_t)(b - a);
+}
+
+// One chunk per peer: [rows A, padded to 4][gradient rows A: nA x d][rows B, padded to 4][values B, padded to 4] (32-bit words; d % 4
+// == 0, so every section starts on a 16-byte boundary).  mat[s][f][k] = rows of family f that rank s holds for owner k.
+struct OwnerXfer {
+    const int32_t* mat;      // [world][2][world], on the device
+    int world, rank, d;
+    int32_t* rows_a; float* grads_a;     // PACK: this rank's lists (sorted by row = owner after owner)   UNPACK: the received pairs,
+    int32_t* rows_b; float* vals_b;      //       sources in rank order
+    float* wire;             // PACK: send buffer   UNPACK: receive buffer
+    int32_t* totals;         // UNPACK: {pairs received A, pairs received B}
+    const float* extra_src;  // UNPACK (nullable): n_extra floats copied to extra_dst (the label table's partial gradient -> the
+    float* extra_dst;        //                    header of the list this rank will all-gather)
+    int n_extra;
+};
+
+__device__ __forceinline__ int64_t owner_pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+__device__ __forceinline__ int64_t owner_chunk(int64_t na, int64_t nb, int d) { return owner_pad4(na) + na * d + 2 * owner_pad4(nb); }
+
+template <bool PACK>
+__global__ void __launch_bounds__(SP_THREADS) owner_xfer_kernel(OwnerXfer a, int blocks_per_peer) {
+    const int peer = (int)(blockIdx.x / blocks_per_peer);
+    const int sub = (int)(blockIdx.x % blocks_per_peer);
+    const int W = a.world;
+    auto cnt = [&](int j, int f) { return (int64_t)(PACK ? a.mat[((int64_t)a.rank * 2 + f) * W + j] : a.mat[((int64_t)j * 2 + f) * W + a.rank]); };
+    int64_t wire_off = 0, la = 0, lb = 0;
+    for (int j = 0; j < peer; ++j) {
+        const int64_t na = cnt(j, 0), nb = cnt(j, 1);
+        wire_off += owner_chunk(na, nb, a.d);
+        la += na;
+        lb += nb;
+    }
+    const int64_t na = cnt(peer, 0), nb = cnt(peer, 1);
+    float* w = a.wire + wire_off;
+    int32_t* w_rows_a = reinterpret_cast<int32_t*>(w);
+    float* w_grads_a = w + owner_pad4(na);
+    int32_t* w_rows_b = reinterpret_cast<int32_t*>(w_grads_a + na * a.d);
+    float* w_vals_b = reinterpret_cast<float*>(w_rows_b) + owner_pad4(nb);
+    const int64_t t0 = (int64_t)sub * blockDim.x + threadIdx.x, stride = (int64_t)blocks_per_peer * blockDim.x;
+    for (int64_t i = t0; i < na; i += stride) {
+        if (PACK) w_rows_a[i] = a.rows_a[la + i]; else a.rows_a[la + i] = w_rows_a[i];
+    }
+    const int64_t n4 = na * (a.d >> 2);
+    float4* g4 = reinterpret_cast<float4*>(a.grads_a + la * a.d);
+    float4* w4 = reinterpret_cast<float4*>(w_grads_a);
+    for (int64_t i = t0; i < n4; i += stride) {
+        if (PACK) w4[i] = g4[i]; else g4[i] = w4[i];
+    }
+    for (int64_t i = t0; i < nb; i += stride) {
+        if (PACK) {
+            w_rows_b[i] = a.rows_b[lb + i];
+            w_vals_b[i] = a.vals_b[lb + i];
+        } else {
+            a.rows_b[lb + i] = w_rows_b[i];
+            a.vals_b[lb + i] = w_vals_b[i];
+        }
+    }
+    if (!PACK && blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            int64_t ta = 0, tb = 0;
+            for (int j = 0; j < W; ++j) { ta += cnt(j, 0); tb += cnt(j, 1); }
+            a.totals[0] = (int32_t)ta;
+            a.totals[1] = (int32_t)tb;
+        }
+        for (int i = threadIdx.x; i < a.n_extra; i += blockDim.x) a.extra_dst[i] = a.extra_src[i];
+    }
+}
+
+// every rank's all-gathered list — [count A, count B, -, -][n_extra floats, padded to 4][rows A: cap_a][gradient rows A: cap_a x d]
+// [rows B: cap_b][values B: cap_b], `stride` words apart — into the (zeroed) dense gradient blocks: plain stores (the owners' row
+// ranges are disjoint); the n_extra floats (the label table's partial gradients) are summed over the ranks in rank order
+__global__ void __launch_bounds__(SP_THREADS)
+owner_scatter_kernel(float* __restrict__ dense_a, float* __restrict__ dense_b, float* __restrict__ extra_out,
+                     const float* __restrict__ lists, int64_t stride, int world, int64_t cap_a, int64_t cap_b, int d, int n_extra) {
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    const int64_t xpad = owner_pad4(n_extra);
+    for (int k = 0; k < world; ++k) {
+        const float* base = lists + (int64_t)k * stride;
+        const int32_t* hdr = reinterpret_cast<const int32_t*>(base);
+        const int32_t* rows_a = reinterpret_cast<const int32_t*>(base + 4 + xpad);
+        const float* grads_a = base + 4 + xpad + cap_a;
+        const int32_t* rows_b = reinterpret_cast<const int32_t*>(grads_a + cap_a * d);
+        const float* vals_b = reinterpret_cast<const float*>(rows_b) + cap_b;
+        const int64_t na = (int64_t)hdr[0] * (d >> 2);
+        const int q = d >> 2;
+        for (int64_t i = t0; i < na; i += step) {
+            const int64_t s_ = i / q;
+            reinterpret_cast<float4*>(dense_a + (int64_t)rows_a[s_] * d)[i - s_ * q] = reinterpret_cast<const float4*>(grads_a)[i];
+        }
+        const int64_t nb = hdr[1];
+        for (int64_t i = t0; i < nb; i += step) dense_b[rows_b[i]] = vals_b[i];
+    }
+    for (int64_t i = t0; i < n_extra; i += step) {
+        float acc = 0.f;
+        for (int k = 0; k < world; ++k) acc += lists[(int64_t)k * stride + 4 + i];
+        extra_out[i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t rat_sparse_workspace(int64_t n) {
@@ -507,4 +630,61 @@ extern "C" int rat_scatter_rows_lists(float* dense_base, const int32_t* rows, co
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     RAT_LAUNCH(scatter_rows_lists_kernel, (unsigned)blocks, SP_THREADS, 0, stream, dense_base, rows, grads, counts_dev, cap, lists, d);
     return rat_check_launch("rat_scatter_rows_lists");
+}
+
+extern "C" int rat_owner_counts(const void* workspace, const int32_t* count_dev, int64_t n, int64_t rows_per_owner, int world,
+                                int32_t* counts_out, void* stream) {
+    RAT_REQUIRE(workspace && count_dev && counts_out && n > 0 && rows_per_owner > 0 && world > 0 && world <= 4096, "bad args");
+    PlanView v = carve(const_cast<void*>(workspace), n);
+    RAT_LAUNCH(owner_counts_kernel, (unsigned)((world + SP_THREADS - 1) / SP_THREADS), SP_THREADS, 0, stream, v.keys_b, v.seg_start,
+               count_dev, rows_per_owner, world, counts_out);
+    return rat_check_launch("rat_owner_counts");
+}
+
+static int owner_blocks_per_peer(int64_t max_pairs, int d, int world) {
+    int64_t b = (max_pairs * (d / 4 + 1) + SP_THREADS * 8 - 1) / (SP_THREADS * 8);
+    const int64_t limit = 2048 / world > 1 ? 2048 / world : 1;
+    return (int)(b < 1 ? 1 : (b > limit ? limit : b));
+}
+
+extern "C" int rat_owner_pack(const int32_t* mat_dev, int world, int rank, int d, const int32_t* rows_a, const float* grads_a,
+                              const int32_t* rows_b, const float* vals_b, int64_t max_pairs, float* wire, void* stream) {
+    RAT_REQUIRE(mat_dev && rows_a && grads_a && wire && world > 0 && rank >= 0 && rank < world && d > 0 && d % 4 == 0, "bad args");
+    RAT_REQUIRE(al16(grads_a) && al16(wire), "gradient rows and the wire buffer must be 16-byte aligned");
+    OwnerXfer a{};
+    a.mat = mat_dev; a.world = world; a.rank = rank; a.d = d;
+    a.rows_a = const_cast<int32_t*>(rows_a); a.grads_a = const_cast<float*>(grads_a);
+    a.rows_b = const_cast<int32_t*>(rows_b); a.vals_b = const_cast<float*>(vals_b);
+    a.wire = wire;
+    const int bpp = owner_blocks_per_peer(max_pairs, d, world);
+    RAT_LAUNCH((owner_xfer_kernel<true>), (unsigned)(bpp * world), SP_THREADS, 0, stream, a, bpp);
+    return rat_check_launch("rat_owner_pack");
+}
+
+extern "C" int rat_owner_unpack(const int32_t* mat_dev, int world, int rank, int d, const float* wire, int64_t max_pairs,
+                                int32_t* rows_a, float* grads_a, int32_t* rows_b, float* vals_b, int32_t* totals,
+                                const float* extra_src, float* extra_dst, int n_extra, void* stream) {
+    RAT_REQUIRE(mat_dev && rows_a && grads_a && wire && totals && world > 0 && rank >= 0 && rank < world && d > 0 && d % 4 == 0, "bad args");
+    RAT_REQUIRE(al16(grads_a) && al16(wire), "gradient rows and the wire buffer must be 16-byte aligned");
+    RAT_REQUIRE(n_extra == 0 || (extra_src && extra_dst), "null pointer");
+    OwnerXfer a{};
+    a.mat = mat_dev; a.world = world; a.rank = rank; a.d = d;
+    a.rows_a = rows_a; a.grads_a = grads_a; a.rows_b = rows_b; a.vals_b = vals_b;
+    a.wire = const_cast<float*>(wire); a.totals = totals;
+    a.extra_src = extra_src; a.extra_dst = extra_dst; a.n_extra = n_extra;
+    const int bpp = owner_blocks_per_peer(max_pairs, d, world);
+    RAT_LAUNCH((owner_xfer_kernel<false>), (unsigned)(bpp * world), SP_THREADS, 0, stream, a, bpp);
+    return rat_check_launch("rat_owner_unpack");
+}
+
+extern "C" int rat_owner_scatter(float* dense_a, float* dense_b, float* extra_out, const float* lists, int64_t stride, int world,
+                                 int64_t cap_a, int64_t cap_b, int d, int n_extra, void* stream) {
+    RAT_REQUIRE(dense_a && lists && world > 0 && stride > 0 && cap_a >= 0 && cap_b >= 0 && d > 0 && d % 4 == 0, "bad args");
+    RAT_REQUIRE((cap_b == 0 || dense_b) && (n_extra == 0 || extra_out), "null pointer");
+    RAT_REQUIRE(cap_a % 4 == 0 && cap_b % 4 == 0 && stride % 4 == 0 && al16(lists) && al16(dense_a), "sections must be 16-byte aligned");
+    int64_t blocks = (cap_a * (d / 4) + SP_THREADS * 4 - 1) / (SP_THREADS * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    RAT_LAUNCH(owner_scatter_kernel, (unsigned)blocks, SP_THREADS, 0, stream, dense_a, dense_b, extra_out, lists, stride, world, cap_a,
+               cap_b, d, n_extra);
+    return rat_check_launch("rat_owner_scatter");
 }

@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class RatField(Structure):
@@ -128,6 +128,10 @@ _SIGNATURES = {
     "rat_clip_opt_fused": (c_int, [_P, _P, _P, c_int64, c_int64, c_float, c_float, _P, _P, c_float, _P, c_int, c_float, c_float, c_int, _P]),
     "rat_scatter_rows": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P]),
     "rat_scatter_rows_lists": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "rat_owner_counts": (c_int, [_P, _P, c_int64, c_int64, c_int, _P, _P]),
+    "rat_owner_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int64, _P, _P]),
+    "rat_owner_unpack": (c_int, [_P, c_int, c_int, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    "rat_owner_scatter": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int64, c_int64, c_int, c_int, _P]),
     "rat_adam_rows_dev": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, _P, c_float, c_float, c_float, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

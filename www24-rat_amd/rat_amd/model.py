@@ -277,6 +277,7 @@ class RAT_m2(BaseModel):
         self._sparse_is_global = False   # the row lists in _sparse were already merged over the ranks
         self._table_lists = None         # dense modes under data parallelism: this backward's table gradients as row lists
         self._pending_reduce = None      # (work handle, gradient buffer) of the dense-net all-reduce started inside backward
+        self._owner_state = None         # owner exchange: this step's plans + count matrix (_owner_prepare)
         self._validate_ids = bool(kwargs.get("validate_ids", True))
         self._id_errors = None
         self._ws = {}
@@ -772,14 +773,25 @@ class RAT_m2(BaseModel):
             g = self._gather_flat_grad()
         pending, self._pending_reduce = self._pending_reduce, None
         lists, self._table_lists = self._table_lists, None
+        world = self._world_size()
+        ring = lambda nbytes: int(2 * nbytes * (world - 1) / world)      # noqa: E731  (an all-reduce moves ~2 (N-1)/N of its size per rank)
         if g is not None:
             n0 = self._n_emb - self._n_sparse                      # [0, n0): "embedding_layer" tensors with a dense gradient
+            form = ("owner_lists" if self._owner_state is not None else "gathered_lists") if lists is not None else \
+                ("owner_lists(sparse)" if self._owner_state is not None else "gathered_lists(sparse)") if self._sparse is not None else \
+                "dense_allreduce"
+            self._exchange_info = dict(form=form, world=world, dense_net_bytes=ring(4 * (g.numel() - n0)),
+                                       table_bytes=ring(4 * n0) if form == "dense_allreduce" else None)
             if pending is not None and pending[1] is g:            # the dense-net part is already on its way
                 if lists is not None:
-                    for part in lists:
-                        self._scatter_merged(g[part[5]:], self._merge_sparse(part), part[3])       # into the zeroed table block
-                    if n0 > self._n_tab:
-                        self._all_reduce_sum(g[self._n_tab:n0])    # the label table (3 x d floats)
+                    if self._owner_state is not None:              # (the label table's partial gradients ride in the lists' headers)
+                        self._exchange_lists_owner(g, lists)
+                    else:
+                        for part in lists:                         # into the zeroed table block
+                            rows, grads, count, width, _t, _b = self._merge_sparse(part)
+                            ops.scatter_rows(g[part[5]:], rows, grads, count, width, lib=self._lib)
+                        if n0 > self._n_tab:
+                            self._all_reduce_sum(g[self._n_tab:n0])    # the label table (3 x d floats)
                 elif n0 > 0:
                     self._all_reduce_sum(g[:n0])
                 self._collective(lambda: pending[0][0].wait())
@@ -796,87 +808,211 @@ class RAT_m2(BaseModel):
                     self._params[n].grad = self._gflat_view(g, n)
                 self._last_gflat = g
         if self._sparse is not None and not self._sparse_is_global:      # (a second call must not merge global lists again)
-            self._sparse = [rec for part in self._sparse for rec in self._merge_sparse(part)["records"]]
+            if self._owner_state is not None and g is not None:
+                self._sparse = self._exchange_lists_owner(g, self._sparse)
+            else:
+                self._sparse = [self._merge_sparse(part) for part in self._sparse]
             self._sparse_is_global = True
+        self._owner_state = None
+        info = self.__dict__.get("_exchange_info")
+        if info is not None and info["table_bytes"] is None:
+            if info["form"].startswith("owner"):
+                info["table_bytes"] = (self.__dict__.get("_owner_stats") or {}).get("wire_bytes")
+            elif lists is not None:                                # all-gather at capacity: my lists to every peer
+                info["table_bytes"] = sum(4 * (p[0].numel() * (1 + p[3]) + 1) for p in lists) * (world - 1)
 
-    # Owner-partitioned exchange of the table-gradient lists: rank k owns the rows [k R/N, (k+1) R/N) of a table
-    # family; every rank sends each owner ITS rows of the local (sorted, unique) list — an all-to-all of exactly the rows that exist
-    # — the owner sorts / reduces only what it received (1/N of the union instead of the whole union on every rank) and the reduced
-    # lists are all-gathered.  Same sums in the same (rank) order as the all-gather form, so the replicas stay bit-identical.  The
-    # split sizes have to be known on the host (one read-back of an N x N count matrix per family and step), which a captured step
-    # cannot do: while a StepGraph is recording, the all-gather-at-capacity form below is used.
+    # Owner-partitioned exchange of the table-gradient lists: rank k owns the rows [k R/N, (k+1) R/N) of a table family; every rank sends
+    # each owner ITS rows of the local (sorted, unique) lists — an all-to-all of exactly the pairs that exist — the owner sorts / reduces
+    # only what it received (1/N of the union instead of the whole union on every rank) and the reduced lists are all-gathered.  Same
+    # sums in the same (rank) order as the all-gather form, so the replicas stay bit-identical.
+    #
+    # Round 5: no host stall, three collectives per step instead of twelve.  The split sizes of the all-to-all are the per-owner counts
+    # of the local lists — a function of the batch's IDS alone.  `_owner_prepare` therefore builds the sort plans and the counts at
+    # the START of the step (rat_owner_counts), all-gathers the N x N matrix and starts its copy to pinned host memory; the host reads
+    # it when the backward has been enqueued — long after the copy has landed.  Both table families and the label table's partial
+    # gradient share ONE wire buffer per peer (rat_owner_pack / rat_owner_unpack) and ONE all-gathered list per rank
+    # (rat_owner_scatter).  Under a captured step the exchange is one eager closure between two graph segments (its buffer sizes
+    # change from step to step; its inputs and outputs — the local lists, the gradient bucket — are static).
     owner_exchange = True
     _OWNER_BUCKET = 4096                 # list capacities are rounded up to this many rows (few distinct plan sizes)
 
     def _merge_sparse(self, part):
-        """one family's local (rows, grads, count) -> {"records": the global list as one or more disjoint (rows, grads, count, width,
-        total_rows, base) records, "stacked": ([lists, cap] rows, [lists, cap, width] grads, [lists] counts) or None}"""
-        if self.owner_exchange and self._tape is None and self._world_size() > 1:
-            return self._merge_sparse_owner(part)
-        return {"records": [self._merge_sparse_gather(part)], "stacked": None}
+        """one family's local (rows, grads, count) -> the global list as ONE (rows, grads, count, width, total_rows, base) record
+        (all-gather at capacity + merge of the union on every rank: the form without owners)"""
+        return self._merge_sparse_gather(part)
 
-    def _scatter_merged(self, dense, merged, width):
-        if merged["stacked"] is not None:
-            rows, grads, counts = merged["stacked"]
-            ops.scatter_rows_lists(dense, rows, grads, counts, width, lib=self._lib)
-        else:
-            for rows, grads, count, _w, _t, _b in merged["records"]:
-                ops.scatter_rows(dense, rows, grads, count, width, lib=self._lib)
+    def _use_owner_exchange(self):
+        # (sparse mode inside a captured step: the optimizer's row kernels are recorded with the list pointers baked in — the
+        # all-gather form has static capacities)
+        return bool(self.owner_exchange) and not (self._tape is not None and self._grad_mode == "sparse")
 
-    def _merge_sparse_owner(self, part):
-        import torch.distributed as dist
-        lib, world, rank = self._lib, self._world_size(), dist.get_rank()
-        rows, grads, count, width, total_rows, base_off = part
-        dev, cap = rows.device, rows.numel()
-        per = -(-int(total_rows) // world)                                    # owner k: rows [k per, (k + 1) per)
-        # (1) my rows per owner range: the list is sorted, so one binary search per range edge (the tail past `count` is masked)
-        pos = self._ws.get(("iota", cap))
-        if pos is None or pos.device != dev:
-            pos = self._ws[("iota", cap)] = torch.arange(cap, dtype=torch.int32, device=dev)
-        big = torch.iinfo(torch.int32).max
-        keyed = torch.where(pos < count, rows, torch.full_like(rows, big))
-        edges = torch.clamp(torch.arange(1, world + 1, dtype=torch.int64, device=dev) * per, max=big - 1).to(torch.int32)
-        ends = torch.searchsorted(keyed, edges)
-        send = torch.diff(ends, prepend=ends.new_zeros(1)).to(torch.int64)    # [world]
-        # (2) the N x N count matrix, on every host
-        mat = self._all_gather_flat(send).view(world, world)
-        S = mat.cpu()
-        in_splits, out_splits = [int(v) for v in S[rank]], [int(v) for v in S[:, rank]]
-        n_send, n_recv = sum(in_splits), sum(out_splits)
-        bucket = lambda n: max(self._OWNER_BUCKET, -(-n // self._OWNER_BUCKET) * self._OWNER_BUCKET)      # noqa: E731
-        cap2 = max(bucket(int(v)) for v in S.sum(0))                          # the same number on every rank
-        # (3) all-to-all of the (row, gradient row) pairs to their owners
-        recv_rows = torch.empty(cap2, dtype=torch.int32, device=dev)
-        recv_grads = torch.empty((cap2, width), dtype=torch.float32, device=dev)
-        self._all_to_all_rows(recv_rows[:n_recv], rows[:n_send], out_splits, in_splits)
-        self._all_to_all_rows(recv_grads[:n_recv], grads[:n_send], out_splits, in_splits)
-        n_recv_dev = mat[:, rank].sum().reshape(1).to(torch.int32)
-        # (4) the owner's merge: sort + fixed-order reduction of what it received (sources in rank order)
-        pkey = ("merge-owner", width, cap2)
-        plan = ops.sparse_plan_rows(recv_rows, n_recv_dev, cap2, 1, total_rows, plan=self._ws.get(pkey), lib=lib)
-        self._ws[pkey] = plan
-        out_rows = torch.empty(cap2, dtype=torch.int32, device=dev)
-        out_grads = torch.empty((cap2, width), dtype=torch.float32, device=dev)
-        ops.sparse_reduce_rows(plan, recv_grads, cap2, 1, width, out_rows, out_grads, lib=lib)
-        # (5) every rank gets every owner's reduced list
-        rows_all = self._all_gather_flat(out_rows).view(world, cap2)
-        grads_all = self._all_gather_flat(out_grads.reshape(-1)).view(world, cap2, width)
-        counts_all = self._all_gather_flat(plan.count)
-        records = [(rows_all[k], grads_all[k], counts_all[k:k + 1], width, total_rows, base_off) for k in range(world)]
-        self._owner_stats = dict(sent=n_send, received=n_recv, capacity=cap2, local_capacity=cap)
-        return {"records": records, "stacked": (rows_all, grads_all, counts_all)}
-
-    def _all_to_all_rows(self, out, inp, out_splits, in_splits):
+    def _raw_all_to_all(self, out, inp, out_splits, in_splits):
         """uneven all-to-all along dim 0 (RCCL on device tensors; gloo on host tensors, staged through the host for device tensors)"""
         import torch.distributed as dist
         if self._staged(inp):
-            def run():
-                ho = torch.empty(out.shape, dtype=out.dtype)
-                dist.all_to_all_single(ho, inp.detach().cpu().contiguous(), out_splits, in_splits)
-                out.copy_(ho)
-            self._collective(run)
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(ho, inp.detach().cpu().contiguous(), out_splits, in_splits)
+            out.copy_(ho)
         else:
-            self._collective(lambda: dist.all_to_all_single(out, inp.contiguous(), out_splits, in_splits))
+            dist.all_to_all_single(out, inp, out_splits, in_splits)
+
+    def _raw_all_gather(self, out, t):
+        import torch.distributed as dist
+        world = self._world_size()
+        if self._staged(t):
+            parts = [torch.empty(t.numel(), dtype=t.dtype) for _ in range(world)]
+            dist.all_gather(parts, t.detach().reshape(-1).cpu())
+            out.copy_(torch.cat(parts))
+        elif t.is_cuda:
+            dist.all_gather_into_tensor(out, t)
+        else:
+            dist.all_gather(list(out.view(world, -1).unbind(0)), t)
+
+    def _build_plans(self, idx, dims):
+        """the sort plans of a batch's table rows (feature tables; LR tables): functions of the ids alone"""
+        c, lib = self._cfg, self._lib
+        B, T, L, S = dims
+        d, F = c["d"], c["nf"]
+        if self._col2field is None or self._col2field.numel() != L:
+            self._col2field = ops.col2field_table(self._fields, L, idx.device)
+        rows_feat = self._n_feat // d
+        # one plan per batch size, kept for the model's life: captured steps point into its workspace (see _merge_sparse_gather)
+        plan = ops.sparse_plan_ids(idx, self._ftab, self._col2field, F, self._flat, d, rows_feat, B, T, L,
+                                   plan=self._ws.get(("plan", 0, B * T * L)), lib=lib)
+        self._ws[("plan", 0, B * T * L)] = plan
+        plan_lr = None
+        if c["use_wide"]:
+            rows_lr = self._n_tab - self._n_feat
+            plan_lr = ops.sparse_plan_ids(idx, self._lr_ftab, self._col2field, F, self._flat[self._n_feat:], 1, rows_lr, B, T, L,
+                                          target_only=True, plan=self._ws.get(("plan", 1, B * L)), lib=lib)
+            self._ws[("plan", 1, B * L)] = plan_lr
+        return plan, plan_lr
+
+    def _owner_prepare(self, idx, dims):
+        """Start of a fused iteration whose table gradients will travel as row lists: plans, per-owner counts, the N x N count matrix
+        on every rank and — asynchronously — on every host."""
+        c, lib = self._cfg, self._lib
+        world, dev = self._world_size(), idx.device
+        d = c["d"]
+        plans = self._build_plans(idx, dims)
+        per_a = -(-(self._n_feat // d) // world)
+        per_b = -(-(self._n_tab - self._n_feat) // world) if plans[1] is not None else 1
+        cnt = self._ws.get(("owner-counts", world))
+        if cnt is None or cnt.device != dev:
+            cnt = self._ws[("owner-counts", world)] = torch.zeros(2 * world, dtype=torch.int32, device=dev)
+        ops.owner_counts(plans[0], per_a, world, cnt[:world], lib=lib)
+        if plans[1] is not None:
+            ops.owner_counts(plans[1], per_b, world, cnt[world:], lib=lib)
+        self._owner_publish(cnt, plans, (per_a, per_b))
+
+    def _owner_publish(self, cnt, plans, per):
+        """cnt: int32 [2][world] on the device, this rank's pairs per (family, owner) -> `_owner_state`"""
+        import torch.distributed as dist
+        world, rank, dev = self._world_size(), dist.get_rank(), cnt.device
+        mat = torch.empty(2 * world * world, dtype=torch.int32, device=dev)
+        host = self._ws.get(("owner-host", world))
+        if host is None:
+            host = torch.empty(2 * world * world, dtype=torch.int32)
+            host = self._ws[("owner-host", world)] = host.pin_memory() if dev.type == "cuda" else host
+        event = torch.cuda.Event() if dev.type == "cuda" else None
+
+        def run():
+            self._raw_all_gather(mat, cnt)
+            host.copy_(mat, non_blocking=True)
+            if event is not None:
+                event.record()
+        self._collective(run)
+        self._owner_state = dict(plans=plans, mat=mat, host=host, event=event, per=per, rank=rank, world=world)
+
+    def _exchange_lists_owner(self, g, lists):
+        """lists: this backward's [(rows, grads, count, width, total_rows, base)] per table family (feature tables[, LR tables]) ->
+        dense modes: the global gradient rows land in the zeroed table block of `g` and the label table's gradient is summed over
+        the ranks; sparse mode: returns the global lists as records for the row optimizer."""
+        st, self._owner_state = self._owner_state, None
+        c, lib = self._cfg, self._lib
+        d, world, rank = c["d"], st["world"], st["rank"]
+        mat, host, event = st["mat"], st["host"], st["event"]
+        rows_a, grads_a, _ca, _wa, total_a, base_a = lists[0]
+        rows_b, vals_b, _cb, _wb, total_b, base_b = lists[1] if len(lists) > 1 else (None, None, None, 1, 0, 0)
+        dev = rows_a.device
+        sparse_mode = self._grad_mode == "sparse"
+        # the label table's slot (the "embedding_layer" tensor without a row list): its partial gradients ride in the lists' headers
+        # (sparse mode: it is part of the dense slice _exchange_gradients all-reduces)
+        n_label = 0 if sparse_mode else self._n_emb - self._n_tab
+        label = g[self._n_tab:self._n_emb] if n_label > 0 else None
+        pad4 = lambda n: (n + 3) // 4 * 4                              # noqa: E731
+        chunk = lambda na, nb: pad4(na) + na * d + 2 * pad4(nb)        # noqa: E731
+        bucket = lambda n: max(self._OWNER_BUCKET, -(-n // self._OWNER_BUCKET) * self._OWNER_BUCKET)      # noqa: E731
+        out = {}
+
+        def run():
+            recording = self._tape is not None        # graph capture: nothing has executed, the matrix is not there yet — issue the
+            if recording:                              # same collectives on token buffers and launch nothing that reads it
+                S = torch.zeros((world, 2, world), dtype=torch.int64)
+            else:
+                if event is not None:
+                    event.synchronize()
+                S = host.view(world, 2, world).to(torch.int64)
+            in_splits = [chunk(int(S[rank, 0, k]), int(S[rank, 1, k])) if not recording else 4 for k in range(world)]
+            out_splits = [chunk(int(S[k, 0, rank]), int(S[k, 1, rank])) if not recording else 4 for k in range(world)]
+            n_send, n_recv = sum(in_splits), sum(out_splits)
+            cap_a = bucket(int(S[:, 0, :].sum(0).max()))
+            cap_b = bucket(int(S[:, 1, :].sum(0).max())) if rows_b is not None else 0
+            max_pairs = int(S.sum(1).max())
+            send = torch.empty(max(n_send, 4), dtype=torch.float32, device=dev)
+            recv = torch.empty(max(n_recv, 4), dtype=torch.float32, device=dev)
+            if not recording:
+                ops.owner_pack(mat, world, rank, d, rows_a, grads_a, rows_b, vals_b, max_pairs, send, lib=lib)
+            self._raw_all_to_all(recv[:n_recv], send[:n_send], out_splits, in_splits)
+            stride = 4 + pad4(n_label) + cap_a * (1 + d) + 2 * cap_b
+            mine = torch.empty(stride, dtype=torch.float32, device=dev)
+            mine_i = mine.view(torch.int32)
+            o_ra = 4 + pad4(n_label)
+            o_ga, o_rb = o_ra + cap_a, o_ra + cap_a * (1 + d)
+            o_vb = o_rb + cap_b
+            if not recording:
+                got_ra = torch.empty(cap_a, dtype=torch.int32, device=dev)
+                got_ga = torch.empty((cap_a, d), dtype=torch.float32, device=dev)
+                got_rb = torch.empty(cap_b, dtype=torch.int32, device=dev) if cap_b else None
+                got_vb = torch.empty(cap_b, dtype=torch.float32, device=dev) if cap_b else None
+                totals = torch.empty(2, dtype=torch.int32, device=dev)
+                if not cap_b:
+                    mine_i[1:2].zero_()
+                ops.owner_unpack(mat, world, rank, d, recv, max_pairs, got_ra, got_ga, got_rb, got_vb, totals,
+                                 extra_src=label, extra_dst=mine[4:4 + n_label] if n_label > 0 else None, lib=lib)
+                # the owner's merge: sort + fixed-order reduction of what it received (sources in rank order), written straight into
+                # the list this rank contributes to the all-gather
+                key = ("merge-owner", 0, cap_a)
+                plan = ops.sparse_plan_rows(got_ra, totals[0:1], cap_a, 1, total_a, plan=self._ws.get(key), count_out=mine_i[0:1], lib=lib)
+                self._ws[key] = plan
+                ops.sparse_reduce_rows(plan, got_ga, cap_a, 1, d, mine_i[o_ra:o_ga], mine[o_ga:o_rb].view(cap_a, d), count=mine_i[0:1], lib=lib)
+                if cap_b:
+                    key = ("merge-owner", 1, cap_b)
+                    plan = ops.sparse_plan_rows(got_rb, totals[1:2], cap_b, 1, total_b, plan=self._ws.get(key), count_out=mine_i[1:2], lib=lib)
+                    self._ws[key] = plan
+                    ops.sparse_reduce_rows(plan, got_vb.view(cap_b, 1), cap_b, 1, 1, mine_i[o_rb:o_vb], mine[o_vb:].view(cap_b, 1),
+                                           count=mine_i[1:2], lib=lib)
+            everyone = torch.empty(world * stride, dtype=torch.float32, device=dev)
+            self._raw_all_gather(everyone, mine)
+            self._owner_stats = dict(sent=int(S[rank].sum()), received=int(S[:, :, rank].sum()), capacity=(cap_a, cap_b),
+                                     local_capacity=rows_a.numel(), floats_sent=n_send, floats_gathered=world * stride, collectives=3,
+                                     # what this rank puts on the links: its chunks for the other owners + its reduced list to every peer
+                                     wire_bytes=4 * ((n_send - in_splits[rank]) + stride * (world - 1)))
+            if recording:
+                return
+            if sparse_mode:
+                ev_i = everyone.view(torch.int32).view(world, stride)
+                ev_f = everyone.view(world, stride)
+                recs = []
+                for k in range(world):
+                    recs.append((ev_i[k, o_ra:o_ga], ev_f[k, o_ga:o_rb].view(cap_a, d), ev_i[k, 0:1], d, total_a, base_a))
+                    if cap_b:
+                        recs.append((ev_i[k, o_rb:o_vb], ev_f[k, o_vb:].view(cap_b, 1), ev_i[k, 1:2], 1, total_b, base_b))
+                out["records"] = recs
+            else:
+                ops.owner_scatter(g[base_a:], g[base_b:] if cap_b else None, label, everyone, stride, world, cap_a, cap_b, d, n_label, lib=lib)
+        self._collective(run)
+        return out.get("records")
 
     def _merge_sparse_gather(self, part):
         """all-gather one family's (rows, grads, count) at capacity and reduce the union: -> the same record, global"""
@@ -1020,6 +1156,11 @@ class RAT_m2(BaseModel):
         scal = self.optimizer.begin_step(counts, count=count)
         self._step_loss = scal[0:1]
         self._bn_counted = counts is not None
+        lists = self._dp() and self._row_lists_travel_lighter(batch[0].shape, world)
+        self._owner_state = None
+        if self._dp() and self._use_owner_exchange() and self._lists_possible and (lists or self._grad_mode == "sparse"):
+            B, T, L = batch[0].shape
+            self._owner_prepare(batch[0], (B, T, L, self._cfg["nf"] + 1))
         try:
             _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
         finally:
@@ -1027,7 +1168,7 @@ class RAT_m2(BaseModel):
             self.__dict__.pop("_step_loss", None)
         if self._graph_test_splits:
             self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
-        self._run_backward(saved, inv, None, table_lists=self._dp() and self._row_lists_travel_lighter(batch[0].shape, world))
+        self._run_backward(saved, inv, None, table_lists=lists)
         if self._graph_test_splits:
             self._collective(lambda: None)
         g = self._last_gflat
@@ -1067,11 +1208,11 @@ class RAT_m2(BaseModel):
     row_list_exchange = None    # None: decide by traffic (_row_lists_travel_lighter); True / False: force (tests, experiments)
     _graph_test_splits = False  # tests: cut the captured step into segments the way collectives do under data parallelism
     use_graph = True           # capture the fused iteration into a hipGraph (CUDA devices only)
-    # Under data parallelism the captured step is a chain of graph segments with the collectives between them (graph.py).  That path is
-    # proven on one GPU with two gloo ranks (tests/test_gpu_dp.py) but has never met RCCL — no multi-GPU box was available to this build
-    # — and at the north-star shapes the step is GPU-bound with or without a graph (B = 512: 3.75 ms of kernels in a 3.76 ms step), so it
-    # is opt-in (`graph_under_dp=True` / bench.py --graph-dp) until it has run on a node.
-    graph_under_dp = False
+    # Under data parallelism the captured step is a chain of graph segments with the collectives between them as eager closures
+    # (graph.py): proven on one GPU with two gloo ranks (tests/test_gpu_dp.py) and with one RCCL rank (tests/test_gpu_rccl.py,
+    # bench.py --dp-rehearsal); on by default since round 5 (the owner exchange no longer needs a host read-back mid-step).  A capture
+    # that fails leaves that batch shape on the eager step (_step_graph_for); `graph_under_dp=False` / bench.py --no-graph-dp turns it off.
+    graph_under_dp = True
     graph_warmup = 2           # eager fused steps of a batch shape before it is captured
     graph_shapes = 2           # at most this many batch shapes get a graph (the full batch and an epoch's tail batch)
 
@@ -1404,10 +1545,9 @@ class RAT_m2(BaseModel):
         d, F = c["d"], c["nf"]
         dev = dx.device
         rows_feat = self._n_feat // d
-        # one plan per batch size, kept for the model's life: captured steps point into its workspace (see _merge_sparse)
-        plan = ops.sparse_plan_ids(idx, self._ftab, self._col2field, F, self._flat, d, rows_feat, B, T, L,
-                                   plan=self._ws.get(("plan", 0, B * T * L)), lib=lib)
-        self._ws[("plan", 0, B * T * L)] = plan
+        # (under the owner exchange the plans were built at the start of the step: _owner_prepare)
+        st = self.__dict__.get("_owner_state")
+        plan, plan_lr = st["plans"] if st is not None else self._build_plans(idx, dims)
         sparse = []
         if mode == "sorted":
             ops.sparse_reduce_grid(plan, dx, dflat, self._col2field, B, T, L, F, d, dense_base=gflat, lib=lib)
@@ -1419,10 +1559,6 @@ class RAT_m2(BaseModel):
             sparse.append((rows, grads, plan.count.clone(), d, rows_feat, 0))
         if c["use_wide"]:                                       # LR tables: width-1 rows, gradient = dlogit of the TARGET sample
             rows_lr = self._n_tab - self._n_feat
-            lr_base = self._flat[self._n_feat:]
-            plan_lr = ops.sparse_plan_ids(idx, self._lr_ftab, self._col2field, F, lr_base, 1, rows_lr, B, T, L, target_only=True,
-                                          plan=self._ws.get(("plan", 1, B * L)), lib=lib)
-            self._ws[("plan", 1, B * L)] = plan_lr
             if mode == "sorted":
                 ops.sparse_reduce_scalar(plan_lr, dlogit, B, L, dense_base=gflat[self._n_feat:], lib=lib)
             else:

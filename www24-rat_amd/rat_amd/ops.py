@@ -188,14 +188,15 @@ def sparse_plan_ids(idx, ftab, col2field, nfields, flat_base, width, total_rows,
     return plan
 
 
-def sparse_plan_rows(rows, counts, cap, world, total_rows, plan=None, lib=None):
+def sparse_plan_rows(rows, counts, cap, world, total_rows, plan=None, count_out=None, lib=None):
+    """count_out: where the number of unique rows is written (default: the plan's own counter) — pass the same tensor to the reduce"""
     lib = lib or get_lib()
     _chk(rows, torch.int32, "rows"), _chk(counts, torch.int32, "counts")
     n = cap * world
     if plan is None or plan.n != n:
         plan = SparsePlan(n, rows.device, lib)
     lib.call("rat_sparse_plan_rows", _p(rows), _p(counts), int(cap), int(world), int(total_rows), _p(plan.ws), plan.ws.numel(),
-             _p(plan.count), _stream(rows))
+             _p(plan.count if count_out is None else count_out), _stream(rows))
     return plan
 
 
@@ -207,11 +208,11 @@ def sparse_reduce_grid(plan, dgrid, dflat, col2field, B, T, L, nfields, d, out_r
              int(bool(target_only)), _p(out_rows), _p(out_grads), _p(dense_base), _stream(dgrid))
 
 
-def sparse_reduce_rows(plan, src_rows, cap, world, d, out_rows, out_grads, lib=None):
+def sparse_reduce_rows(plan, src_rows, cap, world, d, out_rows, out_grads, count=None, lib=None):
     lib = lib or get_lib()
     _chk(src_rows, name="src_rows"), _chk(out_grads, name="out_grads"), _chk(out_rows, torch.int32, "out_rows")
-    lib.call("rat_sparse_reduce_rows", _p(plan.ws), _p(plan.count), _p(src_rows), int(cap), int(world), d, _p(out_rows), _p(out_grads),
-             _stream(src_rows))
+    lib.call("rat_sparse_reduce_rows", _p(plan.ws), _p(plan.count if count is None else count), _p(src_rows), int(cap), int(world), d,
+             _p(out_rows), _p(out_grads), _stream(src_rows))
 
 
 def sparse_reduce_scalar(plan, per_sample, B, L, out_rows=None, out_vals=None, dense_base=None, lib=None):
@@ -762,3 +763,35 @@ def scatter_rows(dense_base, rows, grads, count, d, lib=None):
     lib = lib or get_lib()
     _chk(rows, torch.int32, "rows"), _chk(count, torch.int32, "count")
     lib.call("rat_scatter_rows", _p(dense_base), _p(rows), _p(grads), _p(count), rows.numel(), int(d), _stream(grads))
+
+
+# ---- owner-partitioned exchange of the row lists (data parallelism; include/rat_hip.h ABI v8) -----------------------------------------
+def owner_counts(plan, rows_per_owner, world, out, lib=None):
+    """out[k] (int32 [world]) = unique rows of `plan` in owner k's range [k per, (k + 1) per)"""
+    lib = lib or get_lib()
+    _chk(out, torch.int32, "out")
+    assert out.numel() == world
+    lib.call("rat_owner_counts", _p(plan.ws), _p(plan.count), int(plan.n), int(rows_per_owner), int(world), _p(out), _stream(out))
+
+
+def owner_pack(mat, world, rank, d, rows_a, grads_a, rows_b, vals_b, max_pairs, wire, lib=None):
+    lib = lib or get_lib()
+    _chk(mat, torch.int32, "mat"), _chk(rows_a, torch.int32, "rows_a"), _chk(grads_a, name="grads_a"), _chk(wire, name="wire")
+    lib.call("rat_owner_pack", _p(mat), int(world), int(rank), int(d), _p(rows_a), _p(grads_a), _p(rows_b), _p(vals_b), int(max_pairs),
+             _p(wire), _stream(wire))
+
+
+def owner_unpack(mat, world, rank, d, wire, max_pairs, rows_a, grads_a, rows_b, vals_b, totals, extra_src=None, extra_dst=None, lib=None):
+    lib = lib or get_lib()
+    _chk(mat, torch.int32, "mat"), _chk(rows_a, torch.int32, "rows_a"), _chk(grads_a, name="grads_a"), _chk(wire, name="wire")
+    _chk(totals, torch.int32, "totals")
+    n_extra = 0 if extra_src is None else extra_src.numel()
+    lib.call("rat_owner_unpack", _p(mat), int(world), int(rank), int(d), _p(wire), int(max_pairs), _p(rows_a), _p(grads_a), _p(rows_b),
+             _p(vals_b), _p(totals), _p(extra_src), _p(extra_dst), int(n_extra), _stream(wire))
+
+
+def owner_scatter(dense_a, dense_b, extra_out, lists, stride, world, cap_a, cap_b, d, n_extra, lib=None):
+    lib = lib or get_lib()
+    _chk(lists, name="lists")
+    lib.call("rat_owner_scatter", _p(dense_a), _p(dense_b), _p(extra_out), _p(lists), int(stride), int(world), int(cap_a), int(cap_b),
+             int(d), int(n_extra), _stream(lists))
