@@ -90,10 +90,19 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
             # stored next to the data in the data's own format: retrieval_{K}_{split}.h5 — the reference's file name and keys
             # (data_generator.py:106-113) — when the split is an HDF5 file, .npz otherwise
             rpath = os.path.join(data_dir, "retrieval_%d_%s%s" % (topk, split, ".h5" if dpath.endswith(".h5") else ".npz"))
+            failed = rpath + ".failed"
             if shard[0] == 0:                                   # one rank computes and writes the file (atomically), the others wait
-                precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
+                if os.path.exists(failed):
+                    os.remove(failed)                           # (a marker of an earlier, failed run)
+                try:
+                    precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
+                except BaseException as exc:                    # tell the pollers before dying: they must not wait for a file that will never come
+                    if shard[1] > 1:
+                        with open(failed, "w") as f:
+                            f.write("%s: %s\n" % (type(exc).__name__, exc))
+                    raise
             if shard[1] > 1:
-                _wait_for_file(rpath, leader=shard[0] == 0)
+                _wait_for_file(rpath, leader=shard[0] == 0, failed_marker=failed)
         elif rpath is None:                                      # (this rank's listing was older than rank 0's)
             rpath = _find(data_dir, "retrieval_%d_%s" % (topk, split))
         out.append(rat_data.batches_from_files(dpath, rpath, bs, pool_path=pool, shuffle=(split == "train") and params.get("shuffle", True),
@@ -101,14 +110,24 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
     return out
 
 
-def _wait_for_file(path, leader, poll_s=2.0):
+def _wait_for_file(path, leader, poll_s=2.0, failed_marker=None, max_wait_s=None):
     """The top-K pre-computation of a large split can take longer than a collective's timeout (10 minutes by default), so the other ranks
     do not sit in a barrier: they poll for the finished file (written under a temporary name and renamed, so existence means complete)
-    and only then meet rank 0 in a barrier that returns at once."""
+    and only then meet rank 0 in a barrier that returns at once.  They give up — exit non-zero — when rank 0 leaves the
+    `failed_marker` behind (its pre-computation raised) or after `max_wait_s` seconds (default: RAT_RETRIEVAL_WAIT_S, else 6 hours)."""
     import time
     import torch.distributed as dist
     if not leader:
+        if max_wait_s is None:
+            max_wait_s = float(os.environ.get("RAT_RETRIEVAL_WAIT_S", 6 * 3600))
+        t_end = time.monotonic() + max_wait_s
         while not os.path.exists(path):
+            if failed_marker is not None and os.path.exists(failed_marker):
+                with open(failed_marker) as f:
+                    raise SystemExit("rank 0 could not write %s: %s" % (path, f.read().strip()))
+            if time.monotonic() > t_end:
+                raise SystemExit("gave up waiting for %s after %.0f s (rank 0 is computing it; RAT_RETRIEVAL_WAIT_S sets the limit)"
+                                 % (path, max_wait_s))
             time.sleep(poll_s)
     dist.barrier()
 
@@ -129,12 +148,16 @@ def precompute_retrieval_file(data_path, pool_path, save_path, rcfg, feature_map
     indices, values, lens = retrieval.precompute_retrieval(data, rcfg, cols, pool_array=pool, device="cuda:%d" % params["gpu"])
     root, ext = os.path.splitext(save_path)
     tmp = "%s.tmp%d%s" % (root, os.getpid(), ext)                # same directory, same extension (np.savez appends .npz otherwise)
-    if save_path.endswith(".h5"):
-        from rat_amd import h5io
-        h5io.write_arrays(tmp, {"indices": np.asarray(indices), "values": np.asarray(values), "lens": np.asarray(lens)})
-    else:
-        np.savez_compressed(tmp, indices=indices, values=values, lens=lens)
-    os.replace(tmp, save_path)                                   # atomic: a reader never sees a partial file
+    try:
+        if save_path.endswith(".h5"):
+            from rat_amd import h5io
+            h5io.write_arrays(tmp, {"indices": np.asarray(indices), "values": np.asarray(values), "lens": np.asarray(lens)})
+        else:
+            np.savez_compressed(tmp, indices=indices, values=values, lens=lens)
+        os.replace(tmp, save_path)                               # atomic: a reader never sees a partial file
+    finally:
+        if os.path.exists(tmp):                                  # (a failed write / rename: nothing half-written stays behind)
+            os.remove(tmp)
 
 
 def main(argv=None):

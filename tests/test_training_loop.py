@@ -132,3 +132,108 @@ def test_ranks_agree_on_early_stopping_and_only_rank0_writes():
         assert r0["first"] == (0.8, 0) and r0["second"][:3] == (0.8, 1, True) and abs(r0["second"][3] - 1e-4) < 1e-12
         state = torch.load(os.path.join(out_dir, "shared.model"))
         assert float(state["fc.bias"][0]) == 1.0              # rank 0's replica
+
+
+def test_a_failed_iteration_takes_its_clock_tick_back(emu_model):
+    """rat_step_begin advances the optimizer's clock and BatchNorm's num_batches_tracked before forward / backward run; an
+    exception in between must not leave them one ahead with no update applied."""
+    case, model, batch = emu_model
+    model.train()
+    model.train_step(batch)
+    opt = model.optimizer
+    step, counts = opt._step, model._bn_counts.clone()
+    flat = model._flat.clone()
+    inner = model._run_backward
+
+    def boom(*a, **k):
+        raise RuntimeError("injected")
+    model._run_backward = boom
+    with pytest.raises(RuntimeError, match="injected"):
+        model.train_step(batch)
+    model._run_backward = inner
+    assert opt._step == step and torch.equal(model._bn_counts, counts) and torch.equal(model._flat, flat)
+    model.train_step(batch)                                   # and the next good step is step + 1 on host and device
+    assert opt._step == step + 1 and int(opt._step_dev[0]) == step + 1
+    assert torch.equal(model._bn_counts, counts + 1)
+
+
+def test_last_grad_norm_follows_the_last_step_whichever_form(emu_model):
+    case, model, batch = emu_model
+    model.train()
+    model.train_step(batch)                                   # fused form
+    fused = model.optimizer.last_grad_norm()
+    assert fused is not None and fused > 0
+    model.optimizer.zero_grad()
+    (model.get_total_loss(batch) * 3.0).backward()            # autograd form, a different gradient
+    model.optimizer.clip_and_step(10.0)
+    plain = model.optimizer.last_grad_norm()
+    assert plain is not None and abs(plain - fused) > 1e-3 * fused
+    model.optimizer.zero_grad()
+    model.get_total_loss(batch).backward()
+    model.optimizer.clip_and_step(None)                       # a step without clipping computes no norm
+    assert model.optimizer.last_grad_norm() is None
+
+
+def test_sparse_rows_with_a_non_adam_optimizer_is_refused_at_construction():
+    _setup_paths()
+    import build_emu
+    import golden_cases as gc
+    import model_cases as mc
+    import rat_amd._lib as L
+    old = L._default
+    L._default = L.RatLib(build_emu.build())
+    try:
+        case = dict(gc.case_by_name("tiny_seq_bn"), embedding_regularizer=0.0, optimizer="SGD")
+        with pytest.raises(NotImplementedError, match="Adam only"):
+            mc.build_model(case, gpu=-1, seed=1, embedding_grad="sparse")
+        mc.build_model(dict(case, optimizer="adam"), gpu=-1, seed=1, embedding_grad="sparse")
+    finally:
+        L._default = old
+
+
+def test_dropout_generator_state_travels_with_the_optimizer_state():
+    """the device-side mask generator's (base seed, counter) is resume state — a restored run continues the mask sequence"""
+    _setup_paths()
+    import build_emu
+    import golden_cases as gc
+    import model_cases as mc
+    import rat_amd._lib as L
+    old = L._default
+    L._default = L.RatLib(build_emu.build())
+    try:
+        case = gc.case_by_name("tiny_seq_bn")
+        a = mc.build_model(case, gpu=-1, seed=1, emb_dropout=0.2)
+        batch = mc.batch_of(case)
+        a.train()
+        assert a.dropout_state() is None
+        for _ in range(2):
+            a.train_step(batch)
+        st = a.dropout_state()
+        assert st["counter"] == 2
+        sd = a.optimizer.state_dict()
+        assert sd["rat_dropout"] == st
+        b = mc.build_model(case, gpu=-1, seed=1, emb_dropout=0.2)
+        b.load_state_dict(a.state_dict())
+        b.optimizer.load_state_dict({k: (v.clone() if torch.is_tensor(v) else v) for k, v in sd.items()})
+        b.train()
+        la, lb = a.train_step(batch), b.train_step(batch)     # third step of both: same weights, same moments, same masks
+        assert float(la) == float(lb) and torch.equal(a._flat, b._flat)
+        assert b.dropout_state() == {"base": st["base"], "counter": 3}
+    finally:
+        L._default = old
+
+
+def test_waiting_ranks_give_up_when_rank0_fails_or_takes_too_long(tmp_path, monkeypatch):
+    """the pollers of run_expid's retrieval pre-computation must not spin forever"""
+    _setup_paths()
+    import run_expid
+    monkeypatch.setattr(dist, "barrier", lambda *a, **k: None)
+    target, marker = str(tmp_path / "retrieval_3_train.npz"), str(tmp_path / "retrieval_3_train.npz.failed")
+    with pytest.raises(SystemExit, match="gave up waiting"):
+        run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=0.05)
+    open(marker, "w").write("MemoryError: top-K\n")
+    with pytest.raises(SystemExit, match="MemoryError: top-K"):
+        run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=5)
+    open(target, "w").write("x")
+    run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=5)       # the file wins
+    run_expid._wait_for_file(target, leader=True)

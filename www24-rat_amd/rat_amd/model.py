@@ -642,6 +642,11 @@ class RAT_m2(BaseModel):
         if mode == "sparse" and self._cfg["lam_emb"] != 0:
             raise NotImplementedError("embedding_grad='sparse' touches only the rows of the batch: the reference's dense L2 term "
                                       "(lambda*W on EVERY row, base_model.py:79-94) cannot be carried — use embedding_regularizer=0")
+        if mode == "sparse" and getattr(self.optimizer, "kind", "Adam") != "Adam":
+            if self._embedding_grad == "sparse":
+                raise NotImplementedError("embedding_grad='sparse' (row lists + lazy row updates) is wired for Adam only; optimizer=%r "
+                                          "needs dense table gradients ('atomic' / 'sorted')" % self.optimizer.kind)
+            mode = "atomic"                     # `auto` on a large table with another optimizer: dense gradients, said here, not at step 1
         self._grad_mode = mode
         self._lists_possible = row_aligned      # (sort + segmented reduction needs table rows on 16-byte boundaries)
         self._n_sparse = self._n_tab if mode == "sparse" else 0
@@ -1162,17 +1167,26 @@ class RAT_m2(BaseModel):
             B, T, L = batch[0].shape
             self._owner_prepare(batch[0], (B, T, L, self._cfg["nf"] + 1))
         try:
-            _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
-        finally:
-            self.__dict__.pop("_bn_counted", None)
-            self.__dict__.pop("_step_loss", None)
-        if self._graph_test_splits:
-            self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
-        self._run_backward(saved, inv, None, table_lists=lists)
-        if self._graph_test_splits:
-            self._collective(lambda: None)
-        g = self._last_gflat
-        self._exchange_gradients(g)
+            try:
+                _y_pred, loss, _reg, saved = self._run_forward(batch, save=True, with_reg=False)
+            finally:
+                self.__dict__.pop("_bn_counted", None)
+                self.__dict__.pop("_step_loss", None)
+            if self._graph_test_splits:
+                self._collective(lambda: None)             # (test knob: a segment boundary where SyncBN / the exchange would put one)
+            self._run_backward(saved, inv, None, table_lists=lists)
+            if self._graph_test_splits:
+                self._collective(lambda: None)
+            g = self._last_gflat
+            self._exchange_gradients(g)
+        except BaseException:
+            # rat_step_begin already advanced the optimizer's clock and the BatchNorm layers' num_batches_tracked, and no update will
+            # follow: take the tick back (host mirror now, device clock at the next prepare_step) so that a caller who catches the
+            # error — a bad batch skipped, an out-of-memory retried at a smaller size — continues with an unshifted bias correction
+            self._owner_state = None
+            if count and self._tape is None:
+                self.optimizer.untick(counts)
+            raise
         reg = self.optimizer.fused_step(g, self._max_gradient_norm, count=count, zeroed=True, ticked=True)
         self._gbuf_clean = self._gbuf is not None and g is self._gbuf[0]
         total = loss + reg[0]
@@ -1360,12 +1374,36 @@ class RAT_m2(BaseModel):
         Under autograd (_RATFunction: another forward may run before this one's backward) the step works on a private copy of the
         words; the fused / captured iteration reads the shared words directly."""
         if self.__dict__.get("_drop_words") is None or self._drop_words.device != self._flat.device:
-            self._drop_base = int(torch.randint(0, 2 ** 62, (1,)))
-            self._drop_words = torch.zeros(self._DROP_WORDS, dtype=torch.int64, device=self._flat.device)
-            self._drop_counter = torch.zeros(1, dtype=torch.int64, device=self._flat.device)
+            self._dropout_state_init()
         ops.dropout_seeds(self._drop_words, self._drop_base, self._drop_counter, lib=self._lib)
         self._drop_step_words = self._drop_words.clone() if self.__dict__.get("_drop_private") else self._drop_words
         self._drop_cursor = 0
+
+    def _dropout_state_init(self, base=None, counter=0):
+        """(base seed, step counter) of the device-side dropout generator.  The base is drawn ONCE from torch's CPU generator
+        (seed_everything governs it) and — under data parallelism, where every rank draws the same number — mixed with the rank, so that
+        the ranks mask their different shards with different masks, like the reference's per-process generators would."""
+        if base is None:
+            base = int(torch.randint(0, 2 ** 62, (1,)))
+            if self._dp():
+                import torch.distributed as dist
+                base = (base ^ (0x9E3779B97F4A7C15 * (dist.get_rank() + 1))) & (2 ** 62 - 1)
+        dev = self._flat.device
+        self._drop_base = int(base)
+        self._drop_words = torch.zeros(self._DROP_WORDS, dtype=torch.int64, device=dev)
+        self._drop_counter = torch.full((1,), int(counter), dtype=torch.int64, device=dev)
+
+    def dropout_state(self):
+        """-> {"base", "counter"} or None when no training forward with dropout has run: what a checkpoint needs to continue the mask
+        sequence.  The reference's `.model` file is the bare state_dict and must stay loadable by it, so the state travels with the
+        optimizer's state_dict (`rat_dropout`, next to the moments and the step count — the resume state the reference does not have)"""
+        if self.__dict__.get("_drop_words") is None:
+            return None
+        return {"base": int(self._drop_base), "counter": int(self._drop_counter.cpu()[0])}
+
+    def load_dropout_state(self, state):
+        if state:
+            self._dropout_state_init(int(state["base"]), int(state["counter"]))
 
     def _dropout_word(self):
         i = self._drop_cursor

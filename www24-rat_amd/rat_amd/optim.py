@@ -49,11 +49,11 @@ class FusedClipAdam(torch.optim.Optimizer):
         m, v = self._buffers()
         group = self.param_groups[0]
         lr, (b1, b2), eps = group["lr"], group.get("betas", (0.0, 0.0)), group.get("eps", 0.0)
+        if self._kind != 0 and sparse:
+            raise NotImplementedError("row-sparse table gradients are wired for Adam only")
         self._step += 1
         self._clock_step = None
         ns = getattr(model, "_n_sparse", 0)
-        if self._kind != 0 and sparse:
-            raise NotImplementedError("row-sparse table gradients are wired for Adam only")
         norm_sq = None
         if max_norm is not None:                         # ONE global norm over dense gradients and sparse row lists alike
             self._norm_sq.zero_()
@@ -62,6 +62,8 @@ class FusedClipAdam(torch.optim.Optimizer):
             for rows, g, count, width, _total, _base in sparse:
                 ops.sumsq_rows(g, count, rows.numel(), width, self._norm_sq, lib=model._lib)
             norm_sq = self._norm_sq
+        self._last_norm_sq = norm_sq                     # (None: this step did not clip)
+        self._last_norm_value = None
         if grad is not None and self._kind != 0:
             ops.clip_opt(model._flat[ns:], grad, v[ns:] if v is not None else None, norm_sq, max_norm or 0.0, lr, self._kind,
                          group.get("alpha", 0.0), eps, lib=model._lib)
@@ -154,7 +156,8 @@ class FusedClipAdam(torch.optim.Optimizer):
         ops.sumsq_reg(grad, model._flat[ns:], n_split, c["lam_emb"], c["lam_net"], acc, reg_out=self._reg_value, lib=lib)
         for rows, g, cnt, width, _total, _base in sparse:
             ops.sumsq_rows(g, cnt, rows.numel(), width, acc, lib=lib)
-        self._last_norm_sq = acc
+        self._last_norm_sq = acc                                     # (a view of the step's scalars: begin_step() of the NEXT step clears it)
+        self._last_norm_value = None
         norm_sq = acc if max_norm is not None else None
         if self._kind != 0:
             ops.clip_opt_fused(model._flat[ns:], grad, v[ns:] if v is not None else None, n_split, c["lam_emb"], c["lam_net"], norm_sq,
@@ -174,15 +177,25 @@ class FusedClipAdam(torch.optim.Optimizer):
         return loss
 
     def last_grad_norm(self):
+        """global gradient norm of the LAST optimizer step (either form), or None if that step did not compute one.  Read it between
+        steps: the fused step keeps the value in the scalars the next begin_step() clears."""
         t = getattr(self, "_last_norm_sq", None)
-        t = self._norm_sq if t is None else t
         return float(torch.sqrt(t)[0]) if t is not None else None
+
+    def untick(self, counters=None):
+        """take back begin_step()'s tick after an iteration that failed before its update (RAT_m2._fused_iteration)"""
+        self._step -= 1
+        self._clock_step = None                          # the device clock is re-synchronised by the next prepare_step()
+        if counters is not None:
+            counters.sub_(1)
 
     def state_dict(self):
         sd = super().state_dict()
         sd["rat_step"] = self._step
         sd["rat_m"] = self._m
         sd["rat_v"] = self._v
+        drop = getattr(self._model, "dropout_state", None)
+        sd["rat_dropout"] = drop() if drop is not None else None          # (base seed, counter) of the device-side mask generator
         return sd
 
     def load_state_dict(self, state_dict):
@@ -190,6 +203,9 @@ class FusedClipAdam(torch.optim.Optimizer):
         self._step = state_dict.pop("rat_step", 0)
         self._clock_step = None                          # the device clock is re-synchronised by the next prepare_step()
         m, v = state_dict.pop("rat_m", None), state_dict.pop("rat_v", None)
+        drop = state_dict.pop("rat_dropout", None)
+        if drop and hasattr(self._model, "load_dropout_state"):
+            self._model.load_dropout_state(drop)
         super().load_state_dict(state_dict)
         mm, vv = self._buffers()
         if m is not None and mm is not None:
