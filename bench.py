@@ -86,6 +86,7 @@ def parse(argv=None):
     ap.add_argument("--no-graph-dp", action="store_true",
                     help="N > 1: eager launches instead of graph segments with the collectives between them (the default)")
     ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
+    ap.add_argument("--inference", action="store_true", help="add the `inference` object (eval forward, eager and hipGraph) even with --no-extras")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements of the default N = 1 line (exact-fp32 run, per-rank B/8 shape, 100 M-row gather)")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the CPU baseline (default 0 = the workload's own batch)")
@@ -722,6 +723,82 @@ def worker(args):
     if extras and args.workload == "synthetic_F20_V1M_K10_d64_B4096" and args.model == "RAT_m2":
         gather_big = big_table_gather(model._lib, model.device)
 
+    # Inference (the reference's logs quote inference throughput: BASELINE.md §1, base_model.py:232-247): the eval
+    # forward of evaluate_generator / predict_generator — model.eval(), no saved activations — on resident batches, eagerly and as a
+    # hipGraph replay (graph.EvalGraph), at the workload's batch and at 256 samples (where the ~25 launches, not the GPU, set the pace)
+    inference = None
+    if not dp and not dry and (extras or args.inference):
+        def forward_flops_per_sample():
+            F_, K_, d_ = spec["F"], spec["K"], spec["d"]
+            T_, S_ = K_ + 1, F_ + 1
+            I_, H_ = spec["num_heads"] * spec["dim_head"], d_ * spec["scale_dim"]
+            if args.model != "RAT_m2":
+                return None
+            enc = spec["depth"] * T_ * S_ * (16 * d_ * I_ + 4 * d_ * H_ + 4 * I_ * (S_ + T_))
+            widths = [F_ * d_] + list(spec["dnn_hidden_units"])
+            head = 2 * (sum(a * b for a, b in zip(widths, widths[1:])) + widths[-1]) + 2 * d_
+            return enc + head
+
+        def eval_region(batches, steps, graph):
+            model.eval()
+            model.eval_graph, model.eval_graph_max_batch = graph, 1 << 30
+            nb = len(batches)
+            with torch.no_grad():
+                for i in range(model.graph_warmup + 3):
+                    model.forward(batches[i % nb])
+                sync()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    model.forward(batches[i % nb])
+                sync()
+            return (time.perf_counter() - t0) / steps
+
+        keep = (model.eval_graph, model.eval_graph_max_batch, model.training)
+        model.__dict__.pop("_eval_graphs", None)
+        fl = forward_flops_per_sample()
+        inference = dict(what="eval forward (model.eval(), torch.no_grad(): evaluate_generator / predict_generator's per-batch call, "
+                              "base_model.py:232-273) on resident batches, %d distinct batches rotated; every token computed unless "
+                              "dead_token_pruning says otherwise" % NBATCH, dead_token_pruning=bool(can_prune and model.prune_dead_tokens),
+                         algorithmic_flop_per_sample=fl, shapes=[])
+        for nb_, st_ in ((B, args.steps * 2), (256, args.steps * 8)):
+            if nb_ > B or (nb_ == 256 and B == 256 and inference["shapes"]):
+                continue
+            batches = [make(5000 + i, 0, nb_) for i in range(NBATCH)]
+            row = dict(batch=nb_, steps=st_)
+            for graph in (False, True):
+                sec = eval_region(batches, st_, graph)
+                tag = "graph" if graph else "eager"
+                row[tag + "_ms_per_batch"] = round(sec * 1e3, 4)
+                row[tag + "_samples_per_s"] = round(nb_ / sec, 1)
+            best = min(row["eager_ms_per_batch"], row["graph_ms_per_batch"])
+            row["value"] = round(nb_ / (best * 1e-3), 1)
+            if fl:
+                tf = fl * nb_ / (best * 1e-3) / 1e12
+                row["roofline"] = dict(bound="mfma", achieved=round(tf, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+            # per-kernel HIP events of the same forwards, eagerly
+            model.eval_graph = False
+            timer.reset()
+            timer.calls_seen = 0
+            with torch.no_grad():
+                model.forward(batches[0])
+                sync()
+                timer.prepare(st_, 1)
+                timer.enabled = True
+                for i in range(st_):
+                    model.forward(batches[i % NBATCH])
+                sync()
+                timer.enabled = False
+            ks = timer.summary(st_)
+            row["kernels"] = {k[0] + (":" + k[1] if k[1] else ""): round(v["ms_per_step"], 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            row["kernels_ms_per_batch"] = round(sum(v["ms_per_step"] for v in ks.values()), 4)
+            inference["shapes"].append(row)
+            del batches
+        inference["value"], inference["unit"] = inference["shapes"][0]["value"], "samples/s"
+        inference["reference_logs"] = "BASELINE.md §1: the reference's published logs give 107k / 37.6k / 22.9k inference samples/s on its own hardware and geometries (MovieLens / KKBox / Tmall), not on this workload"
+        model.eval_graph, model.eval_graph_max_batch = keep[0], keep[1]
+        model.train(keep[2])
+        timer.reset()
+
     if rank == 0:
         primary, per_rank_batch, scaling = (weak, B, "weak") if weak is not None else (strong, B // world, "strong")
         elapsed, ksum = primary
@@ -833,6 +910,8 @@ def worker(args):
         if per_rank is not None:
             per_rank["ratio_to_headline"] = round(per_rank["value"] / result["value"], 4)
             result["per_rank_shape"] = per_rank
+        if inference is not None:
+            result["inference"] = inference
         if alt is not None:
             result["exact_f32" if alt["arith"] == "f32" else "alt_arith"] = alt
         if args.model != "RAT_m2":

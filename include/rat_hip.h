@@ -68,6 +68,16 @@ int rat_gather_bwd(const float* dgrid, const float* dflat, const int32_t* idx, c
 int rat_check_ids(const int32_t* idx, const int32_t* label_ids, const RatField* fields_dev, int nfields, int B, int T,
                   int L, int32_t* counts, void* stream);
 
+/* ---- a1 / a2 on the device: inputs_to_device + the label-token rule for a batch that already sits in HBM (ABI v8) --------------
+ * base_model.py:125-133, RAT_m2.py:110-118.  X [B][T][L] (x_type: RAT_DTYPE_*, integer-valued) -> idx int32; y [B][T] (fp32 / fp64)
+ * -> label_ids int32 (2 in column 0, the retrieved sample's label elsewhere) and y_true fp32 [B] (= y[:, 0]).  One launch. */
+#define RAT_DTYPE_I32 0
+#define RAT_DTYPE_I64 1
+#define RAT_DTYPE_F32 2
+#define RAT_DTYPE_F64 3
+int rat_batch_prepare(const void* X, int x_type, const void* y, int y_type, int32_t* idx, int32_t* label_ids, float* y_true,
+                      int B, int T, int L, void* stream);
+
 /* ---- K0: device-side batch assembly ---------------------------------------------------------------------
  * replaces Dataset.__getitem__ + default_collate + inputs_to_device for retrieval-augmented batches
  * (fuxictr/pytorch/data_generator.py:66-78, 239-241; base_model.py:125-133): the encoded query table

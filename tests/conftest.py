@@ -23,3 +23,21 @@ gpu_twin = pytest.mark.skipif(not FULL_CPU, reason="emulator repeat of a -m gpu 
 def twin(*values, **kw):
     """pytest.param(...) carrying the gpu_twin skip"""
     return pytest.param(*values, marks=gpu_twin, **kw)
+
+
+@pytest.fixture()
+def knob():
+    """knob(lib, name, value): set a diagnostic knob of a loaded kernel library (rat_debug_set_knob — the library reads RAT_* variables
+    once, at load, never per launch) for the rest of the test; the previous value comes back afterwards."""
+    undo = []
+
+    def set_knob(lib, name, value):
+        import ctypes
+        fn = lib.cdll.rat_debug_set_knob
+        fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
+        old = fn(name.encode(), int(value))
+        assert old != -2 ** 31, "unknown knob %r" % name
+        undo.append((fn, name.encode(), old))
+    yield set_knob
+    for fn, name, old in reversed(undo):
+        fn(name, old)

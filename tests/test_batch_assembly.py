@@ -124,3 +124,48 @@ def test_gpu_training_step_from_device_batch_equals_host_batch():
             batch = (X, y, rv, rl)
         losses.append(float(model.train_step(batch)))
     assert losses[0] == losses[1], losses
+
+
+def _prepare_vs_oracle(lib, dev, X, y):
+    """rat_batch_prepare (inputs_to_device + the label-token rule, one launch) against the oracle's model_inputs on the collated batch,
+    for every element type a loader may hand over — and into caller-provided (a captured step's static) tensors"""
+    ridx, rlab, ryt = bo.model_inputs(X, y)
+    for xt in (torch.float64, torch.float32, torch.int64, torch.int32):
+        for yt in (torch.float64, torch.float32):
+            idx, lab, y_true = ops.batch_prepare(torch.from_numpy(X).to(xt).to(dev), torch.from_numpy(y).to(yt).to(dev), lib=lib)
+            assert idx.dtype == torch.int32 and np.array_equal(idx.cpu().numpy(), ridx), (xt, yt)
+            assert np.array_equal(lab.cpu().numpy(), rlab) and np.array_equal(y_true.cpu().numpy(), ryt), (xt, yt)
+    out = (torch.full(ridx.shape, -7, dtype=torch.int32, device=dev), torch.full(rlab.shape, -7, dtype=torch.int32, device=dev),
+           torch.full(ryt.shape, -7.0, device=dev))
+    got = ops.batch_prepare(torch.from_numpy(X).to(dev), torch.from_numpy(y).to(dev), out=out, lib=lib)
+    assert all(a.data_ptr() == b.data_ptr() for a, b in zip(got, out))
+    assert np.array_equal(out[0].cpu().numpy(), ridx) and np.array_equal(out[1].cpu().numpy(), rlab) and np.array_equal(out[2].cpu().numpy(), ryt)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_emulated_batch_prepare_matches_oracle(emu, name):
+    _prepare_vs_oracle(emu, "cpu", GOLD[name + "/X"], GOLD[name + "/y"])        # the REAL reference's collated (X, y)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_prepare_matches_oracle_and_feeds_the_step():
+    from rat_amd._lib import get_lib
+    for name in sorted(CASES):
+        _prepare_vs_oracle(get_lib(), "cuda", GOLD[name + "/X"], GOLD[name + "/y"])
+    rs = np.random.RandomState(11)
+    X = rs.randint(0, 50000, (4096, 11, 20)).astype(np.float64)
+    y = rs.randint(0, 2, (4096, 11)).astype(np.float64)
+    _prepare_vs_oracle(get_lib(), "cuda", X, y)
+    # a training step fed with the 4-tuple already on the device (what bench.py times) == the same step fed from the host
+    import golden_cases as gc
+    import model_cases as mc
+    case = gc.case_by_name("mltag_shape")
+    batch = mc.batch_of(case)
+    losses = []
+    for on_device in (False, True):
+        model = mc.build_model(case, gpu=0, seed=1)
+        mc.load_weights(model, case)
+        model.train()
+        b = tuple(t.to(model.device) for t in batch) if on_device else batch
+        losses.append([float(model.train_step(b)) for _ in range(5)])          # steps 4, 5: graph replays writing into the static inputs
+    assert losses[0] == losses[1], losses

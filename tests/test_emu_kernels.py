@@ -59,14 +59,14 @@ def test_attn_fwd_bwd(emu, case, mode):
 
 
 @pytest.fixture()
-def two_blocks(monkeypatch):
-    monkeypatch.setenv("RAT_MAX_BLOCKS", "2")
+def two_blocks(emu, knob):
+    knob(emu, "max_blocks", 2)
 
 
 @pytest.mark.parametrize("mode", ["intra", "cross"])
 def test_attn_fwd_bwd_bf16x3(emu, mode, two_blocks):
     """the split-operand bf16 MFMA kernels (plane images in LDS, transposed block reads, pre-split weight fragments) through the
-    emulated v_mfma_f32_16x16x32_bf16 / ds_read_b64_tr_b16.  RAT_MAX_BLOCKS=2 (test knob of the library): two work-groups loop over 4-5 chunks each — persistent weight-gradient accumulators, double-buffered row maps, load-ahead, a ragged
+    emulated v_mfma_f32_16x16x32_bf16 / ds_read_b64_tr_b16.  knob max_blocks = 2: two work-groups loop over 4-5 chunks each — persistent weight-gradient accumulators, double-buffered row maps, load-ahead, a ragged
     last chunk."""
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), mode, arith="bf16x3")
 
@@ -79,10 +79,10 @@ def test_attn_fwd_bwd_bf16x3_narrower_embedding(emu, case, mode, two_blocks):
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
 
 
-def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(emu, two_blocks, monkeypatch):
-    """for L <= 12 pass 1 of attn_bwd3_kernel leaves P in LDS and pass 2 reads it (the default; RAT_ATTN_BWD_PH=0 recomputes) — both forms"""
+def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(emu, two_blocks, knob):
+    """for L <= 12 pass 1 of attn_bwd3_kernel leaves P in LDS and pass 2 reads it (the default; knob attn_bwd_ph = 0 recomputes) — both forms"""
     kc.check_attn(emu, "cpu", (2, 3, 7, 64, 8, 10, True), "intra", arith="bf16x3")
-    monkeypatch.setenv("RAT_ATTN_BWD_PH", "0")
+    knob(emu, "attn_bwd_ph", 0)
     kc.check_attn(emu, "cpu", (3, 11, 4, 64, 8, 10, True), "cross", arith="bf16x3")
 
 
@@ -93,16 +93,16 @@ def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
 
 @pytest.mark.parametrize("case,mode", [pytest.param((1, 11, 4, 64, 8, 10, True), "cross", id="L11"), pytest.param((1, 2, 33, 64, 8, 10, True), "intra", id="L33"),
                                        twin((3, 16, 2, 64, 8, 10, True), "cross", id="L16")])
-def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, monkeypatch):
+def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, knob):
     """attn_fwd3m_kernel (QK^T and PV on the bf16 MFMA as well; opt-in: measured slower than the VALU core): one key
     block with masked keys (L = 11), exactly one block (16), three blocks with one sequence per chunk (33)"""
-    monkeypatch.setenv("RAT_ATTN_FWD_CORE", "mfma")
+    knob(emu, "attn_fwd_core_mfma", 1)
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
 
 
 @gpu_twin
-def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blocks, monkeypatch):
-    monkeypatch.setenv("RAT_ATTN_FWD_CORE", "mfma")
+def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blocks, knob):
+    knob(emu, "attn_fwd_core_mfma", 1)
     kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), "intra", arith="bf16x3")
 
 
@@ -124,7 +124,7 @@ def test_attention_output_dropout(emu, case, arith):
 
 
 def test_persistent_kernels_loop_over_several_chunks(emu, two_blocks):
-    """exact-fp32 fast kernels and the FFN with every work-group looping over several chunks (RAT_MAX_BLOCKS=2)"""
+    """exact-fp32 fast kernels and the FFN with every work-group looping over several chunks (knob max_blocks = 2)"""
     kc.check_attn(emu, "cpu", (2, 5, 9, 64, 8, 10, True), "intra")
     kc.check_ffn(emu, "cpu", 200, 64, 128)
     kc.check_ffn(emu, "cpu", 200, 64, 128, arith="bf16x3")

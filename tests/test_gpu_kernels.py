@@ -70,11 +70,11 @@ def test_attn_fwd_bwd_bf16x3_narrower_embedding(lib, d, mode):
     kc.check_attn(lib, "cuda", (3, 5, 3, d, 8, 10, True), mode, arith="bf16x3")
 
 
-def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(lib, monkeypatch):
-    """for L <= 12 pass 1 of attn_bwd3_kernel leaves P in LDS and pass 2 reads it (the default; RAT_ATTN_BWD_PH=0 recomputes) — both forms"""
+def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(lib, knob):
+    """for L <= 12 pass 1 of attn_bwd3_kernel leaves P in LDS and pass 2 reads it (the default; knob attn_bwd_ph = 0 recomputes) — both forms"""
     kc.check_attn(lib, "cuda", (40, 11, 21, 64, 8, 10, True), "cross", arith="bf16x3")
     kc.check_attn(lib, "cuda", (7, 3, 12, 64, 8, 10, True), "intra", arith="bf16x3")
-    monkeypatch.setenv("RAT_ATTN_BWD_PH", "0")
+    knob(lib, "attn_bwd_ph", 0)
     kc.check_attn(lib, "cuda", (40, 11, 21, 64, 8, 10, True), "cross", arith="bf16x3")
 
 
@@ -96,9 +96,9 @@ def test_attn_with_a_subset_of_query_positions(lib, case, mode, nq, arith):
 
 @pytest.mark.parametrize("case", B3_CASES, ids=str)
 @pytest.mark.parametrize("mode", ["intra", "cross"])
-def test_attn_fwd_bf16x3_matrix_core(lib, case, mode, monkeypatch):
+def test_attn_fwd_bf16x3_matrix_core(lib, case, mode, knob):
     """the opt-in forward kernel with QK^T / PV on the bf16 MFMA as well (attn_fwd3m_kernel; DESIGN.md §9: correct, measured slower)"""
-    monkeypatch.setenv("RAT_ATTN_FWD_CORE", "mfma")
+    knob(lib, "attn_fwd_core_mfma", 1)
     kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
 
 

@@ -1,16 +1,17 @@
 """A training RUN on the MI355X against the oracle (-m gpu): north_star's "AUC / Logloss matching the reference within 1e-4 on identical
 inputs" checked over a trajectory, not one step — WITH A CONTROL.  The datasets are not available offline, so the
 data are the structured synthetic split of rat_amd.data.synthetic_split (labels depend on the ids through a logistic rule, neighbours
-share the first column's id: the model has something to learn) at the MovieLens-Tag shape of BASELINE.json configs[0] (F = 3, K = 10,
-d = 16, 2 heads x 10, depth 4, scale 4, DNN 400^3, B = 256), 80 different batches, 2048 held-out samples.
+share the first column's id: the model has something to learn), 80 different batches, 2048 held-out samples, at two geometries
+(GEOMETRIES below): the MovieLens-Tag shape of BASELINE.json configs[0] (F = 3, K = 10, d = 16, 2 heads x 10, depth 4, scale 4, DNN
+400^3, B = 256) and — round 5 — a d = 64, 8 x 10 heads geometry on which the bf16x3 ENCODER kernels run (the headline's arithmetic).
 
 Five trajectories from the same initial weights on the same batches:
     oracle fp64            the reference's arithmetic in double precision: the "truth" of this run
     oracle fp32            the same in fp32 (torch on the host's cores) — what the reference itself computes
     oracle fp32, 1 thread  the same with another summation order inside torch's kernels: a second fp32 sample
     HIP exact fp32         train_step() with arith="f32" (fp32 MFMA everywhere), fused iteration, hipGraph replays from step 3
-    HIP bf16x3             the product's default arithmetic (arith="auto": at this geometry, d = 16, the DNN head's GEMMs run bf16x3
-                           and the encoder the exact-fp32 kernels; the d = 64 encoder kernels are pinned per step by the golden cases)
+    HIP bf16x3             the product's default arithmetic (arith="auto": at d = 16 the DNN head's GEMMs run bf16x3 and the encoder
+                           the exact-fp32 kernels; at d = 64 the encoder's projections / FFN run bf16x3 as well)
 Per-step losses of two implementations that agree to rounding on every single step (tests/test_gpu_model.py) still separate over a run:
 Adam's early steps are sign-like, so a gradient element that rounds to the other side of zero moves its weight by 2 lr.  The control
 turns that sentence into a measurement: the fp32 oracle separates from the fp64 oracle at the same rate.  Measured on the MI355X box
@@ -30,8 +31,20 @@ import torch
 pytestmark = pytest.mark.gpu
 CONTROL_THREADS = (1, 2, 3, 4, 6, 8, 12, 16)
 
+# Two geometries.  "d16": BASELINE.json configs[0]'s — the encoder runs the exact-fp32 kernels there whatever
+# `arith` says, bf16x3 only reaches the head's GEMMs.  "d64_bf16x3": the geometry that SELECTS the bf16x3 encoder kernels, the ones that
+# produce the headline number (embedding_dim 64, 8 heads x 10, hidden 128), small enough around them (F = 5, K = 4, depth 2, B = 128,
+# DNN 64-32) for the fp64 oracle to follow 80 steps in a few minutes; the run asserts that those kernels were the ones launched.
+GEOMETRIES = {
+    "d16": dict(workload="mltag_like_K10_d16_B256", spec={}, encoder_bf16x3=False),
+    "d64_bf16x3": dict(workload="mltag_like_K10_d16_B256",
+                       spec=dict(F=5, K=4, d=64, batch=128, num_heads=8, dim_head=10, depth=2, scale_dim=2, dnn_hidden_units=[64, 32]),
+                       encoder_bf16x3=True),
+}
 
-def test_eighty_training_steps_end_as_close_to_fp64_as_the_fp32_reference_does():
+
+@pytest.mark.parametrize("geometry", list(GEOMETRIES))
+def test_eighty_training_steps_end_as_close_to_fp64_as_the_fp32_reference_does(geometry):
     from collections import OrderedDict
     from oracle import rat_m2_oracle as orc
     from rat_amd import data as rd
@@ -42,8 +55,8 @@ def test_eighty_training_steps_end_as_close_to_fp64_as_the_fp32_reference_does()
     assert torch.cuda.is_available()
     threads = min(16, torch.get_num_threads())                     # (the oracle's small ops thrash on a many-core host)
     torch.set_num_threads(threads)
-    name = "mltag_like_K10_d16_B256"
-    spec = dict(synthetic.WORKLOADS[name])
+    geo = GEOMETRIES[geometry]
+    spec = dict(synthetic.WORKLOADS[geo["workload"]], **geo["spec"])
     # 40 ids per field instead of 30 000: every id recurs often enough for 80 steps to learn the rule (held-out AUC ~0.68 from 0.5)
     fm = FeatureMap.from_specs("trajectory", OrderedDict(
         ("c%02d" % i, {"source": "", "type": "categorical", "vocab_size": 40, "index": i}) for i in range(spec["F"])))
@@ -75,6 +88,11 @@ def test_eighty_training_steps_end_as_close_to_fp64_as_the_fp32_reference_does()
         else:
             for k, v in model.state_dict().items():
                 assert torch.equal(v.detach().cpu(), w0[k]), k
+        # which arithmetic the encoder kernels really ran: the bf16x3 instantiations exist for this geometry or they do not
+        assert (model.arith == "bf16x3") == (geo["encoder_bf16x3"] and arith == "auto"), (geometry, arith, model.arith)
+        # (RAT_m2.arith is what every encoder launch is given; "bf16x3" is only offered when the library has those instantiations
+        # for this geometry: arith_modes() asks rat_attn_fwd_workspace)
+        assert ("bf16x3" in model.arith_modes()) == geo["encoder_bf16x3"]
         model.train()
         losses = [float(model.train_step(b)) for b in train]
         assert any(e[1] for e in model._step_graphs.values()), "steps 3.. were hipGraph replays"

@@ -237,3 +237,61 @@ def test_waiting_ranks_give_up_when_rank0_fails_or_takes_too_long(tmp_path, monk
     open(target, "w").write("x")
     run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=5)       # the file wins
     run_expid._wait_for_file(target, leader=True)
+
+
+def _eval_worker(rank, world, port, emu_path, out_dir):
+    _setup_paths()
+    import golden_cases as gc
+    import model_cases as mc
+    import rat_amd._lib as L
+    from rat_amd import data as rd
+    L._default = L.RatLib(emu_path)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = gc.case_by_name("tiny_seq_bn")
+    model = mc.build_model(case, gpu=-1, seed=1)
+    mc.load_weights(model, case)
+    fm_rows = 37                                               # 37 rows in batches of 8: ragged shards (8 = 3 + 3 + 2) and a 5-row tail (2 + 2 + 1)
+    X, y, rv, rl = mc.batch_of(case)
+    reps = -(-fm_rows // X.shape[0])
+    ids = torch.cat([X[:, 0, :]] * reps)[:fm_rows].numpy()
+    labels = (torch.arange(fm_rows) % 2).double().numpy()[:, None]
+    data = np.concatenate([ids, labels], axis=1)
+    K = X.shape[1] - 1
+    retr = np.stack([(np.arange(fm_rows) + 1 + k) % fm_rows for k in range(K)], axis=1)
+    gen = rd.RetrievalBatches(data, data, retr, np.zeros((fm_rows, K)), np.full(fm_rows, K), 8)
+    seen = []
+    inner = model.forward
+
+    def counting(batch):
+        seen.append(int(batch[0].shape[0]))
+        return inner(batch)
+    model.forward = counting
+    sharded = model.evaluate_generator(gen)
+    n_sharded = sum(seen)
+    assert gen.shard == (0, 1) and not gen.keep_all            # the source is handed back as it came
+    model.shard_evaluation = False
+    seen.clear()
+    full = model.evaluate_generator(gen)
+    torch.save({"sharded": sharded, "full": full, "rows_sharded": n_sharded, "rows_full": sum(seen)}, os.path.join(out_dir, "e%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluation_is_sharded_by_rank_and_every_rank_gets_the_global_metrics():
+    """evaluate_generator (base_model.py:232-247) under data parallelism — each rank forwards its slice of every
+    batch (ragged, nothing dropped), the predictions are all-gathered, every rank computes the same metrics as an unsharded pass"""
+    _setup_paths()
+    import build_emu
+    emu_path = build_emu.build()
+    port = 25500 + (os.getpid() % 2000)
+    world = 3
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_eval_worker, args=(world, port, emu_path, out_dir), nprocs=world, join=True)
+        res = [torch.load(os.path.join(out_dir, "e%d.pt" % r)) for r in range(world)]
+    assert sum(r["rows_sharded"] for r in res) == 37 and all(r["rows_full"] == 37 for r in res)
+    assert max(r["rows_sharded"] for r in res) <= 15           # 4 x ceil(8 / 3) + ceil(5 / 3): a third of the work, not all of it
+    for r in res:
+        assert r["sharded"].keys() == res[0]["full"].keys()
+        for k in r["sharded"]:
+            assert abs(r["sharded"][k] - res[0]["full"][k]) < 1e-9, (k, r["sharded"], res[0]["full"])

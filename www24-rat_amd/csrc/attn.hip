@@ -2296,9 +2296,8 @@ static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
 }
 // PH instantiation of attn_bwd3_kernel: P of a chunk inside the dy planes' 24 KB
 static bool b3_ph_fits(int L, int nsq_chunk) { return (size_t)nsq_chunk * B3_H * L * L * 4 <= (size_t)3 * B3_XP; }
-static bool b3_ph_enabled() {                          // on unless RAT_ATTN_BWD_PH=0 (same-box A/B: L = 11 1.2477 -> 1.2322 ms, -1.2 %)
-    const char* e = getenv("RAT_ATTN_BWD_PH");
-    return e == nullptr || e[0] != '0';
+static bool b3_ph_enabled() {                          // on unless the attn_bwd_ph knob is 0 (same-box A/B: L = 11 1.2477 -> 1.2322 ms, -1.2 %)
+    return rat_knob(RAT_KNOB_ATTN_BWD_PH) != 0;
 }
 // `valid` of the split jobs whose N is the embedding dimension (rat_split_weights: n_valid)
 static int b3_nvalid(int d) { return d == B3_D ? 0 : d; }
@@ -2378,12 +2377,11 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(p_qkv), 2};
         W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(p_out), 3};
         const unsigned b3_blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-        // RAT_ATTN_FWD_CORE=mfma selects attn_fwd3m_kernel (the attention core on the matrix pipe as well).  It is correct (same
+        // the attn_fwd_core_mfma knob (RAT_ATTN_FWD_CORE=mfma at load) selects attn_fwd3m_kernel (the attention core on the matrix pipe as well).  It is correct (same
         // parity gates) but MEASURED SLOWER than the VALU core at this geometry — 0.80 / 0.69 ms against 0.64 / 0.52 ms per launch at
         // L = 21 / 11 (profiles/round3/r3_attn_fwd_core_ab.txt): 16 x 16 score tiles are 43-47 % full at L = 21 / 11, and what the
         // matrix pipe saves is spent on the VALU again, splitting Q|K|V and P into bf16 chunks and laying them out — so it is opt-in.
-        const char* core_env = getenv("RAT_ATTN_FWD_CORE");
-        const bool mfma_core = core_env != nullptr && std::string(core_env) == "mfma";
+        const bool mfma_core = rat_knob(RAT_KNOB_ATTN_FWD_CORE_MFMA) == 1;
         if (dpad) {
             if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
             else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false, false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);

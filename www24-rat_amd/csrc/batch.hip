@@ -72,3 +72,55 @@ extern "C" int rat_batch_assemble(const int32_t* data_ids, const float* data_lab
     RAT_LAUNCH(batch_assemble_kernel, (unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, stream, a);
     return rat_check_launch("rat_batch_assemble");
 }
+
+// ---- inputs_to_device + the label-token rule for a batch that is ALREADY on the device (ABI v8) --------------------------------------
+// base_model.py:125-133 (X stays what it is, y.float()) and RAT_m2.py:110-118 (the target's label token is id 2, a retrieved sample's its
+// label): X [B][T][L] of any of four element types -> idx int32; y [B][T] -> label_ids int32 (column 0: 2) and y_true fp32 (= y[:, 0]).
+// One launch instead of the five ATen launches the same conversion costs (to(int32), clone, index fill, slice copy, to(float32)), and it
+// writes straight into the static input tensors of a captured step.
+namespace {
+template <class TX, class TY>
+__global__ void __launch_bounds__(256)
+batch_prepare_kernel(const TX* __restrict__ X, const TY* __restrict__ y, int32_t* __restrict__ idx, int32_t* __restrict__ label_ids,
+                     float* __restrict__ y_true, int64_t n_ids, int64_t n_lab, int T) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ids; i += (int64_t)gridDim.x * blockDim.x) {
+        idx[i] = (int32_t)X[i];
+        if (i < n_lab) {
+            const TY v = y[i];
+            const bool target = (i % T) == 0;
+            label_ids[i] = target ? 2 : (int32_t)v;
+            if (target) y_true[i / T] = (float)v;
+        }
+    }
+}
+template <class TX>
+int prepare_y(int y_type, const void* X, const void* y, int32_t* idx, int32_t* label_ids, float* y_true, int64_t n_ids, int64_t n_lab,
+              int T, void* stream) {
+    const int64_t n = n_ids > n_lab ? n_ids : n_lab;
+    const int64_t blocks = (n + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+    if (y_type == RAT_DTYPE_F32)
+        RAT_LAUNCH((batch_prepare_kernel<TX, float>), grid, 256, 0, stream, static_cast<const TX*>(X), static_cast<const float*>(y), idx,
+                   label_ids, y_true, n_ids, n_lab, T);
+    else if (y_type == RAT_DTYPE_F64)
+        RAT_LAUNCH((batch_prepare_kernel<TX, double>), grid, 256, 0, stream, static_cast<const TX*>(X), static_cast<const double*>(y), idx,
+                   label_ids, y_true, n_ids, n_lab, T);
+    else
+        return rat_fail("rat_batch_prepare: y must be fp32 or fp64");
+    return rat_check_launch("rat_batch_prepare");
+}
+}  // namespace
+
+extern "C" int rat_batch_prepare(const void* X, int x_type, const void* y, int y_type, int32_t* idx, int32_t* label_ids, float* y_true,
+                                 int B, int T, int L, void* stream) {
+    RAT_REQUIRE(X && y && idx && label_ids && y_true, "null pointer");
+    RAT_REQUIRE(B > 0 && T > 0 && L > 0, "bad dims");
+    const int64_t n_ids = (int64_t)B * T * L, n_lab = (int64_t)B * T;          // (L >= 1: n_ids >= n_lab, every label index is visited)
+    switch (x_type) {
+        case RAT_DTYPE_I32: return prepare_y<int32_t>(y_type, X, y, idx, label_ids, y_true, n_ids, n_lab, T, stream);
+        case RAT_DTYPE_I64: return prepare_y<int64_t>(y_type, X, y, idx, label_ids, y_true, n_ids, n_lab, T, stream);
+        case RAT_DTYPE_F32: return prepare_y<float>(y_type, X, y, idx, label_ids, y_true, n_ids, n_lab, T, stream);
+        case RAT_DTYPE_F64: return prepare_y<double>(y_type, X, y, idx, label_ids, y_true, n_ids, n_lab, T, stream);
+        default: return rat_fail("rat_batch_prepare: X must be int32, int64, fp32 or fp64");
+    }
+}

@@ -1702,7 +1702,7 @@ extern "C" int rat_ffn_bwd_res(const float* x, const float* dy, float* dx, const
 
 // 1 if rat_ffn_bwd_res_rows accepts this layer (the bf16x3 weight-stationary kernel: d = 64 or 40 / 48 / 56, hidden = 2 d)
 extern "C" int rat_ffn_bwd_rows_supported(int d, int hidden, int arith) {
-    static const bool t3 = [] { const char* e = getenv("RAT_FFN_BWD"); return e != nullptr && e[0] == 't' && e[1] == '3'; }();
+    const bool t3 = rat_knob(RAT_KNOB_FFN_BWD_T3) == 1;
     if (t3 || arith != RAT_ARITH_BF16X3) return 0;
     return (d == F3_D && hidden == F3_H) || ((d == 40 || d == 48 || d == 56) && hidden == 2 * d);
 }
@@ -1769,7 +1769,7 @@ static int ffn_bwd_res_launch(const float* x, const float* dy, float* dx, const 
         W.w1 = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.w2t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + F3_WP), 2};
         W.w1t = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + 2 * F3_WP), 4};
-        static const bool t3 = [] { const char* e = getenv("RAT_FFN_BWD"); return e != nullptr && e[0] == 't' && e[1] == '3'; }();
+        const bool t3 = rat_knob(RAT_KNOB_FFN_BWD_T3) == 1;
         if (t3) {                                                 // the round-2/3 kernel (token-stationary), kept for A/Bs: RAT_FFN_BWD=t3
             if (dpad) RAT_LAUNCH((ffn_bwd_t3_kernel<true>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);
             else RAT_LAUNCH((ffn_bwd_t3_kernel<false>), blocks, FB_THREADS, f3_bwd_smem(), stream, a, W);

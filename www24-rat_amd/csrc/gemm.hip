@@ -271,7 +271,7 @@ void plan_split(int M, int N, int K, int& slices, int& kper, int target = 1024) 
     slices = 1;
     kper = (K + GM_K - 1) / GM_K * GM_K;
     if (tiles >= 512 || K < 8 * GM_K) return;
-    static const int forced = [] { const char* e = getenv("RAT_SGEMM_SPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int forced = rat_knob(RAT_KNOB_SGEMM_SPLIT_TARGET);
     if (forced) target = forced;
     int want = (target + tiles - 1) / tiles;
     const int max_slices = K / (2 * GM_K);

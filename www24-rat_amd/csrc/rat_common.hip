@@ -20,11 +20,44 @@ int rat_check_launch(const char* what) {
     return 0;
 }
 
-// Test knob (never set by the product): RAT_MAX_BLOCKS=<n> caps the grid of the persistent encoder kernels so that small test
-// problems make every work-group loop over SEVERAL chunks (persistent accumulators, double-buffered row maps, load-ahead).
+// Diagnostic knobs.  The product never sets them, and no launch reads the environment: the table is filled ONCE, when the library is
+// loaded, from the RAT_* variables below (what the A/B scripts under tools/ set before they start a process), and
+// rat_debug_set_knob changes an entry at run time (what the tests do around single calls).
+//   max_blocks (RAT_MAX_BLOCKS=<n>)            caps the grid of the persistent encoder kernels so that small test problems make every
+//                                              work-group loop over SEVERAL chunks (persistent accumulators, double-buffered row maps)
+//   attn_bwd_ph (RAT_ATTN_BWD_PH=0)            0: pass 2 of attn_bwd3_kernel recomputes P instead of reading pass 1's copy (L <= 12)
+//   attn_fwd_core_mfma (RAT_ATTN_FWD_CORE=mfma) 1: attn_fwd3m_kernel (QK^T / PV on the matrix pipe; correct, measured slower)
+//   attn_bwd_core_mfma (RAT_ATTN_BWD_CORE=mfma|valu) 1 / 0: force the matrix-pipe / VALU backward core whatever L says (-1: by L)
+//   ffn_bwd_t3 (RAT_FFN_BWD=t3)                1: round 3's feed-forward backward kernel
+//   sgemm_split_target (RAT_SGEMM_SPLIT_TARGET=<n>)  work-groups the split-K rule of the head's GEMMs aims for (0: built-in)
+static int g_knobs[RAT_KNOB_COUNT];
+static const char* const g_knob_names[RAT_KNOB_COUNT] = {"max_blocks", "attn_bwd_ph", "attn_fwd_core_mfma", "attn_bwd_core_mfma", "ffn_bwd_t3",
+                                                         "sgemm_split_target"};
+static const bool g_knobs_loaded = [] {
+    auto env = [](const char* n) { const char* e = getenv(n); return e ? std::string(e) : std::string(); };
+    const std::string mb = env("RAT_MAX_BLOCKS"), ph = env("RAT_ATTN_BWD_PH"), fc = env("RAT_ATTN_FWD_CORE"), bc = env("RAT_ATTN_BWD_CORE"),
+                      ff = env("RAT_FFN_BWD"), st = env("RAT_SGEMM_SPLIT_TARGET");
+    g_knobs[RAT_KNOB_MAX_BLOCKS] = mb.empty() ? 0 : atoi(mb.c_str());
+    g_knobs[RAT_KNOB_ATTN_BWD_PH] = (ph.empty() || ph[0] != '0') ? 1 : 0;
+    g_knobs[RAT_KNOB_ATTN_FWD_CORE_MFMA] = fc == "mfma" ? 1 : 0;
+    g_knobs[RAT_KNOB_ATTN_BWD_CORE_MFMA] = bc == "mfma" ? 1 : (bc == "valu" ? 0 : -1);
+    g_knobs[RAT_KNOB_FFN_BWD_T3] = ff.rfind("t3", 0) == 0 ? 1 : 0;
+    g_knobs[RAT_KNOB_SGEMM_SPLIT_TARGET] = st.empty() ? 0 : (atoi(st.c_str()) > 0 ? atoi(st.c_str()) : 0);
+    return true;
+}();
+int rat_knob(int which) { return g_knobs[which]; }
+// diagnostic hook (not part of include/rat_hip.h): set knob `name`, returns its previous value; unknown name: INT_MIN
+extern "C" int rat_debug_set_knob(const char* name, int value) {
+    for (int i = 0; i < RAT_KNOB_COUNT; ++i)
+        if (name != nullptr && std::string(name) == g_knob_names[i]) {
+            const int old = g_knobs[i];
+            g_knobs[i] = value;
+            return old;
+        }
+    return -2147483647 - 1;
+}
 int rat_max_blocks() {
-    const char* e = getenv("RAT_MAX_BLOCKS");            // read per launch: tests set and clear it around single calls
-    const int n = e ? atoi(e) : 0;
+    const int n = g_knobs[RAT_KNOB_MAX_BLOCKS];
     return n > 0 && n < 256 ? n : 256;
 }
 

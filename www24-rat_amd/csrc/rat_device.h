@@ -52,6 +52,9 @@ unsigned long long* rat_prof_buffer();                // device pointer set by r
 const char* rat_set_error(const std::string& msg);   // stores thread-local, returns c_str
 int rat_fail(const std::string& msg);                 // sets error, returns -1
 int rat_check_launch(const char* what);               // hipGetLastError -> 0 / -1
+enum { RAT_KNOB_MAX_BLOCKS, RAT_KNOB_ATTN_BWD_PH, RAT_KNOB_ATTN_FWD_CORE_MFMA, RAT_KNOB_ATTN_BWD_CORE_MFMA, RAT_KNOB_FFN_BWD_T3,
+       RAT_KNOB_SGEMM_SPLIT_TARGET, RAT_KNOB_COUNT };
+int rat_knob(int which);                              // diagnostic knobs (rat_common.hip): read from the environment ONCE, at load
 int rat_max_blocks();                                 // 256 (one work-group per CU) unless the RAT_MAX_BLOCKS test knob lowers it
 
 #define RAT_REQUIRE(cond, msg)                  \

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "rat_last_error": (c_char_p, []),
     "rat_gather_fwd": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "rat_gather_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "rat_batch_prepare": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, _P]),
     "rat_batch_assemble": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_int, _P]),
     "rat_attn_fwd": (c_int, [_P, _P, _P, _P, POINTER(RatAttnParams), POINTER(RatSeqMap), c_int, c_int, c_int, c_float, _P]),
     "rat_attn_bwd_workspace": (c_size_t, [c_int, c_int, c_int]),

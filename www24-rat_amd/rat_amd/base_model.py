@@ -298,19 +298,53 @@ class BaseModel(nn.Module):
         return epoch_loss
 
     # ---- eval ----------------------------------------------------------------------------------------
+    shard_evaluation = True    # data parallelism: every rank evaluates 1/world of each batch, the predictions are all-gathered
+
     def evaluate_generator(self, data_generator):
-        """base_model.py:232-247."""
+        """base_model.py:232-247.  Under data parallelism (and a batch source that can shard: rat_amd.data) each rank runs the forward
+        on its slice of every batch — nothing is dropped — and all ranks compute the metrics from the all-gathered predictions, so they
+        agree on early stopping / lr decay by construction."""
         self.eval()
         preds, trues = [], []
-        with torch.no_grad():
-            for batch_data in data_generator:
-                out = self.forward(batch_data)
-                preds.append(out["y_pred"])
-                trues.append(out["y_true"])
-        y_pred = torch.cat(preds).double().cpu().numpy().reshape(-1)
-        y_true = torch.cat(trues).double().cpu().numpy().reshape(-1)
+        world = self._world_size()
+        sharded = bool(self.shard_evaluation and self._dp() and world > 1 and getattr(data_generator, "shard", None) == (0, 1))
+        if sharded:
+            data_generator.shard, data_generator.keep_all = (self._rank(), world), True
+        try:
+            with torch.no_grad():
+                for batch_data in data_generator:
+                    out = self.forward(batch_data)
+                    preds.append(out["y_pred"])
+                    trues.append(out["y_true"])
+        finally:
+            if sharded:
+                data_generator.shard, data_generator.keep_all = (0, 1), False
+        empty = torch.zeros((0, 1), dtype=torch.float32, device=self.device)
+        y_pred, y_true = torch.cat(preds or [empty]).reshape(-1), torch.cat(trues or [empty]).reshape(-1)
+        if sharded:
+            y_pred, y_true = self._gather_ragged(y_pred, y_true)
+        y_pred = y_pred.double().cpu().numpy().reshape(-1)
+        y_true = y_true.double().cpu().numpy().reshape(-1)
         self.check_id_errors()
         return self.evaluate_metrics(y_true, y_pred, self._validation_metrics)
+
+    def _gather_ragged(self, *vectors):
+        """all-gather of equally long float vectors whose length differs from rank to rank -> the concatenation over ranks, in rank order"""
+        import torch.distributed as dist
+        world = self._world_size()
+        staged = dist.get_backend() == "gloo"
+        dev = torch.device("cpu") if staged else self.device
+        n = torch.tensor([vectors[0].numel()], dtype=torch.int64, device=dev)
+        counts = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(counts, n)
+        counts = [int(c[0]) for c in counts]
+        cap = max(max(counts), 1)
+        mine = torch.zeros((len(vectors), cap), dtype=torch.float32, device=dev)
+        for i, v in enumerate(vectors):
+            mine[i, :v.numel()] = v.to(dev, torch.float32)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        return tuple(torch.cat([parts[r][i, :counts[r]] for r in range(world)]) for i in range(len(vectors)))
 
     def evaluate_metrics(self, y_true, y_pred, metrics):
         return evaluate_metrics(y_true, y_pred, metrics)

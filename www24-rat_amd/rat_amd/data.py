@@ -77,7 +77,7 @@ class RetrievalBatches:
         n = len(self.ids)
         order = self._rng.permutation(n) if self.shuffle else np.arange(n)
         for b in range(len(self)):
-            rows = shard_rows(order[b * self.batch_size:(b + 1) * self.batch_size], self.shard)
+            rows = shard_rows(order[b * self.batch_size:(b + 1) * self.batch_size], self.shard, getattr(self, "keep_all", False))
             if len(rows) == 0:
                 continue
             ridx = self.retr_indices[rows]                                              # [B, K]
@@ -87,12 +87,13 @@ class RetrievalBatches:
                    torch.from_numpy(self.retr_lens[rows]))
 
 
-def shard_rows(rows, shard):
-    """rows of one GLOBAL batch -> this rank's equal share (see RetrievalBatches.__init__)"""
+def shard_rows(rows, shard, keep_all=False):
+    """rows of one GLOBAL batch -> this rank's equal share (see RetrievalBatches.__init__).  keep_all (evaluation): nothing is dropped —
+    rank r takes rows [r c, (r + 1) c) with c = ceil(len / world), the last ranks may get fewer (or none)."""
     rank, world = shard
     if world == 1:
         return rows
-    per = len(rows) // world
+    per = -(-len(rows) // world) if keep_all else len(rows) // world
     return rows[rank * per:(rank + 1) * per]
 
 
@@ -155,7 +156,8 @@ class DeviceRetrievalBatches:
         order = self._rng.permutation(self.n) if self.shuffle else np.arange(self.n)
         order_dev = torch.from_numpy(order.astype(np.int64)).to(self.device)      # one small upload per epoch
         for b in range(len(self)):
-            rows = shard_rows(order_dev[b * self.batch_size:(b + 1) * self.batch_size], getattr(self, "shard", (0, 1)))
+            rows = shard_rows(order_dev[b * self.batch_size:(b + 1) * self.batch_size], getattr(self, "shard", (0, 1)),
+                              getattr(self, "keep_all", False))
             if len(rows) == 0:
                 continue
             yield self.assemble(rows)

@@ -100,3 +100,30 @@ class StepGraph:
         opt._clock_step = opt._step
         model._gbuf_clean = True
         return self.loss.clone()[0]
+
+
+class EvalGraph:
+    """The inference forward (BaseModel.evaluate_generator / predict_generator's `self.forward(batch)`, base_model.py:232-273) of one
+    batch shape as ONE hipGraph: ~25 launches replayed with a single call.  It pays where the forward is shorter than the host needs to
+    issue it (BASELINE.json configs[0]: B = 256, d = 16) and changes nothing where the GPU is the limit (bench.py's `inference` object
+    reports both).  Single device only; the weights are read at replay time (the bf16x3 planes are re-split inside the graph), so a
+    graph stays valid across optimizer steps; `load_state_dict` copies in place and keeps it valid too."""
+
+    def __init__(self, model, batch):
+        self.model = model
+        self.static = tuple(torch.empty_like(t) for t in batch)
+        for s, t in zip(self.static, batch):
+            s.copy_(t)
+        self._stream = torch.cuda.Stream(device=batch[0].device)
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=self._stream, capture_error_mode="thread_local"):
+            y_pred, _loss, _reg, _saved = model._run_forward(self.static, save=False, with_reg=False)
+        self.y_pred = y_pred
+
+    def run(self, batch):
+        for s, t in zip(self.static, batch):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.y_pred.clone()

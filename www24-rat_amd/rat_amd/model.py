@@ -652,6 +652,7 @@ class RAT_m2(BaseModel):
         self._n_sparse = self._n_tab if mode == "sparse" else 0
         self._gbuf = None
         self.__dict__.pop("_step_graphs", None)        # captured steps point into the old buffers
+        self.__dict__.pop("_eval_graphs", None)
         self._build_descriptors()
         self.set_arith(self._arith_request)
 
@@ -1099,15 +1100,19 @@ class RAT_m2(BaseModel):
                              % (bad_ids, bad_labels))
 
     # ------------------------------------------------------------------------------ batch plumbing
-    def _prepare_batch(self, inputs):
+    def _prepare_batch(self, inputs, out=None):
         """inputs_to_device (base_model.py:125-133) + the slicing of RAT_m2.forward lines 110-116: ids become int32
-        once, on the host side of the boundary; the target row's label token is id 2."""
+        once, on the host side of the boundary; the target row's label token is id 2.  A 4-tuple that already sits on the device
+        takes ONE launch (rat_batch_prepare), written straight into `out` (a captured step's static inputs) when given."""
         if isinstance(inputs, DeviceBatch):            # assembled on the device by rat_batch_assemble (data.py)
             return inputs.idx, inputs.label_ids, inputs.y_true
         X, y = inputs[0], inputs[1]
         if len(inputs) >= 4:
             assert inputs[3].ndim == 1, "RIM does not support label-wise retrieval-enhanced training"
         assert X.ndim == 3, "retrieval augmented mode requires input_shape like [Bx(1+K)xF]"
+        if X.is_cuda and y.is_cuda and X.device == self.device and y.dtype in (torch.float32, torch.float64) \
+                and X.dtype in (torch.int32, torch.int64, torch.float32, torch.float64):
+            return ops.batch_prepare(X, y, out=out, lib=self._lib)
         idx = X.to(torch.int32) if X.dtype != torch.int32 else X
         labels = y.to(torch.int32).clone()
         labels[:, 0] = 2
@@ -1119,13 +1124,54 @@ class RAT_m2(BaseModel):
     # ------------------------------------------------------------------------------ public forward
     def forward(self, inputs):
         """RAT_m2.forward (RAT_m2.py:104-152)."""
-        batch = self._prepare_batch(inputs)
+        ready = None
+        if not self.training and not isinstance(inputs, DeviceBatch) and inputs[0].is_cuda and inputs[0].ndim == 3:
+            entry = self.__dict__.get("_eval_graphs", {}).get(self._eval_graph_key(tuple(inputs[0].shape)))
+            ready = entry[1] if entry is not None and entry[1] else None
+        batch = self._prepare_batch(inputs, out=ready.static if ready is not None else None)
         self.batch_size = batch[0].shape[0]
         if torch.is_grad_enabled() and self.training:
             y_pred, _, _ = _RATFunction.apply(self, batch, False, *[self._params[n] for n in self._order])
         else:
-            y_pred, _, _, _ = self._run_forward(batch, save=False, with_reg=False)
+            graph = self._eval_graph_for(batch) if not self.training else None
+            if graph is not None:
+                y_pred = graph.run(batch)
+            else:
+                y_pred, _, _, _ = self._run_forward(batch, save=False, with_reg=False)
         return {"y_true": batch[2].unsqueeze(-1), "y_pred": y_pred}
+
+    # The inference forward as a hipGraph (graph.EvalGraph): used for batches of at most `eval_graph_max_batch` samples — where the
+    # forward is short enough for its ~25 launches to be the limit (measured: bench.py `inference`) — after `graph_warmup` eager
+    # forwards of a shape; at most `graph_shapes` shapes (the full batch and an evaluation set's tail batch).
+    eval_graph = True
+    eval_graph_max_batch = 1024
+
+    def _eval_graph_key(self, shape):
+        return (tuple(shape), self.arith, self.gemm_arith, bool(self.prune_dead_tokens), bool(self._validate_ids), bool(self._head_strips))
+
+    def _eval_graph_for(self, batch):
+        if not (self.eval_graph and self.use_graph and batch[0].is_cuda and not self._dp() and batch[0].shape[0] <= self.eval_graph_max_batch):
+            return None
+        graphs = self.__dict__.setdefault("_eval_graphs", {})
+        key = self._eval_graph_key(tuple(batch[0].shape))
+        entry = graphs.get(key)
+        if entry is None:
+            if len(graphs) >= self.graph_shapes:
+                return None
+            entry = graphs[key] = [0, None]
+        if entry[1] is None:
+            entry[0] += 1
+            if entry[0] <= self.graph_warmup:
+                return None
+            from .graph import EvalGraph
+            try:
+                entry[1] = EvalGraph(self, batch)
+            except Exception as exc:
+                import logging
+                logging.warning("hipGraph capture of the inference forward failed (%s: %s); continuing with eager launches",
+                                type(exc).__name__, exc)
+                entry[1] = False
+        return entry[1] or None
 
     # ------------------------------------------------------------------------------ the fused training iteration
     def _fused_train_step(self, inputs):
@@ -1136,10 +1182,15 @@ class RAT_m2(BaseModel):
         On a GPU the iteration is captured into a hipGraph after `graph_warmup` eager steps of the same batch shape and replayed
         from then on (graph.StepGraph; `use_graph = False` keeps it eager).  Dropout does not: its generator state lives on the
         device (_dropout_begin), so every replay draws new masks."""
-        batch = self._prepare_batch(inputs)
-        self.batch_size = batch[0].shape[0]
         if not self.training:
             raise RuntimeError("train_step() on a model in eval mode")
+        # a batch shape that already has its graph: the conversion writes into the graph's static inputs (no copies in front of the replay)
+        ready = None
+        if not isinstance(inputs, DeviceBatch) and inputs[0].is_cuda and inputs[0].ndim == 3:
+            entry = self.__dict__.get("_step_graphs", {}).get(self._step_graph_key(tuple(inputs[0].shape)))
+            ready = entry[1] if entry is not None and entry[1] else None
+        batch = self._prepare_batch(inputs, out=ready.static if ready is not None else None)
+        self.batch_size = batch[0].shape[0]
         if any(p.grad is not None for p in self._params.values()):       # optimizer.zero_grad() of the reference's iteration
             self.optimizer.zero_grad()
             self._gbuf_clean = False
@@ -1230,20 +1281,23 @@ class RAT_m2(BaseModel):
     graph_warmup = 2           # eager fused steps of a batch shape before it is captured
     graph_shapes = 2           # at most this many batch shapes get a graph (the full batch and an epoch's tail batch)
 
+    def _step_graph_key(self, shape):
+        c = self._cfg
+        group = self.optimizer.param_groups[0]
+        return (tuple(shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens),
+                # kernel arguments and control flow the recorded launches carry: a change of any of them takes a new capture
+                self._max_gradient_norm, self.optimizer.kind, tuple(group.get("betas", ())), group.get("eps"), group.get("alpha"),
+                c["lam_emb"], c["lam_net"], self._grad_mode,
+                self.row_list_exchange, bool(self._graph_test_splits), bool(self._validate_ids), bool(self._head_strips),
+                bool(self.defer_slab_reductions), bool(self.owner_exchange))
+
     def _step_graph_for(self, batch):
         if not (self.use_graph and batch[0].is_cuda):
             return None
         if self._dp() and not self.graph_under_dp:
             return None
-        c = self._cfg
         graphs = self.__dict__.setdefault("_step_graphs", {})
-        group = self.optimizer.param_groups[0]
-        key = (tuple(batch[0].shape), self.arith, self.gemm_arith, self._world_size(), self._dp(), bool(self.prune_dead_tokens),
-               # kernel arguments and control flow the recorded launches carry: a change of any of them takes a new capture
-               self._max_gradient_norm, self.optimizer.kind, tuple(group.get("betas", ())), group.get("eps"), group.get("alpha"),
-               c["lam_emb"], c["lam_net"], self._grad_mode,
-               self.row_list_exchange, bool(self._graph_test_splits), bool(self._validate_ids), bool(self._head_strips),
-               bool(self.defer_slab_reductions))
+        key = self._step_graph_key(tuple(batch[0].shape))
         entry = graphs.get(key)
         if entry is None:
             if len(graphs) >= self.graph_shapes:

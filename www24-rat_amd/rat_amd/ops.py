@@ -134,6 +134,28 @@ def batch_assemble(data_ids, data_labels, pool_ids, pool_labels, retr_indices, r
 
 
 # ----------------------------------------------------------------------------- K1
+_DTYPE_CODE = {torch.int32: 0, torch.int64: 1, torch.float32: 2, torch.float64: 3}       # RAT_DTYPE_* (include/rat_hip.h)
+
+
+def batch_prepare(X, y, out=None, lib=None):
+    """device tensors X [B,T,L] (int32 / int64 / fp32 / fp64), y [B,T] (fp32 / fp64) -> (idx int32, label ids int32, y_true fp32 [B]);
+    `out`: three tensors of those shapes to write into (the static inputs of a captured step)"""
+    lib = lib or get_lib()
+    B, T, L = X.shape
+    if X.dtype not in _DTYPE_CODE or y.dtype not in (torch.float32, torch.float64):
+        raise TypeError("batch_prepare: X %s / y %s" % (X.dtype, y.dtype))
+    X, y = X.contiguous(), y.contiguous()
+    if out is None:
+        out = (torch.empty((B, T, L), dtype=torch.int32, device=X.device), torch.empty((B, T), dtype=torch.int32, device=X.device),
+               torch.empty((B,), dtype=torch.float32, device=X.device))
+    idx, labels, y_true = out
+    _chk(idx, torch.int32, "idx"), _chk(labels, torch.int32, "label_ids"), _chk(y_true, name="y_true")
+    assert tuple(idx.shape) == (B, T, L) and tuple(labels.shape) == (B, T) and y_true.numel() == B
+    lib.call("rat_batch_prepare", _p(X), _DTYPE_CODE[X.dtype], _p(y), _DTYPE_CODE[y.dtype], _p(idx), _p(labels), _p(y_true), B, T, L,
+             _stream(X))
+    return idx, labels, y_true
+
+
 def gather_fwd(idx, label_ids, ftab, nfields, label_table, B, T, L, d, lib=None):
     lib = lib or get_lib()
     _chk(idx, torch.int32, "idx"), _chk(label_ids, torch.int32, "label_ids"), _chk(label_table, name="label_table")
