@@ -83,6 +83,11 @@ def parse(argv=None):
                     help="with one rank: run the N > 1 code path anyway (RCCL process group of one rank, the model's data-parallel "
                          "path with every collective issued, barriers, weak and strong regions) — the 1-GPU rehearsal of the scaling job")
     ap.add_argument("--graph-dp", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--no-eager-first", action="store_true",
+                    help="N > 1 with graphs: skip the eager measurement that is taken first as the fall-back of a stalled graph attempt")
+    ap.add_argument("--graph-attempt-timeout", type=float, default=240.0,
+                    help="N > 1 with graphs: seconds the segmented-graph regions may take before every rank gives up and rank 0 prints "
+                         "the eager result")
     ap.add_argument("--no-graph-dp", action="store_true",
                     help="N > 1: eager launches instead of graph segments with the collectives between them (the default)")
     ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
@@ -666,18 +671,180 @@ def worker(args):
         region_info[label] = info
         return elapsed, (timer.summary(steps) if (kernel_pass or not graph_mode) else {})
 
+    def assemble(weak, strong, region_info, graph_mode):
+        primary, per_rank_batch, scaling = (weak, B, "weak") if weak is not None else (strong, B // world, "strong")
+        elapsed, ksum = primary
+        work = algorithmic_work(spec, per_rank_batch, args.model)
+        arith = getattr(model, "arith", "f32")
+        kernels = []
+        for key, st in sorted(ksum.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+            row = dict(kernel=key[0] + (":" + key[1] if key[1] else ""), launches_per_step=round(st["launches_per_step"], 2),
+                       avg_ms=round(st["avg_ms"], 4), ms_per_step=round(st["ms_per_step"], 4))
+            wk = work(*key)
+            if wk:
+                bound, amount = wk
+                if bound == "mfma":
+                    tf = amount / (st["avg_ms"] * 1e-3) / 1e12
+                    row.update(bound="mfma", achieved=round(tf, 3), unit="TFLOP/s", frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+                else:
+                    gbs = amount / (st["avg_ms"] * 1e-3) / 1e9
+                    row.update(bound="hbm", achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
+            kernels.append(row)
+        # dominant kernel = the C-ABI entry point with the most time per step (all its launches, both attention phases pooled)
+        pooled = {}
+        for key, st in ksum.items():
+            p = pooled.setdefault(key[0], dict(ms=0.0, n=0.0, amount=0.0, bound=None))
+            p["ms"] += st["ms_per_step"]
+            p["n"] += st["launches_per_step"]
+            wk = work(*key)
+            if wk:
+                p["bound"] = wk[0]
+                p["amount"] += wk[1] * st["launches_per_step"]
+        dom_name, dom = max(((k, v) for k, v in pooled.items() if v["bound"]), key=lambda kv: kv[1]["ms"])
+        avg_s = dom["ms"] / dom["n"] * 1e-3
+        per_launch = dom["amount"] / dom["n"]
+        if dom["bound"] == "mfma":
+            achieved, peak, unit = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        traffic, traffic_src = pmc_traffic(dom_name, args.workload) if (args.model == "RAT_m2" and per_rank_batch == B) else (None, None)
+        roofline = dict(kernel=dom_name, bound=dom["bound"], achieved=round(achieved, 3), peak=peak, unit=unit,
+                        frac=round(achieved / peak, 4), traffic=traffic,
+                        traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, %s)" % traffic_src,
+                        algorithmic=round(per_launch, 1), algorithmic_unit="FLOP/launch" if dom["bound"] == "mfma" else "bytes/launch",
+                        avg_launch_ms=round(avg_s * 1e3, 4), launches_per_step=round(dom["n"], 2))
+        if dom["bound"] == "mfma" and arith == "bf16x3":
+            # 3-way bf16 split, 6 of the 9 cross products, fp32 accumulate: `peak` stays the exact-fp32 MFMA peak (continuity
+            # with round 1); `peak_effective` = dense bf16 MFMA peak / 6 products per fp32-equivalent FLOP
+            eff = PEAK_BF16_MFMA_TFLOPS / 6.0
+            roofline.update(peak_effective=round(eff, 1), frac_effective=round(achieved / eff, 4),
+                            peak_effective_note="bf16 MFMA dense peak 2500 TFLOP/s / 6 bf16 products per fp32 product")
+        # north_star's two named targets, from the same HIP-event records
+        targets = {}
+        for nm in ("rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted"):
+            p = pooled.get(nm)
+            if p and p["n"] > 0 and p["bound"] == "hbm":
+                ms = p["ms"] / p["n"]                         # the HIP-event pair as it stands (VERDICT r3: no overhead subtraction)
+                gbs = p["amount"] / p["n"] / (ms * 1e-3) / 1e9
+                targets[nm] = dict(bound="hbm", avg_launch_ms=round(ms, 4),
+                                   timing="HIP-event pair around the launch inside the training step, nothing subtracted; rocprofv3 "
+                                          "durations of the same kernel: " + ROCPROF_NOTE,
+                                   algorithmic_bytes=round(p["amount"] / p["n"]), achieved_GBps=round(gbs, 1),
+                                   frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4))
+        if gather_big is not None:
+            targets["rat_gather_fwd_V100M"] = gather_big
+        T = spec["K"] + 1
+        cross_ms = cross_fl = 0.0
+        for key, st in ksum.items():
+            if key[0] in KernelTimer.ATTN_ARGS and key[1].startswith("L%dh" % T) and T != spec["F"] + 1:
+                cross_ms += st["ms_per_step"]
+                cross_fl += work(*key)[1] * st["launches_per_step"]
+        if cross_ms > 0:
+            tf = cross_fl / (cross_ms * 1e-3) / 1e12
+            targets["cross_attention"] = dict(bound="mfma", what="all L=T=%d fused-attention launches of a step, fwd + bwd" % T,
+                                              ms_per_step=round(cross_ms, 4), algorithmic_flop_per_step=round(cross_fl),
+                                              achieved_TFLOPs=round(tf, 2), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
+        gbatch = per_rank_batch * world
+        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64; 1/2/4/8 MI355X",
+                      value=round(gbatch * args.steps / elapsed, 1),
+                      unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                      ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling=scaling, vs_baseline=None,
+                      dtype="f32", arith={"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
+                                          "bf16x3": "bf16x3-split MFMA, fp32 accumulate"}.get(arith, arith),
+                      data="synthetic (%d distinct batches rotated)" % NBATCH,
+                      config=dict(workload=args.workload, fields=spec["F"], vocab_rows=spec["total_vocab"], retrieved=spec["K"],
+                                  embedding_dim=spec["d"], batch_per_gpu=per_rank_batch, global_batch=gbatch, heads=spec["num_heads"],
+                                  dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
+                                  dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam", embedding_grad=model._grad_mode,
+                                  embedding_regularizer=model._cfg["lam_emb"], sync_batch_norm=bool(dp and spec["batch_norm"]),
+                                  parallelism="dp%d" % world),
+                      roofline=roofline, targets=targets, kernels=kernels)
+        if dp:
+            result["world"] = dist.get_world_size()
+            result["first_barrier_s"] = round(first_barrier_s, 3) if first_barrier_s is not None else None
+            result["communication"] = {k: v.get("communication") for k, v in region_info.items() if v.get("communication")}
+        if strong is not None and weak is not None:
+            el, _ = strong
+            result["strong_scaling"] = dict(value=round(B * args.steps / el, 1), unit="samples/s", ms_per_step=round(el / args.steps * 1e3, 3),
+                                            global_batch=B, batch_per_gpu=B // world,
+                                            partitioning="one global batch of %d samples, rank r trains on rows [r*%d, (r+1)*%d)" % (B, B // world, B // world))
+        result["step_mode"] = dict(region_info.get(scaling, {}),
+                                   what="train_step(): fused iteration (forward, BCE, backward, [exchange], two-sweep clip+Adam with the "
+                                        "regulariser folded in)" + (", replayed as a captured hipGraph; `kernels` / `roofline` / `targets` "
+                                        "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
+                                        else ", eager launches"))
+        result["config"]["dead_token_pruning"] = bool(can_prune and model.prune_dead_tokens)
+        if args.dp_rehearsal:
+            result["dp_rehearsal"] = "one rank through the N > 1 code path (RCCL group of one rank, every collective of the step issued)"
+        if pruned is not None:
+            pruned["speedup"] = round(pruned["value"] / result["value"], 4)
+            result["dead_token_pruning"] = pruned
+        if per_rank is not None:
+            per_rank["ratio_to_headline"] = round(per_rank["value"] / result["value"], 4)
+            result["per_rank_shape"] = per_rank
+        if inference is not None:
+            result["inference"] = inference
+        if alt is not None:
+            result["exact_f32" if alt["arith"] == "f32" else "alt_arith"] = alt
+        if args.model != "RAT_m2":
+            result["config"]["variant"] = args.model
+        if dry:
+            result["dry_run_cpu"] = True
+        return result
+
     want_weak = not dp or args.scaling in ("both", "weak")
     want_strong = dp and args.scaling in ("both", "strong")
-    weak = strong = None
-    if want_weak:                                  # every rank its own batches of B samples
-        batches = [make(1000 + 16 * rank + i) for i in range(NBATCH)]
-        weak = timed_region(batches, args.steps, args.warmup, "weak")
-        del batches
-    if want_strong:                                # one global batch of B samples, rank r takes rows [r B/N, (r+1) B/N)
-        per = B // world
-        batches = [make(2000 + i, rank * per, (rank + 1) * per) for i in range(NBATCH)]
-        strong = timed_region(batches, args.steps, max(args.warmup, 2) if weak is None else 2, "strong")
-        del batches
+
+    def run_regions():
+        weak = strong = None
+        if want_weak:                                  # every rank its own batches of B samples
+            batches = [make(1000 + 16 * rank + i) for i in range(NBATCH)]
+            weak = timed_region(batches, args.steps, args.warmup, "weak")
+            del batches
+        if want_strong:                                # one global batch of B samples, rank r takes rows [r B/N, (r+1) B/N)
+            per = B // world
+            batches = [make(2000 + i, rank * per, (rank + 1) * per) for i in range(NBATCH)]
+            strong = timed_region(batches, args.steps, max(args.warmup, 2) if weak is None else 2, "strong")
+            del batches
+        return weak, strong
+
+    alt = per_rank = pruned = inference = gather_big = None
+    attempts = None
+    if dp and graph_mode and not args.no_eager_first:
+        # First contact with N > 1 RCCL ranks must be SURVIVABLE: the eager step (the form that has met RCCL) is measured first and
+        # its result line is ready before the segmented-graph form is tried; a watchdog ends a graph attempt that stalls — every rank
+        # exits 0 and rank 0 prints the eager line (with a note) instead of leaving the job in a collective until some outer timeout.
+        import threading
+        graph_mode = False
+        model.use_graph = False
+        weak_e, strong_e = run_regions()
+        info_e = dict(region_info)
+        fallback = assemble(weak_e, strong_e, info_e, False) if rank == 0 else None
+
+        def bail():
+            if rank == 0:
+                fallback["step_mode"]["graph_attempt"] = "the segmented-graph form did not finish within %.0f s and was abandoned; these are the eager numbers" % args.graph_attempt_timeout
+                emit(json.dumps(fallback))
+            os._exit(0)
+        dog = threading.Timer(args.graph_attempt_timeout, bail)
+        dog.daemon = True
+        sync()
+        dog.start()
+        graph_mode = True
+        model.use_graph = True
+        region_info.clear()
+        weak, strong = run_regions()
+        dog.cancel()
+        captured = any(e[1] for e in model.__dict__.get("_step_graphs", {}).values())
+        first_e, first_g = (weak_e or strong_e)[0], (weak or strong)[0]
+        attempts = dict(eager_ms_per_step=round(first_e / args.steps * 1e3, 3), graph_ms_per_step=round(first_g / args.steps * 1e3, 3),
+                        graph_captured=bool(captured), reported="graph" if first_g <= first_e else "eager")
+        if first_g > first_e:                          # the eager form was the faster one on this machine: report it
+            weak, strong, graph_mode = weak_e, strong_e, False
+            region_info.clear()
+            region_info.update(info_e)
+    else:
+        weak, strong = run_regions()
 
     # exact-fp32 arithmetic timed beside the default one in the SAME invocation; N = 1 only
     alt = None
@@ -800,124 +967,9 @@ def worker(args):
         timer.reset()
 
     if rank == 0:
-        primary, per_rank_batch, scaling = (weak, B, "weak") if weak is not None else (strong, B // world, "strong")
-        elapsed, ksum = primary
-        work = algorithmic_work(spec, per_rank_batch, args.model)
-        arith = getattr(model, "arith", "f32")
-        kernels = []
-        for key, st in sorted(ksum.items(), key=lambda kv: -kv[1]["ms_per_step"]):
-            row = dict(kernel=key[0] + (":" + key[1] if key[1] else ""), launches_per_step=round(st["launches_per_step"], 2),
-                       avg_ms=round(st["avg_ms"], 4), ms_per_step=round(st["ms_per_step"], 4))
-            wk = work(*key)
-            if wk:
-                bound, amount = wk
-                if bound == "mfma":
-                    tf = amount / (st["avg_ms"] * 1e-3) / 1e12
-                    row.update(bound="mfma", achieved=round(tf, 3), unit="TFLOP/s", frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
-                else:
-                    gbs = amount / (st["avg_ms"] * 1e-3) / 1e9
-                    row.update(bound="hbm", achieved=round(gbs, 1), unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4))
-            kernels.append(row)
-        # dominant kernel = the C-ABI entry point with the most time per step (all its launches, both attention phases pooled)
-        pooled = {}
-        for key, st in ksum.items():
-            p = pooled.setdefault(key[0], dict(ms=0.0, n=0.0, amount=0.0, bound=None))
-            p["ms"] += st["ms_per_step"]
-            p["n"] += st["launches_per_step"]
-            wk = work(*key)
-            if wk:
-                p["bound"] = wk[0]
-                p["amount"] += wk[1] * st["launches_per_step"]
-        dom_name, dom = max(((k, v) for k, v in pooled.items() if v["bound"]), key=lambda kv: kv[1]["ms"])
-        avg_s = dom["ms"] / dom["n"] * 1e-3
-        per_launch = dom["amount"] / dom["n"]
-        if dom["bound"] == "mfma":
-            achieved, peak, unit = per_launch / avg_s / 1e12, PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
-        else:
-            achieved, peak, unit = per_launch / avg_s / 1e9, PEAK_HBM_GBS, "GB/s"
-        traffic, traffic_src = pmc_traffic(dom_name, args.workload) if (args.model == "RAT_m2" and per_rank_batch == B) else (None, None)
-        roofline = dict(kernel=dom_name, bound=dom["bound"], achieved=round(achieved, 3), peak=peak, unit=unit,
-                        frac=round(achieved / peak, 4), traffic=traffic,
-                        traffic_unit="bytes/launch (rocprofv3 PMC: 2 x FETCH_SIZE + WRITE_SIZE, %s)" % traffic_src,
-                        algorithmic=round(per_launch, 1), algorithmic_unit="FLOP/launch" if dom["bound"] == "mfma" else "bytes/launch",
-                        avg_launch_ms=round(avg_s * 1e3, 4), launches_per_step=round(dom["n"], 2))
-        if dom["bound"] == "mfma" and arith == "bf16x3":
-            # 3-way bf16 split, 6 of the 9 cross products, fp32 accumulate: `peak` stays the exact-fp32 MFMA peak (continuity
-            # with round 1); `peak_effective` = dense bf16 MFMA peak / 6 products per fp32-equivalent FLOP
-            eff = PEAK_BF16_MFMA_TFLOPS / 6.0
-            roofline.update(peak_effective=round(eff, 1), frac_effective=round(achieved / eff, 4),
-                            peak_effective_note="bf16 MFMA dense peak 2500 TFLOP/s / 6 bf16 products per fp32 product")
-        # north_star's two named targets, from the same HIP-event records
-        targets = {}
-        for nm in ("rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted"):
-            p = pooled.get(nm)
-            if p and p["n"] > 0 and p["bound"] == "hbm":
-                ms = p["ms"] / p["n"]                         # the HIP-event pair as it stands (VERDICT r3: no overhead subtraction)
-                gbs = p["amount"] / p["n"] / (ms * 1e-3) / 1e9
-                targets[nm] = dict(bound="hbm", avg_launch_ms=round(ms, 4),
-                                   timing="HIP-event pair around the launch inside the training step, nothing subtracted; rocprofv3 "
-                                          "durations of the same kernel: " + ROCPROF_NOTE,
-                                   algorithmic_bytes=round(p["amount"] / p["n"]), achieved_GBps=round(gbs, 1),
-                                   frac_of_8TBps=round(gbs / PEAK_HBM_GBS, 4))
-        if gather_big is not None:
-            targets["rat_gather_fwd_V100M"] = gather_big
-        T = spec["K"] + 1
-        cross_ms = cross_fl = 0.0
-        for key, st in ksum.items():
-            if key[0] in KernelTimer.ATTN_ARGS and key[1].startswith("L%dh" % T) and T != spec["F"] + 1:
-                cross_ms += st["ms_per_step"]
-                cross_fl += work(*key)[1] * st["launches_per_step"]
-        if cross_ms > 0:
-            tf = cross_fl / (cross_ms * 1e-3) / 1e12
-            targets["cross_attention"] = dict(bound="mfma", what="all L=T=%d fused-attention launches of a step, fwd + bwd" % T,
-                                              ms_per_step=round(cross_ms, 4), algorithmic_flop_per_step=round(cross_fl),
-                                              achieved_TFLOPs=round(tf, 2), frac_of_f32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4))
-        gbatch = per_rank_batch * world
-        result = dict(metric="training samples/sec at B=4096, K=10 retrieved, d=64; 1/2/4/8 MI355X",
-                      value=round(gbatch * args.steps / elapsed, 1),
-                      unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                      ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling=scaling, vs_baseline=None,
-                      dtype="f32", arith={"f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32), fp32 accumulate",
-                                          "bf16x3": "bf16x3-split MFMA, fp32 accumulate"}.get(arith, arith),
-                      data="synthetic (%d distinct batches rotated)" % NBATCH,
-                      config=dict(workload=args.workload, fields=spec["F"], vocab_rows=spec["total_vocab"], retrieved=spec["K"],
-                                  embedding_dim=spec["d"], batch_per_gpu=per_rank_batch, global_batch=gbatch, heads=spec["num_heads"],
-                                  dim_head=spec["dim_head"], depth=spec["depth"], scale_dim=spec["scale_dim"],
-                                  dnn=spec["dnn_hidden_units"], step="fwd+bwd+clip+adam", embedding_grad=model._grad_mode,
-                                  embedding_regularizer=model._cfg["lam_emb"], sync_batch_norm=bool(dp and spec["batch_norm"]),
-                                  parallelism="dp%d" % world),
-                      roofline=roofline, targets=targets, kernels=kernels)
-        if dp:
-            result["world"] = dist.get_world_size()
-            result["first_barrier_s"] = round(first_barrier_s, 3) if first_barrier_s is not None else None
-            result["communication"] = {k: v.get("communication") for k, v in region_info.items() if v.get("communication")}
-        if strong is not None and weak is not None:
-            el, _ = strong
-            result["strong_scaling"] = dict(value=round(B * args.steps / el, 1), unit="samples/s", ms_per_step=round(el / args.steps * 1e3, 3),
-                                            global_batch=B, batch_per_gpu=B // world,
-                                            partitioning="one global batch of %d samples, rank r trains on rows [r*%d, (r+1)*%d)" % (B, B // world, B // world))
-        result["step_mode"] = dict(region_info.get(scaling, {}),
-                                   what="train_step(): fused iteration (forward, BCE, backward, [exchange], two-sweep clip+Adam with the "
-                                        "regulariser folded in)" + (", replayed as a captured hipGraph; `kernels` / `roofline` / `targets` "
-                                        "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
-                                        else ", eager launches"))
-        result["config"]["dead_token_pruning"] = bool(can_prune and model.prune_dead_tokens)
-        if args.dp_rehearsal:
-            result["dp_rehearsal"] = "one rank through the N > 1 code path (RCCL group of one rank, every collective of the step issued)"
-        if pruned is not None:
-            pruned["speedup"] = round(pruned["value"] / result["value"], 4)
-            result["dead_token_pruning"] = pruned
-        if per_rank is not None:
-            per_rank["ratio_to_headline"] = round(per_rank["value"] / result["value"], 4)
-            result["per_rank_shape"] = per_rank
-        if inference is not None:
-            result["inference"] = inference
-        if alt is not None:
-            result["exact_f32" if alt["arith"] == "f32" else "alt_arith"] = alt
-        if args.model != "RAT_m2":
-            result["config"]["variant"] = args.model
-        if dry:
-            result["dry_run_cpu"] = True
+        result = assemble(weak, strong, region_info, graph_mode)
+        if attempts is not None:
+            result["step_mode"]["attempts"] = attempts
         if not dp and not args.no_cpu_baseline and not dry:
             result["cpu_baseline"] = cpu_baseline(args.workload, spec, args.cpu_batch or B, seed=1000, model=args.model,
                                                   timed_steps=args.cpu_steps)

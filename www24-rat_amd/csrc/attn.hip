@@ -97,6 +97,25 @@ __device__ __forceinline__ int64_t seq_token(const AttnArgs& a, int64_t q, int p
     return (q / a.q_div) * a.hi_stride + (q % a.q_div) * a.lo_stride + (int64_t)p * a.pos_stride;
 }
 
+// The same for the bf16x3 kernels, which only run when every token's byte offset fits 32 bits (b3_off32_ok): the whole map in 32-bit
+// arithmetic (exact modulo 2^32, and the true values are below it).  The 64-bit form kept a loop-invariant 64-bit product per lane
+// alive across the chunk loop of attn_bwd3_kernel — the one value that kernel spilled to scratch (round 4's resource report: 12 bytes
+// of scratch, a `scratch_load_dwordx2 ... Folded Reload` inside the loop, which waits for vmcnt(0)).
+__device__ __forceinline__ void map_rows(const AttnArgs& a, int64_t chunk, int64_t* rowtok, int& nsq, int& rows);
+__device__ __forceinline__ void map_rows32(const AttnArgs& a, int64_t chunk, int64_t* rowtok, int& nsq, int& rows) {
+    const int64_t q0 = chunk * a.nsq_chunk;
+    const int64_t left = a.nseq - q0;
+    nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+    rows = nsq * a.L;
+    if (threadIdx.x < ATT_ROWS) {
+        const unsigned r = threadIdx.x, Lu = (unsigned)a.L;
+        const unsigned sq = r / Lu, p = r - sq * Lu;
+        const unsigned qq = (unsigned)q0 + sq, dv = a.q_div > 0x7fffffffLL ? 0x7fffffffu : (unsigned)a.q_div, hi = qq / dv;
+        const unsigned tok = hi * (unsigned)a.hi_stride + (qq - hi * dv) * (unsigned)a.lo_stride + p * (unsigned)a.pos_stride;
+        rowtok[r] = (int)r < rows ? (int64_t)tok : (int64_t)-1;
+    }
+}
+
 // rows of this chunk -> token ids (-1 for padding rows)
 __device__ __forceinline__ void map_rows(const AttnArgs& a, int64_t chunk, int64_t* rowtok, int& nsq, int& rows) {
     const int64_t q0 = chunk * a.nsq_chunk;
@@ -107,6 +126,35 @@ __device__ __forceinline__ void map_rows(const AttnArgs& a, int64_t chunk, int64
         const int r = threadIdx.x;
         rowtok[r] = r < rows ? seq_token(a, q0 + r / a.L, r % a.L) : (int64_t)-1;
     }
+}
+
+// the 64-bit map with the lane's row number made opaque at every call: nothing of it can be hoisted out of the chunk loop (A/B only)
+__device__ __forceinline__ void map_rows_nohoist(const AttnArgs& a, int64_t chunk, int64_t* rowtok, int& nsq, int& rows) {
+    const int64_t q0 = chunk * a.nsq_chunk;
+    const int64_t left = a.nseq - q0;
+    nsq = left < a.nsq_chunk ? (int)left : a.nsq_chunk;
+    rows = nsq * a.L;
+    if (threadIdx.x < ATT_ROWS) {
+        int r = threadIdx.x;
+#ifndef RAT_EMU
+        asm volatile("" : "+v"(r));
+#endif
+        rowtok[r] = r < rows ? seq_token(a, q0 + r / a.L, r % a.L) : (int64_t)-1;
+    }
+}
+// Which form the bf16x3 kernels use is a same-box A/B decision (profiles/round5/r5_map_rows_ab.txt): RAT_MAP_FWD / RAT_MAP_BWD
+// 0 = 64-bit (round 4), 1 = 32-bit, 2 = 64-bit without hoisting.
+#ifndef RAT_MAP_FWD
+#define RAT_MAP_FWD 0
+#endif
+#ifndef RAT_MAP_BWD
+#define RAT_MAP_BWD 0
+#endif
+template <int MODE>
+__device__ __forceinline__ void map_rows_b3(const AttnArgs& a, int64_t chunk, int64_t* rowtok, int& nsq, int& rows) {
+    if (MODE == 1) map_rows32(a, chunk, rowtok, nsq, rows);
+    else if (MODE == 2) map_rows_nohoist(a, chunk, rowtok, nsq, rows);
+    else map_rows(a, chunk, rowtok, nsq, rows);
 }
 
 // load `width` floats per row from a token-indexed global array into an LDS tile (padding rows -> 0)
@@ -1217,7 +1265,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
     }
     {
         int nsq0, rows0;
-        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
+        map_rows_b3<RAT_MAP_FWD>(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
     RAT_PROF_DECL
@@ -1236,7 +1284,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         b3_layer_norm_to_planes<DPAD>(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr, dreal, colok);
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
-            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
+            map_rows_b3<RAT_MAP_FWD>(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
         RAT_PROF_MARK(0);
@@ -1670,7 +1718,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Att
     }
     {
         int nsq0, rows0;
-        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
+        map_rows_b3<RAT_MAP_FWD>(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
     RAT_PROF_DECL
@@ -1691,7 +1739,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3m_kernel(AttnArgs a, Att
         b3_layer_norm_to_planes(rowtok[threadIdx.x >> 3] >= 0, x0, x1, a.eps, xp, gam, bet, nullptr, nullptr);
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
-            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
+            map_rows_b3<RAT_MAP_FWD>(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
         RAT_PROF_MARK(0);
@@ -1874,7 +1922,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
     for (int e = threadIdx.x; e < (int)((B3_OFF_MISC - B3_OFF_QKV) / 4); e += ATT_THREADS) qkv[e] = 0.f;   // pad columns, slack
     {
         int nsq0, rows0;
-        map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
+        map_rows_b3<RAT_MAP_BWD>(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
     RAT_PROF_DECL
@@ -1938,7 +1986,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         }
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
-            map_rows(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
+            map_rows_b3<RAT_MAP_BWD>(a, chunk + gridDim.x, (rowtok0 + (parity ^ 1) * ATT_ROWS), nsq1, rows1);
         }
         __syncthreads();
         RAT_PROF_MARK(0);

@@ -1144,7 +1144,7 @@ class RAT_m2(BaseModel):
     # forward is short enough for its ~25 launches to be the limit (measured: bench.py `inference`) — after `graph_warmup` eager
     # forwards of a shape; at most `graph_shapes` shapes (the full batch and an evaluation set's tail batch).
     eval_graph = True
-    eval_graph_max_batch = 1024
+    eval_graph_max_batch = 4096
 
     def _eval_graph_key(self, shape):
         return (tuple(shape), self.arith, self.gemm_arith, bool(self.prune_dead_tokens), bool(self._validate_ids), bool(self._head_strips))
