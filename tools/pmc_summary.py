@@ -56,6 +56,21 @@ def main():
         for alias, src in (("rat_attn_bwd_ex:f32", "rat_attn_bwd"),):
             pass
         print(json.dumps(res, indent=1))
+    elif sys.argv[1] == "coexec":
+        data, names = read(sys.argv[2])
+        res = {"_comment": "rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY "
+                           "GRBM_GUI_ACTIVE --kernel-trace -- python3 tools/kbench.py attn_bwd attn_fwd ffn_fwd ffn_bwd --arith bf16x3 --reps 2 "
+                           "(north-star shapes; the program directly after --).  coexec_frac = cycles in which a VALU and an MFMA instruction "
+                           "execute together / (1024 SIMDs x kernel cycles); the other fractions as in the pmc_busy file.", "kernels": {}}
+        for e, c in data.items():
+            cyc = avg(c["GRBM_GUI_ACTIVE"]) / 8.0
+            busy, co = avg(c["SQ_VALU_MFMA_BUSY_CYCLES"]), avg(c["SQ_VALU_MFMA_COEXEC_CYCLES"])
+            res["kernels"][e] = dict(kernel=names[e], launches=len(c["GRBM_GUI_ACTIVE"]), kernel_cycles=int(cyc),
+                                     mfma_busy_frac=round(busy / (1024 * cyc), 3), coexec_frac=round(co / (1024 * cyc), 3),
+                                     coexec_over_mfma_busy=round(co / busy, 3) if busy else None,
+                                     valu_active_frac=round(4 * avg(c["SQ_ACTIVE_INST_VALU"]) / (1024 * cyc), 3),
+                                     wait_any_frac=round(avg(c["SQ_WAIT_ANY"]) / avg(c["SQ_WAVE_CYCLES"]), 3))
+        print(json.dumps(res, indent=1))
     else:
         data, names = read(sys.argv[2])
         res = {"_comment": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY "

@@ -2009,7 +2009,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             RAT_SCHED_FENCE();
         }
         RAT_PROF_MARK(2);
-        if (rat_wave() < B3_I / 16) {                                        // wave = inner-dimension tile of O^T
+#ifdef RAT_DWOUT_R4                                                           // A/B only: round 4's assignment (wave = inner tile, waves 5-7 idle)
+        if (rat_wave() < B3_I / 16) {
             const int mt = rat_wave(), l = rat_lane(), g = l >> 4, col = 16 * mt + (l & 15);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -2024,6 +2025,30 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
                 }
             }
         }
+#else
+        {   // dW_out^T is 5 inner tiles x 4 column tiles.  Waves 0-3 own inner tile w (4 column tiles each, as before); inner tile 4 —
+            // round 4 gave all of it to wave 4, which shares a SIMD with wave 0: 96 MFMAs on that SIMD against 48 on the others, three
+            // waves idle — is dealt one column tile each to waves 4-7: 60 MFMAs per SIMD.
+            static_assert(B3_I / 16 == 5 && OSLOTS == 4 && ATT_WAVES == 8, "the dW_out assignment is written for 5 x 4 tiles on 8 waves");
+            const int w = rat_wave(), mt = w < 4 ? w : 4, l = rat_lane(), g = l >> 4, col = 16 * mt + (l & 15);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ob[(size_t)rat_col_slot_row(s, g, j) * B3_LDT + col];
+                const RatB3 af = rat_split8_frag(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+                if (w < 4) {
+#pragma unroll
+                    for (int nt = 0; nt < OSLOTS; ++nt) {
+                        acco[nt] = rat_mfma3(af, dyp.col_frag(nt, s), acco[nt]);
+                        RAT_SCHED_FENCE();
+                    }
+                } else {
+                    acco[0] = rat_mfma3(af, dyp.col_frag(w - 4, s), acco[0]);
+                }
+            }
+        }
+#endif
         __syncthreads();
         RAT_PROF_MARK(3);
         // ---- P3: attention backward on the VALU — the two passes of attn_bwd_kernel<64, 10>.  Same-box A/B of the loop shapes
@@ -2241,12 +2266,25 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s_wqkv[(int64_t)rat_acc_row(mt, r) * dreal + col] = accq[i][r];
         }
+#ifdef RAT_DWOUT_R4
         if (w < B3_I / 16)
 #pragma unroll
             for (int nt = 0; nt < OSLOTS; ++nt)
                 if (!DPAD || rat_acc_col(nt) < dreal)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s_wout[(int64_t)rat_acc_col(nt) * B3_I + rat_acc_row(w, r)] = acco[nt][r];
+#else
+        if (w < 4) {
+#pragma unroll
+            for (int nt = 0; nt < OSLOTS; ++nt)
+                if (!DPAD || rat_acc_col(nt) < dreal)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_wout[(int64_t)rat_acc_col(nt) * B3_I + rat_acc_row(w, r)] = acco[nt][r];
+        } else if (!DPAD || rat_acc_col(w - 4) < dreal) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_wout[(int64_t)rat_acc_col(w - 4) * B3_I + rat_acc_row(4, r)] = acco[0][r];
+        }
+#endif
     }
     // db_out / dgamma / dbeta: 64 row-slot partials per column -> LDS -> fixed-order column sums
     float* red = reinterpret_cast<float*>(smem);                             // [64][68]
