@@ -86,6 +86,17 @@ def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(emu, two_blocks, knob)
     kc.check_attn(emu, "cpu", (3, 11, 4, 64, 8, 10, True), "cross", arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode", [pytest.param((2, 6, 21, 64, 8, 10, True), "intra", id="L21_two_tiles"),
+                                       pytest.param((3, 11, 4, 64, 8, 10, True), "cross", id="L11_one_tile"),
+                                       twin((1, 31, 2, 64, 8, 10, True), "cross", id="L31")])
+def test_attn_bwd_bf16x3_matrix_pipe_core(emu, case, mode, two_blocks, knob):
+    """attn_bwd3_kernel<.., MC>: the backward core on v_mfma_f32_16x16x4_f32 (one wave per (sequence, head) pair, P / dS through a
+    wave-private LDS tile) — forced on by the knob at lengths the host would leave to the VALU passes: two 16-row tiles with a ragged
+    second one (L = 21), one ragged tile (L = 11)"""
+    knob(emu, "attn_bwd_core_mfma", 1)
+    kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
+
+
 def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
     kc.check_attn_queries(emu, "cpu", (2, 3, 7, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
     kc.check_attn_dropout(emu, "cpu", (1, 3, 5, 40, 8, 10, True), "cross", arith="bf16x3")

@@ -78,6 +78,18 @@ def test_attn_bwd_bf16x3_probabilities_handed_to_pass_two(lib, knob):
     kc.check_attn(lib, "cuda", (40, 11, 21, 64, 8, 10, True), "cross", arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode", [((40, 6, 21, 64, 8, 10, True), "intra"), ((30, 11, 4, 64, 8, 10, True), "cross"), ((9, 31, 9, 64, 8, 10, True), "cross"),
+                                       ((9, 31, 16, 64, 8, 10, True), "intra"), ((5, 28, 3, 64, 8, 10, True), "cross"), ((7, 3, 32, 64, 8, 10, True), "intra")],
+                         ids=["L21", "L11", "L31", "L16", "L28", "L32"])
+def test_attn_bwd_bf16x3_matrix_pipe_core(lib, case, mode, knob):
+    """the backward core on the matrix pipe (attn_bwd3_kernel<.., MC>): forced on at every length class (ragged tiles, full tiles, one
+    and two tiles per sequence) and — L 31, 28, 32 — selected by the host's own rule"""
+    knob(lib, "attn_bwd_core_mfma", 1)
+    kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
+    knob(lib, "attn_bwd_core_mfma", -1)
+    kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
+
+
 def test_attn_narrower_embedding_with_queries_and_dropout(lib):
     kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
     kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "cross", nq=1, arith="bf16x3")

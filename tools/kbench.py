@@ -38,9 +38,11 @@ def main():
     ap.add_argument("--arith", default="f32", choices=["f32", "bf16x3", "both"])
     ap.add_argument("--gather-rows", type=int, default=50_000, help="gather: rows per field (2500000 with --gather-F 40 = configs[3]'s 25.6 GB table)")
     ap.add_argument("--gather-F", type=int, default=20)
+    ap.add_argument("--T", type=int, default=11, help="samples per batch row (retrieved + 1): the cross-sample sequence length")
+    ap.add_argument("--S", type=int, default=21, help="tokens per sample (fields + 1): the intra-sample sequence length")
     args = ap.parse_args()
     dev = "cuda"
-    B, T, S, d, heads, dh, H = args.B, 11, 21, 64, 8, 10, 128
+    B, T, S, d, heads, dh, H = args.B, args.T, args.S, 64, 8, 10, 128
     I = heads * dh
     tok = B * T * S
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -77,7 +79,7 @@ def main():
         nb = B * (T * S * d * 4 + 2 * T * F * d * 4 + T * F * 4)
         print("gather_bwd %.4f ms  %.0f GB/s  (%.1f %% of 8 TB/s)" % (ms, nb / ms / 1e6, 100 * nb / ms / 1e6 / 8000))
         del table, gtable, dy
-        S = 21
+        S = args.S
     x = torch.randn(B, T, S, d, generator=g).to(dev)
     dy = torch.randn(B, T, S, d, generator=g).to(dev)
     if "merge" in args.which:

@@ -1884,10 +1884,185 @@ __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes
     epi(mt0 + 1, nt, acc[1]);
 }
 
+// ---- the attention-backward core on the MATRIX pipe (round 5; tools/probes/attn_bwd_core_probe.hip is its stand-alone twin) -----------
+// Every (sequence, head) pair of the chunk is ONE wave's job, exact fp32 on v_mfma_f32_16x16x4_f32 (no operand splitting):
+//   S = Q K^T and dP = dO V^T as 16 x 16 tiles over k = dim_head (10 -> 12, three steps); p = exp2(S scale log2e - lse) and
+//   dS = p (dP - delta) on the accumulators; P, then dS, through a wave-private [16][33] LDS tile into the A operands of
+//   dV += P^T dO, dQ = dS K, dK += dS^T Q.  Nothing is recomputed (5 products per pair; the two VALU passes do 7) and there is no
+//   work-group barrier inside the core.  NIT = 16-row tiles per sequence (1: L <= 16, 2: L <= 32).
+// Measured per chunk on the MI355X (profiles/round5/r5_attn_bwd_core_probe.txt, cycles, every CU busy):
+//   L 31: 20.8 k against 27.4 k for the VALU passes (x 0.76), L 16: 13.2 k against 16.1 k (x 0.82) — but L 21: 30.2 k against 19.9 k and
+//   L 11: 16.2 k against 11.3 k: a pair costs ~10.4 k (NIT 2) / ~3.2 k (NIT 1) cycles whatever L is, the VALU passes ~14 L^2.  Inside
+//   the kernel (profiles/round5/r5_attn_bwd_core_ab.txt): L 31 1.745 against 1.830 ms per launch alone, 1.70 against 1.88 ms in the
+//   Tmall-like step (0.39 -> 0.435 of the fp32 MFMA roofline); L 16 no difference (+-3 %).  So the host selects it for L >= 28 only
+//   (b3_matrix_core): BASELINE configs[4]'s cross-sample sequences (K = 30 -> L = 31).
+template <int NIT>
+__device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const float* dob, const float* lses, float* scratch, int L, int nsq,
+                                                 float scale) {
+    constexpr int SCR = 16 * 33 + 16;
+    const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
+    float* scr = scratch + w * SCR;
+    float* dl = scr + 16 * 33;
+    const float sl2 = scale * RAT_LOG2E;
+    const int npairs = nsq * B3_H;
+    const bool cm = m < B3_DH;                                // this lane's column of a [.][dim_head] operand exists
+    const int mc = m;                                         // (loads are unconditional at their natural address — rows / columns past the
+                                                              //  operand stay inside the kernel's LDS — and masked by a select: base + immediate)
+    for (int pair = w; pair < npairs; pair += ATT_WAVES) {
+        const int h = pair % B3_H, sq = pair / B3_H;
+        const int r0 = sq * L, cq = h * B3_DH, ck = B3_I + h * B3_DH, cv = 2 * B3_I + h * B3_DH;
+        f32x4 adK[NIT], adV[NIT];
+#pragma unroll
+        for (int jt = 0; jt < NIT; ++jt) adK[jt] = adV[jt] = rat_zero4();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i0 = 16 * it;
+            const int irows = L - i0 < 16 ? L - i0 : 16;
+            {                                                 // delta_i = dO_i . O_i for the tile's rows
+                const int rr = r0 + i0 + m;
+                const float* a_ = dob + (size_t)rr * B3_LDT + cq;
+                const float* b_ = ob + (size_t)rr * B3_LDT + cq;
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < B3_DH; c += 2) {
+                    const float2 x = *reinterpret_cast<const float2*>(a_ + c), y = *reinterpret_cast<const float2*>(b_ + c);
+                    d = fmaf(x.x, y.x, d);
+                    d = fmaf(x.y, y.y, d);
+                }
+                if (l < 16) dl[l] = m < irows ? d : 0.f;
+            }
+            // stage 1 operands (A: lane holds [row m][k g]; B: [k g][col m]), all requested before the first MFMA
+            float aq[3], ao[3], bk[3][NIT], bv[3][NIT];
+            const int ri = r0 + i0 + m;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int cc = 4 * ks + g;
+                aq[ks] = qkv[(size_t)ri * B3_LDQ + cq + cc];
+                ao[ks] = dob[(size_t)ri * B3_LDT + cq + cc];
+#pragma unroll
+                for (int jt = 0; jt < NIT; ++jt) {
+                    const int rj = r0 + 16 * jt + m;
+                    bk[ks][jt] = qkv[(size_t)rj * B3_LDQ + ck + cc];
+                    bv[ks][jt] = qkv[(size_t)rj * B3_LDQ + cv + cc];
+                }
+            }
+            f32x4 aS[NIT], aP[NIT];
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt) aS[jt] = aP[jt] = rat_zero4();
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const bool okc = 4 * ks + g < B3_DH, oki = okc && m < irows;
+                const float xq = oki ? aq[ks] : 0.f, xo = oki ? ao[ks] : 0.f;
+#pragma unroll
+                for (int jt = 0; jt < NIT; ++jt) {
+                    const bool okj = okc && 16 * jt + m < L;
+                    aS[jt] = RAT_MFMA16(xq, okj ? bk[ks][jt] : 0.f, aS[jt]);
+                    aP[jt] = RAT_MFMA16(xo, okj ? bv[ks][jt] : 0.f, aP[jt]);
+                }
+            }
+            RAT_WAVE_FENCE();
+            // p and dS on the accumulators (C layout: column m = key, rows 4 g + r = query)
+            f32x4 dS[NIT];
+            {
+                float lse4[4], d4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ii = 4 * g + r;
+                    lse4[r] = lses[(r0 + i0 + ii) * B3_H + h];
+                    d4[r] = dl[ii];
+                }
+#pragma unroll
+                for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = 4 * g + r < irows && 16 * jt + m < L;
+                        const float p = ok ? rat_exp2(aS[jt][r] * sl2 - lse4[r]) : 0.f;
+                        scr[(4 * g + r) * 33 + 16 * jt + m] = p;
+                        dS[jt][r] = p * (aP[jt][r] - d4[r]);
+                    }
+            }
+            RAT_WAVE_FENCE();
+            // dV[j][c] += sum_i P[i][j] dO[i][c]   (A = P^T from the tile, B = dO; rows beyond the tile carry P = 0)
+            {
+                float bdo[4], ap[4][NIT];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ii = 4 * ks + g;
+                    bdo[ks] = dob[(size_t)(r0 + i0 + ii) * B3_LDT + cq + mc];
+#pragma unroll
+                    for (int jt = 0; jt < NIT; ++jt) ap[ks][jt] = scr[ii * 33 + 16 * jt + m];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float b = (cm && 4 * ks + g < irows) ? bdo[ks] : 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < NIT; ++jt) adV[jt] = RAT_MFMA16(ap[ks][jt], b, adV[jt]);
+                }
+            }
+            RAT_WAVE_FENCE();
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(4 * g + r) * 33 + 16 * jt + m] = dS[jt][r];
+            RAT_WAVE_FENCE();
+            // dK[j][c] += sum_i dS[i][j] Q[i][c]   (A = dS^T, B = Q);   dQ[i][c] = sum_j dS[i][j] K[j][c]   (A = dS, B = K)
+            {
+                float bq[4], at[4][NIT];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int ii = 4 * ks + g;
+                    bq[ks] = qkv[(size_t)(r0 + i0 + ii) * B3_LDQ + cq + mc];
+#pragma unroll
+                    for (int jt = 0; jt < NIT; ++jt) at[ks][jt] = scr[ii * 33 + 16 * jt + m];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float b = (cm && 4 * ks + g < irows) ? bq[ks] : 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < NIT; ++jt) adK[jt] = RAT_MFMA16(at[ks][jt], b, adK[jt]);
+                }
+            }
+            f32x4 adQ = rat_zero4();
+#pragma unroll
+            for (int half = 0; half < NIT; ++half) {
+                float bkk[4], as[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int jj = 16 * half + 4 * ks + g;
+                    bkk[ks] = qkv[(size_t)(r0 + jj) * B3_LDQ + ck + mc];
+                    as[ks] = scr[m * 33 + jj];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) adQ = RAT_MFMA16(as[ks], (cm && 16 * half + 4 * ks + g < L) ? bkk[ks] : 0.f, adQ);
+            }
+            if (cm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < irows) ob[(size_t)(r0 + i0 + 4 * g + r) * B3_LDT + cq + m] = adQ[r] * scale;
+            RAT_WAVE_FENCE();
+        }
+        if (cm)
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * g + r;
+                    if (j < L) {
+                        qkv[(size_t)(r0 + j) * B3_LDQ + ck + m] = adK[jt][r] * scale;
+                        qkv[(size_t)(r0 + j) * B3_LDQ + cv + m] = adV[jt][r];
+                    }
+                }
+    }
+}
+static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP, "the matrix core's wave-private tiles live in the dead dy planes");
+
 // PH: sequences of at most 12 tokens — the probabilities P of pass 1 fit the (then dead) dy planes (64 rows x L x 8 heads x 4 B <= 24 KB)
 // and are handed to pass 2, which then needs neither the q . k product nor the exponential again
-template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false>
+// MC: the attention core on the matrix pipe (b3_bwd_core_mfma) instead of the two VALU passes; sequences of at most 32 tokens, every
+// position a query
+template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false, bool MC = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
+    static_assert(!MC || (!QSUB && !PH), "the matrix core computes every query and hands nothing over");
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                  // LayerNorm(x)
     const PlanesX dyp{smem + B3_OFF_DYP};                                    // dy (x out_scale)
@@ -2064,7 +2239,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         const int nq = QSUB ? a.nq : L;
         const int ntasks = nsq * B3_H * L, nqtasks = QSUB ? nsq * B3_H * nq : ntasks;
         const float sl2 = a.scale * RAT_LOG2E;
-        for (int task = threadIdx.x; task < nqtasks; task += ATT_THREADS) {
+        if (MC) {                                                            // (the dy planes are dead since P2b: the wave-private tiles go there)
+            if (L <= 16) b3_bwd_core_mfma<1>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);
+            else b3_bwd_core_mfma<2>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);
+        }
+        for (int task = threadIdx.x; !MC && task < nqtasks; task += ATT_THREADS) {
             const int i = task % nq;
             const int h = (task / nq) % B3_H;
             const int sq = task / (nq * B3_H);
@@ -2103,7 +2282,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         }
         __syncthreads();
         RAT_PROF_MARK(4);
-        for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
+        for (int task = threadIdx.x; !MC && task < ntasks; task += ATT_THREADS) {
             const int j = task % L;
             const int h = (task / L) % B3_H;
             const int sq = task / (L * B3_H);
@@ -2382,6 +2561,13 @@ static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
 }
 // PH instantiation of attn_bwd3_kernel: P of a chunk inside the dy planes' 24 KB
 static bool b3_ph_fits(int L, int nsq_chunk) { return (size_t)nsq_chunk * B3_H * L * L * 4 <= (size_t)3 * B3_XP; }
+// the matrix-pipe backward core (b3_bwd_core_mfma) by sequence length — see its comment for the measurements behind the rule; the
+// attn_bwd_core_mfma knob forces it on (1, any L <= 32) or off (0)
+static bool b3_matrix_core(int L) {
+    const int k = rat_knob(RAT_KNOB_ATTN_BWD_CORE_MFMA);
+    if (L > 32 || k == 0) return false;
+    return k == 1 || L >= 28;
+}
 static bool b3_ph_enabled() {                          // on unless the attn_bwd_ph knob is 0 (same-box A/B: L = 11 1.2477 -> 1.2322 ms, -1.2 %)
     return rat_knob(RAT_KNOB_ATTN_BWD_PH) != 0;
 }
@@ -2577,6 +2763,10 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
             else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_bwd3_kernel<true, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         } else if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.add_lds)
+            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (b3_matrix_core(a.L) && a.nq >= a.L)
+            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())
             RAT_LAUNCH((attn_bwd3_kernel<false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);

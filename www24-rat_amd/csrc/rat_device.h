@@ -46,6 +46,13 @@ typedef float f32x4 __attribute__((vector_size(16)));
 #define RAT_PROF_FLUSH(ptr, base) do { } while (0)
 #define RAT_TRACE(ptr, on, slot) do { } while (0)
 #endif
+// lanes of ONE wave exchanging data through a wave-private LDS tile: order the wave's own LDS writes before its reads (no
+// work-group barrier).  Emulation: the wave's lanes are OS threads — a real wave barrier.
+#ifdef RAT_EMU
+#define RAT_WAVE_FENCE() emu::wave_sync()
+#else
+#define RAT_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 unsigned long long* rat_prof_buffer();                // device pointer set by rat_debug_set_prof (nullptr by default)
 
 // ------------------------------------------------------------------------------------------- host side
