@@ -17,9 +17,12 @@ constexpr int GATHER_THREADS = 256;
 #define GB_TRIP 2                         // rows requested before the first atomic of a trip
 #endif
 #ifndef RAT_GATHER_ITEMS
-#define RAT_GATHER_ITEMS 4
+#define RAT_GATHER_ITEMS 2
 #endif
-constexpr int GATHER_ITEMS = RAT_GATHER_ITEMS;       // independent rows in flight per thread
+// independent rows in flight per thread.  Same-box A/B, round 5 (profiles/round5/r5_gather_items_ab.txt; alone, 3 interleaved rounds):
+// 2 rows 43.6 us on the 25.6 GB table (0.675 of 8 TB/s) and 74.4 us at N2 (0.80) against 46.2 us (0.636) / 78.4 us (0.76) with 4 rows,
+// 1 row the same as 2, 3 and 8 rows slower; inside the N2 training step (behind the optimizer's sweep) 85-88 us with any of them.
+constexpr int GATHER_ITEMS = RAT_GATHER_ITEMS;
 
 // vectorised path: d % 4 == 0, one item = one 16-byte piece of one grid row
 __global__ void __launch_bounds__(GATHER_THREADS)
