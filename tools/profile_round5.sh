@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic: the measurement passes behind profiles/round5 (run on the GPU box from the repo root: bash tools/profile_round4.sh <outdir>)
+# Diagnostic: the measurement passes behind profiles/round5 (run on the GPU box from the repo root: bash tools/profile_round5.sh <outdir>)
 out=${1:-gpurun_out/prof5}
 export TMPDIR=/tmp
 mkdir -p $out

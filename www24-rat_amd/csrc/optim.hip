@@ -153,6 +153,9 @@ __device__ __forceinline__ void opt_st4_stream(float* p, int64_t i4, float4 v) {
 #endif
 }
 
+#ifndef RAT_SUMSQ_UNROLL
+#define RAT_SUMSQ_UNROLL 4
+#endif
 __global__ void __launch_bounds__(OPT_THREADS)
 sumsq_reg_kernel(const float* __restrict__ g, const float* __restrict__ w, int64_t n, int64_t n_split, float lam_a, float lam_b,
                  const float* lam_scale_dev, float* norm_sq_out, float* reg_out, int vec) {
@@ -165,8 +168,7 @@ sumsq_reg_kernel(const float* __restrict__ g, const float* __restrict__ w, int64
     int64_t head = 0;
     if (vec) {
         const int64_t n4 = n >> 2, s4 = n_split >> 2;
-        for (int64_t i = tid; i < n4; i += nthr) {
-            const float4 gv = opt_ld4_stream(g, i), wv = opt_ld4(w, i);
+        auto one = [&](int64_t i, const float4& gv, const float4& wv) {
             const bool a = i < s4;
             const float l = a ? la : lb;
             float t;
@@ -177,7 +179,20 @@ sumsq_reg_kernel(const float* __restrict__ g, const float* __restrict__ w, int64
             float q = wv.x * wv.x;
             q = fmaf(wv.y, wv.y, q); q = fmaf(wv.z, wv.z, q); q = fmaf(wv.w, wv.w, q);
             if (a) wa += q; else wb += q;
+        };
+        int64_t i = tid;
+        // RAT_SUMSQ_UNROLL pieces per trip, all 2 U loads requested before the first is consumed (same-box A/B: profiles/round5/r5_sumsq_ab.txt)
+        for (; i + (int64_t)(RAT_SUMSQ_UNROLL - 1) * nthr < n4; i += (int64_t)RAT_SUMSQ_UNROLL * nthr) {
+            float4 gv[RAT_SUMSQ_UNROLL], wv[RAT_SUMSQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RAT_SUMSQ_UNROLL; ++u) {
+                gv[u] = opt_ld4_stream(g, i + (int64_t)u * nthr);
+                wv[u] = opt_ld4(w, i + (int64_t)u * nthr);
+            }
+#pragma unroll
+            for (int u = 0; u < RAT_SUMSQ_UNROLL; ++u) one(i + (int64_t)u * nthr, gv[u], wv[u]);
         }
+        for (; i < n4; i += nthr) one(i, opt_ld4_stream(g, i), opt_ld4(w, i));
         head = n4 << 2;
     }
     for (int64_t i = head + tid; i < n; i += nthr) {
