@@ -153,6 +153,9 @@ __device__ __forceinline__ void opt_st4_stream(float* p, int64_t i4, float4 v) {
 #endif
 }
 
+#ifndef RAT_ADAM_UNROLL
+#define RAT_ADAM_UNROLL 1               // pieces per trip of clip_adam_fused_kernel's vector loop (A/B: profiles/round5/r5_sumsq_ab.txt)
+#endif
 #ifndef RAT_SUMSQ_UNROLL
 #define RAT_SUMSQ_UNROLL 4
 #endif
@@ -245,9 +248,7 @@ clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __re
     }
     if (vec) {
         const int64_t n4 = n >> 2, s4 = n_split >> 2;
-        for (int64_t i = tid; i < n4; i += nthr) {
-            float4 wv = opt_ld4(w, i), mv = opt_ld4_stream(m, i), vv = opt_ld4_stream(v, i);
-            const float4 gv = opt_ld4_stream(g, i);
+        auto one = [&](int64_t i, float4 wv, float4 mv, float4 vv, const float4& gv) {
             const float l = i < s4 ? la : lb;
             opt_adam1(wv.x, gv.x, mv.x, vv.x, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
             opt_adam1(wv.y, gv.y, mv.y, vv.y, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
@@ -255,7 +256,21 @@ clip_adam_fused_kernel(float* __restrict__ w, float* __restrict__ g, float* __re
             opt_adam1(wv.w, gv.w, mv.w, vv.w, l, coef, step_size, beta1, beta2, eps, inv_sqrt_bc2);
             opt_st4(w, i, wv); opt_st4_stream(m, i, mv); opt_st4_stream(v, i, vv);
             if (zero_g) opt_st4_stream(g, i, make_float4(0.f, 0.f, 0.f, 0.f));
+        };
+        int64_t i = tid;
+#if RAT_ADAM_UNROLL > 1
+        for (; i + (int64_t)(RAT_ADAM_UNROLL - 1) * nthr < n4; i += (int64_t)RAT_ADAM_UNROLL * nthr) {
+            float4 wv[RAT_ADAM_UNROLL], mv[RAT_ADAM_UNROLL], vv[RAT_ADAM_UNROLL], gv[RAT_ADAM_UNROLL];
+#pragma unroll
+            for (int u = 0; u < RAT_ADAM_UNROLL; ++u) {
+                const int64_t k = i + (int64_t)u * nthr;
+                wv[u] = opt_ld4(w, k); mv[u] = opt_ld4_stream(m, k); vv[u] = opt_ld4_stream(v, k); gv[u] = opt_ld4_stream(g, k);
+            }
+#pragma unroll
+            for (int u = 0; u < RAT_ADAM_UNROLL; ++u) one(i + (int64_t)u * nthr, wv[u], mv[u], vv[u], gv[u]);
         }
+#endif
+        for (; i < n4; i += nthr) one(i, opt_ld4(w, i), opt_ld4_stream(m, i), opt_ld4_stream(v, i), opt_ld4_stream(g, i));
         head = n4 << 2;
     }
     for (int64_t i = head + tid; i < n; i += nthr) {

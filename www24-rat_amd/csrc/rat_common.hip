@@ -130,7 +130,7 @@ static thread_local std::vector<RatReduceEntry> g_deferred;
 
 // `first_block < 0` marks a VECTOR entry (size, stride multiples of 4, 16-byte aligned pointers): a lane sums four neighbouring positions
 // with 16-byte loads — 256 positions per block instead of 64, the same slab order and the same quarter tree per position, so the sums
-// are bit-identical to the scalar form's (round 5: 236 MB of slabs per north-star step, 49 -> R5_SLAB us).
+// are bit-identical to the scalar form's (round 5: 236 MB of slabs per north-star step, 49 -> 47 us).
 __global__ void __launch_bounds__(256) rat_reduce_slabs_batch_kernel(RatReduceTable t) {
     __shared__ float4 part4[256];
     float* part = reinterpret_cast<float*>(part4);
