@@ -105,3 +105,46 @@ def test_every_collective_of_a_step_runs_on_rccl_with_one_rank(tmp_path, mode):
     assert float(bad.double().mean()) < 2e-3 and float((a - b).abs().max()) <= 1.05e-2, (float(bad.double().mean()), float((a - b).abs().max()))
     for s in range(steps):
         assert abs(got["losses"][s] - one["losses"][s]) < 2e-5, (s, got["losses"][s], one["losses"][s])
+
+
+def _bench(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_PORT"] = str(35500 + (os.getpid() % 2000))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+def test_bench_rehearsal_measures_eager_first_then_graphs_and_reports_the_exchange():
+    """bench.py's N > 1 path on one RCCL rank: the eager regions are measured first, then the segmented-graph regions; the line carries
+    both attempts, the world size, the exchange form with what it put on the links and the per-phase HIP-event times"""
+    import json
+    r, lines = _bench(["--dp-rehearsal", "--workload", "tiny", "--steps", "3", "--warmup", "2"])
+    if "RCCL" in r.stderr and r.returncode != 0 and "init_process_group" in r.stderr:
+        pytest.skip("RCCL could not bring up a one-rank communicator here")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    att = out["step_mode"]["attempts"]
+    assert att["graph_captured"] is True and att["reported"] in ("graph", "eager") and att["eager_ms_per_step"] > 0 and att["graph_ms_per_step"] > 0
+    assert out["world"] == 1 and out["first_barrier_s"] is not None
+    comm = out["communication"]["weak"]
+    assert comm["backend"] == "nccl" and comm["exchange_form"] in ("owner_lists", "dense_allreduce", "gathered_lists")
+    assert {"exchange", "optimizer"} <= set(comm["phases_ms_per_step"])
+    if comm["exchange_form"] == "owner_lists":
+        assert comm["owner_lists"]["collectives_per_step"] == 3 and "exchange_counts" in comm["phases_ms_per_step"]
+    assert "strong_scaling" in out
+
+
+def test_bench_rehearsal_survives_a_stalled_graph_attempt():
+    """the watchdog around the graph attempt: with a timeout it cannot meet, every rank exits 0 and rank 0 prints the EAGER line with a note"""
+    import json
+    r, lines = _bench(["--dp-rehearsal", "--workload", "tiny", "--steps", "3", "--warmup", "2", "--graph-attempt-timeout", "0.001"])
+    if r.returncode != 0 and "init_process_group" in r.stderr:
+        pytest.skip("RCCL could not bring up a one-rank communicator here")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert "abandoned" in out["step_mode"]["graph_attempt"] and out["step_mode"]["graph"] is False and out["value"] > 0
