@@ -401,7 +401,7 @@ __device__ __forceinline__ void core_mfma2(const Tiles& t, int L, int nsq, float
 // FORM 0: valu, 1: valu with P handed over, 2: mfma, 3: mfma without LDS transposes
 template <int FORM>
 __global__ void __launch_bounds__(NT) probe(const float* g_qkv, const float* g_ob, const float* g_dob, const float* g_lse, float* out,
-                                           long long* cyc, int L, int iters) {
+                                           long long* cyc, int L, int iters, int stagger) {
     extern __shared__ float sm[];
     Tiles t;
     t.qkv = sm;
@@ -422,6 +422,9 @@ __global__ void __launch_bounds__(NT) probe(const float* g_qkv, const float* g_o
         const long long t0 = clock64();
         if (FORM == 0) core_valu<false>(t, L, nsq, scale);
         else if (FORM == 1) core_valu<true>(t, L, nsq, scale);
+        if (FORM >= 2 && stagger > 0 && (threadIdx.x >> 6) >= NW / 2)
+            for (int z = 0; z < stagger; ++z) __builtin_amdgcn_s_sleep(1);      // the SIMD's second wave starts ~64 x stagger cycles late
+        if (FORM < 2) {}
         else if (FORM == 2 && L <= 16) core_mfma<1>(t, L, nsq, scale);
         else if (FORM == 2) core_mfma<2>(t, L, nsq, scale);
         else if (L <= 16) core_mfma2<1>(t, L, nsq, scale);
@@ -440,6 +443,7 @@ __global__ void __launch_bounds__(NT) probe(const float* g_qkv, const float* g_o
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 200, blocks = 256;
+    const int stagger = argc > 2 ? atoi(argv[2]) : 0;       // waves 4-7 start the matrix-pipe core 64 x stagger cycles late
     std::vector<float> qkv(ROWS * LDQ), ob(ROWS * LDT), dob(ROWS * LDT), lse(ROWS * H);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
@@ -459,7 +463,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     CK(hipFuncSetAttribute((const void*)probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     CK(hipFuncSetAttribute((const void*)probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    printf("attention-backward core per chunk (64-row tile, 8 heads x 10), %d work-groups x %d threads, %d iterations; LDS %zu bytes\n", blocks, NT, iters, smem);
+    printf("attention-backward core per chunk (64-row tile, 8 heads x 10), %d work-groups x %d threads, %d iterations; LDS %zu bytes; stagger %d\n", blocks, NT, iters, smem, stagger);
     printf("%4s %4s %8s | %10s %10s %10s %10s | %9s %9s | %s\n", "L", "nsq", "pairs", "valu", "valu+P", "mfma", "mfma2", "mfma/best", "mfma2/best", "max |diff| of mfma, mfma2 against valu");
     const int Ls[] = {11, 21, 31, 16, 9, 6};
     for (int L : Ls) {
@@ -472,10 +476,10 @@ int main(int argc, char** argv) {
             const bool ph_fits = (size_t)nsq * H * L * L <= (size_t)PBUF;
             if (form == 1 && !ph_fits) { c[1] = -1; continue; }
             CK(hipMemset(d_out, 0, nout * 4));
-            if (form == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters);
-            else if (form == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters);
-            else if (form == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters);
-            else hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters);
+            if (form == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
+            else if (form == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
+            else if (form == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
+            else hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(cyc.data(), d_cyc, blocks * 8, hipMemcpyDeviceToHost));
