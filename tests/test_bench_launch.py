@@ -31,6 +31,16 @@ def test_bench_gpus2_self_launch_dry_run():
     assert {"rat_gather_fwd", "cross_attention"} <= set(out["targets"])
     assert out["step_mode"]["graph"] is False             # hipGraph capture needs a GPU
     assert "cpu_baseline" not in out                      # N = 1 only (and never in a dry run)
+    # what the N > 1 line says about its communication: world as torch.distributed reports it, and per region the
+    # exchange form with the bytes it put on the links and the per-phase times of the step
+    assert out["world"] == 2 and out["first_barrier_s"] is not None
+    for region in ("weak", "strong"):
+        comm = out["communication"][region]
+        assert comm["world"] == 2 and comm["backend"] == "gloo" and comm["exchange_form"] in ("owner_lists", "gathered_lists", "dense_allreduce")
+        assert {"exchange", "optimizer", "sync_bn"} <= set(comm["phases_ms_per_step"])
+        assert comm["dense_net_bytes_sent_per_rank"] > 0 and comm["table_bytes_sent_per_rank"] is not None
+        if comm["exchange_form"] == "owner_lists":
+            assert comm["owner_lists"]["collectives_per_step"] == 3 and comm["owner_lists"]["pairs_sent"] > 0
 
 
 def _clean_env():
