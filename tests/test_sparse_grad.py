@@ -173,3 +173,76 @@ def test_owner_partitioned_exchange_on_ragged_lists(emu_default):
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
         assert float(r0[k].abs().sum()) > 0
+
+
+def _owner_worker_random(rank, world, port, emu_path, out_dir):
+    for p in (os.path.dirname(HERE), HERE, os.path.join(os.path.dirname(HERE), "www24-rat_amd"), os.path.join(HERE, "emu")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import rat_amd._lib as L
+    import sparse_cases as sc2
+    from rat_amd import ops
+    L._default = L.RatLib(emu_path)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _case, model, _batch = sc2._model("tiny_seq_bn", -1, "atomic", batch_norm=False)
+    d = model._cfg["d"]
+    rows_a_total, rows_b_total = model._n_feat // d, model._n_tab - model._n_feat
+    per_a, per_b = -(-rows_a_total // world), -(-rows_b_total // world)
+    assert rows_a_total % world != 0 or rows_b_total % world != 0        # the last owner's range is shorter than the others'
+    out = {}
+    for trial in range(3):
+        rs = np.random.RandomState(1000 * trial + rank)
+        mine_a = sorted(rs.choice(rows_a_total, size=rs.randint(0, min(12, rows_a_total)), replace=False).tolist())
+        mine_b = sorted(rs.choice(rows_b_total, size=rs.randint(0, min(9, rows_b_total)), replace=False).tolist())
+        cap_a, cap_b = 16, 12
+
+        def make(mine, width, cap, seed):
+            rows = torch.full((cap,), 777777, dtype=torch.int32)
+            rows[:len(mine)] = torch.tensor(mine, dtype=torch.int32)
+            return rows, torch.randn(cap, width, generator=torch.Generator().manual_seed(seed)), torch.tensor([len(mine)], dtype=torch.int32)
+        ra, ga, ca = make(mine_a, d, cap_a, 31 * trial + rank)
+        rb, gb, cb = make(mine_b, 1, cap_b, 57 * trial + rank)
+        parts = [(ra, ga, ca, d, rows_a_total, 0), (rb, gb, cb, 1, rows_b_total, model._n_feat)]
+        label = torch.randn(model._n_emb - model._n_tab, generator=torch.Generator().manual_seed(5 * trial + rank))
+        dense = {}
+        for owner in (True, False):
+            g = torch.zeros(model._flat.numel())
+            g[model._n_tab:model._n_emb] = label
+            if owner:
+                cnt = torch.zeros(2 * world, dtype=torch.int32)
+                for f, (mine, per) in enumerate(((mine_a, per_a), (mine_b, per_b))):
+                    for r_ in mine:
+                        cnt[f * world + r_ // per] += 1
+                model._owner_publish(cnt, (None, None), (per_a, per_b))
+                model._exchange_lists_owner(g, parts)
+            else:
+                for part in parts:
+                    rows, grads, count, width, _t, base = model._merge_sparse(part)
+                    ops.scatter_rows(g[base:], rows, grads, count, width, lib=model._lib)
+                # (an all-reduce over more than two ranks sums in an unspecified order; the owner form sums the label partials in
+                # rank order — the reference is formed the same way)
+                parts_l = [torch.empty_like(label) for _ in range(world)]
+                dist.all_gather(parts_l, label)
+                acc = torch.zeros_like(label)
+                for t_ in parts_l:
+                    acc = acc + t_
+                g[model._n_tab:model._n_emb] = acc
+            dense[owner] = g
+        assert torch.equal(dense[True], dense[False]), trial
+        out[trial] = dense[True]
+    torch.save(out, os.path.join(out_dir, "rnd%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_owner_partitioned_exchange_four_ranks_random_lists(emu_default):
+    """four ranks (a world that does not divide the row counts: the last owner's range is shorter), random ragged lists — empty ones
+    included — of both table families: owner form == all-gather form bit for bit, identical on every rank"""
+    import build_emu
+    port = 23500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_owner_worker_random, args=(4, port, build_emu.build(), out_dir), nprocs=4, join=True)
+        res = [torch.load(os.path.join(out_dir, "rnd%d.pt" % r)) for r in range(4)]
+    for k in res[0]:
+        assert all(torch.equal(res[0][k], res[r][k]) for r in range(1, 4)), k
