@@ -2058,11 +2058,11 @@ static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP, "the 
 
 // PH: sequences of at most 12 tokens — the probabilities P of pass 1 fit the (then dead) dy planes (64 rows x L x 8 heads x 4 B <= 24 KB)
 // and are handed to pass 2, which then needs neither the q . k product nor the exponential again
-// MC: the attention core on the matrix pipe (b3_bwd_core_mfma) instead of the two VALU passes; sequences of at most 32 tokens, every
-// position a query
-template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false, bool MC = false>
+// MC (1 / 2 = 16-row tiles per sequence): the attention core on the matrix pipe (b3_bwd_core_mfma) instead of the two VALU passes;
+// sequences of at most 32 tokens, every position a query
+template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false, int MC = 0>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
-    static_assert(!MC || (!QSUB && !PH), "the matrix core computes every query and hands nothing over");
+    static_assert(MC == 0 || (!QSUB && !PH), "the matrix core computes every query and hands nothing over");   // MC = 16-row tiles per sequence (1 / 2)
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                  // LayerNorm(x)
     const PlanesX dyp{smem + B3_OFF_DYP};                                    // dy (x out_scale)
@@ -2239,10 +2239,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         const int nq = QSUB ? a.nq : L;
         const int ntasks = nsq * B3_H * L, nqtasks = QSUB ? nsq * B3_H * nq : ntasks;
         const float sl2 = a.scale * RAT_LOG2E;
-        if (MC) {                                                            // (the dy planes are dead since P2b: the wave-private tiles go there)
-            if (L <= 16) b3_bwd_core_mfma<1>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);
-            else b3_bwd_core_mfma<2>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);
-        }
+        if (MC) b3_bwd_core_mfma<(MC > 0 ? MC : 1)>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);   // (the dy planes are dead since P2b: the wave-private tiles go there)
         for (int task = threadIdx.x; !MC && task < nqtasks; task += ATT_THREADS) {
             const int i = task % nq;
             const int h = (task / nq) % B3_H;
@@ -2763,10 +2760,14 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
             else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_bwd3_kernel<true, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         } else if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.add_lds)
-            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.add_lds && a.L > 16)
+            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 2>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.L > 16)
+            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 2>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.add_lds)          // (sequences of at most 16 tokens: only when the knob forces it)
+            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (b3_matrix_core(a.L) && a.nq >= a.L)
-            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())
             RAT_LAUNCH((attn_bwd3_kernel<false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
