@@ -75,7 +75,7 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, r
 
 
 @pytest.mark.parametrize("batch_norm,row_lists,owner", [twin(False, True, True, id="bn_off"), pytest.param(True, True, True, id="sync_bn"),
-                                                        pytest.param(True, True, False, id="sync_bn_gather_at_capacity"),
+                                                        twin(True, True, False, id="sync_bn_gather_at_capacity"),
                                                         pytest.param(True, False, True, id="sync_bn_dense_tables")])
 def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
     _setup_paths()
@@ -129,7 +129,7 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
     assert abs(float(r0["loss"] + r1["loss"]) - float(full_loss)) < 1e-5
 
 
-@pytest.mark.parametrize("row_lists", [pytest.param(True, id="row_lists"), twin(False, id="dense_tables")])
+@pytest.mark.parametrize("row_lists", [twin(True, id="row_lists"), twin(False, id="dense_tables")])
 def test_one_rank_through_the_data_parallel_path_equals_the_plain_step(row_lists):
     """`dp_single_rank`: a process group of ONE rank issues every collective of the step (SyncBN all-gathers, the async dense-net
     all-reduce, the row-list all-gathers + merge or the dense table all-reduce) and must land where the plain step lands — the

@@ -102,7 +102,7 @@ def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
     kc.check_attn_dropout(emu, "cpu", (1, 3, 5, 40, 8, 10, True), "cross", arith="bf16x3")
 
 
-@pytest.mark.parametrize("case,mode", [pytest.param((1, 11, 4, 64, 8, 10, True), "cross", id="L11"), pytest.param((1, 2, 33, 64, 8, 10, True), "intra", id="L33"),
+@pytest.mark.parametrize("case,mode", [pytest.param((1, 11, 4, 64, 8, 10, True), "cross", id="L11"), twin((1, 2, 33, 64, 8, 10, True), "intra", id="L33"),
                                        twin((3, 16, 2, 64, 8, 10, True), "cross", id="L16")])
 def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, knob):
     """attn_fwd3m_kernel (QK^T and PV on the bf16 MFMA as well; opt-in: measured slower than the VALU core): one key

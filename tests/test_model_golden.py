@@ -43,7 +43,7 @@ def test_train_step_api_matches_the_reference_run(name):
 
 
 # northstar_shape: bf16x3 kernels, RatSeqMap.queries; tmall_real_heads: 32 heads in groups of 8 (the grouped backward reads dy per group)
-@pytest.mark.parametrize("name", [twin("tiny_seq_bn"), twin("mltag_shape"), "northstar_shape", "tmall_real_heads", "m3_tiny_seq"])
+@pytest.mark.parametrize("name", [twin("tiny_seq_bn"), twin("mltag_shape"), "northstar_shape", twin("tmall_real_heads"), "m3_tiny_seq"])
 def test_dead_token_pruning_changes_nothing(name):
     mc.check_pruning_equivalence(name, gpu=-1)
 
