@@ -27,23 +27,28 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _make(case_name, batch_norm=False):
+def _make(case_name, batch_norm=False, rows=0):
+    """rows > 0: the case's batch repeated / cut to that many samples (a world of 8 needs at least 8)"""
     import golden_cases as gc
     import model_cases as mc
     case = dict(gc.case_by_name(case_name))
     case["batch_norm"] = batch_norm
     model = mc.build_model(case, gpu=-1, seed=1)
     mc.load_weights(model, case)
-    return case, model, mc.batch_of(case)
+    batch = mc.batch_of(case)
+    if rows:
+        reps = -(-rows // batch[0].shape[0])
+        batch = tuple(torch.cat([t] * reps)[:rows] for t in batch)
+    return case, model, batch
 
 
-def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, row_lists=True, owner=True):
+def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, row_lists=True, owner=True, rows=0):
     _setup_paths()
     import rat_amd._lib as L
     L._default = L.RatLib(emu_path)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    case, model, batch = _make(case_name, batch_norm)
+    case, model, batch = _make(case_name, batch_norm, rows)
     per = batch[0].shape[0] // world
     shard = tuple(t[rank * per:(rank + 1) * per] for t in batch)
     model.train()
@@ -161,3 +166,40 @@ def test_one_rank_through_the_data_parallel_path_equals_the_plain_step(row_lists
     assert r0["merges"] == (4 if row_lists else 0)
     np.testing.assert_allclose(r0["flat"][keep].numpy(), ref[keep].numpy(), rtol=2e-4, atol=2e-6)
     assert abs(float(r0["loss"]) - float(full_loss)) < 1e-5
+
+
+def test_eight_rank_step_equals_full_batch_step():
+    """The world size the north star names: 8 ranks (gloo, host-emulated kernels), ONE sample each, SyncBN, the owner-partitioned
+    exchange with eight owners (row ranges that do not divide evenly, owners that receive nothing) == the single-process step on the
+    8-sample batch; all eight replicas bit-identical."""
+    _setup_paths()
+    import build_emu
+    import rat_amd._lib as L
+    emu_path = build_emu.build()
+    old = L._default
+    L._default = L.RatLib(emu_path)
+    world = 8
+    try:
+        case, model, batch = _make("tiny_seq_bn", True, rows=world)
+        model.train()
+        for _ in range(2):
+            full_loss = model.train_step(batch)
+        ref = model._flat.clone()
+        import model_cases as mc
+        keep = torch.ones_like(ref, dtype=torch.bool)
+        for name in mc.noise_tensors(model):
+            o = model._offsets[name]
+            keep[o:o + model._params[name].numel()] = False
+    finally:
+        L._default = old
+    port = 21500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as out_dir:
+        mp.spawn(_worker, args=(world, port, "tiny_seq_bn", emu_path, out_dir, True, True, True, world), nprocs=world, join=True)
+        res = [torch.load(os.path.join(out_dir, "rank%d.pt" % r)) for r in range(world)]
+    for r in res[1:]:
+        assert torch.equal(res[0]["flat"], r["flat"]), "replicas diverged"
+    stats = [r["owner_stats"] for r in res]
+    assert all(s_ is not None and s_["collectives"] == 3 for s_ in stats)
+    assert sum(s_["sent"] for s_ in stats) == sum(s_["received"] for s_ in stats) > 0
+    np.testing.assert_allclose(res[0]["flat"][keep].numpy(), ref[keep].numpy(), rtol=2e-4, atol=2e-6)
+    assert abs(sum(float(r["loss"]) for r in res) - float(full_loss)) < 1e-5
