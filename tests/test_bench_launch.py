@@ -72,3 +72,20 @@ def test_bench_launcher_deadline(tmp_path):
                        capture_output=True, text=True, timeout=300, env=_clean_env())
     assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
     assert "launch timeout" in r.stderr
+
+
+def test_bench_gpus8_self_launch_dry_run():
+    """the scaling job's largest invocation, `python bench.py --gpus 8`, end to end on CPU (8 gloo ranks, host-emulated kernels): weak region
+    on the dense all-reduce, strong region (one sample per rank) on the owner exchange with eight owners, one JSON line"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-cpu", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1500, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world"] == 8 and out["config"]["global_batch"] == 8 * out["config"]["batch_per_gpu"]
+    assert out["strong_scaling"]["batch_per_gpu"] * 8 == out["strong_scaling"]["global_batch"]
+    comm = out["communication"]
+    assert comm["weak"]["world"] == 8 and comm["strong"]["exchange_form"] in ("owner_lists", "dense_allreduce", "gathered_lists")
+    if comm["strong"]["exchange_form"] == "owner_lists":
+        assert comm["strong"]["owner_lists"]["collectives_per_step"] == 3
