@@ -176,6 +176,9 @@ __global__ void __launch_bounds__(256) sgemm_reduce_kernel(GemmArgs g) {
 typedef RatPlanes<80, 0, 64 * 80> GmPlanesR;           // [64 r][32 k]
 typedef RatPlanes<128, 7, 32 * 128> GmPlanesK;         // [32 k][64 r]
 constexpr int GM3_OPERAND = 3 * 64 * 80;               // bytes per operand (the larger of the two images)
+#ifndef RAT_SGEMM_KSUB
+#define RAT_SGEMM_KSUB 1
+#endif
 
 template <bool KMAJOR>
 struct Tile3 {
@@ -212,11 +215,13 @@ struct Tile3 {
     }
 };
 
-template <bool KA, bool KB>
+// KSUB: 32-wide k sub-tiles per trip.  KSUB = 2 (-DRAT_SGEMM_KSUB=2: 48 MFMAs per wave between a request and its use, half the barriers
+// per k, 61 KB of LDS) was built in round 5 on the theory that the loads of the next sub-tile arrive late at the head's small grids —
+// measured: no shape faster, the 1280-tile input-gradient product 0.047 -> 0.088 ms (occupancy), profiles/round5/r5_sgemm_ksub_ab.txt.
+// The product runs KSUB = 1.
+template <bool KA, bool KB, int KSUB = 1>
 __global__ void __launch_bounds__(GM_THREADS) sgemm3_kernel(GemmArgs g) {
     RAT_DYN_SMEM(smem);
-    const Tile3<KA> At{smem};
-    const Tile3<KB> Bt{smem + GM3_OPERAND};
     const int tiles_n = (g.N + GM_TILE - 1) / GM_TILE;
     const int tile = blockIdx.x / g.slices, slice = blockIdx.x - tile * g.slices;
     const int m0 = (tile / tiles_n) * GM_TILE;
@@ -224,35 +229,49 @@ __global__ void __launch_bounds__(GM_THREADS) sgemm3_kernel(GemmArgs g) {
     const int kbeg = slice * g.kper, kend = kbeg + g.kper < g.K ? kbeg + g.kper : g.K;
     const int wave = rat_wave();
     const int wm = (wave >> 1) * 2, wn = (wave & 1) * 2;
-    const TileLoader la{g.A, g.M, g.K, g.lda, m0, KA, g.veca != 0};
-    const TileLoader lb{g.B, g.N, g.K, g.ldb, n0, KB, g.vecb != 0};
+    const TileLoader la{g.A, g.M, kend, g.lda, m0, KA, g.veca != 0};       // (K = this slice's end: a sub-tile past it reads zeros)
+    const TileLoader lb{g.B, g.N, kend, g.ldb, n0, KB, g.vecb != 0};
     f32x4 acc[2][2];
     acc[0][0] = acc[0][1] = acc[1][0] = acc[1][1] = rat_zero4();
-    float4 ra[GM_VEC], rb[GM_VEC];
-    la.fetch(kbeg, ra);
-    lb.fetch(kbeg, rb);
-    for (int k0 = kbeg; k0 < kend; k0 += GM_K) {
-        At.stash(ra);
-        Bt.stash(rb);
+    float4 ra[KSUB][GM_VEC], rb[KSUB][GM_VEC];
+#pragma unroll
+    for (int s = 0; s < KSUB; ++s) {
+        la.fetch(kbeg + s * GM_K, ra[s]);
+        lb.fetch(kbeg + s * GM_K, rb[s]);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += KSUB * GM_K) {
+#pragma unroll
+        for (int s = 0; s < KSUB; ++s) {
+            Tile3<KA>{smem + (size_t)s * 2 * GM3_OPERAND}.stash(ra[s]);
+            Tile3<KB>{smem + (size_t)s * 2 * GM3_OPERAND + GM3_OPERAND}.stash(rb[s]);
+        }
         __syncthreads();
-        if (k0 + GM_K < kend) {                            // next tile's loads fly while this one is multiplied
-            la.fetch(k0 + GM_K, ra);
-            lb.fetch(k0 + GM_K, rb);
+        if (k0 + KSUB * GM_K < kend) {                     // next trip's loads fly while this one is multiplied
+#pragma unroll
+            for (int s = 0; s < KSUB; ++s) {
+                la.fetch(k0 + (KSUB + s) * GM_K, ra[s]);
+                lb.fetch(k0 + (KSUB + s) * GM_K, rb[s]);
+            }
         }
-        const RatB3 a0 = At.frag(wm), a1 = At.frag(wm + 1), b0 = Bt.frag(wn), b1 = Bt.frag(wn + 1);
-        {
-            f32x4 c[2] = {acc[0][0], acc[1][0]};
-            const RatB3 aa[2] = {a0, a1};
-            rat_mfma3_block<2>(c, aa, b0);
-            acc[0][0] = c[0];
-            acc[1][0] = c[1];
-        }
-        {
-            f32x4 c[2] = {acc[0][1], acc[1][1]};
-            const RatB3 aa[2] = {a0, a1};
-            rat_mfma3_block<2>(c, aa, b1);
-            acc[0][1] = c[0];
-            acc[1][1] = c[1];
+#pragma unroll
+        for (int s = 0; s < KSUB; ++s) {
+            const Tile3<KA> At{smem + (size_t)s * 2 * GM3_OPERAND};
+            const Tile3<KB> Bt{smem + (size_t)s * 2 * GM3_OPERAND + GM3_OPERAND};
+            const RatB3 a0 = At.frag(wm), a1 = At.frag(wm + 1), b0 = Bt.frag(wn), b1 = Bt.frag(wn + 1);
+            {
+                f32x4 c[2] = {acc[0][0], acc[1][0]};
+                const RatB3 aa[2] = {a0, a1};
+                rat_mfma3_block<2>(c, aa, b0);
+                acc[0][0] = c[0];
+                acc[1][0] = c[1];
+            }
+            {
+                f32x4 c[2] = {acc[0][1], acc[1][1]};
+                const RatB3 aa[2] = {a0, a1};
+                rat_mfma3_block<2>(c, aa, b1);
+                acc[0][1] = c[0];
+                acc[1][1] = c[1];
+            }
         }
         __syncthreads();
     }
@@ -308,7 +327,13 @@ static int sgemm_launch(int trans_a, int trans_b, int M, int N, int K, const flo
     if (arith == RAT_ARITH_BF16X3 && g.veca && g.vecb && K >= 2 * GM_K && M >= 16 && N >= 16) {
         const size_t smem3 = (size_t)2 * GM3_OPERAND;
         const bool ka = g.ta != 0, kb = g.tb == 0;
-        if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
+        const bool two = RAT_SGEMM_KSUB == 2 && g.slices == 1 && K >= 4 * GM_K;       // (split products keep their occupancy: one sub-tile per trip)
+        if (two) {
+            if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
+            else if (ka) RAT_LAUNCH((sgemm3_kernel<true, false, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
+            else if (kb) RAT_LAUNCH((sgemm3_kernel<false, true, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
+            else RAT_LAUNCH((sgemm3_kernel<false, false, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
+        } else if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
         else if (ka) RAT_LAUNCH((sgemm3_kernel<true, false>), tiles * g.slices, GM_THREADS, smem3, stream, g);
         else if (kb) RAT_LAUNCH((sgemm3_kernel<false, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
         else RAT_LAUNCH((sgemm3_kernel<false, false>), tiles * g.slices, GM_THREADS, smem3, stream, g);
