@@ -1374,6 +1374,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         // O (the Q columns of the valid rows; padding rows are exact zeros) -> planes, and -> o_save for the backward: whole 320-byte
         // rows in 16-byte pieces with the non-temporal hint (round 4; before, every core lane stored its head's 40 bytes in five
         // scattered 8-byte stores at the end of its key loop).  lse_save leaves the same way, from the LDS copy.
+#ifndef RAT_O_HALF                                                // 640 whole pieces on 512 threads (2 trips, the second a quarter full)
         for (int e = threadIdx.x; e < ATT_ROWS * (B3_I / 8); e += ATT_THREADS) {
             const int r = e / (B3_I / 8), o8 = e - r * (B3_I / 8);
             const float* src = qkv + (size_t)r * B3_LDQ + 8 * o8;
@@ -1387,6 +1388,20 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
                 rat_st4_stream(a.o_save + tok * B3_I + 8 * o8 + 4, v1);
             }
         }
+#else
+        // A/B only (-DRAT_O_HALF): HALF pieces (4 columns), 1280 on 512 threads = 3 trips of half the work — measured no faster (L 21 equal,
+        // L 11 +0.7 %, profiles/round5/r5_ohalf_ab.txt): the pass is not bound by the busiest thread's work
+        for (int e = threadIdx.x; e < ATT_ROWS * (B3_I / 4); e += ATT_THREADS) {
+            const int r = e / (B3_I / 4), q4 = e - r * (B3_I / 4);
+            const float4 v = *reinterpret_cast<const float4*>(qkv + (size_t)r * B3_LDQ + 4 * q4);
+            unsigned h0, h1, m0, m1, l0, l1;
+            rat_split2(v.x, v.y, h0, m0, l0);
+            rat_split2(v.z, v.w, h1, m1, l1);
+            op.store_half(r, q4, h0, h1, m0, m1, l0, l1);
+            const int64_t tok = rowtok[r];
+            if (a.o_save != nullptr && tok >= 0) rat_st4_stream(a.o_save + tok * B3_I + 4 * q4, v);
+        }
+#endif
         if (a.lse_save != nullptr && (int)threadIdx.x < 2 * ATT_ROWS) {
             const int r = threadIdx.x >> 1, part = threadIdx.x & 1;
             const int64_t tok = rowtok[r];
