@@ -89,6 +89,9 @@ def parse(argv=None):
     ap.add_argument("--graph-attempt-timeout", type=float, default=240.0,
                     help="N > 1 with graphs: seconds the segmented-graph regions may take before every rank gives up and rank 0 prints "
                          "the eager result")
+    ap.add_argument("--region-timeout", type=float, default=600.0,
+                    help="N > 1: seconds the strong-scaling region may take once the weak region's line is ready; after that every rank "
+                         "exits 0 and rank 0 prints the line without `strong_scaling`")
     ap.add_argument("--no-graph-dp", action="store_true",
                     help="N > 1: eager launches instead of graph segments with the collectives between them (the default)")
     ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
@@ -107,7 +110,8 @@ def parse(argv=None):
                     help="N > 1: bound (s) on the process-group rendezvous and on every collective's completion (RCCL watchdog / gloo)")
     ap.add_argument("--fault", default=None,
                     help="test hook RANK:WHERE — that rank exits with code 17 at `init` (before the rendezvous), `barrier` (after the "
-                         "first barrier) or `step` (inside the timed region): the launcher must notice and end the job")
+                         "first barrier) or `step` (inside the timed region): the launcher must notice and end the job; `strong`: that rank "
+                         "raises inside the strong-scaling region: the line must still come out, without `strong_scaling`")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo process group, the host-emulation build of the kernels (tests/emu), "
                          "workload `dryrun`; the printed numbers mean nothing")
@@ -621,6 +625,8 @@ def worker(args):
             model.train_step(batches[i % nb])
             if i == 0:
                 fault("step")
+                if label == "strong" and args.fault == "%d:strong" % rank:
+                    raise RuntimeError("--fault %s: injected into the strong-scaling region" % args.fault)
         sync()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
@@ -796,7 +802,13 @@ def worker(args):
     want_weak = not dp or args.scaling in ("both", "weak")
     want_strong = dp and args.scaling in ("both", "strong")
 
-    def run_regions():
+    def run_regions(mode):
+        """weak region, then strong region.  The strong region is the one that runs the row-list (owner) exchange — uneven all-to-alls
+        whose sizes come from a host read-back — and the weak region's number is the job's `value`: once the weak region is through,
+        its line is kept ready and the strong region runs under a watchdog and a try / except.  If it stalls (a rank died, a collective
+        hangs) or raises, every rank leaves with exit code 0 and rank 0 prints the line WITHOUT `strong_scaling` but with
+        `strong_scaling_error` — the headline of an 8-GPU run is not lost to its secondary measurement."""
+        import threading
         weak = strong = None
         if want_weak:                                  # every rank its own batches of B samples
             batches = [make(1000 + 16 * rank + i) for i in range(NBATCH)]
@@ -805,7 +817,28 @@ def worker(args):
         if want_strong:                                # one global batch of B samples, rank r takes rows [r B/N, (r+1) B/N)
             per = B // world
             batches = [make(2000 + i, rank * per, (rank + 1) * per) for i in range(NBATCH)]
-            strong = timed_region(batches, args.steps, max(args.warmup, 2) if weak is None else 2, "strong")
+            guard = None
+            if weak is not None and not dry:
+                keep = assemble(weak, None, dict(region_info), mode) if rank == 0 else None
+
+                def give_up(why):
+                    if rank == 0:
+                        keep["strong_scaling_error"] = why
+                        emit(json.dumps(keep))
+                    os._exit(0)
+                guard = threading.Timer(args.region_timeout, give_up, args=("the strong-scaling region did not finish within %.0f s" % args.region_timeout,))
+                guard.daemon = True
+                guard.start()
+            try:
+                strong = timed_region(batches, args.steps, max(args.warmup, 2) if weak is None else 2, "strong")
+            except Exception as exc:                   # (this rank's error; the other ranks' watchdogs end them)
+                if guard is None:
+                    raise
+                guard.cancel()
+                give_up("%s: %s" % (type(exc).__name__, exc))
+            finally:
+                if guard is not None:
+                    guard.cancel()
             del batches
         return weak, strong
 
@@ -818,7 +851,7 @@ def worker(args):
         import threading
         graph_mode = False
         model.use_graph = False
-        weak_e, strong_e = run_regions()
+        weak_e, strong_e = run_regions(False)
         info_e = dict(region_info)
         fallback = assemble(weak_e, strong_e, info_e, False) if rank == 0 else None
 
@@ -834,7 +867,7 @@ def worker(args):
         graph_mode = True
         model.use_graph = True
         region_info.clear()
-        weak, strong = run_regions()
+        weak, strong = run_regions(True)
         dog.cancel()
         captured = any(e[1] for e in model.__dict__.get("_step_graphs", {}).values())
         first_e, first_g = (weak_e or strong_e)[0], (weak or strong)[0]
@@ -845,7 +878,7 @@ def worker(args):
             region_info.clear()
             region_info.update(info_e)
     else:
-        weak, strong = run_regions()
+        weak, strong = run_regions(graph_mode)
 
     # exact-fp32 arithmetic timed beside the default one in the SAME invocation; N = 1 only
     alt = None

@@ -148,3 +148,16 @@ def test_bench_rehearsal_survives_a_stalled_graph_attempt():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert "abandoned" in out["step_mode"]["graph_attempt"] and out["step_mode"]["graph"] is False and out["value"] > 0
+
+
+def test_bench_rehearsal_keeps_the_headline_when_the_strong_region_fails():
+    """the weak-scaling line is ready before the strong-scaling region starts: an exception there (injected) must not cost the job's
+    `value` — rc 0, one line, no `strong_scaling`, the error named"""
+    import json
+    r, lines = _bench(["--dp-rehearsal", "--workload", "tiny", "--steps", "3", "--warmup", "2", "--fault", "0:strong", "--no-eager-first"])
+    if r.returncode != 0 and "init_process_group" in r.stderr:
+        pytest.skip("RCCL could not bring up a one-rank communicator here")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert "strong_scaling" not in out and "injected" in out["strong_scaling_error"] and out["value"] > 0 and out["scaling"] == "weak"
