@@ -398,7 +398,131 @@ __device__ __forceinline__ void core_mfma2(const Tiles& t, int L, int nsq, float
     }
 }
 
-// FORM 0: valu, 1: valu with P handed over, 2: mfma, 3: mfma without LDS transposes
+// ---- hybrid: dV and dK take P / dS straight from the accumulators (permuted contraction index, transposed results), only dS goes through the
+// wave-private LDS tile for dQ = dS K: 72 MFMAs per pair like core_mfma, one LDS round trip and two fences per 16-row tile instead of two / five.
+template <int NIT>
+__device__ __forceinline__ void core_mfma3(const Tiles& t, int L, int nsq, float scale) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, m = l & 15;
+    float* scr = t.scr + w * SCR;
+    float* dl = scr + 16 * 33;
+    const float sl2 = scale * LOG2E;
+    const int npairs = nsq * H;
+    const bool cm = m < DH;
+    for (int pair = w; pair < npairs; pair += NW) {
+        const int h = pair % H, sq = pair / H;
+        const int r0 = sq * L, cq = h * DH, ck = I + h * DH, cv = 2 * I + h * DH;
+        f32x4 adK[NIT], adV[NIT];                              // TRANSPOSED: lane (g, m) holds [c = 4 g + r][key 16 jt + m]
+#pragma unroll
+        for (int jt = 0; jt < NIT; ++jt) adK[jt] = adV[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i0 = 16 * it;
+            const int irows = L - i0 < 16 ? L - i0 : 16;
+            {
+                const int rr = r0 + i0 + m;
+                const float* a = t.dob + (size_t)rr * LDT + cq;
+                const float* b = t.ob + (size_t)rr * LDT + cq;
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < DH; c += 2) {
+                    const float2 x = *reinterpret_cast<const float2*>(a + c), y = *reinterpret_cast<const float2*>(b + c);
+                    d = fmaf(x.x, y.x, d);
+                    d = fmaf(x.y, y.y, d);
+                }
+                if (l < 16) dl[l] = m < irows ? d : 0.f;
+            }
+            float aq[3], ao[3], bk[3][NIT], bv[3][NIT];
+            const int ri = r0 + i0 + m;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int cc = 4 * ks + g;
+                aq[ks] = t.qkv[(size_t)ri * LDQ + cq + cc];
+                ao[ks] = t.dob[(size_t)ri * LDT + cq + cc];
+#pragma unroll
+                for (int jt = 0; jt < NIT; ++jt) {
+                    const int rj = r0 + 16 * jt + m;
+                    bk[ks][jt] = t.qkv[(size_t)rj * LDQ + ck + cc];
+                    bv[ks][jt] = t.qkv[(size_t)rj * LDQ + cv + cc];
+                }
+            }
+            // A operands of dV^T / dK^T, permuted like the accumulator rows: lane (g', c = m) holds X[i0 + 4 g' + r][c]
+            float pdo[4], pq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * g + r;
+                const float o_ = t.dob[(size_t)(r0 + i0 + row) * LDT + cq + m], q_ = t.qkv[(size_t)(r0 + i0 + row) * LDQ + cq + m];
+                pdo[r] = (cm && row < irows) ? o_ : 0.f;
+                pq[r] = (cm && row < irows) ? q_ : 0.f;
+            }
+            f32x4 aS[NIT], aP[NIT];
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt) aS[jt] = aP[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const bool okc = 4 * ks + g < DH, oki = okc && m < irows;
+                const float xq = oki ? aq[ks] : 0.f, xo = oki ? ao[ks] : 0.f;
+#pragma unroll
+                for (int jt = 0; jt < NIT; ++jt) {
+                    const bool okj = okc && 16 * jt + m < L;
+                    aS[jt] = mfma4(xq, okj ? bk[ks][jt] : 0.f, aS[jt]);
+                    aP[jt] = mfma4(xo, okj ? bv[ks][jt] : 0.f, aP[jt]);
+                }
+            }
+            wave_fence();
+            float lse4[4], d4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lse4[r] = t.lses[(r0 + i0 + 4 * g + r) * H + h];
+                d4[r] = dl[4 * g + r];
+            }
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = 4 * g + r < irows && 16 * jt + m < L;
+                    const float p = ok ? __builtin_amdgcn_exp2f(aS[jt][r] * sl2 - lse4[r]) : 0.f;
+                    const float ds = p * (aP[jt][r] - d4[r]);
+                    scr[(4 * g + r) * 33 + 16 * jt + m] = ds;
+                    adV[jt] = mfma4(pdo[r], p, adV[jt]);        // dV^T[c][j] += dO[i][c] P[i][j]
+                    adK[jt] = mfma4(pq[r], ds, adK[jt]);        // dK^T[c][j] += Q[i][c] dS[i][j]
+                }
+            wave_fence();
+            f32x4 adQ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int half = 0; half < NIT; ++half) {
+                float bkk[4], as[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int jj = 16 * half + 4 * ks + g;
+                    bkk[ks] = t.qkv[(size_t)(r0 + jj) * LDQ + ck + m];
+                    as[ks] = scr[m * 33 + jj];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) adQ = mfma4(as[ks], (cm && 16 * half + 4 * ks + g < L) ? bkk[ks] : 0.f, adQ);
+            }
+            if (cm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < irows) t.ob[(size_t)(r0 + i0 + 4 * g + r) * LDT + cq + m] = adQ[r] * scale;
+            wave_fence();
+        }
+#pragma unroll
+        for (int jt = 0; jt < NIT; ++jt) {
+            const int row = 16 * jt + m;
+            if (row < L)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * g + r;
+                    if (c < DH) {
+                        t.qkv[(size_t)(r0 + row) * LDQ + ck + c] = adK[jt][r] * scale;
+                        t.qkv[(size_t)(r0 + row) * LDQ + cv + c] = adV[jt][r];
+                    }
+                }
+        }
+    }
+}
+
+// FORM 0: valu, 1: valu with P handed over, 2: mfma, 3: mfma without LDS transposes, 4: hybrid
 template <int FORM>
 __global__ void __launch_bounds__(NT) probe(const float* g_qkv, const float* g_ob, const float* g_dob, const float* g_lse, float* out,
                                            long long* cyc, int L, int iters, int stagger) {
@@ -427,8 +551,10 @@ __global__ void __launch_bounds__(NT) probe(const float* g_qkv, const float* g_o
         if (FORM < 2) {}
         else if (FORM == 2 && L <= 16) core_mfma<1>(t, L, nsq, scale);
         else if (FORM == 2) core_mfma<2>(t, L, nsq, scale);
-        else if (L <= 16) core_mfma2<1>(t, L, nsq, scale);
-        else core_mfma2<2>(t, L, nsq, scale);
+        else if (FORM == 3 && L <= 16) core_mfma2<1>(t, L, nsq, scale);
+        else if (FORM == 3) core_mfma2<2>(t, L, nsq, scale);
+        else if (L <= 16) core_mfma3<1>(t, L, nsq, scale);
+        else core_mfma3<2>(t, L, nsq, scale);
         __syncthreads();
         total += clock64() - t0;
     }
@@ -463,23 +589,25 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     CK(hipFuncSetAttribute((const void*)probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     CK(hipFuncSetAttribute((const void*)probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    CK(hipFuncSetAttribute((const void*)probe<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     printf("attention-backward core per chunk (64-row tile, 8 heads x 10), %d work-groups x %d threads, %d iterations; LDS %zu bytes; stagger %d\n", blocks, NT, iters, smem, stagger);
-    printf("%4s %4s %8s | %10s %10s %10s %10s | %9s %9s | %s\n", "L", "nsq", "pairs", "valu", "valu+P", "mfma", "mfma2", "mfma/best", "mfma2/best", "max |diff| of mfma, mfma2 against valu");
+    printf("%4s %4s %8s | %10s %10s %10s %10s %10s | %9s %9s %9s | %s\n", "L", "nsq", "pairs", "valu", "valu+P", "mfma", "mfma2", "hybrid", "mfma/best", "mfma2/best", "hybr/best", "max |diff| of mfma, mfma2, hybrid against valu");
     const int Ls[] = {11, 21, 31, 16, 9, 6};
     for (int L : Ls) {
         const int nsq = ROWS / L;
         std::vector<float> ref(nout), got(nout);
-        long long c[4] = {0, 0, 0, 0};
-        double worst[4] = {0, 0, 0, 0}, scale_ref = 0.0;
+        long long c[5] = {0, 0, 0, 0, 0};
+        double worst[5] = {0, 0, 0, 0, 0}, scale_ref = 0.0;
         std::vector<long long> cyc(blocks);
-        for (int form = 0; form < 4; ++form) {
+        for (int form = 0; form < 5; ++form) {
             const bool ph_fits = (size_t)nsq * H * L * L <= (size_t)PBUF;
             if (form == 1 && !ph_fits) { c[1] = -1; continue; }
             CK(hipMemset(d_out, 0, nout * 4));
             if (form == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
             else if (form == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
             else if (form == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
-            else hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
+            else if (form == 3) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
+            else hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(NT), smem, 0, d_qkv, d_ob, d_dob, d_lse, d_out, d_cyc, L, iters, stagger);
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(cyc.data(), d_cyc, blocks * 8, hipMemcpyDeviceToHost));
@@ -501,8 +629,8 @@ int main(int argc, char** argv) {
             }
         }
         const long long best = (c[1] > 0 && c[1] < c[0]) ? c[1] : c[0];
-        printf("%4d %4d %8d | %10lld %10lld %10lld %10lld | %9.3f %9.3f | %.2e %.2e (largest |value| %.3f)\n", L, nsq, nsq * H * L * L, c[0], c[1], c[2], c[3],
-               (double)c[2] / (double)best, (double)c[3] / (double)best, worst[2], worst[3], scale_ref);
+        printf("%4d %4d %8d | %10lld %10lld %10lld %10lld %10lld | %9.3f %9.3f %9.3f | %.2e %.2e %.2e (largest |value| %.3f)\n", L, nsq, nsq * H * L * L, c[0], c[1], c[2], c[3], c[4],
+               (double)c[2] / (double)best, (double)c[3] / (double)best, (double)c[4] / (double)best, worst[2], worst[3], worst[4], scale_ref);
     }
     return 0;
 }
