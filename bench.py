@@ -94,6 +94,9 @@ def parse(argv=None):
                          "exits 0 and rank 0 prints the line without `strong_scaling`")
     ap.add_argument("--no-graph-dp", action="store_true",
                     help="N > 1: eager launches instead of graph segments with the collectives between them (the default)")
+    ap.add_argument("--no-group-loop", action="store_true",
+                    help="diagnostic (wide heads: heads = G x 8 at d = 64): G forward launches per layer instead of the one that loops over "
+                         "the head groups (rat_attn_fwd_groups)")
     ap.add_argument("--batch", type=int, default=0, help="diagnostic: override the workload's batch size (the line then names it in config)")
     ap.add_argument("--inference", action="store_true", help="add the `inference` object (eval forward, eager and hipGraph) even with --no-extras")
     ap.add_argument("--no-extras", action="store_true",
@@ -206,10 +209,11 @@ class _HostEvent:
 class KernelTimer:
     """HIP-event timing of C-ABI launches on torch's current stream (the stream the kernels are launched on)."""
 
-    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
+    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_attn_fwd_groups", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
              "rat_ffn_bwd_res", "rat_ffn_bwd_res_rows", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map",
              "rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted")
-    ATTN_ARGS = {"rat_attn_fwd": (5, 7), "rat_attn_bwd": (9, 11), "rat_attn_fwd_ex": (6, 8), "rat_attn_bwd_ex": (10, 12)}   # (map, heads)
+    ATTN_ARGS = {"rat_attn_fwd": (5, 7), "rat_attn_bwd": (9, 11), "rat_attn_fwd_ex": (6, 8), "rat_attn_bwd_ex": (10, 12),
+                 "rat_attn_fwd_groups": (8, 10)}                                                          # (map, heads)
 
     def __init__(self, lib, everything=False, host_events=False):
         self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
@@ -580,6 +584,8 @@ def worker(args):
     can_prune = hasattr(model, "prune_dead_tokens") and args.model in ("RAT_m2", "RAT_m3")
     if can_prune:
         model.prune_dead_tokens = bool(args.prune)
+    if args.no_group_loop:
+        model.group_loop = False
     graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or not args.no_graph_dp)
     model.use_graph = graph_mode
     model.graph_under_dp = not args.no_graph_dp
@@ -781,6 +787,9 @@ def worker(args):
                                         "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
                                         else ", eager launches"))
         result["config"]["dead_token_pruning"] = bool(can_prune and model.prune_dead_tokens)
+        if spec["num_heads"] > 8 and spec["d"] == 64:
+            result["config"]["wide_heads"] = "one forward launch per layer, head groups looped inside" if getattr(model, "group_loop", False) \
+                else "one forward launch per head group"
         if args.dp_rehearsal:
             result["dp_rehearsal"] = "one rank through the N > 1 code path (RCCL group of one rank, every collective of the step issued)"
         if pruned is not None:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RAT_ABI_VERSION 8
+#define RAT_ABI_VERSION 9
 #define RAT_ARITH_F32 0        /* arithmetic selectors of the encoder GEMMs: see rat_attn_fwd_ex */
 #define RAT_ARITH_BF16X3 1
 
@@ -185,6 +185,25 @@ int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const flo
                     const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace, size_t workspace_bytes,
                     const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale,
                     float ln_eps, float dropout_p, uint64_t dropout_seed, int arith, void* stream);
+
+/* ---- wide heads in one forward launch (ABI v9).  heads = G x 8 (16 ... 64), dim_head 10, embedding_dim 64 — BASELINE configs[4], the
+ * shipped Tmall config's 32 heads (configs/RAT_m2/tmall_x1_002/model_config.yaml:23) at d = 64.  heads * dim_head is too wide for the
+ * fused kernels' LDS tile, but the head groups are independent given LayerNorm(x) (RAT_m2.py:192-202: the heads only meet in to_out),
+ * so a caller may run the layer as G launches of rat_attn_fwd_ex on 8 heads each (res = x, then res = y) — or as ONE launch that loads
+ * and normalises each 64-row chunk once and loops over the groups inside it, adding bias, Dropout and the residual once:
+ *   y = out_scale * Dropout(to_out(concat_g softmax(Q_g K_g^T * scale) V_g)) + res        (bf16x3 arithmetic only)
+ * planes: rat_attn_groups_planes_bytes() bytes, 16-byte aligned, filled by rat_split_weights_batch from the 4 G jobs of
+ *   rat_attn_groups_split_jobs (they read group g's rows of the Q / K / V blocks of to_qkv.weight and its columns of to_out.weight in
+ *   place: no permuted copy of the weights) — valid until the weights change; w_host = the layer's full-width parameters.
+ * o_save [G][ntok][80], lse_save [G][ntok][8] (or both NULL): group-major, so that slice g is exactly what rat_attn_bwd_ex takes for
+ *   a launch on group g; ntok = tokens of x (the slice stride).
+ * rat_attn_groups_planes_bytes returns 0 (and rat_attn_groups_split_jobs 0 jobs) for dimensions this form does not serve. */
+size_t rat_attn_groups_planes_bytes(int d, int heads, int dim_head);
+int rat_attn_groups_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes,
+                               RatSplitJob* jobs_out /* [4 * heads / 8] */);
+int rat_attn_fwd_groups(const float* x, const float* res, float* y, float* o_save, float* lse_save, int64_t ntok,
+                        const RatAttnParams* w_host, const void* planes, const RatSeqMap* map_host, int d, int heads, int dim_head,
+                        float softmax_scale, float out_scale, float ln_eps, float dropout_p, uint64_t dropout_seed, void* stream);
 
 /* ---- K2d: the attention core alone, for sequences longer than the fused kernel's 64-row tile — RAT_m0 attends jointly over all
  * T*S tokens of a sample (RAT_m0.py:123-127; 231 at the north-star shape).  That variant runs LayerNorm as K2c and the two

@@ -274,6 +274,70 @@ def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed
             close(g, wt.grad, 1e-4, 1e-4 * scale, name)
 
 
+def check_attn_groups(lib, dev, case, mode, res_mode="x", dropout=0.0, seed=7):
+    """rat_attn_fwd_groups: wide heads (heads = G x 8) in ONE launch that loops over the head groups inside a chunk.
+    y against float64 attention over ALL heads; o_save / lse_save slice g bit-identical to what a rat_attn_fwd_ex launch on a contiguous
+    copy of group g's weights saves (the per-group form the backward consumes); then the backward as G rat_attn_bwd_ex launches on those
+    slices against float64 gradients."""
+    B, T, S, d, heads, dh, proj = case
+    assert proj and heads % 8 == 0 and heads > 8
+    G, ig, I = heads // 8, 8 * dh, heads * dh
+    rs = np.random.RandomState(seed)
+    x = rnd(rs, B, T, S, d)
+    other = rnd(rs, B, T, S, d)
+    ws = attn_weights(rs, d, heads, dh, proj)
+    dy = rnd(rs, B, T, S, d)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    att = attn_reference(xr, *wr, heads, dh, mode) - xr
+    xd, dyd, od = x.to(dev), dy.to(dev), other.to(dev)
+    drop = (0.0, 0)
+    if dropout > 0:
+        drop = (dropout, 987654321)
+        mask = ops.dropout(torch.ones_like(xd), drop[0], drop[1], lib=lib).cpu().double()
+        att = mask * att
+    ref = att + (xr if res_mode == "x" else other.double())
+    ref.backward(dy.double())
+    wd = [w.to(dev) for w in ws]
+    params = ops.attn_params(*wd)
+    smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
+    nbytes = ops.attn_groups_planes_bytes(d, heads, dh, lib=lib)
+    assert nbytes > 0 and ops.attn_groups_planes_bytes(d, 8, dh, lib=lib) == 0
+    planes = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    jobs = ops.attn_groups_split_jobs(params, d, heads, dh, planes, lib=lib)
+    assert len(jobs) == 4 * G
+    arr, n = ops.split_job_array(jobs)
+    ops.split_weights_batch(arr, n, xd, lib=lib)
+    y, o_save, lse = ops.attn_fwd_groups(xd, xd if res_mode == "x" else od, params, planes, smap, d, heads, dh, save=True, dropout=drop, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    y2, _, _ = ops.attn_fwd_groups(xd, xd if res_mode == "x" else od, params, planes, smap, d, heads, dh, save=False, dropout=drop, lib=lib)
+    assert torch.equal(y, y2), "inference form (nothing saved)"
+    # group g alone, on contiguous copies of its weight slices (what the model's grouped backward uses)
+    wq = wd[2].view(3, G, ig, d).permute(1, 0, 2, 3).contiguous()
+    wo = wd[3].view(d, G, ig).permute(1, 0, 2).contiguous()
+    zero_b = torch.zeros_like(wd[4])
+    ntok = B * T * S
+    dx = None
+    t_ln = torch.zeros((2, G, d), dtype=torch.float32, device=dev)
+    t_w = torch.zeros((G, 3 * ig, d), dtype=torch.float32, device=dev)
+    t_wo = torch.zeros((G, d, ig), dtype=torch.float32, device=dev)
+    g_b, t_b = torch.zeros_like(wd[4]), torch.zeros_like(wd[4])
+    for g in range(G):
+        p_g = ops.attn_params(wd[0], wd[1], wq[g].view(3 * ig, d), wo[g], wd[4] if g == 0 else zero_b)
+        _, o_g, l_g = ops.attn_fwd_ex(xd, None, p_g, smap, d, 8, dh, save=True, arith="bf16x3", lib=lib)
+        assert torch.equal(o_g, o_save[g]) and torch.equal(l_g, lse[g]), ("saved O / lse of group", g)
+        grads = ops.attn_params(t_ln[0, g], t_ln[1, g], t_w[g], t_wo[g], g_b if g == 0 else t_b)
+        add = (dyd if res_mode == "x" else None) if g == 0 else dx
+        dx, _ = ops.attn_bwd_ex(xd, dyd, add, o_save[g], lse[g], p_g, grads, smap, d, 8, dh, out=dx, arith="bf16x3", dropout=drop, lib=lib)
+    scale = max(1.0, ntok ** 0.5 / 4)
+    close(dx, xr.grad, 1e-4, 1e-4, "dx")
+    close(t_w.view(G, 3, ig, d).permute(1, 0, 2, 3).reshape(3 * I, d), wr[2].grad, 1e-4, 1e-4 * scale, "w_qkv")
+    close(t_wo.permute(1, 0, 2).reshape(d, I), wr[3].grad, 1e-4, 1e-4 * scale, "w_out")
+    close(g_b, wr[4].grad, 1e-4, 1e-4 * scale, "b_out")
+    close(t_ln[0].sum(0), wr[0].grad, 1e-4, 1e-4 * scale, "ln_g")
+    close(t_ln[1].sum(0), wr[1].grad, 1e-4, 1e-4 * scale, "ln_b")
+
+
 def check_attn_core(lib, dev, nseq, L, heads, dh, softmax_scale=None):
     """rat_attn_core_fwd / bwd against float64 softmax attention on random projected rows."""
     rs = np.random.RandomState(17)

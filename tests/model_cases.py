@@ -123,6 +123,60 @@ def check_training(name, gpu):
     np.testing.assert_allclose(yp, gold["eval_after/y_pred"], rtol=0, atol=eval_after_atol(case))
 
 
+def check_wide_heads_group_loop(gpu, batch=3, topk=2, nfields=2, heads=16, depth=1, dropout=0.0):
+    """Wide heads at embedding_dim 64 (heads = G x 8): the forward of a layer as ONE launch looping over the head groups
+    (rat_attn_fwd_groups) against G launches of the 8-head kernel, on the same weights and batch: loss, predictions and every gradient
+    agree to rounding (only the order in which the groups' partial output projections are summed differs), the loss equals the oracle's,
+    and the one-launch form is what actually ran."""
+    from oracle import rat_m2_oracle as orc
+    from rat_amd import ops
+    case = dict(gc.case_by_name("northstar_shape"), name="wide_heads_probe", batch=batch, topk=topk, num_heads=heads, depth=depth,
+                fields=gc.case_by_name("northstar_shape")["fields"][:nfields], batch_norm=False, embedding_regularizer=0.0)
+    out = {}
+    calls = []
+    real = ops.attn_fwd_groups
+    ops.attn_fwd_groups = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        for loop in (True, False):
+            model = build_model(case, gpu=gpu, seed=1, dropout=dropout)
+            load_weights(model, case)
+            assert model.arith == "bf16x3" and model._attn_mode(ops.intra_map(batch, topk + 1, nfields + 1)) == ("grouped", 8)
+            model.group_loop = loop
+            model.train()
+            if dropout:
+                model._dropout_state_init(base=4242)                 # the same masks in both forms
+            model.optimizer.zero_grad()
+            n0 = len(calls)
+            tb = tuple(t.to(model.device) for t in batch_of(case))
+            loss = model.get_total_loss(tb)
+            loss.backward()
+            assert (len(calls) - n0 == 2 * depth) if loop else (len(calls) == n0)
+            grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None}
+            model.eval()
+            with torch.no_grad():
+                yp = model.forward(tb)["y_pred"].cpu()
+            assert (len(calls) - n0 == 4 * depth) if loop else (len(calls) == n0)         # the inference forward takes it too
+            out[loop] = (float(loss.detach()), grads, yp)
+    finally:
+        ops.attn_fwd_groups = real
+    (l1, g1, y1), (l0, g0, y0) = out[True], out[False]
+    assert abs(l1 - l0) < 2e-6 and float((y1 - y0).abs().max()) < 2e-6
+    assert sorted(g1) == sorted(g0) and len(g1) >= 20
+    for k in g1:
+        scale = float(g0[k].abs().max()) + 1e-30
+        assert float((g1[k] - g0[k]).abs().max()) / scale < 1e-4, k
+    if dropout == 0:
+        model = build_model(case, gpu=gpu, seed=1)
+        load_weights(model, case)
+        w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        cfg = orc.Config(fields=orc.fields_from_specs(gc.feature_specs(case)), embedding_dim=64, num_heads=heads, dim_head=10, depth=depth,
+                         scale_dim=case["scale_dim"], dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=False,
+                         use_wide=case["use_wide"])
+        b = batch_of(case)
+        ref_loss = orc.loss_and_grads(w, b[0], b[1], cfg, training=True)[0]
+        assert abs(l1 - float(ref_loss)) < 2e-6, (l1, float(ref_loss))
+
+
 CHECKPOINT_CASES = ["tiny_seq_bn", "m0_tiny_seq", "m1_tiny_seq", "m3_tiny_seq"]
 
 

@@ -151,6 +151,13 @@ def test_attn_core_strided(emu, B, T, S, heads, dh):
     kc.check_attn_core_strided(emu, "cpu", B, T, S, heads, dh)
 
 
+@pytest.mark.parametrize("case,mode,res_mode,dropout", [pytest.param((1, 3, 5, 64, 16, 10, True), "intra", "x", 0.0, id="G2_intra"),
+                                                        pytest.param((1, 4, 3, 64, 32, 10, True), "cross", "other", 0.25, id="G4_cross_dropout")])
+def test_attn_wide_heads_group_loop(emu, case, mode, res_mode, dropout, two_blocks):
+    """rat_attn_fwd_groups (attn_fwd3_kernel<GRP>): every head group of a chunk inside one launch"""
+    kc.check_attn_groups(emu, "cpu", case, mode, res_mode=res_mode, dropout=dropout)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

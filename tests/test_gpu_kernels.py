@@ -124,6 +124,16 @@ def test_attn_core_strided(lib, B, T, S, heads, dh):
     kc.check_attn_core_strided(lib, "cuda", B, T, S, heads, dh)
 
 
+@pytest.mark.parametrize("case,mode,res_mode,dropout", [pytest.param((40, 11, 21, 64, 16, 10, True), "intra", "x", 0.0, id="G2_intra_L21"),
+                                                        pytest.param((40, 11, 21, 64, 32, 10, True), "cross", "x", 0.0, id="G4_cross_L11"),
+                                                        pytest.param((30, 31, 9, 64, 32, 10, True), "cross", "other", 0.25, id="G4_cross_L31_dropout"),
+                                                        pytest.param((30, 31, 9, 64, 32, 10, True), "intra", "x", 0.1, id="G4_intra_L9_dropout"),
+                                                        pytest.param((7, 3, 64, 64, 64, 10, True), "intra", "x", 0.0, id="G8_L64")])
+def test_attn_wide_heads_group_loop(lib, case, mode, res_mode, dropout):
+    """rat_attn_fwd_groups (attn_fwd3_kernel<GRP>): every head group of a chunk inside one launch"""
+    kc.check_attn_groups(lib, "cuda", case, mode, res_mode=res_mode, dropout=dropout)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

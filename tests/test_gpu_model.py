@@ -228,6 +228,12 @@ def test_composed_attention_path(name, monkeypatch):
     mc.check_training(name, gpu=0)
 
 
+@pytest.mark.parametrize("heads,dropout", [(32, 0.0), (16, 0.2)], ids=["h32", "h16_dropout"])
+def test_wide_heads_forward_group_loop_equals_the_per_group_launches(heads, dropout):
+    """BASELINE configs[4]'s head geometry (32 x 10 at d = 64): rat_attn_fwd_groups inside the model against the per-group launches"""
+    mc.check_wide_heads_group_loop(gpu=0, batch=40, topk=6, nfields=7, heads=heads, depth=2, dropout=dropout)
+
+
 def test_grouped_heads_mode_is_selected_for_wide_heads():
     """32 heads x 10: four launches of the fused kernel on 8 heads each (model._attn_mode)"""
     import golden_cases as gc

@@ -72,7 +72,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), sym
     from rat_amd._lib import ABI_VERSION
-    assert lib.rat_version() == ABI_VERSION == 8
+    assert lib.rat_version() == ABI_VERSION == 9
 
 
 def test_no_silent_fallback_when_library_is_missing(tmp_path, monkeypatch):

@@ -66,6 +66,8 @@ struct AttnArgs {
     float eps, scale;
     int vec_x, vec_wqkv, vec_wout;
     RatDrop drop;        // Dropout behind the output projection (RAT_m2.py:186-189); the EX instantiations only
+    int groups;          // attn_fwd3_kernel<GRP>: head groups looped over inside a chunk (wide heads: heads = groups x 8)
+    int64_t group_tok;   // ... o_save / lse_save are [groups][group_tok][.]: token stride between two groups' slices
     unsigned long long* prof;
 };
 
@@ -1084,6 +1086,7 @@ constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
 constexpr size_t B3_FWD_LSE = (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8;   // [64][8] log-sum-exp of the chunk
 constexpr size_t B3_FWD_WOUT = B3_FWD_LSE + (size_t)64 * B3_H * 4;      // the output projection's fragment planes, LDS-resident (36 KB)
 constexpr size_t b3_fwd_smem() { return B3_FWD_WOUT + B3_W_OUT; }
+constexpr size_t B3_GRP_PLANES = B3_W_QKV + B3_W_OUT;                  // rat_attn_fwd_groups: [W_qkv | W_out] fragment planes per head group
 static_assert(b3_fwd_smem() <= 160 * 1024, "LDS budget (forward)");
 // weight fragment planes held in LDS (same [n tile][K step][plane][lane] x 16 B layout as RatWPlanes): a fragment is three 16-byte
 // LDS reads instead of a round trip to L2.  The forward kernel has 41 KB of LDS to spare, W_out's planes are 36 KB.
@@ -1237,8 +1240,14 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const BW& Bw, int n_ti
 
 // QSUB: RatSeqMap.queries < L is honoured (a separate instantiation: the ordinary one must not carry a second trip count)
 // DPAD: embedding_dim 40 / 48 / 56 inside the 64-wide tiles (zero-padded weight planes; see b3_layer_norm_to_planes)
-template <bool EX, bool QSUB = false, bool DPAD = false>
+// GRP (wide heads, round 5): heads = a.groups x 8.  The head groups are independent given LayerNorm(x), so ONE launch loads and
+// normalises a chunk once and then loops over the groups — Q|K|V projection, attention core, O -> planes / o_save, output projection
+// per group, the projection's partial sums kept in the accumulator registers across the loop — and adds bias, Dropout and the residual
+// once at the end: one LayerNorm / x load / y read-modify-write per chunk instead of one per group launch (rat_attn_fwd_groups).
+// Group g's fragment planes are W.qkv / W.out + g x B3_GRP_PLANES; W_out's come from L2 (four groups' planes do not fit the LDS).
+template <bool EX, bool QSUB = false, bool DPAD = false, bool GRP = false>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
+    static_assert(!GRP || (EX && !QSUB && !DPAD), "the group loop is written for the general (EX) form at embedding_dim 64");
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                 // LayerNorm(x) planes; later the fp32 output staging tile
     float* qkv = reinterpret_cast<float*>(smem + 3 * B3_XP);                // [64][244] fp32 Q|K|V; O overwrites Q
@@ -1249,8 +1258,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
     constexpr int LDY = B3_D + 4;
     const int L = a.L;
     // W_out's fragment planes: global -> LDS once per work-group (every chunk's output projection then reads them from LDS)
-    for (int e = threadIdx.x; e < (int)(B3_W_OUT / 16); e += ATT_THREADS)
-        reinterpret_cast<rat_u4*>(smem + B3_FWD_WOUT)[e] = W.out.base[e];
+    if (!GRP)
+        for (int e = threadIdx.x; e < (int)(B3_W_OUT / 16); e += ATT_THREADS)
+            reinterpret_cast<rat_u4*>(smem + B3_FWD_WOUT)[e] = W.out.base[e];
     const RatWPlanesLds wout_lds{smem + B3_FWD_WOUT, 3};
 
     for (int e = threadIdx.x; e < 3 * B3_OP / 4; e += ATT_THREADS) reinterpret_cast<float*>(op.base)[e] = 0.f;   // incl. the slack
@@ -1288,8 +1298,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         }
         __syncthreads();
         RAT_PROF_MARK(0);
+        float pf = 0.f;
+        f32x4 yacc[2] = {rat_zero4(), rat_zero4()};              // GRP: this wave's two output-projection tiles, summed over the groups
+        const int ngroups = GRP ? a.groups : 1;
+        for (int grp = 0; grp < ngroups; ++grp) {                // (one trip unless GRP; the body keeps its indentation)
+        const RatWPlanes wq = GRP ? RatWPlanes{W.qkv.base + (size_t)grp * (B3_GRP_PLANES / 16), W.qkv.steps} : W.qkv;
+        const RatWPlanes wo = GRP ? RatWPlanes{W.out.base + (size_t)grp * (B3_GRP_PLANES / 16), W.out.steps} : W.out;
+        float* const o_save = (GRP && a.o_save != nullptr) ? a.o_save + (int64_t)grp * a.group_tok * B3_I : a.o_save;
+        float* const lse_save = (GRP && a.lse_save != nullptr) ? a.lse_save + (int64_t)grp * a.group_tok * B3_H : a.lse_save;
         // Q|K|V = LN(x) W_qkv^T
-        b3_gemm_rows<2>(xp, W.qkv, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
+        b3_gemm_rows<2>(xp, wq, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
 #pragma unroll
             for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * B3_LDQ + col] = acc[r];
@@ -1303,8 +1321,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         //  states merged by lane shuffles): 9-17 % slower.  tools/ab_attn.sh.  Round 3: two queries per lane over ALL keys (half the LDS
         //  bytes per pair, bit-identical): +9.5 % / +4 % at L = 21 / 11; softmax against the Cauchy-Schwarz bound |q| max|k| (no running
         //  maximum, no rescaling, independent keys): +-0 / +3 % — tools/experiments/attn_fwd3_core_variants.hip.txt.)
-        float pf = 0.f;
-        if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks)   // (no prefetch: +2-3 %, same-box A/B)
+        if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks && (!GRP || grp == ngroups - 1))   // (no prefetch: +2-3 %, same-box A/B)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, dreal);
         typedef HeadVec<B3_DH> HV;
         const int nq = QSUB ? a.nq : L;                          // queries that matter per sequence (RatSeqMap.queries; normally L)
@@ -1383,9 +1400,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             rat_split8(v0, v1, h, m, l);
             op.store(r, o8, h, m, l);
             const int64_t tok = rowtok[r];
-            if (a.o_save != nullptr && tok >= 0) {
-                rat_st4_stream(a.o_save + tok * B3_I + 8 * o8, v0);
-                rat_st4_stream(a.o_save + tok * B3_I + 8 * o8 + 4, v1);
+            if (o_save != nullptr && tok >= 0) {
+                rat_st4_stream(o_save + tok * B3_I + 8 * o8, v0);
+                rat_st4_stream(o_save + tok * B3_I + 8 * o8 + 4, v1);
             }
         }
 #else
@@ -1399,17 +1416,24 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             rat_split2(v.z, v.w, h1, m1, l1);
             op.store_half(r, q4, h0, h1, m0, m1, l0, l1);
             const int64_t tok = rowtok[r];
-            if (a.o_save != nullptr && tok >= 0) rat_st4_stream(a.o_save + tok * B3_I + 4 * q4, v);
+            if (o_save != nullptr && tok >= 0) rat_st4_stream(o_save + tok * B3_I + 4 * q4, v);
         }
 #endif
-        if (a.lse_save != nullptr && (int)threadIdx.x < 2 * ATT_ROWS) {
+        if (lse_save != nullptr && (int)threadIdx.x < 2 * ATT_ROWS) {
             const int r = threadIdx.x >> 1, part = threadIdx.x & 1;
             const int64_t tok = rowtok[r];
-            if (tok >= 0) rat_st4_stream(a.lse_save + tok * B3_H + 4 * part, *reinterpret_cast<const float4*>(lse_s + r * B3_H + 4 * part));
+            if (tok >= 0) rat_st4_stream(lse_save + tok * B3_H + 4 * part, *reinterpret_cast<const float4*>(lse_s + r * B3_H + 4 * part));
         }
         __syncthreads();
         RAT_PROF_MARK(3);
         // y = O W_out^T + b_out (+ residual), staged through LDS for whole-row stores
+        if (GRP) {                                               // this group's partial projection stays in the accumulators
+            b3_gemm_rows<3>(op, wo, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yacc[mt & 1][r] += acc[r];       // (mt = 2 (wave >> 2) + {0, 1})
+            });
+            continue;                                            // (O -> planes of the next group waits behind two barriers: no third one here)
+        }
 #ifdef RAT_FWD_WOUT_L2                                           // (A/B knob: round 3's form, fragments from L2)
         b3_gemm_rows<3>(op, W.out, B3_D / 16, [&](int mt, int nt, const f32x4& acc) {
 #else
@@ -1420,6 +1444,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
 #pragma unroll
             for (int r = 0; r < 4; ++r) ys[(size_t)rat_acc_row(mt, r) * LDY + col] = acc[r] + bias;
         });
+        }                                                        // (group loop)
+        if (GRP) {                                               // the x planes under `ys` were last read two barriers ago (last group's Q|K|V)
+            const int w = rat_wave(), col = rat_acc_col(w & 3);
+            const float bias = a.b_out[col];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ys[(size_t)rat_acc_row(2 * (w >> 2) + i, r) * LDY + col] = yacc[i][r] + bias;
+        }
         __syncthreads();
         RAT_PROF_MARK(4);
         if (EX) {
@@ -2693,6 +2726,67 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     else if (dim_head == 10) RAT_LAUNCH((attn_fwd_kernel<0, 10>), blocks, ATT_THREADS, smem, stream, a);   // e.g. the shipped KKBox d = 40
     else RAT_LAUNCH((attn_fwd_kernel<0, 0>), blocks, ATT_THREADS, smem, stream, a);
     return rat_check_launch("rat_attn_fwd");
+}
+
+// ---- wide heads in ONE forward launch (round 5): heads = G x 8, dim_head 10, embedding_dim 64 — BASELINE configs[4], the shipped Tmall
+// config's 32 heads at d = 64.  `planes`: G x [W_qkv | W_out] fragment planes of the groups' weight slices, filled by the jobs of
+// rat_attn_groups_split_jobs (rows g*80.. of the Q, K and V blocks of to_qkv.weight; columns g*80.. of to_out.weight — no permuted copy
+// of the weights is needed).  o_save / lse_save: [G][ntok][80] / [G][ntok][8], group-major, so that every group's slice is what
+// rat_attn_bwd_ex expects for a launch on that group.
+static int b3_groups(int d, int heads, int dim_head) {
+    return (d == B3_D && dim_head == B3_DH && heads > B3_H && heads % B3_H == 0 && heads / B3_H <= 8) ? heads / B3_H : 0;
+}
+extern "C" size_t rat_attn_groups_planes_bytes(int d, int heads, int dim_head) {
+    return (size_t)b3_groups(d, heads, dim_head) * B3_GRP_PLANES;
+}
+extern "C" int rat_attn_groups_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes, RatSplitJob* jobs_out) {
+    RAT_REQUIRE(w_host && jobs_out, "null pointer");
+    const int G = b3_groups(d, heads, dim_head);
+    if (G == 0 || planes == nullptr || w_host->w_out == nullptr) return 0;
+    RAT_REQUIRE(aligned16(planes) && w_host->w_qkv, "planes must be 16-byte aligned");
+    const int I = heads * dim_head;
+    int n = 0;
+    for (int g = 0; g < G; ++g) {
+        char* ws = static_cast<char*>(planes) + (size_t)g * B3_GRP_PLANES;
+        for (int part = 0; part < 3; ++part)                     // Q, K, V rows of this group: 5 column tiles each, consecutive in the planes
+            jobs_out[n++] = RatSplitJob{w_host->w_qkv + ((size_t)part * I + (size_t)g * B3_I) * d, ws + (size_t)part * (B3_W_QKV / 3), B3_I, d, d, 0, 0, 0};
+        jobs_out[n++] = RatSplitJob{w_host->w_out + (size_t)g * B3_I, ws + B3_W_QKV, B3_D, B3_I, I, 0, 0, 0};
+    }
+    return n;
+}
+extern "C" int rat_attn_fwd_groups(const float* x, const float* res, float* y, float* o_save, float* lse_save, int64_t ntok,
+                                   const RatAttnParams* w_host, const void* planes, const RatSeqMap* map_host, int d, int heads,
+                                   int dim_head, float softmax_scale, float out_scale, float ln_eps, float dropout_p,
+                                   uint64_t dropout_seed, void* stream) {
+    const int G = b3_groups(d, heads, dim_head);
+    RAT_REQUIRE(G > 0, "rat_attn_fwd_groups serves embedding_dim 64, dim_head 10 and 16 ... 64 heads in groups of 8");
+    if (check_dims(map_host, d, B3_H, dim_head, false)) return -1;
+    RAT_REQUIRE(x && y && planes && w_host && w_host->ln_g && w_host->ln_b && w_host->b_out, "null pointer");
+    RAT_REQUIRE((o_save == nullptr) == (lse_save == nullptr) && ntok > 0, "o_save and lse_save come together, [G][ntok][.]");
+    RAT_REQUIRE(aligned16(x) && aligned16(y) && aligned16(res) && aligned16(o_save) && aligned16(lse_save) && aligned16(planes),
+                "tensors must be 16-byte aligned");
+    RAT_REQUIRE(b3_off32_ok(map_host), "token offsets beyond 32 bits");
+    AttnArgs a{};
+    fill_common(a, w_host, map_host, d, B3_H, dim_head, ln_eps);
+    if (softmax_scale > 0.f) a.scale = softmax_scale;
+    a.out_scale = out_scale;
+    a.res = res;
+    a.x = x;
+    a.y = y;
+    a.o_save = o_save;
+    a.lse_save = lse_save;
+    a.groups = G;
+    a.group_tok = ntok;
+    a.vec_x = 1;
+    RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
+    if (dropout_p > 0.f)
+        a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p), w_host->drop_seed_dev};
+    Attn3W W{};
+    W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(planes), 2};
+    W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(static_cast<const char*>(planes) + B3_W_QKV), 3};
+    const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
+    RAT_LAUNCH((attn_fwd3_kernel<true, false, false, true>), blocks, ATT_THREADS, B3_FWD_WOUT, stream, a, W);
+    return rat_check_launch("rat_attn_fwd_groups");
 }
 
 // 1 when the fused kernels (forward AND backward) serve these dimensions, 0 when the caller has to take the composed path

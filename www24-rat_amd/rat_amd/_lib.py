@@ -11,7 +11,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "lib", "librat_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class RatField(Structure):
@@ -73,6 +73,10 @@ _SIGNATURES = {
     "rat_ffn_bwd_drop": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int64, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "rat_attn_planes_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rat_attn_split_jobs": (c_int, [POINTER(RatAttnParams), c_int, c_int, c_int, _P, POINTER(RatSplitJob)]),
+    "rat_attn_groups_planes_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rat_attn_groups_split_jobs": (c_int, [POINTER(RatAttnParams), c_int, c_int, c_int, _P, POINTER(RatSplitJob)]),
+    "rat_attn_fwd_groups": (c_int, [_P, _P, _P, _P, _P, c_int64, POINTER(RatAttnParams), _P, POINTER(RatSeqMap), c_int, c_int, c_int,
+                                    c_float, c_float, c_float, c_float, ctypes.c_uint64, _P]),
     "rat_ffn_planes_bytes": (c_size_t, [c_int, c_int]),
     "rat_ffn_split_jobs": (c_int, [_P, _P, c_int, c_int, _P, POINTER(RatSplitJob)]),
     "rat_split_weights_batch": (c_int, [POINTER(RatSplitJob), c_int, _P]),

@@ -384,6 +384,12 @@ class RAT_m2(BaseModel):
         if mode == "grouped":
             if desc[0][3] is None:
                 raise NotImplementedError("grouped attention needs an output projection")
+            gplanes = getattr(desc[1], "gplanes", None)
+            if gplanes is not None and per == 8 and self.arith == "bf16x3" and self.group_loop:
+                # ONE launch: LayerNorm / x / residual once per chunk, the head groups looped over inside it (rat_attn_fwd_groups);
+                # o, l are group-major, slice g is what the backward's launch on group g reads
+                y, o, l = ops.attn_fwd_groups(x, x, desc[1], gplanes, smap, d, heads, dh, save=save, out=out, dropout=drop, lib=lib)
+                return y, (("loop", o, l, drop) if save else None)
             y, kept = None, []
             for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(desc[0], per)):
                 # Dropout(sum of the groups' partial projections + bias) = sum of the equally masked partials: same seed in every launch
@@ -434,6 +440,10 @@ class RAT_m2(BaseModel):
             t_w = torch.empty((groups, 3 * ig, d), dtype=torch.float32, device=dy.device)
             t_wo = torch.empty((groups, d, ig), dtype=torch.float32, device=dy.device)
             dx = out                                     # (a caller's grid: must NOT be dy itself — every group reads dy)
+            if att[0] == "loop":                         # the forward ran as one launch: per-group weight copies are made here
+                _, o_all, l_all, drop = att
+                att = [(w_g, wo_g, params_g, zb, o_all[g], l_all[g], drop)
+                       for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(names, per))]
             for g, (w_g, wo_g, params_g, zb, o, l, drop) in enumerate(att):
                 first = g == 0
                 grads_g = ops.attn_params(t_ln[0, g], t_ln[1, g], t_w[g], t_wo[g], g_bout if first else t_b)
@@ -481,12 +491,13 @@ class RAT_m2(BaseModel):
         d, heads, dh, H = c["d"], c["heads"], c["dh"], c["hidden"]
         self._split_jobs = (None, 0)
         a_bytes = ops.attn_planes_bytes(d, heads, dh, lib=lib)
+        g_bytes = ops.attn_groups_planes_bytes(d, heads, dh, lib=lib)      # wide heads: per-group planes of the one-launch forward
         f_bytes = ops.ffn_planes_bytes(d, H, lib=lib)
         slots = []
         for blk in self._blocks:
             for which in ("intra", "cross"):
-                if a_bytes and blk[which][0][3] is not None:
-                    slots.append((blk, which, a_bytes))
+                if (a_bytes or g_bytes) and blk[which][0][3] is not None:
+                    slots.append((blk, which, a_bytes or g_bytes))
             if f_bytes:
                 slots.append((blk, "ffn", f_bytes))
         if not slots:
@@ -502,10 +513,14 @@ class RAT_m2(BaseModel):
                 got = ops.ffn_split_jobs(w1, w2, d, H, view, lib=lib)
                 if got:
                     blk["ffn_planes"] = view
-            else:
+            elif a_bytes:
                 got = ops.attn_split_jobs(blk[which][1], d, heads, dh, view, lib=lib)
                 if got:
                     blk[which][1].planes = view.data_ptr()
+            else:
+                got = ops.attn_groups_split_jobs(blk[which][1], d, heads, dh, view, lib=lib)
+                if got:
+                    blk[which][1].gplanes = view
             jobs += got
         self._split_jobs = ops.split_job_array(jobs)
 
@@ -1278,6 +1293,8 @@ class RAT_m2(BaseModel):
     # bench.py --dp-rehearsal); on by default since round 5 (the owner exchange no longer needs a host read-back mid-step).  A capture
     # that fails leaves that batch shape on the eager step (_step_graph_for); `graph_under_dp=False` / bench.py --no-graph-dp turns it off.
     graph_under_dp = True
+    group_loop = True          # wide heads (heads = G x 8 at d = 64): the forward of a layer as ONE launch that loops over the head groups
+                               # (rat_attn_fwd_groups) instead of G launches; False: the per-group launches (A/B, tests)
     graph_warmup = 2           # eager fused steps of a batch shape before it is captured
     graph_shapes = 2           # at most this many batch shapes get a graph (the full batch and an epoch's tail batch)
 

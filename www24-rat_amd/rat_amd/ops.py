@@ -92,6 +92,21 @@ def attn_split_jobs(params, d, heads, dim_head, planes, lib=None):
     return [jobs[i] for i in range(n)]
 
 
+def attn_groups_planes_bytes(d, heads, dim_head, lib=None):
+    """bytes of the per-group [W_qkv | W_out] fragment planes attn_fwd_groups reads; 0: that form does not serve these dimensions"""
+    return (lib or get_lib()).size("rat_attn_groups_planes_bytes", d, heads, dim_head)
+
+
+def attn_groups_split_jobs(params, d, heads, dim_head, planes, lib=None):
+    """-> list of RatSplitJob (4 per head group) that fill ``planes`` from the FULL-width weights of ``params``, in place"""
+    lib = lib or get_lib()
+    jobs = (RatSplitJob * (4 * max(heads // 8, 1)))()
+    n = lib.cdll.rat_attn_groups_split_jobs(ctypes.byref(params), d, heads, dim_head, _p(planes), jobs)
+    if n < 0:
+        raise RuntimeError("rat_attn_groups_split_jobs: " + lib.last_error())
+    return [jobs[i] for i in range(n)]
+
+
 def ffn_split_jobs(w1, w2, d, hidden, planes, lib=None):
     lib = lib or get_lib()
     jobs = (RatSplitJob * 3)()
@@ -334,6 +349,24 @@ def attn_fwd_ex(x, res, params, seqmap, d, heads, dim_head, softmax_scale=0.0, o
     lib.call("rat_attn_fwd_ex", _p(x), _p(res), _p(y), _p(o_save), _p(lse), ctypes.byref(params), ctypes.byref(seqmap), d, heads,
              dim_head, float(softmax_scale), float(out_scale), eps, drop_p, drop_seed, ARITH[arith],
              _p(ws), ws.numel() * 4 if ws is not None else 0, _stream(x))
+    return y, o_save, lse
+
+
+def attn_fwd_groups(x, res, params, planes, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, save=False, eps=1e-5, out=None,
+                    dropout=(0.0, 0), lib=None):
+    """Wide heads (heads = G x 8) in ONE launch: y = out_scale * Dropout(to_out(attention(LayerNorm(x)))) + res, the head groups looped
+    over inside each chunk.  -> (y, o_save [G, ntok, 80], lse [G, ntok, 8]); slice g is what attn_bwd_ex takes for group g."""
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(planes, torch.uint8, "planes")
+    y = out if out is not None else torch.empty_like(x)
+    ntok, G = x.numel() // d, heads // 8
+    o_save = lse = None
+    if save:
+        o_save = torch.empty((G, ntok, 8 * dim_head), dtype=torch.float32, device=x.device)
+        lse = torch.empty((G, ntok, 8), dtype=torch.float32, device=x.device)
+    drop_p, drop_seed = _drop_args(params, dropout)
+    lib.call("rat_attn_fwd_groups", _p(x), _p(res), _p(y), _p(o_save), _p(lse), ntok, ctypes.byref(params), _p(planes),
+             ctypes.byref(seqmap), d, heads, dim_head, float(softmax_scale), float(out_scale), eps, drop_p, drop_seed, _stream(x))
     return y, o_save, lse
 
 
