@@ -209,11 +209,11 @@ class _HostEvent:
 class KernelTimer:
     """HIP-event timing of C-ABI launches on torch's current stream (the stream the kernels are launched on)."""
 
-    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_attn_fwd_groups", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
+    HEAVY = ("rat_attn_fwd", "rat_attn_bwd", "rat_attn_fwd_ex", "rat_attn_bwd_ex", "rat_attn_fwd_groups", "rat_attn_bwd_groups", "rat_ffn_fwd", "rat_ffn_bwd", "rat_ffn_fwd_res",
              "rat_ffn_bwd_res", "rat_ffn_bwd_res_rows", "rat_attn_core_fwd", "rat_attn_core_bwd", "rat_attn_core_fwd_map", "rat_attn_core_bwd_map",
              "rat_gather_fwd", "rat_gather_bwd", "rat_gather_bwd_sorted")
     ATTN_ARGS = {"rat_attn_fwd": (5, 7), "rat_attn_bwd": (9, 11), "rat_attn_fwd_ex": (6, 8), "rat_attn_bwd_ex": (10, 12),
-                 "rat_attn_fwd_groups": (8, 10)}                                                          # (map, heads)
+                 "rat_attn_fwd_groups": (8, 10), "rat_attn_bwd_groups": (11, 13)}                         # (map, heads)
 
     def __init__(self, lib, everything=False, host_events=False):
         self.lib, self.inner, self.records, self.enabled, self.everything = lib, lib.call, [], False, everything
@@ -787,9 +787,10 @@ def worker(args):
                                         "are HIP-event timings of the same K steps run eagerly right after the timed region" if graph_mode
                                         else ", eager launches"))
         result["config"]["dead_token_pruning"] = bool(can_prune and model.prune_dead_tokens)
-        if spec["num_heads"] > 8 and spec["d"] == 64:
-            result["config"]["wide_heads"] = "one forward launch per layer, head groups looped inside" if getattr(model, "group_loop", False) \
-                else "one forward launch per head group"
+        if spec["num_heads"] > 8 and hasattr(model, "_groups_supported") and model._groups_supported():
+            both = bool(model._groups_supported() & 2)
+            result["config"]["wide_heads"] = ("one %s launch per layer, head groups looped inside" % ("forward and one backward" if both else "forward")
+                                              if getattr(model, "group_loop", False) else "one launch per head group and direction")
         if args.dp_rehearsal:
             result["dp_rehearsal"] = "one rank through the N > 1 code path (RCCL group of one rank, every collective of the step issued)"
         if pruned is not None:

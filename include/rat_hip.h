@@ -197,7 +197,20 @@ int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const flo
  *   place: no permuted copy of the weights) — valid until the weights change; w_host = the layer's full-width parameters.
  * o_save [G][ntok][80], lse_save [G][ntok][8] (or both NULL): group-major, so that slice g is exactly what rat_attn_bwd_ex takes for
  *   a launch on group g; ntok = tokens of x (the slice stride).
- * rat_attn_groups_planes_bytes returns 0 (and rat_attn_groups_split_jobs 0 jobs) for dimensions this form does not serve. */
+ * rat_attn_groups_planes_bytes returns 0 (and rat_attn_groups_split_jobs 0 jobs) for dimensions this form does not serve.
+ *
+ * The same for the shipped Tmall geometry itself (embedding_dim <= 16, dim_head 10, 16 ... 64 heads; exact fp32, any `arith`): the weights are
+ * addressed in place, `planes` is ignored (NULL), and up to 32 heads the BACKWARD is one launch too (rat_attn_bwd_groups): with one
+ * 16-wide column tile the weight-gradient accumulators of four head groups fit the registers that one group needs at embedding_dim 64.
+ * Gradients arrive in the layer's full-width layout (grads_host = [3*heads*dim_head][d], [d][heads*dim_head], [d], [d], [d]); dx = add +
+ * LayerNorm-backward(...) as rat_attn_bwd_ex; workspace: rat_attn_bwd_groups_workspace() bytes (0: not served).
+ * rat_attn_groups_supported: bit 0 = rat_attn_fwd_groups serves these dimensions, bit 1 = rat_attn_bwd_groups does. */
+int rat_attn_groups_supported(int d, int heads, int dim_head);
+size_t rat_attn_bwd_groups_workspace(int d, int heads, int dim_head);
+int rat_attn_bwd_groups(const float* x, const float* dy, const float* add, const float* o_save, const float* lse_save, int64_t ntok,
+                        float* dx, const RatAttnParams* w_host, const RatAttnParams* grads_host, float* workspace, size_t workspace_bytes,
+                        const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale, float out_scale, float ln_eps,
+                        float dropout_p, uint64_t dropout_seed, void* stream);
 size_t rat_attn_groups_planes_bytes(int d, int heads, int dim_head);
 int rat_attn_groups_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes,
                                RatSplitJob* jobs_out /* [4 * heads / 8] */);

@@ -338,6 +338,59 @@ def check_attn_groups(lib, dev, case, mode, res_mode="x", dropout=0.0, seed=7):
     close(t_ln[1].sum(0), wr[1].grad, 1e-4, 1e-4 * scale, "ln_b")
 
 
+def check_attn_groups_small_d(lib, dev, case, mode, res_mode="x", dropout=0.0, seed=9):
+    """rat_attn_fwd_groups / rat_attn_bwd_groups at a small embedding dimension (the shipped Tmall geometry: d = 10, 32 heads x 10):
+    the whole wide-head layer in ONE launch per direction, weights addressed in place.  y, dx and every parameter gradient (delivered
+    in the layer's full-width layout) against float64; the saved O / lse slices bit-identical to an 8-head launch on a contiguous copy of
+    each group's weights (the same arithmetic in the same order)."""
+    B, T, S, d, heads, dh, proj = case
+    assert proj and heads % 8 == 0 and heads > 8 and d <= 16
+    G, ig, I = heads // 8, 8 * dh, heads * dh
+    assert ops.attn_groups_supported(d, heads, dh, lib=lib) == (3 if G <= 4 else 1)
+    assert ops.attn_groups_supported(d, 8, dh, lib=lib) == 0 and ops.attn_groups_planes_bytes(d, heads, dh, lib=lib) == 0
+    rs = np.random.RandomState(seed)
+    x = rnd(rs, B, T, S, d)
+    other = rnd(rs, B, T, S, d)
+    ws = attn_weights(rs, d, heads, dh, proj)
+    dy = rnd(rs, B, T, S, d)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    att = attn_reference(xr, *wr, heads, dh, mode) - xr
+    xd, dyd, od = x.to(dev), dy.to(dev), other.to(dev)
+    drop = (0.0, 0)
+    if dropout > 0:
+        drop = (dropout, 192837465)
+        att = ops.dropout(torch.ones_like(xd), drop[0], drop[1], lib=lib).cpu().double() * att
+    ref = att + (xr if res_mode == "x" else other.double())
+    ref.backward(dy.double())
+    wd = [w.to(dev) for w in ws]
+    params = ops.attn_params(*wd)
+    smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
+    y, o_save, lse = ops.attn_fwd_groups(xd, xd if res_mode == "x" else od, params, None, smap, d, heads, dh, save=True, dropout=drop, lib=lib)
+    close(y, ref, 2e-5, 2e-5, "y")
+    wq = wd[2].view(3, G, ig, d).permute(1, 0, 2, 3).contiguous()
+    wo = wd[3].view(d, G, ig).permute(1, 0, 2).contiguous()
+    for g in range(G):
+        p_g = ops.attn_params(wd[0], wd[1], wq[g].view(3 * ig, d), wo[g], wd[4])
+        _, o_g, l_g = ops.attn_fwd_ex(xd, None, p_g, smap, d, 8, dh, save=True, lib=lib)
+        assert torch.equal(o_g, o_save[g]) and torch.equal(l_g, lse[g]), ("saved O / lse of group", g)
+    if G > 4:
+        return
+    gs = [torch.full_like(w, 7.0) for w in wd]                   # (overwritten, not accumulated)
+    if res_mode == "x":
+        dx, _ = ops.attn_bwd_groups(xd, dyd, dyd, o_save, lse, params, ops.attn_params(*gs), smap, d, heads, dh, dropout=drop, lib=lib)
+        want = xr.grad
+    else:                                                        # dx = add + ..., in place over `add`
+        add = rnd(rs, B, T, S, d)
+        buf = add.clone().to(dev)
+        dx, _ = ops.attn_bwd_groups(xd, dyd, buf, o_save, lse, params, ops.attn_params(*gs), smap, d, heads, dh, out=buf, dropout=drop, lib=lib)
+        want = xr.grad + add.double()
+    scale = max(1.0, (B * T * S) ** 0.5 / 4)
+    close(dx, want, 1e-4, 1e-4, "dx")
+    for name, g_, w_ in zip(["ln_g", "ln_b", "w_qkv", "w_out", "b_out"], gs, wr):
+        close(g_, w_.grad, 1e-4, 1e-4 * scale, name)
+
+
 def check_attn_core(lib, dev, nseq, L, heads, dh, softmax_scale=None):
     """rat_attn_core_fwd / bwd against float64 softmax attention on random projected rows."""
     rs = np.random.RandomState(17)

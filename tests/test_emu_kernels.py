@@ -158,6 +158,14 @@ def test_attn_wide_heads_group_loop(emu, case, mode, res_mode, dropout, two_bloc
     kc.check_attn_groups(emu, "cpu", case, mode, res_mode=res_mode, dropout=dropout)
 
 
+@pytest.mark.parametrize("case,mode,res_mode,dropout", [pytest.param((2, 3, 5, 10, 32, 10, True), "intra", "x", 0.0, id="tmall_G4_intra"),
+                                                        pytest.param((1, 4, 3, 10, 16, 10, True), "cross", "other", 0.25, id="G2_cross_dropout"),
+                                                        twin((1, 3, 2, 16, 24, 10, True), "intra", "x", 0.0, id="G3_d16")])
+def test_attn_wide_heads_small_d_one_launch_per_direction(emu, case, mode, res_mode, dropout, two_blocks):
+    """attn_fwd_wide_kernel / attn_bwd_wide_kernel: the shipped Tmall head geometry (32 x 10 at d = 10) with the head groups looped inside"""
+    kc.check_attn_groups_small_d(emu, "cpu", case, mode, res_mode=res_mode, dropout=dropout)
+
+
 ATTN_EX_CASES = [  # (B, T, S, d, heads, dh, project_out), mode, residual mode, out_scale, softmax_scale
     ((2, 3, 4, 8, 1, 8, True), "intra", "none", 0.5, 0.5),
     ((2, 3, 4, 8, 1, 8, True), "cross", "acc", 0.5, 0.5),

@@ -79,6 +79,25 @@ def test_two_training_steps(name):
     mc.check_training(name, gpu=-1)
 
 
+def test_shipped_tmall_heads_one_launch_per_layer_and_direction(monkeypatch):
+    """tmall_real_heads (32 heads x 10 at d = 10, golden vectors from the real reference): every attention layer runs as ONE
+    rat_attn_fwd_groups and ONE rat_attn_bwd_groups launch (head groups looped inside a chunk, weights in place, gradients straight into
+    the full-width tensors) — and with `group_loop = False` as four 8-head launches per direction: the same golden vectors either way."""
+    from rat_amd import models, ops
+    calls = {"fwd": 0, "bwd": 0}
+    fwd, bwd = ops.attn_fwd_groups, ops.attn_bwd_groups
+    monkeypatch.setattr(ops, "attn_fwd_groups", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), fwd(*a, **k))[1])
+    monkeypatch.setattr(ops, "attn_bwd_groups", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), bwd(*a, **k))[1])
+    mc.check_eval("tmall_real_heads", gpu=-1)
+    assert calls == {"fwd": 4, "bwd": 0}                          # depth 2 x (intra, cross)
+    mc.check_training("tmall_real_heads", gpu=-1)
+    assert calls["bwd"] == 2 * 4 and calls["fwd"] == 4 + 2 * 4 + 4
+    monkeypatch.setattr(models.RAT_m2, "group_loop", False)
+    n = dict(calls)
+    mc.check_eval("tmall_real_heads", gpu=-1)
+    assert calls == n
+
+
 def test_dropout_training_is_consistent():
     """emb_dropout / net_dropout / attention dropout > 0: masks are counter-based functions of per-layer seed words that live on
     the device (rat_dropout_seeds: base seed from torch's generator once, a device counter per training forward), so (a) the
@@ -134,10 +153,9 @@ def test_dropout_training_is_consistent():
 
 
 def test_wide_heads_select_the_composed_attention_path():
-    """32 heads x 10 (the shipped Tmall config) does not fit the fused attention kernel; the model-level parity of that geometry
-    (golden case tmall_real_heads) runs on the GPU (tests/test_gpu_model.py) — under the one-OS-thread-per-lane emulator its
-    ~1000 work-groups per launch take a quarter of an hour.  The composed path itself is emulated at kernel level
-    (tests/test_emu_kernels.py::test_attn_core_strided) and at model level by test_m2_composed_attention_path."""
+    """32 heads x 10 (the shipped Tmall config) does not fit the fused attention kernel: it runs in head groups
+    (test_shipped_tmall_heads_one_launch_per_layer_and_direction); sequences beyond 64 tokens take the composed path, emulated at kernel
+    level (tests/test_emu_kernels.py::test_attn_core_strided) and at model level by test_m2_composed_attention_path."""
     import rat_amd._lib as L
     from rat_amd import ops
     assert not ops.attn_fused_supported(10, 32, 10, 9, lib=L._default)       # real Tmall heads

@@ -77,6 +77,10 @@ _SIGNATURES = {
     "rat_attn_groups_split_jobs": (c_int, [POINTER(RatAttnParams), c_int, c_int, c_int, _P, POINTER(RatSplitJob)]),
     "rat_attn_fwd_groups": (c_int, [_P, _P, _P, _P, _P, c_int64, POINTER(RatAttnParams), _P, POINTER(RatSeqMap), c_int, c_int, c_int,
                                     c_float, c_float, c_float, c_float, ctypes.c_uint64, _P]),
+    "rat_attn_groups_supported": (c_int, [c_int, c_int, c_int]),
+    "rat_attn_bwd_groups_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "rat_attn_bwd_groups": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, POINTER(RatAttnParams), POINTER(RatAttnParams), _P, c_size_t,
+                                    POINTER(RatSeqMap), c_int, c_int, c_int, c_float, c_float, c_float, c_float, ctypes.c_uint64, _P]),
     "rat_ffn_planes_bytes": (c_size_t, [c_int, c_int]),
     "rat_ffn_split_jobs": (c_int, [_P, _P, c_int, c_int, _P, POINTER(RatSplitJob)]),
     "rat_split_weights_batch": (c_int, [POINTER(RatSplitJob), c_int, _P]),

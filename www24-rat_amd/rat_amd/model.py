@@ -351,6 +351,14 @@ class RAT_m2(BaseModel):
             self._fused_cache[key] = hit
         return hit
 
+    def _groups_supported(self):
+        """rat_attn_groups_supported for this model's head geometry (bit 0: one-launch forward, bit 1: one-launch backward)"""
+        v = self.__dict__.get("_groups_sup")
+        if v is None:
+            c = self._cfg
+            v = self._groups_sup = ops.attn_groups_supported(c["d"], c["heads"], c["dh"], lib=self._lib)
+        return v
+
     def _attn_is_fused(self, smap):
         return self._attn_mode(smap)[0] == "fused"
 
@@ -385,10 +393,13 @@ class RAT_m2(BaseModel):
             if desc[0][3] is None:
                 raise NotImplementedError("grouped attention needs an output projection")
             gplanes = getattr(desc[1], "gplanes", None)
-            if gplanes is not None and per == 8 and self.arith == "bf16x3" and self.group_loop:
+            sup = self._groups_supported()
+            if per == 8 and self.group_loop and ((gplanes is not None and self.arith == "bf16x3") if d == 64 else bool(sup & 1)):
                 # ONE launch: LayerNorm / x / residual once per chunk, the head groups looped over inside it (rat_attn_fwd_groups);
-                # o, l are group-major, slice g is what the backward's launch on group g reads
-                y, o, l = ops.attn_fwd_groups(x, x, desc[1], gplanes, smap, d, heads, dh, save=save, out=out, dropout=drop, lib=lib)
+                # o, l are group-major, slice g is what the backward's launch on group g reads.  d = 64: bf16x3 group planes; small d
+                # (the shipped Tmall geometry): exact fp32, weights in place, and the backward is one launch too
+                y, o, l = ops.attn_fwd_groups(x, x, desc[1], gplanes if d == 64 else None, smap, d, heads, dh, save=save, out=out,
+                                              dropout=drop, lib=lib)
                 return y, (("loop", o, l, drop) if save else None)
             y, kept = None, []
             for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(desc[0], per)):
@@ -428,6 +439,14 @@ class RAT_m2(BaseModel):
                                  dropout=att[2], out=out, lib=lib)
             return dx
         assert out is None or mode == "grouped", "a caller-provided gradient grid is wired for the fused and the grouped kernels only"
+        if mode == "grouped" and att[0] == "loop" and (self._groups_supported() & 2):
+            # small embedding dimension: the whole wide-head backward in one launch, gradients straight into the full-width tensors
+            _, o_all, l_all, drop = att
+            ws = self._workspace("attn_groups", lib.size("rat_attn_bwd_groups_workspace", d, heads, dh))
+            grads = ops.attn_params(*[G(n) for n in names])
+            dx, _ = ops.attn_bwd_groups(x_in, dy, dy, o_all, l_all, desc[1], grads, smap, d, heads, dh, workspace=ws, out=out,
+                                        dropout=drop, lib=lib)
+            return dx
         if mode == "grouped":
             groups, ig = heads // per, per * dh
             ws = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, per, dh))

@@ -352,12 +352,36 @@ def attn_fwd_ex(x, res, params, seqmap, d, heads, dim_head, softmax_scale=0.0, o
     return y, o_save, lse
 
 
+def attn_groups_supported(d, heads, dim_head, lib=None):
+    """bit 0: attn_fwd_groups serves these dimensions (d = 64 on bf16x3 planes, or d <= 16 in place); bit 1: attn_bwd_groups does too"""
+    return int((lib or get_lib()).size("rat_attn_groups_supported", int(d), int(heads), int(dim_head)))
+
+
+def attn_bwd_groups(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, eps=1e-5,
+                    workspace=None, out=None, dropout=(0.0, 0), lib=None):
+    """Backward of attn_fwd_groups in ONE launch (small embedding dimensions): dx = add + LayerNorm-backward(...); `grads` receives the
+    gradients in the layer's full-width layout."""
+    lib = lib or get_lib()
+    _chk(x, name="x"), _chk(dy, name="dy"), _chk(o_save, name="o_save"), _chk(lse, name="lse")
+    need = lib.size("rat_attn_bwd_groups_workspace", d, heads, dim_head)
+    if need == 0:
+        raise ValueError("attn_bwd_groups does not serve d=%d heads=%d dim_head=%d" % (d, heads, dim_head))
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    dx = out if out is not None else torch.empty_like(x)
+    drop_p, drop_seed = _drop_args(params, dropout)
+    lib.call("rat_attn_bwd_groups", _p(x), _p(dy), _p(add), _p(o_save), _p(lse), x.numel() // d, _p(dx), ctypes.byref(params),
+             ctypes.byref(grads), _p(workspace), workspace.numel() * 4, ctypes.byref(seqmap), d, heads, dim_head, float(softmax_scale),
+             float(out_scale), eps, drop_p, drop_seed, _stream(x))
+    return dx, workspace
+
+
 def attn_fwd_groups(x, res, params, planes, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, save=False, eps=1e-5, out=None,
                     dropout=(0.0, 0), lib=None):
     """Wide heads (heads = G x 8) in ONE launch: y = out_scale * Dropout(to_out(attention(LayerNorm(x)))) + res, the head groups looped
     over inside each chunk.  -> (y, o_save [G, ntok, 80], lse [G, ntok, 8]); slice g is what attn_bwd_ex takes for group g."""
     lib = lib or get_lib()
-    _chk(x, name="x"), _chk(planes, torch.uint8, "planes")
+    _chk(x, name="x"), _chk(planes, torch.uint8, "planes")                    # planes: None at small embedding dimensions
     y = out if out is not None else torch.empty_like(x)
     ntok, G = x.numel() // d, heads // 8
     o_save = lse = None
