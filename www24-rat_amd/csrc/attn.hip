@@ -224,6 +224,79 @@ struct RowFetch {
     }
 };
 
+// The same idea for the generic kernels' instantiations with compile-time geometry (GD = embedding_dim, GI = heads x dim_head, GH =
+// heads: the shipped MovieLens shape 10 / 20 / 2, BASELINE configs[0] 16 / 20 / 2): the chunk's x, dy, O and lse are fetched as 8-byte
+// pieces, every request issued before the first LDS store — ONE memory round trip instead of one per trip of four run-time loops
+// (x 2, dy 2, O 3, lse 1 at d = 10).  Needs 8-byte aligned arrays (checked by the caller, a uniform branch).
+template <int GD, int GI, int GH>
+struct SmallFetch {
+    static constexpr int PX = GD / 2, NX = (ATT_ROWS * PX + ATT_THREADS - 1) / ATT_THREADS;
+    static constexpr int PO = GI / 2, NO = (ATT_ROWS * PO + ATT_THREADS - 1) / ATT_THREADS;
+    static constexpr int NL = (ATT_ROWS * GH + ATT_THREADS - 1) / ATT_THREADS;
+    float2 x[NX], dy[NX], o[NO];
+    float l[NL];
+    static __device__ __forceinline__ float2 ld2(const float* p, bool ok) {
+        return ok ? *reinterpret_cast<const float2*>(p) : make_float2(0.f, 0.f);
+    }
+    __device__ __forceinline__ void issue(const float* xsrc, const float* dysrc, const float* osrc, const float* lsrc, const int64_t* rowtok) {
+        int64_t tx[NX], to[NO], tl[NL];
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            tx[it] = e < ATT_ROWS * PX ? rowtok[e / PX] : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < NO; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            to[it] = (osrc != nullptr && e < ATT_ROWS * PO) ? rowtok[e / PO] : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            tl[it] = (lsrc != nullptr && e < ATT_ROWS * GH) ? rowtok[e / GH] : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            x[it] = ld2(xsrc + tx[it] * GD + 2 * (e % PX), tx[it] >= 0);
+            dy[it] = ld2(dysrc + tx[it] * GD + 2 * (e % PX), dysrc != nullptr && tx[it] >= 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NO; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            o[it] = ld2(osrc + to[it] * GI + 2 * (e % PO), to[it] >= 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            l[it] = tl[it] >= 0 ? lsrc[tl[it] * GH + e % GH] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void stash(float* xs, float* dys, float* ob, float* lses, int ldx, int ldt, float dymul) const {
+#pragma unroll
+        for (int it = 0; it < NX; ++it) {
+            const int e = threadIdx.x + ATT_THREADS * it;
+            if (e < ATT_ROWS * PX) {
+                *reinterpret_cast<float2*>(xs + (size_t)(e / PX) * ldx + 2 * (e % PX)) = x[it];
+                if (dys != nullptr) *reinterpret_cast<float2*>(dys + (size_t)(e / PX) * ldx + 2 * (e % PX)) = make_float2(dy[it].x * dymul, dy[it].y * dymul);
+            }
+        }
+        if (ob != nullptr) {
+#pragma unroll
+            for (int it = 0; it < NO; ++it) {
+                const int e = threadIdx.x + ATT_THREADS * it;
+                if (e < ATT_ROWS * PO) *reinterpret_cast<float2*>(ob + (size_t)(e / PO) * ldt + 2 * (e % PO)) = o[it];
+            }
+#pragma unroll
+            for (int it = 0; it < NL; ++it) {
+                const int e = threadIdx.x + ATT_THREADS * it;
+                if (e < ATT_ROWS * GH) lses[e] = l[it];
+            }
+        }
+    }
+};
+__device__ __forceinline__ bool aligned8_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
 // Warm L2 with the NEXT chunk's rows: every thread touches one dword of one 128-byte line (64 rows x `bytes` per
 // source).  Issued at the start of a phase that performs no other global loads, so the HBM round trip hides behind it
 // and the next iteration's tile loads hit L2.  Returns the touched value; the caller keeps it alive until loop end.
@@ -456,6 +529,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
             RowFetch<FAST ? TD : 4> fx;
             fx.issue(a.x, rowtok);
             fx.stash(xs, ldx);
+        } else if (GD > 0 && GH > 0 && GD % 2 == 0 && TDH > 0 && aligned8_dev(a.x)) {
+            SmallFetch<(GD > 0 ? GD : 2), (GH > 0 && TDH > 0 ? GH * TDH : 2), (GH > 0 ? GH : 1)> sf;
+            sf.issue(a.x, nullptr, nullptr, nullptr, rowtok);
+            sf.stash(xs, nullptr, nullptr, nullptr, ldx, 0, 1.0f);
         } else {
             load_rows(xs, ldx, a.x, rowtok, D, a.vec_x != 0);
         }
@@ -672,11 +749,18 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 __syncthreads();
                 load_rows(dys, ldx, a.dy, rowtok, D, false, a.out_scale, &a.drop);
             }
+        } else if (GD > 0 && GH > 0 && GD % 2 == 0 && TDH > 0 && (!EX || a.drop.threshold == 0) && aligned8_dev(a.x) && aligned8_dev(a.dy) &&
+                   aligned8_dev(a.o_save)) {
+            SmallFetch<(GD > 0 ? GD : 2), (GH > 0 && TDH > 0 ? GH * TDH : 2), (GH > 0 ? GH : 1)> sf;
+            sf.issue(a.x, a.dy, a.o_save, a.lse_save, rowtok);
+            sf.stash(xs, dys, ob, lses, ldx, ldt, EX ? a.out_scale : 1.0f);
         } else {
             load_rows(xs, ldx, a.x, rowtok, D, a.vec_x != 0);
             load_rows(dys, ldx, a.dy, rowtok, D, a.vec_x != 0, EX ? a.out_scale : 1.0f, EX ? &a.drop : nullptr);
             load_rows(ob, ldt, a.o_save, rowtok, I, (I % 4) == 0 && a.vec_x != 0);
         }
+        if (FAST || !(GD > 0 && GH > 0 && GD % 2 == 0 && TDH > 0 && (!EX || a.drop.threshold == 0) && aligned8_dev(a.x) && aligned8_dev(a.dy) &&
+                      aligned8_dev(a.o_save)))
         for (int e = threadIdx.x; e < ATT_ROWS * H; e += ATT_THREADS) {
             const int64_t tok = rowtok[e / H];
             lses[e] = tok >= 0 ? a.lse_save[tok * H + e % H] : 0.f;
