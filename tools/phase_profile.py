@@ -31,6 +31,9 @@ PHASES = {
     72: ("ffn_bwd_t4 (wave 0; RAT_FFN_BWD=t3: consume + stage | chain | dx partial | barrier 1 | dx store + prefetch | dW | barrier 2)",
          ["split x / dy -> planes", "barrier 1", "h / dh chain + gelu (hidden tile 0)", "barrier 2", "prefetch issue + dx gemm + store", "dW1, dW2",
           "barrier 3"]),
+    84: ("attn_bwd wide heads, small d (attn_bwd_wide_kernel)",
+         ["chunk: x, dy, LayerNorm", "group: O, lse, weights -> LDS", "QKV, dO, dW_out GEMMs", "pass 1 (dQ)", "pass 2 (dK, dV)", "dQ copy",
+          "d(LN out) partials + dW_qkv", "partials -> registers", "chunk: LayerNorm backward + store"]),
     60: ("attn_bwd bf16x3", ["loads, LN, planes", "QKV gemm (wave 0)", "dO gemm (wave 0)", "dW_out + barrier", "pass1 (dQ)", "pass2 (dK,dV)",
                              "dQKV -> planes", "dXn gemm (wave 0)", "dW_qkv + barrier", "LN bwd + store"]),
 }

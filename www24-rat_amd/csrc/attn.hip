@@ -1483,6 +1483,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
         map_rows(a, blockIdx.x, rowtok0, nsq0, rows0);
     }
     __syncthreads();
+    RAT_PROF_DECL
     int parity = 0;
     for (int64_t chunk = blockIdx.x; chunk < a.nchunks; chunk += gridDim.x, parity ^= 1) {
         const int64_t* rowtok = rowtok0 + parity * ATT_ROWS;
@@ -1521,6 +1522,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
 #pragma unroll
         for (int k = 0; k < WG_COLS; ++k) gsum[k] = 0.f;
         float pf = 0.f;
+        RAT_PROF_MARK(0);
         for (int grp = 0; grp < G; ++grp) {
             const float* const o_g = a.o_save + (int64_t)grp * a.group_tok * WG_I;
             const float* const lse_g = a.lse_save + (int64_t)grp * a.group_tok * WG_H;
@@ -1538,6 +1540,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
                 }
             }
             __syncthreads();                                     // (also: LayerNorm of xs, the dy tile — first group)
+            RAT_PROF_MARK(1);
             // (1) recompute Q|K|V   (2) dO = dy W_out[:, group]   (3) dW_out^T[group] += O^T dy
             {
                 const RatLdsRows A{xs, WG_LDX};
@@ -1567,6 +1570,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
                 }
             }
             __syncthreads();
+            RAT_PROF_MARK(2);
             // (4) attention backward on the VALU: attn_bwd_kernel's two passes at compile-time dim_head 10
             typedef HeadVec<WG_DH> HV;
             const int ntasks = nsq * WG_H * L;
@@ -1610,6 +1614,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
                 dq.store(op, WG_DH, a.scale);
             }
             __syncthreads();
+            RAT_PROF_MARK(3);
             for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
                 const int j = task % L;
                 const int h = (task / L) % WG_H;
@@ -1636,11 +1641,13 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
                 dv.store(kp + WG_I, WG_DH, 1.0f);
             }
             __syncthreads();
+            RAT_PROF_MARK(4);
             for (int e = threadIdx.x; e < rows * WG_I; e += ATT_THREADS) {     // dQ (in ob) -> the Q columns: qkv = d[Q|K|V]
                 const int r = e / WG_I, c = e - r * WG_I;
                 qkv[(size_t)r * WG_LDQ + c] = ob[(size_t)r * WG_LDT + c];
             }
             __syncthreads();
+            RAT_PROF_MARK(5);
             // (5) d(LN out) partials = dQKV W_qkv[group]: ONE column tile, the contraction (15 k-blocks) split four ways over the waves
             //     (wave = (row-tile pair w & 1, K part w >> 1)); the partial tiles land side by side in dob / ob (dead now)
             {
@@ -1670,6 +1677,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
                 }
             }
             __syncthreads();
+            RAT_PROF_MARK(6);
             {   // this thread's columns of the four partial tiles -> the running sum over the groups
                 const int r = threadIdx.x >> 3;
 #pragma unroll
@@ -1681,6 +1689,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
                 }
             }
             __syncthreads();                                     // (the next group's O overwrites ob)
+            RAT_PROF_MARK(7);
         }
         // ---- once per chunk: LayerNorm backward + the added gradient
         {
@@ -1719,7 +1728,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
 #ifndef RAT_EMU
         asm volatile("" ::"v"(pf));
 #endif
+        RAT_PROF_MARK(8);
     }
+    RAT_PROF_FLUSH(a.prof, 84);
 
     // ---- this work-group's parameter-gradient slab in the layer's FULL layout: [dW_qkv [3 I][d] | dW_out [d][I] | db_out | dgamma | dbeta]
     float* slab = a.slabs + (int64_t)blockIdx.x * a.slab_stride;
