@@ -159,7 +159,8 @@ def test_attn_ex_fwd_bwd(lib, case, mode, res_mode, out_scale, softmax_scale):
     kc.check_attn_ex(lib, "cuda", case, mode, res_mode, out_scale, softmax_scale)
 
 
-@pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (100000, 64, 128), (5000, 40, 80)])
+@pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (100000, 64, 128), (5000, 40, 80),
+                                           (20011, 10, 40), (20011, 10, 20)])          # (the shipped d = 10 geometries: weights in LDS, one-sweep loads)
 def test_ffn_fwd_bwd(lib, ntok, d, hidden):
     kc.check_ffn(lib, "cuda", ntok, d, hidden)
 

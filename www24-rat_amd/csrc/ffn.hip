@@ -98,13 +98,14 @@ __device__ __forceinline__ void ffn_zero_cols(float* tile, int ld, int c0) {
 }
 
 // hs[rows][0:H] = xs W1^T + b1 ; optionally gs = gelu(hs)   (MODE 0: hs <- gelu(h) only; MODE 1: hs <- gelu'(h), gs <- gelu(h))
-template <int TD, int MODE>
-__device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
-                                           int mt_valid, int rows, int64_t tok0 = 0) {
+// MT: row tiles per (wave) task — FFN_MT = one task per column tile (the wide shapes); 1 = one task per 16 x 16 tile, for hidden widths of
+// two or three column tiles, where FFN_MT leaves most waves without a task and two or three waves with all the GELU evaluations
+template <int TD, int MODE, int MT, class BW>
+__device__ __forceinline__ void ffn_hidden_on(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
+                                              int mt_valid, int rows, int64_t tok0, const BW& Bw) {
     constexpr bool FAST = TD > 0;
     const RatLdsRows A{xs, g.ldx};
-    const RatGlobalWnkT<!FAST> Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
-    rat_gemm_phase<FAST, FFN_MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+    rat_gemm_phase<FAST, MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
         const int col = rat_acc_col(nt);
         if (FAST || col < g.H) {
             const float bias = a.b1[col];
@@ -134,6 +135,46 @@ __device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, c
     });
 }
 
+template <int TD, int MODE>
+__device__ __forceinline__ void ffn_hidden(const FfnArgs& a, const FfnGeom& g, const float* xs, float* hs, float* gs,
+                                           int mt_valid, int rows, int64_t tok0 = 0) {
+    const RatGlobalWnkT<!(TD > 0)> Bw{a.w1, g.H, g.D, g.D, a.vec_w1 != 0};
+    ffn_hidden_on<TD, MODE, FFN_MT>(a, g, xs, hs, gs, mt_valid, rows, tok0, Bw);
+}
+
+// ---- the shipped d = 10 geometries (MovieLens hidden 40, Tmall hidden 20), round 5.  A chunk of these kernels is a chain of four or five
+// phases of a few MFMAs each; what they waited for was (a) their weight fragments, fetched from L2 per 16 x 16 tile, (b) run-time load loops
+// (load -> wait -> LDS store per trip) and (c) two or three waves doing a phase's whole epilogue while the others idle.  SMALL = d 10:
+//   * both weight matrices are copied to LDS once per work-group: w1s [H16][12] (row = hidden unit, the 10 weights of that unit; the fourth
+//     k-quad of a fragment reads the next row's first floats — finite, and multiplied by the zero padding columns of the activation tile),
+//     w2s [16][H16 + 4] (row = output feature, rows >= d zero);
+//   * a full chunk's 64 rows x 10 floats are contiguous: 160 aligned 16-byte loads (x and dy in one sweep) instead of 640 scalar ones in loops;
+//   * one GEMM task per 16 x 16 tile (MT = 1): every wave gets a task.
+constexpr int FFN_SMALL_LD1 = 12;
+constexpr int ffn_small_w_floats(int hidden) { return ((hidden + 15) / 16 * 16) * FFN_SMALL_LD1 + 16 + 16 * ((hidden + 15) / 16 * 16 + 4); }
+__device__ __forceinline__ void ffn_small_stage_weights(const FfnArgs& a, int D, int H, int H16, float* w1s, float* w2s) {
+    const int total = ffn_small_w_floats(H);
+    for (int e = threadIdx.x; e < total; e += FFN_THREADS) w1s[e] = 0.f;          // (w2s follows w1s)
+    __syncthreads();
+    for (int e = threadIdx.x; e < H * D; e += FFN_THREADS) w1s[(e / D) * FFN_SMALL_LD1 + e % D] = a.w1[e];
+    for (int e = threadIdx.x; e < D * H; e += FFN_THREADS) w2s[(e / H) * (H16 + 4) + e % H] = a.w2[e];
+}
+// the chunk's contiguous 64 x 10 floats as 160 16-byte pieces (threads < 160); piece e covers flat elements 4 e ... 4 e + 3
+__device__ __forceinline__ float4 ffn_small_piece(const float* src, int64_t tok0) {
+    return (int)threadIdx.x < FFN_ROWS * 10 / 4 ? *reinterpret_cast<const float4*>(src + tok0 * 10 + 4 * threadIdx.x) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void ffn_small_stash(float* tile, int ld, const float4& v) {
+    if ((int)threadIdx.x < FFN_ROWS * 10 / 4) {
+        const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * threadIdx.x + j, r = f / 10;
+            tile[(size_t)r * ld + (f - 10 * r)] = e4[j];
+        }
+    }
+}
+__device__ __forceinline__ bool ffn_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // GD / GHID: embedding_dim / hidden width of a generic (TD = 0) instantiation as compile-time constants (0 = run-time): the shipped
 // d = 10 configs (MovieLens hidden 40, Tmall hidden 20) — every LDS stride and loop bound folds, the SGPR spills of the run-time form go
 template <int TD, int GD = 0, int GHID = 0>
@@ -144,6 +185,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
     float* xs = reinterpret_cast<float*>(smem);
     float* hs = xs + (size_t)FFN_ROWS * g.ldx;
     float* ys = hs + (size_t)FFN_ROWS * g.ldh;                  // [64][ldx] output staging (whole-row coalesced stores)
+    constexpr bool SMALL = !FAST && GD == 10 && GHID > 0 && GHID <= 64;
+    float* const w1s = ys + (size_t)FFN_ROWS * g.ldx;           // SMALL: the two weight matrices (ffn_small_stage_weights)
+    float* const w2s = w1s + g.H16 * FFN_SMALL_LD1 + 16;
+    if (SMALL) ffn_small_stage_weights(a, g.D, g.H, g.H16, w1s, w2s);
     ffn_zero_cols(xs, g.ldx, g.D);
     ffn_zero_cols(hs, g.ldh, g.H);
     __syncthreads();
@@ -152,10 +197,12 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         const int64_t tok0 = chunk * FFN_ROWS;
         const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
         const int mt_valid = (rows + 15) / 16;
-        ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, FAST || a.vec_x != 0);
+        if (SMALL && rows == FFN_ROWS && ffn_aligned16(a.x)) ffn_small_stash(xs, g.ldx, ffn_small_piece(a.x, tok0));
+        else ffn_load(xs, g.ldx, a.x, tok0, rows, g.D, FAST || a.vec_x != 0);
         __syncthreads();
         RAT_PROF_MARK(0);
-        ffn_hidden<TD, 0>(a, g, xs, hs, nullptr, mt_valid, rows, tok0);
+        if (SMALL) ffn_hidden_on<TD, 0, 1>(a, g, xs, hs, nullptr, mt_valid, rows, tok0, RatLdsRows{w1s, FFN_SMALL_LD1});
+        else ffn_hidden<TD, 0>(a, g, xs, hs, nullptr, mt_valid, rows, tok0);
         __syncthreads();
         float pf = 0.f;
         {   // touch one dword per 128-byte line of the NEXT chunk's x rows: they travel HBM -> L2 behind the second GEMM
@@ -167,8 +214,7 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
         // y = gelu(h) W2^T + b2 + x
         {
             const RatLdsRows A{hs, g.ldh};
-            const RatGlobalWnkT<!FAST> Bw{a.w2, g.D, g.H, g.H, a.vec_w2 != 0};
-            rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto y_epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < g.D) {
                     const float bias = a.b2[col];
@@ -182,7 +228,9 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_fwd_kernel(FfnArgs a) {
                         ys[o] = a.drop2.apply(acc[r] + bias, (tok0 + row) * g.D + col) + rv;
                     }
                 }
-            });
+            };
+            if (SMALL) rat_gemm_phase<false, 1, FFN_WAVES, FFN_MT, 0>(A, RatLdsRows{w2s, g.H16 + 4}, mt_valid, g.D16 / 16, g.H16 / 16, y_epi);
+            else rat_gemm_phase<FAST, 2, FFN_WAVES, FFN_MT, 0>(A, RatGlobalWnkT<!FAST>{a.w2, g.D, g.H, g.H, a.vec_w2 != 0}, mt_valid, g.D16 / 16, g.H16 / 16, y_epi);
         }
         __syncthreads();
         ffn_store(a.y, ys, g.ldx, tok0, rows, g.D, FAST || a.vec_x != 0);
@@ -207,6 +255,10 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
     float* dys = xs + (size_t)FFN_ROWS * g.ldx;                 // [64][ldx] dL/dy
     float* hs = dys + (size_t)FFN_ROWS * g.ldx;                 // [64][ldh] h = W1 x + b1
     float* gs = hs + (size_t)FFN_ROWS * g.ldh;                  // [64][ldh] gelu(h), later dh
+    constexpr bool SMALL = GD == 10 && GHID > 0 && GHID <= 64;
+    float* const w1s = gs + (size_t)FFN_ROWS * g.ldh;           // SMALL: the two weight matrices (ffn_small_stage_weights)
+    float* const w2s = w1s + g.H16 * FFN_SMALL_LD1 + 16;
+    if (SMALL) ffn_small_stage_weights(a, g.D, g.H, g.H16, w1s, w2s);
 
     f32x4 acc1[WSLOTS], acc2[WSLOTS];                           // dW1 tiles (H16/16 x D16/16), dW2 tiles (D16/16 x H16/16)
 #pragma unroll
@@ -226,8 +278,14 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         const int64_t tok0 = chunk * FFN_ROWS;
         const int rows = a.ntok - tok0 < FFN_ROWS ? (int)(a.ntok - tok0) : FFN_ROWS;
         const int mt_valid = (rows + 15) / 16;
-        ffn_load(xs, g.ldx, a.x, tok0, rows, D, FAST || a.vec_x != 0);
-        ffn_load(dys, g.ldx, a.dy, tok0, rows, D, FAST || a.vec_x != 0);
+        if (SMALL && rows == FFN_ROWS && ffn_aligned16(a.x) && ffn_aligned16(a.dy)) {
+            const float4 vx = ffn_small_piece(a.x, tok0), vd = ffn_small_piece(a.dy, tok0);
+            ffn_small_stash(xs, g.ldx, vx);
+            ffn_small_stash(dys, g.ldx, vd);
+        } else {
+            ffn_load(xs, g.ldx, a.x, tok0, rows, D, FAST || a.vec_x != 0);
+            ffn_load(dys, g.ldx, a.dy, tok0, rows, D, FAST || a.vec_x != 0);
+        }
         if (a.drop2.threshold != 0) {                           // dy through the output Dropout: every product below takes the masked dy
             __syncthreads();
             for (int e = threadIdx.x; e < rows * D; e += FFN_THREADS) {
@@ -237,7 +295,8 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
         }
         __syncthreads();
         RAT_PROF_MARK(0);
-        ffn_hidden<TD, 1>(a, g, xs, hs, gs, mt_valid, rows, tok0);
+        if (SMALL) ffn_hidden_on<TD, 1, 1>(a, g, xs, hs, gs, mt_valid, rows, tok0, RatLdsRows{w1s, FFN_SMALL_LD1});
+        else ffn_hidden<TD, 1>(a, g, xs, hs, gs, mt_valid, rows, tok0);
         __syncthreads();
         RAT_PROF_MARK(1);
         // dW2 += dy^T gelu(h) ; db2 += colsum(dy)
@@ -278,6 +337,8 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             if (FAST) {
                 const RatGlobalWnkT<false> Bw{a.w2t, H, D, D, true};
                 rat_gemm_phase<true, FFN_MT, FFN_WAVES, FFN_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, dh_epi);
+            } else if (SMALL) {                                  // B[k][n] = W2[k][n] from the LDS copy (rows k >= d, columns n >= H are zero)
+                rat_gemm_phase<false, 1, FFN_WAVES, FFN_MT, 0>(A, RatLdsCols{w2s, g.H16 + 4}, mt_valid, g.H16 / 16, g.D16 / 16, dh_epi);
             } else {
                 const RatGlobalWknT<true> Bw{a.w2, D, H, H};
                 rat_gemm_phase<false, FFN_MT, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.H16 / 16, g.D16 / 16, dh_epi);
@@ -303,6 +364,8 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
             if (FAST) {
                 const RatGlobalWnkT<false> Bw{a.w1t, D, H, H, true};
                 rat_gemm_phase<true, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, dx_epi);
+            } else if (SMALL) {                                  // B[k][n] = W1[k][n] (columns n >= d of the tile: finite, dropped by the epilogue)
+                rat_gemm_phase<false, 1, FFN_WAVES, FFN_MT, 0>(A, RatLdsCols{w1s, FFN_SMALL_LD1}, mt_valid, g.D16 / 16, g.H16 / 16, dx_epi);
             } else {
                 const RatGlobalWknT<true> Bw{a.w1, H, D, D};
                 rat_gemm_phase<false, 2, FFN_WAVES, FFN_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.H16 / 16, dx_epi);
@@ -1647,10 +1710,10 @@ extern "C" int rat_ffn_fwd_res(const float* x, const float* res, float* y, const
     } else if (fast == 16 && hidden == 32) {
         if (xres) RAT_LAUNCH((ffn_fwd_t_kernel<16, 32, true>), tgrid, FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
         else RAT_LAUNCH((ffn_fwd_t_kernel<16, 32, false>), tgrid, FT_THREADS, (FfnTGeom<16, 32>::fwd_smem), stream, a);
-    } else if (d == 10 && hidden == 40) {                       // shipped MovieLens geometry
-        RAT_LAUNCH((ffn_fwd_kernel<0, 10, 40>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
+    } else if (d == 10 && hidden == 40) {                       // shipped MovieLens geometry (+ the LDS copies of the weights)
+        RAT_LAUNCH((ffn_fwd_kernel<0, 10, 40>), (unsigned)blocks, FFN_THREADS, smem + (size_t)ffn_small_w_floats(40) * 4, stream, a);
     } else if (d == 10 && hidden == 20) {                       // shipped Tmall geometry
-        RAT_LAUNCH((ffn_fwd_kernel<0, 10, 20>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
+        RAT_LAUNCH((ffn_fwd_kernel<0, 10, 20>), (unsigned)blocks, FFN_THREADS, smem + (size_t)ffn_small_w_floats(20) * 4, stream, a);
     } else if (d == 16 && hidden == 64) {                       // BASELINE configs[0] (d = 16, scale_dim 4)
         RAT_LAUNCH((ffn_fwd_kernel<0, 16, 64>), (unsigned)blocks, FFN_THREADS, smem, stream, a);
     } else {
@@ -1790,9 +1853,9 @@ static int ffn_bwd_res_launch(const float* x, const float* dy, float* dx, const 
     } else if (fast == 16 && hidden == 32) {
         RAT_LAUNCH((ffn_bwd_t_kernel<16, 32>), blocks, FB_THREADS, (FfnBTGeom<16, 32>::smem), stream, a);
     } else if (d == 10 && hidden == 40) {
-        RAT_LAUNCH((ffn_bwd_kernel<10, 40>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+        RAT_LAUNCH((ffn_bwd_kernel<10, 40>), blocks, FFN_THREADS, g.bwd_smem() + (size_t)ffn_small_w_floats(40) * 4, stream, a);
     } else if (d == 10 && hidden == 20) {
-        RAT_LAUNCH((ffn_bwd_kernel<10, 20>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
+        RAT_LAUNCH((ffn_bwd_kernel<10, 20>), blocks, FFN_THREADS, g.bwd_smem() + (size_t)ffn_small_w_floats(20) * 4, stream, a);
     } else if (d == 16 && hidden == 64) {
         RAT_LAUNCH((ffn_bwd_kernel<16, 64>), blocks, FFN_THREADS, g.bwd_smem(), stream, a);
     } else {
