@@ -483,6 +483,20 @@ __device__ __forceinline__ float head_dot(const V& a, const V& b) {
     return s;
 }
 
+// LDS copies of the two weight matrices for the compile-time-geometry instantiations (d <= 16): wq_s [Q16][20] row = Q|K|V column n, the d
+// weights of that column (rows >= 3 I and columns >= d zero), wo_s [16][I16 + 4] row = output feature (rows >= d zero).  As RatLdsRows they
+// are the B operand of the forward projections, as RatLdsCols of the backward's dO = dy W_out and d(LN out) = dQKV W_qkv.
+constexpr int CT_LDW = 20;
+__host__ __device__ inline size_t ct_weight_floats(const AttnGeom& g) { return (size_t)g.Q16 * CT_LDW + (size_t)16 * (g.I16 + 4); }
+__device__ __forceinline__ void ct_stage_weights(const AttnArgs& a, const AttnGeom& g, float* wq_s, float* wo_s) {
+    const int total = (int)ct_weight_floats(g);
+    for (int e = threadIdx.x; e < total; e += ATT_THREADS) wq_s[e] = 0.f;     // (wo_s follows wq_s)
+    __syncthreads();
+    for (int e = threadIdx.x; e < g.Q3 * g.D; e += ATT_THREADS) wq_s[(e / g.D) * CT_LDW + e % g.D] = a.w_qkv[e];
+    if (a.w_out != nullptr)
+        for (int e = threadIdx.x; e < g.D * g.I; e += ATT_THREADS) wo_s[(e / g.I) * (g.I16 + 4) + e % g.I] = a.w_out[e];
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // EX = false: the plain PreNorm(Attention)(x) + x layer (residual = x, output scale 1) — the _ex constants fold away
 // GC: columns per lane of the 8-lanes-per-row phases in the generic (TD = 0) kernels — 16 serves embedding_dim <= 128; the instantiations
@@ -502,6 +516,15 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
     const int L = a.L, D = g.D, I = g.I, dh = TDH > 0 ? TDH : a.dh;
     const int ldx = g.ldx, ldq = g.ldq;
 
+    // Compile-time geometry (GH, GD: the shipped d = 10 shapes, BASELINE configs[0]): both weight matrices are copied to LDS once per
+    // work-group (ct_stage_weights) and — two heads — every 16 x 16 tile of a projection is a wave's task of its own.  At these sizes a GEMM
+    // phase is a handful of MFMAs: fetching its weight fragments from L2 per tile and leaving half the waves without a task WAS the phase
+    // (same-box A/B: profiles/round5/r5_small_d_ab.txt).
+    constexpr bool CTW = !FAST && GH > 0 && GD > 0 && TDH > 0;
+    constexpr int MTQ = (CTW && GH <= 2) ? 1 : ATT_MT, MTO = (CTW && GH <= 2) ? 1 : 2;
+    float* const wq_s = reinterpret_cast<float*>(rowtok + 2 * ATT_ROWS);      // CTW: [Q16][20] to_qkv.weight, [16][I16 + 4] to_out.weight
+    float* const wo_s = wq_s + (size_t)g.Q16 * CT_LDW;
+    if (CTW) ct_stage_weights(a, g, wq_s, wo_s);
     zero_cols(xs, ldx, D);
     zero_cols(qkv, ldq, g.Q3);
     __syncthreads();
@@ -549,13 +572,14 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         // Q|K|V = LN(x) W_qkv^T  -> qkv[rows][0:3I]
         {
             const RatLdsRows A{xs, ldx};
-            const RatGlobalWnkT<!FAST> Bw{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0};
-            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < g.Q3)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * ldq + col] = acc[r];
-            });
+            };
+            if (CTW) rat_gemm_phase<false, MTQ, ATT_WAVES, ATT_MT, 0>(A, RatLdsRows{wq_s, CT_LDW}, mt_valid, g.Q16 / 16, g.D16 / 16, epi);
+            else rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, RatGlobalWnkT<!FAST>{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0}, mt_valid, g.Q16 / 16, g.D16 / 16, epi);
         }
         __syncthreads();
         RAT_PROF_MARK(1);
@@ -641,15 +665,16 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd_kernel(AttnArgs a) {
         // staged in xs (free since the QKV projection) so that the residual add and the store are whole-row, 16-byte accesses.
         if (a.w_out != nullptr) {
             const RatLdsRows A{qkv, ldq};
-            const RatGlobalWnkT<!FAST> Bw{a.w_out, D, I, I, a.vec_wout != 0};
-            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, Bw, mt_valid, g.D16 / 16, g.I16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < D) {
                     const float bias = a.b_out[col];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xs[(size_t)rat_acc_row(mt, r) * ldx + col] = acc[r] + bias;
                 }
-            });
+            };
+            if (CTW) rat_gemm_phase<false, MTO, ATT_WAVES, ATT_MT, 0>(A, RatLdsRows{wo_s, g.I16 + 4}, mt_valid, g.D16 / 16, g.I16 / 16, epi);
+            else rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, 0>(A, RatGlobalWnkT<!FAST>{a.w_out, D, I, I, a.vec_wout != 0}, mt_valid, g.D16 / 16, g.I16 / 16, epi);
             __syncthreads();
             store_rows_residual(a.y, xs, ldx, EX ? a.res : a.x, rowtok, rows, D, FAST || a.vec_x != 0, EX ? a.out_scale : 1.0f,
                                 EX ? &a.drop : nullptr);
@@ -701,6 +726,11 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
     const int q_tn = g.D16 / 16, q_tiles = (g.Q16 / 16) * q_tn;       // dW_qkv tiles: (3I16/16) x (D16/16)
     const int o_tn = g.D16 / 16, o_tiles = (g.I16 / 16) * o_tn;       // dW_out^T tiles: (I16/16) x (D16/16)
 
+    constexpr bool CTW = !FAST && GH > 0 && GD > 0 && TDH > 0;   // weights in LDS, two heads: one GEMM task per tile (see attn_fwd_kernel)
+    constexpr int MTQ = (CTW && GH <= 2) ? 1 : ATT_MT, MTO = (CTW && GH <= 2) ? 1 : 2;
+    float* const wq_s = reinterpret_cast<float*>(rowtok + 2 * ATT_ROWS);
+    float* const wo_s = wq_s + (size_t)g.Q16 * CT_LDW;
+    if (CTW) ct_stage_weights(a, g, wq_s, wo_s);
     zero_cols(xs, ldx, D);
     zero_cols(dys, ldx, D);
     zero_cols(qkv, ldq, g.Q3);
@@ -779,25 +809,27 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
         // (1) recompute Q|K|V
         {
             const RatLdsRows A{xs, ldx};
-            const RatGlobalWnkT<!FAST> Bw{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0};
-            rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.Q16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < g.Q3)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) qkv[(size_t)rat_acc_row(mt, r) * ldq + col] = acc[r];
-            });
+            };
+            if (CTW) rat_gemm_phase<false, MTQ, ATT_WAVES, ATT_MT, 0>(A, RatLdsRows{wq_s, CT_LDW}, mt_valid, g.Q16 / 16, g.D16 / 16, epi);
+            else rat_gemm_phase<FAST, ATT_MT, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, RatGlobalWnkT<!FAST>{a.w_qkv, g.Q3, D, D, a.vec_wqkv != 0}, mt_valid, g.Q16 / 16, g.D16 / 16, epi);
         }
         RAT_PROF_MARK(3);
         if (has_out) {
             // (2) dO = dy W_out  (dob[rows][0:I])
             const RatLdsRows A{dys, ldx};
-            const RatGlobalWknT<!FAST> Bw{a.w_out, D, I, I};
-            rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, Bw, mt_valid, g.I16 / 16, g.D16 / 16, [&](int mt, int nt, const f32x4& acc) {
+            auto epi = [&](int mt, int nt, const f32x4& acc) {
                 const int col = rat_acc_col(nt);
                 if (FAST || col < I)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dob[(size_t)rat_acc_row(mt, r) * ldt + col] = acc[r];
-            });
+            };
+            if (CTW) rat_gemm_phase<false, MTO, ATT_WAVES, ATT_MT, 0>(A, RatLdsCols{wo_s, g.I16 + 4}, mt_valid, g.I16 / 16, g.D16 / 16, epi);
+            else rat_gemm_phase<FAST, 2, ATT_WAVES, ATT_MT, (FAST ? TD / 16 : 0)>(A, RatGlobalWknT<!FAST>{a.w_out, D, I, I}, mt_valid, g.I16 / 16, g.D16 / 16, epi);
             RAT_PROF_MARK(4);
             // (3) dW_out += dy^T O ; db_out += colsum(dy)
             const RatLdsCols At{ob, ldt};                          // transposed tile grid (I16/16 x D16/16): dW_out^T = O^T dy,
@@ -946,7 +978,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
                 const int w = rat_wave(), mb = w & 1, part = w >> 1;
                 const int kbt = g.Q16 / 16, k0 = part * kbt / 4, k1 = (part + 1) * kbt / 4;
                 f32x4 acc[2] = {rat_zero4(), rat_zero4()};
-                if (k1 > k0) rat_wave_gemm_col<2, 0>(acc, A, Bw, 2 * mb, 0, k1, k0);
+                if (k1 > k0 && CTW) rat_wave_gemm_col<2, 0>(acc, A, RatLdsCols{wq_s, CT_LDW}, 2 * mb, 0, k1, k0);
+                else if (k1 > k0) rat_wave_gemm_col<2, 0>(acc, A, Bw, 2 * mb, 0, k1, k0);
                 float* pt = (part < 2 ? dob : ob) + 16 * (part & 1);
                 const int col = rat_acc_col(0);
 #pragma unroll
@@ -3403,7 +3436,9 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
     a.lse_save = lse_save;
     a.vec_x = (d % 4 == 0) && aligned16(x) && aligned16(y) && aligned16(res);
     const AttnGeom g(d, heads, dim_head);
-    const size_t smem = g.fwd_smem();
+    // (+ the LDS copies of the weights for the instantiations with compile-time geometry: attn_fwd_kernel CTW)
+    const bool ct_shape = dim_head == 10 && ((d == 10 && (heads == 8 || heads == 2)) || (d == 16 && heads == 2));
+    const size_t smem = g.fwd_smem() + (ct_shape ? ct_weight_floats(g) * sizeof(float) : 0);
     const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
     const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() * per_cu ? a.nchunks : rat_max_blocks() * per_cu);
     RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
@@ -3674,7 +3709,8 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
     a.slabs = workspace;
     a.slab_stride = g.slab_floats();
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-    const size_t smem = g.bwd_smem(heads);
+    const bool ct_shape = dim_head == 10 && ((d == 10 && (heads == 8 || heads == 2)) || (d == 16 && heads == 2));
+    const size_t smem = g.bwd_smem(heads) + (ct_shape ? ct_weight_floats(g) * sizeof(float) : 0);     // (attn_bwd_kernel CTW)
     const int fast = fast_dim(a, {x, dy, add, o_save, dx});
     const bool dpad = d != B3_D && b3_dim(d) && heads == fast_heads(dim_head) && aligned16(x) && aligned16(dy) && aligned16(add) &&
                       aligned16(o_save) && aligned16(dx) && aligned16(w_host->w_qkv) && aligned16(w_host->w_out);
