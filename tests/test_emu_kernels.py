@@ -152,7 +152,7 @@ def test_attn_core_strided(emu, B, T, S, heads, dh):
 
 
 @pytest.mark.parametrize("case,mode,res_mode,dropout", [pytest.param((1, 3, 5, 64, 16, 10, True), "intra", "x", 0.0, id="G2_intra"),
-                                                        pytest.param((1, 4, 3, 64, 32, 10, True), "cross", "other", 0.25, id="G4_cross_dropout")])
+                                                        twin((1, 4, 3, 64, 32, 10, True), "cross", "other", 0.25, id="G4_cross_dropout")])
 def test_attn_wide_heads_group_loop(emu, case, mode, res_mode, dropout, two_blocks):
     """rat_attn_fwd_groups (attn_fwd3_kernel<GRP>): every head group of a chunk inside one launch"""
     kc.check_attn_groups(emu, "cpu", case, mode, res_mode=res_mode, dropout=dropout)
