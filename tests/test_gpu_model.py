@@ -234,6 +234,36 @@ def test_wide_heads_forward_group_loop_equals_the_per_group_launches(heads, drop
     mc.check_wide_heads_group_loop(gpu=0, batch=40, topk=6, nfields=7, heads=heads, depth=2, dropout=dropout)
 
 
+@pytest.mark.parametrize("variant", ["RAT_m1", "RAT_m0", "RAT_m3"])
+def test_variants_with_the_shipped_tmall_heads(variant):
+    """32 heads x 10 at d = 10 in the other model variants: RAT_m1's transformers run the wide-head layers through the same one-launch
+    forward / backward as RAT_m2 (equal to the per-group launches), RAT_m0's joint sequences take the composed path whatever the head
+    count, RAT_m3's shared-query attention has only the fused form and says so"""
+    import golden_cases as gc
+    case = dict(gc.case_by_name("tmall_real_heads"), name="tm_" + variant, model=variant, batch_norm=False)
+    if variant == "RAT_m3":
+        model = mc.build_model(case, gpu=0, seed=1)
+        mc.load_weights(model, case)
+        model.train()
+        with pytest.raises(NotImplementedError, match="RAT_m3 with num_heads"):
+            model.get_total_loss(tuple(t.to(model.device) for t in mc.batch_of(case)))
+        return
+    out = {}
+    for loop in (True, False):
+        model = mc.build_model(case, gpu=0, seed=1)
+        mc.load_weights(model, case)
+        model.group_loop = loop
+        model.train()
+        model.optimizer.zero_grad()
+        loss = model.get_total_loss(tuple(t.to(model.device) for t in mc.batch_of(case)))
+        loss.backward()
+        out[loop] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    (l1, g1), (l0, g0) = out[True], out[False]
+    assert abs(l1 - l0) < 2e-6 and len(g1) >= 20
+    for k in g1:
+        assert float((g1[k] - g0[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-30) < 1e-4, k
+
+
 def test_grouped_heads_mode_is_selected_for_wide_heads():
     """32 heads x 10: four launches of the fused kernel on 8 heads each (model._attn_mode)"""
     import golden_cases as gc

@@ -1823,6 +1823,11 @@ class RAT_m3(RAT_m2):
         B, T, L, S = dims
         d, H = c["d"], c["hidden"]
         h, dh, sc = self._m3_heads, self._m3_dh, self._m3_scale
+        if not ops.attn_fused_supported(d, h, dh, max(T, S), lib=lib):
+            # (RAT_m2 runs wide heads in groups and long sequences through the composed path; RAT_m3's shared-query attention has only
+            #  the fused form — no shipped config needs more: configs/ holds RAT_m2 experiments only)
+            raise NotImplementedError("RAT_m3 with num_heads * dim_head = %d at embedding_dim %d, sequences of %d tokens: the fused attention "
+                                      "kernels do not serve these dimensions" % (h * dh, d, max(T, S)))
         imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
         last = len(self._blocks) - 1
         for bi, blk in enumerate(self._blocks):
