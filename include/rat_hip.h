@@ -133,7 +133,9 @@ typedef struct RatAttnParams {      /* HOST struct of device pointers; state_dic
 typedef struct RatSplitJob {
     const float* w; /* source matrix, row-major with leading dimension ld                                   */
     void* out;      /* fragment planes of B[k][n] = transpose ? w[k*ld + n] : w[n*ld + k], n < N, k < K       */
-    int32_t N, K, ld, transpose, perm;
+    int32_t N, K, ld, transpose, perm; /* perm: bit 0 = the k order of stacked accumulator tiles (rat_ffn_split_jobs); bits 8-19 `blk`, bits 20-31
+                       * `stride` (ABI v9, 0 = off): the job reads `blk` consecutive ROWS of w out of every `stride` — row i -> (i / blk) * stride +
+                       * i % blk — a head group's Q | K | V rows in place (rat_attn_groups_split_jobs) */
     int32_t reserved; /* 0, or n_valid | k_valid << 16: the matrix has only n_valid of the N rows / k_valid of the K columns the planes
                        * cover (0 = all); the rest is written as zeros.  Filled in by rat_*_split_jobs for layers narrower than the
                        * kernels' tiles (embedding_dim 40 / 48 / 56 inside the 64-wide bf16x3 tiles). */
@@ -213,7 +215,8 @@ int rat_attn_bwd_groups(const float* x, const float* dy, const float* add, const
                         float dropout_p, uint64_t dropout_seed, void* stream);
 size_t rat_attn_groups_planes_bytes(int d, int heads, int dim_head);
 int rat_attn_groups_split_jobs(const RatAttnParams* w_host, int d, int heads, int dim_head, void* planes,
-                               RatSplitJob* jobs_out /* [4 * heads / 8] */);
+                               RatSplitJob* jobs_out /* [4 * heads / 8] */);   /* slice g of `planes` (rat_attn_groups_planes_bytes() / G each) is also a
+                               * valid RatAttnParams.planes for rat_attn_bwd_ex on group g */
 int rat_attn_fwd_groups(const float* x, const float* res, float* y, float* o_save, float* lse_save, int64_t ntok,
                         const RatAttnParams* w_host, const void* planes, const RatSeqMap* map_host, int d, int heads, int dim_head,
                         float softmax_scale, float out_scale, float ln_eps, float dropout_p, uint64_t dropout_seed, void* stream);

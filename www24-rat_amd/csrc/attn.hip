@@ -1857,7 +1857,8 @@ constexpr size_t B3_W_BYTES = B3_W_QKV + B3_W_OUT + B3_W_OUTT + B3_W_QKVT;
 constexpr size_t B3_FWD_LSE = (size_t)3 * B3_XP + (size_t)64 * B3_LDQ * 4 + (size_t)3 * B3_OP + 2 * 64 * 8;   // [64][8] log-sum-exp of the chunk
 constexpr size_t B3_FWD_WOUT = B3_FWD_LSE + (size_t)64 * B3_H * 4;      // the output projection's fragment planes, LDS-resident (36 KB)
 constexpr size_t b3_fwd_smem() { return B3_FWD_WOUT + B3_W_OUT; }
-constexpr size_t B3_GRP_PLANES = B3_W_QKV + B3_W_OUT;                  // rat_attn_fwd_groups: [W_qkv | W_out] fragment planes per head group
+constexpr size_t B3_GRP_PLANES = B3_W_BYTES;                           // rat_attn_fwd_groups: a head group's planes = the full RatAttnParams.planes set
+//                                                                        [W_qkv | W_out^T | W_qkv^T | W_out], so that the backward's launch on the group takes them too
 static_assert(b3_fwd_smem() <= 160 * 1024, "LDS budget (forward)");
 // weight fragment planes held in LDS (same [n tile][K step][plane][lane] x 16 B layout as RatWPlanes): a fragment is three 16-byte
 // LDS reads instead of a round trip to L2.  The forward kernel has 41 KB of LDS to spare, W_out's planes are 36 KB.
@@ -3502,9 +3503,9 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
 }
 
 // ---- wide heads in ONE forward launch (round 5): heads = G x 8, dim_head 10, embedding_dim 64 — BASELINE configs[4], the shipped Tmall
-// config's 32 heads at d = 64.  `planes`: G x [W_qkv | W_out] fragment planes of the groups' weight slices, filled by the jobs of
-// rat_attn_groups_split_jobs (rows g*80.. of the Q, K and V blocks of to_qkv.weight; columns g*80.. of to_out.weight — no permuted copy
-// of the weights is needed).  o_save / lse_save: [G][ntok][80] / [G][ntok][8], group-major, so that every group's slice is what
+// config's 32 heads at d = 64.  `planes`: G x the full plane set [W_qkv | W_out^T | W_qkv^T | W_out] of the groups' weight slices, filled by
+// the jobs of rat_attn_groups_split_jobs (rows g*80.. of the Q, K and V blocks of to_qkv.weight; columns g*80.. of to_out.weight — no
+// permuted copy of the weights is needed); slice g of it is a valid RatAttnParams.planes for rat_attn_bwd_ex on that group.  o_save / lse_save: [G][ntok][80] / [G][ntok][8], group-major, so that every group's slice is what
 // rat_attn_bwd_ex expects for a launch on that group.
 static int b3_groups(int d, int heads, int dim_head) {
     return (d == B3_D && dim_head == B3_DH && heads > B3_H && heads % B3_H == 0 && heads / B3_H <= 8) ? heads / B3_H : 0;
@@ -3529,11 +3530,15 @@ extern "C" int rat_attn_groups_split_jobs(const RatAttnParams* w_host, int d, in
     RAT_REQUIRE(aligned16(planes) && w_host->w_qkv, "planes must be 16-byte aligned");
     const int I = heads * dim_head;
     int n = 0;
-    for (int g = 0; g < G; ++g) {
+    const int rows = (B3_I << 8) | (I << 20);                    // RatSplitJob.perm: the group's Q | K | V rows = 80 out of every I (rat_split_row)
+    for (int g = 0; g < G; ++g) {                                // the four jobs of rat_attn_split_jobs on group g's slices, read in place
         char* ws = static_cast<char*>(planes) + (size_t)g * B3_GRP_PLANES;
-        for (int part = 0; part < 3; ++part)                     // Q, K, V rows of this group: 5 column tiles each, consecutive in the planes
-            jobs_out[n++] = RatSplitJob{w_host->w_qkv + ((size_t)part * I + (size_t)g * B3_I) * d, ws + (size_t)part * (B3_W_QKV / 3), B3_I, d, d, 0, 0, 0};
-        jobs_out[n++] = RatSplitJob{w_host->w_out + (size_t)g * B3_I, ws + B3_W_QKV, B3_D, B3_I, I, 0, 0, 0};
+        const float* wq = w_host->w_qkv + (size_t)g * B3_I * d;
+        const float* wo = w_host->w_out + (size_t)g * B3_I;
+        jobs_out[n++] = RatSplitJob{wq, ws, B3_Q3, d, d, 0, rows, 0};                                              // forward + backward
+        jobs_out[n++] = RatSplitJob{wo, ws + B3_W_QKV, B3_I, d, I, 1, 0, 0};                                       // backward: dO
+        jobs_out[n++] = RatSplitJob{wq, ws + B3_W_QKV + B3_W_OUTT, B3_D, B3_Q3, d, 1, rows, 0};                    // backward: d(LN out)
+        jobs_out[n++] = RatSplitJob{wo, ws + B3_W_QKV + B3_W_OUTT + B3_W_QKVT, B3_D, B3_I, I, 0, 0, 0};            // forward: out-proj
     }
     return n;
 }
@@ -3595,7 +3600,7 @@ extern "C" int rat_attn_fwd_groups(const float* x, const float* res, float* y, f
         a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p), w_host->drop_seed_dev};
     Attn3W W{};
     W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(planes), 2};
-    W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(static_cast<const char*>(planes) + B3_W_QKV), 3};
+    W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(static_cast<const char*>(planes) + B3_W_QKV + B3_W_OUTT + B3_W_QKVT), 3};
     const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
     RAT_LAUNCH((attn_fwd3_kernel<true, false, false, true>), blocks, ATT_THREADS, B3_FWD_WOUT, stream, a, W);
     return rat_check_launch("rat_attn_fwd_groups");
@@ -3745,6 +3750,8 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
             RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())
             RAT_LAUNCH((attn_bwd3_kernel<false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (a.nq >= a.L && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())      // (wide heads: groups 1 ... G - 1 add onto dx, not dy)
+            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_bwd3_kernel<true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);       // (computes every position)
     } else if (!aligned8(o_save)) {                    // run-time dim_head kernel: 4-byte accesses, dim_head <= DH_MAX

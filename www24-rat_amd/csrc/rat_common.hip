@@ -279,6 +279,13 @@ __device__ __forceinline__ void rat_split_bounds(int N, int K, int valid, int& n
     nv = (valid & 0xffff) ? (valid & 0xffff) : N;
     kv = (valid >> 16) ? (valid >> 16) : K;
 }
+// RatSplitJob.perm bits 8 ... 31 (ABI v9): the ROWS of `w` that the job reads are `blk` consecutive rows out of every `stride` — row
+// index i (n without transpose, k with it) -> (i / blk) * stride + i % blk.  That is how a head group's Q | K | V rows (three blocks of 80
+// rows, heads * dim_head rows apart) are read in place from to_qkv.weight even when a 32-wide k step straddles two blocks.
+__device__ __forceinline__ int rat_split_row(int i, int perm) {
+    const int blk = (perm >> 8) & 0xfff, stride = (perm >> 20) & 0xfff;
+    return blk == 0 ? i : (i / blk) * stride + i % blk;
+}
 __global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __restrict__ w, int N, int K, int ld, int transpose, int perm,
                                                                 rat_u4* __restrict__ out, int ntiles, int steps, int valid) {
     int nv, kv;
@@ -292,8 +299,8 @@ __global__ void __launch_bounds__(256) rat_split_weights_kernel(const float* __r
         for (int j = 0; j < 8; ++j) {
             // perm: k slot j of lane group g <-> k = 32 s + 4 g + j (j < 4), 32 s + 16 + 4 g + (j - 4) (j >= 4) — the order in which
             // two stacked 16-row accumulator tiles present their rows as a B fragment (ffn.hip)
-            const int k = 32 * s + (perm ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);
-            v[j] = (n < nv && k < kv) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
+            const int k = 32 * s + ((perm & 1) ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);
+            v[j] = (n < nv && k < kv) ? (transpose ? w[(size_t)rat_split_row(k, perm) * ld + n] : w[(size_t)rat_split_row(n, perm) * ld + k]) : 0.f;
         }
         rat_u4 h, m, l;
         rat_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);
@@ -323,8 +330,8 @@ __global__ void __launch_bounds__(256) rat_split_weights_batch_kernel(RatSplitTa
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = 32 * s + (perm ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);      // as rat_split_weights_kernel
-            v[j] = (n < nv && k < kv) ? (transpose ? w[(size_t)k * ld + n] : w[(size_t)n * ld + k]) : 0.f;
+            const int k = 32 * s + ((perm & 1) ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : 8 * g + j);      // as rat_split_weights_kernel
+            v[j] = (n < nv && k < kv) ? (transpose ? w[(size_t)rat_split_row(k, perm) * ld + n] : w[(size_t)rat_split_row(n, perm) * ld + k]) : 0.f;
         }
         rat_u4 h, m, l;
         rat_split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), h, m, l);

@@ -362,8 +362,10 @@ class RAT_m2(BaseModel):
     def _attn_is_fused(self, smap):
         return self._attn_mode(smap)[0] == "fused"
 
-    def _group_weights(self, names, per):
-        """contiguous per-group copies of the projection weights: rows of Q | K | V and columns of to_out"""
+    def _group_weights(self, names, per, gplanes=None):
+        """contiguous per-group copies of the projection weights: rows of Q | K | V and columns of to_out.  gplanes: the layer's per-group
+        bf16x3 plane sets (rat_attn_groups_split_jobs, refreshed once per step): slice g rides along as RatAttnParams.planes, so that the
+        launch on group g does not split its weights again (three small launches per call)"""
         c = self._cfg
         d, dh, groups = c["d"], c["dh"], c["heads"] // per
         ig = per * dh
@@ -375,7 +377,11 @@ class RAT_m2(BaseModel):
         out = []
         for g in range(groups):
             w_g, wo_g = wq[g].view(3 * ig, d), wo[g]
-            out.append((w_g, wo_g, ops.attn_params(ln_g, ln_b, w_g, wo_g, b_out if g == 0 else zero_bias), zero_bias))
+            pl = None
+            if gplanes is not None and self.arith == "bf16x3":
+                nb = gplanes.numel() // groups
+                pl = gplanes[g * nb:(g + 1) * nb]
+            out.append((w_g, wo_g, ops.attn_params(ln_g, ln_b, w_g, wo_g, b_out if g == 0 else zero_bias, planes=pl), zero_bias))
         return out
 
     def _attn_layer_forward(self, desc, x, smap, save, out=None):
@@ -462,7 +468,7 @@ class RAT_m2(BaseModel):
             if att[0] == "loop":                         # the forward ran as one launch: per-group weight copies are made here
                 _, o_all, l_all, drop = att
                 att = [(w_g, wo_g, params_g, zb, o_all[g], l_all[g], drop)
-                       for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(names, per))]
+                       for g, (w_g, wo_g, params_g, zb) in enumerate(self._group_weights(names, per, getattr(desc[1], "gplanes", None)))]
             for g, (w_g, wo_g, params_g, zb, o, l, drop) in enumerate(att):
                 first = g == 0
                 grads_g = ops.attn_params(t_ln[0, g], t_ln[1, g], t_w[g], t_wo[g], g_bout if first else t_b)
