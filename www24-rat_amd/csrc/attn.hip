@@ -1181,7 +1181,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_kernel(AttnArgs a) {
 // 48 VGPRs per lane that one group needs at d = 64.  Group g's weights are addressed in place: rows g*80.. of the Q, K and V blocks of
 // to_qkv.weight (80 = 5 tiles of 16, so a tile never straddles two blocks), columns g*80.. of to_out.weight.  The parameter-gradient
 // slabs are written in the layer's FULL layout ([3 I][d], [d][I], I = 80 G), so the gradients land in place as well.
-// LDS map = the 8-head generic kernels' (xs [64][20], dys [64][20], qkv [64][244], ob / dob [64][84], ...): 116 KB backward.
+// LDS map = the 8-head generic kernels' (xs [64][20], dys [64][20], qkv [64][244], ob / dob [64][84], ...) + the current group's weight
+// slices (wide_stage_wq / _wo): 74 KB forward (two work-groups per CU), 138 KB backward.
 constexpr int WG_H = 8, WG_DH = 10, WG_I = WG_H * WG_DH, WG_Q3 = 3 * WG_I, WG_LDX = 20, WG_LDQ = WG_Q3 + 4, WG_LDT = WG_I + 4, WG_COLS = 2,
               WG_MAXG = 4;
 static_assert(WG_I % 16 == 0, "a 16-row weight tile must not straddle the Q / K / V blocks");
