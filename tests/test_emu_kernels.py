@@ -111,6 +111,17 @@ def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, knob):
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode", [pytest.param((2, 3, 21, 64, 8, 10, True), "intra", id="L21_two_tiles"),
+                                       pytest.param((3, 11, 4, 64, 8, 10, True), "cross", id="L11_one_tile"),
+                                       twin((1, 31, 2, 64, 8, 10, True), "cross", id="L31")])
+def test_attn_fwd_exact_fp32_matrix_pipe_core(emu, case, mode, two_blocks, knob):
+    """attn_fwd3_kernel<.., MCF>: the forward core on v_mfma_f32_16x16x4_f32 (S^T = K Q^T, the row softmax in the accumulators, which then
+    ARE the B operand of O^T = V^T P^T) — forced on by the knob at lengths the host would leave to the VALU loop: two 16-row tiles with a
+    ragged second one (L = 21), one ragged tile (L = 11); L = 31 is where the host selects it by itself"""
+    knob(emu, "attn_fwd_core_mfma", 2)
+    kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
+
+
 @gpu_twin
 def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blocks, knob):
     knob(emu, "attn_fwd_core_mfma", 1)

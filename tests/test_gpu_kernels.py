@@ -90,6 +90,19 @@ def test_attn_bwd_bf16x3_matrix_pipe_core(lib, case, mode, knob):
     kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode", [((40, 6, 21, 64, 8, 10, True), "intra"), ((30, 11, 4, 64, 8, 10, True), "cross"), ((9, 31, 9, 64, 8, 10, True), "cross"),
+                                       ((9, 31, 16, 64, 8, 10, True), "intra"), ((5, 28, 3, 64, 8, 10, True), "cross"), ((7, 3, 32, 64, 8, 10, True), "intra")],
+                         ids=["L21", "L11", "L31", "L16", "L28", "L32"])
+def test_attn_fwd_exact_fp32_matrix_pipe_core(lib, case, mode, knob):
+    """the forward core on the matrix pipe (attn_fwd3_kernel<.., MCF>): forced on at every length class, forced off, and by the host's own
+    rule (L 28 ... 32); also through the entry point with a residual of its own (the EX instantiation) and with dropout"""
+    for k in (2, 3, 0):
+        knob(lib, "attn_fwd_core_mfma", k)
+        kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
+    knob(lib, "attn_fwd_core_mfma", 2)
+    kc.check_attn_dropout(lib, "cuda", case, mode, arith="bf16x3")
+
+
 def test_attn_narrower_embedding_with_queries_and_dropout(lib):
     kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
     kc.check_attn_queries(lib, "cuda", (30, 6, 14, 40, 8, 10, True), "cross", nq=1, arith="bf16x3")

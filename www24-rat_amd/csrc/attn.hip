@@ -2013,14 +2013,108 @@ __device__ __forceinline__ void b3_gemm_rows(const PA& A, const BW& Bw, int n_ti
 
 // QSUB: RatSeqMap.queries < L is honoured (a separate instantiation: the ordinary one must not carry a second trip count)
 // DPAD: embedding_dim 40 / 48 / 56 inside the 64-wide tiles (zero-padded weight planes; see b3_layer_norm_to_planes)
+// ---- the attention-FORWARD core on the matrix pipe, exact fp32 (round 5; the backward's twin is b3_bwd_core_mfma) ----------------------
+// Every (sequence, head) pair of the chunk is ONE wave's job on v_mfma_f32_16x16x4_f32, per 16-query tile:
+//   S^T = K Q^T (A = K rows, B = Q rows; k = dim_head 10 -> 12, three steps): the accumulator of key tile jt holds, in lane (g, m),
+//   S^T[key 16 jt + 4 g + r][query m] — a query's scores over ALL keys sit in the registers of the four lanes (g, m), so the row
+//   softmax is in-register maxima / sums plus two cross-row swaps (b3m_rows_max / _sum); and the SAME registers are the B operand
+//   of O^T = V^T P^T: k-step (jt, r) contracts over the keys {16 jt + 4 g + r : g} with A = V[that key][c = m] — the probabilities
+//   never leave their registers (no LDS round trip, no shuffles, nothing split: this is what the bf16x3 core of attn_fwd3m_kernel
+//   spent its VALU time on).  7 NIT MFMAs per query tile (NIT = 16-row tiles per sequence), ~40 VALU instructions of softmax.
+// Dispatch by length like the backward (b3_fwd_matrix_core): sequences of 28 ... 32 tokens (BASELINE configs[4]: K = 30 -> L = 31),
+// where the 32 x 32 tile is 94 % full; at L = 21 / 11 the VALU loop stays (profiles/round5/r5_attn_fwd_core_mfma_ab.txt).
+__device__ __forceinline__ float b3m_rows_max(float v);
+__device__ __forceinline__ float b3m_rows_sum(float v);
+template <int NIT>
+__device__ __forceinline__ void b3_fwd_core_mfma(float* qkv, float* lse_s, int L, int nsq, float scale) {
+    const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
+    const float sl2 = scale * RAT_LOG2E;
+    const int npairs = nsq * B3_H;
+    for (int pair = w; pair < npairs; pair += ATT_WAVES) {
+        const int h = pair % B3_H, sq = pair / B3_H;
+        const int r0 = sq * L, cq = h * B3_DH, ck = B3_I + cq, cv = 2 * B3_I + cq;
+        // per pair: K as the A operand of S^T (lane: K[key 16 jt + m][k 4 ks + g]) and V as the A operand of O^T (lane: V[key 16 jt + 4 g + r][c m]);
+        // loads at their natural address (rows / columns past the operand stay inside the tile), masked by a select
+        float ak[3][NIT], av[4][NIT];
+#pragma unroll
+        for (int jt = 0; jt < NIT; ++jt) {
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) ak[ks][jt] = qkv[(size_t)(r0 + 16 * jt + m) * B3_LDQ + ck + 4 * ks + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r][jt] = qkv[(size_t)(r0 + 16 * jt + 4 * g + r) * B3_LDQ + cv + m];
+        }
+#pragma unroll
+        for (int jt = 0; jt < NIT; ++jt) {
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) ak[ks][jt] = (4 * ks + g < B3_DH && 16 * jt + m < L) ? ak[ks][jt] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r][jt] = (m < B3_DH && 16 * jt + 4 * g + r < L) ? av[r][jt] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i0 = 16 * it;
+            if (i0 >= L) break;                                   // (wave-uniform)
+            const bool qok = i0 + m < L;
+            float bq[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) bq[ks] = qkv[(size_t)(r0 + i0 + m) * B3_LDQ + cq + 4 * ks + g];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) bq[ks] = (4 * ks + g < B3_DH && qok) ? bq[ks] : 0.f;
+            f32x4 st[NIT];
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt) st[jt] = rat_zero4();
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < NIT; ++jt) st[jt] = RAT_MFMA16(ak[ks][jt], bq[ks], st[jt]);
+            // softmax over the keys of query column m: st[jt][r] = S^T[key 16 jt + 4 g + r][query i0 + m]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[jt][r] = 16 * jt + 4 * g + r < L ? st[jt][r] * sl2 : -INFINITY;
+                    mx = fmaxf(mx, st[jt][r]);
+                }
+            mx = b3m_rows_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[jt][r] = rat_exp2(st[jt][r] - mx);          // (keys beyond L: exp2(-inf) = 0)
+                    sum += st[jt][r];
+                }
+            sum = b3m_rows_sum(sum);
+            // O^T[c][query] = sum over keys V[key][c] P^T[key][query]: the accumulators ARE the B operand, k-step (jt, r)
+            f32x4 ot = rat_zero4();
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot = RAT_MFMA16(av[r][jt], st[jt][r], ot);
+            const float inv = 1.0f / sum;
+            if (qok) {                                            // ot[r] = O[query i0 + m][c = 4 g + r] (unnormalised); O replaces Q in place
+                float* op = qkv + (size_t)(r0 + i0 + m) * B3_LDQ + cq + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < B3_DH) op[r] = ot[r] * inv;
+                if (g == 0) lse_s[(r0 + i0 + m) * B3_H + h] = mx + rat_log2(sum);
+            }
+        }
+    }
+}
+
 // GRP (wide heads, round 5): heads = a.groups x 8.  The head groups are independent given LayerNorm(x), so ONE launch loads and
 // normalises a chunk once and then loops over the groups — Q|K|V projection, attention core, O -> planes / o_save, output projection
 // per group, the projection's partial sums kept in the accumulator registers across the loop — and adds bias, Dropout and the residual
 // once at the end: one LayerNorm / x load / y read-modify-write per chunk instead of one per group launch (rat_attn_fwd_groups).
 // Group g's fragment planes are W.qkv / W.out + g x B3_GRP_PLANES; W_out's come from L2 (four groups' planes do not fit the LDS).
-template <bool EX, bool QSUB = false, bool DPAD = false, bool GRP = false>
+// MCF (1 / 2 = 16-row tiles per sequence): the attention core on the matrix pipe (b3_fwd_core_mfma) instead of the VALU loop; every position
+// a query, sequences of at most 32 tokens
+template <bool EX, bool QSUB = false, bool DPAD = false, bool GRP = false, int MCF = 0>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
     static_assert(!GRP || (EX && !QSUB && !DPAD), "the group loop is written for the general (EX) form at embedding_dim 64");
+    static_assert(MCF == 0 || !QSUB, "the matrix core computes every query");
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                 // LayerNorm(x) planes; later the fp32 output staging tile
     float* qkv = reinterpret_cast<float*>(smem + 3 * B3_XP);                // [64][244] fp32 Q|K|V; O overwrites Q
@@ -2098,8 +2192,9 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, dreal);
         typedef HeadVec<B3_DH> HV;
         const int nq = QSUB ? a.nq : L;                          // queries that matter per sequence (RatSeqMap.queries; normally L)
-        const int ntasks = nsq * B3_H * nq;
+        const int ntasks = MCF ? 0 : nsq * B3_H * nq;
         const float sl2 = a.scale * RAT_LOG2E;
+        if (MCF) b3_fwd_core_mfma<(MCF > 0 ? MCF : 1)>(qkv, lse_s, L, nsq, a.scale);
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % nq;
             const int h = (task / nq) % B3_H;
@@ -3386,6 +3481,14 @@ static bool b3_matrix_core(int L) {
     if (L > 32 || k == 0) return false;
     return k == 1 || L >= 28;
 }
+// the matrix-pipe FORWARD core (b3_fwd_core_mfma): attn_fwd_core_mfma knob 0 = by length (28 ... 32 tokens), 2 = forced on (L <= 32), 3 = off
+// (1 selects attn_fwd3m_kernel, round 3's bf16x3 core)
+static int b3_fwd_matrix_core(int L, int nq) {
+    const int k = rat_knob(RAT_KNOB_ATTN_FWD_CORE_MFMA);
+    if (L > 32 || nq < L || k == 3 || k == 1) return 0;
+    if (k != 2 && L < 28) return 0;
+    return L > 16 ? 2 : 1;
+}
 static bool b3_ph_enabled() {                          // on unless the attn_bwd_ph knob is 0 (same-box A/B: L = 11 1.2477 -> 1.2322 ms, -1.2 %)
     return rat_knob(RAT_KNOB_ATTN_BWD_PH) != 0;
 }
@@ -3482,7 +3585,13 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
             if (plain) RAT_LAUNCH((attn_fwd3m_kernel<false>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_fwd3m_kernel<true>), b3_blocks, ATT_THREADS, b3m_fwd_smem(), stream, a, W);
         } else if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else if (plain && b3_fwd_matrix_core(a.L, a.nq) == 2)
+            RAT_LAUNCH((attn_fwd3_kernel<false, false, false, false, 2>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else if (plain && b3_fwd_matrix_core(a.L, a.nq) == 1)      // (sequences of at most 16 tokens: only when the knob forces it)
+            RAT_LAUNCH((attn_fwd3_kernel<false, false, false, false, 1>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else if (b3_fwd_matrix_core(a.L, a.L) == 2)                // (EX computes every position whatever `queries` says)
+            RAT_LAUNCH((attn_fwd3_kernel<true, false, false, false, 2>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);   // (computes every position)
         return rat_check_launch("rat_attn_fwd (bf16x3)");
     }
@@ -3603,7 +3712,8 @@ extern "C" int rat_attn_fwd_groups(const float* x, const float* res, float* y, f
     W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(planes), 2};
     W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(static_cast<const char*>(planes) + B3_W_QKV + B3_W_OUTT + B3_W_QKVT), 3};
     const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-    RAT_LAUNCH((attn_fwd3_kernel<true, false, false, true>), blocks, ATT_THREADS, B3_FWD_WOUT, stream, a, W);
+    if (b3_fwd_matrix_core(a.L, a.L) == 2) RAT_LAUNCH((attn_fwd3_kernel<true, false, false, true, 2>), blocks, ATT_THREADS, B3_FWD_WOUT, stream, a, W);
+    else RAT_LAUNCH((attn_fwd3_kernel<true, false, false, true>), blocks, ATT_THREADS, B3_FWD_WOUT, stream, a, W);
     return rat_check_launch("rat_attn_fwd_groups");
 }
 

@@ -26,7 +26,8 @@ int rat_check_launch(const char* what) {
 //   max_blocks (RAT_MAX_BLOCKS=<n>)            caps the grid of the persistent encoder kernels so that small test problems make every
 //                                              work-group loop over SEVERAL chunks (persistent accumulators, double-buffered row maps)
 //   attn_bwd_ph (RAT_ATTN_BWD_PH=0)            0: pass 2 of attn_bwd3_kernel recomputes P instead of reading pass 1's copy (L <= 12)
-//   attn_fwd_core_mfma (RAT_ATTN_FWD_CORE=mfma) 1: attn_fwd3m_kernel (QK^T / PV on the matrix pipe; correct, measured slower)
+//   attn_fwd_core_mfma (RAT_ATTN_FWD_CORE=mfma|mfma32|valu) 1: attn_fwd3m_kernel (bf16x3 QK^T / PV; correct, measured slower); 2 / 3: force the
+//                                              exact-fp32 matrix-pipe core of attn_fwd3_kernel on (L <= 32) / off (0: by length, 28 ... 32 tokens)
 //   attn_bwd_core_mfma (RAT_ATTN_BWD_CORE=mfma|valu) 1 / 0: force the matrix-pipe / VALU backward core whatever L says (-1: by L)
 //   ffn_bwd_t3 (RAT_FFN_BWD=t3)                1: round 3's feed-forward backward kernel
 //   sgemm_split_target (RAT_SGEMM_SPLIT_TARGET=<n>)  work-groups the split-K rule of the head's GEMMs aims for (0: built-in)
@@ -39,7 +40,7 @@ static const bool g_knobs_loaded = [] {
                       ff = env("RAT_FFN_BWD"), st = env("RAT_SGEMM_SPLIT_TARGET");
     g_knobs[RAT_KNOB_MAX_BLOCKS] = mb.empty() ? 0 : atoi(mb.c_str());
     g_knobs[RAT_KNOB_ATTN_BWD_PH] = (ph.empty() || ph[0] != '0') ? 1 : 0;
-    g_knobs[RAT_KNOB_ATTN_FWD_CORE_MFMA] = fc == "mfma" ? 1 : 0;
+    g_knobs[RAT_KNOB_ATTN_FWD_CORE_MFMA] = fc == "mfma" ? 1 : (fc == "mfma32" ? 2 : (fc == "valu" ? 3 : 0));
     g_knobs[RAT_KNOB_ATTN_BWD_CORE_MFMA] = bc == "mfma" ? 1 : (bc == "valu" ? 0 : -1);
     g_knobs[RAT_KNOB_FFN_BWD_T3] = ff.rfind("t3", 0) == 0 ? 1 : 0;
     g_knobs[RAT_KNOB_SGEMM_SPLIT_TARGET] = st.empty() ? 0 : (atoi(st.c_str()) > 0 ? atoi(st.c_str()) : 0);
