@@ -168,4 +168,7 @@ def test_gpu_batch_prepare_matches_oracle_and_feeds_the_step():
         model.train()
         b = tuple(t.to(model.device) for t in batch) if on_device else batch
         losses.append([float(model.train_step(b)) for _ in range(5)])          # steps 4, 5: graph replays writing into the static inputs
-    assert losses[0] == losses[1], losses
+    # step 1 is bit-identical (the forward has no atomics); later losses follow weights updated with table gradients that fp32 atomics
+    # summed in an order that differs from run to run (embedding_grad "atomic", the default): equal to rounding, not to the bit
+    assert losses[0][0] == losses[1][0], losses
+    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-6, atol=0)
