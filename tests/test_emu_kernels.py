@@ -152,9 +152,17 @@ def test_persistent_kernels_loop_over_several_chunks(emu, two_blocks):
     kc.check_ffn(emu, "cpu", 200, 64, 128, arith="bf16x3")
 
 
-@pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (1, 70, 1, 10, None), (2, 33, 2, 7, 0.3)])
+# (1, 70, 1, 10) and (3, 49, 2, 10): dim_head 10 with 48+ tokens — the forward on the matrix pipe (core_fwd_mfma_kernel): five key tiles = an odd
+# count (the second tile of the last key block is the spare zero tile), a ragged last tile; several pairs per work-group with RAT_MAX_BLOCKS
+@pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (1, 70, 1, 10, None), (2, 33, 2, 7, 0.3), (3, 49, 2, 10, 0.4)])
 def test_attn_core_fwd_bwd(emu, nseq, L, heads, dh, softmax_scale):
     kc.check_attn_core(emu, "cpu", nseq, L, heads, dh, softmax_scale)
+
+
+def test_attn_core_matrix_pipe_forward_several_pairs_per_work_group(emu, knob):
+    """core_fwd_mfma_kernel with fewer work-groups than (sequence, head) pairs: the K / V tiles are re-staged per pair"""
+    knob(emu, "max_blocks", 1)                                   # 8 work-groups for 10 pairs
+    kc.check_attn_core(emu, "cpu", 5, 50, 2, 10, None)
 
 
 @pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (1, 5, 3, 3, 10)])

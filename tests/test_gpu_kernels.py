@@ -127,12 +127,17 @@ def test_attn_fwd_bf16x3_matrix_core(lib, case, mode, knob):
     kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
 
 
-@pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None)])
-def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale):
+@pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None),
+                                                           (5, 48, 3, 10, 0.3), (3, 900, 2, 10, None), (300, 60, 32, 10, None)])
+def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale, knob):
+    """(dim_head 10 with 48 ... 1024 tokens: the forward runs on the matrix pipe — core_fwd_mfma_kernel; the knob's value 3 keeps the VALU kernel)"""
     kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)
+    if dh == 10 and L >= 48:
+        knob(lib, "attn_fwd_core_mfma", 3)
+        kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)
 
 
-@pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (64, 31, 9, 32, 10), (16, 11, 21, 8, 10)])
+@pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (64, 31, 9, 32, 10), (16, 11, 21, 8, 10), (6, 61, 5, 8, 10)])
 def test_attn_core_strided(lib, B, T, S, heads, dh):
     kc.check_attn_core_strided(lib, "cuda", B, T, S, heads, dh)
 

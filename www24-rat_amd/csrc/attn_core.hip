@@ -241,6 +241,142 @@ int core_check(int64_t nseq, int L, int heads, int dh, size_t smem) {
     return 0;
 }
 
+// ---- the forward core on the matrix pipe, exact fp32, for LONG sequences at dim_head 10 (round 5) ----------------------------------
+// The construction of attn.hip's b3_fwd_core_mfma as a flash loop: a 256-thread work-group owns one (sequence, head) pair, its K and V
+// rows staged in LDS ([L16][12] each); a wave owns 16-query tiles and walks the keys 32 at a time:
+//   S^T = K Q^T on v_mfma_f32_16x16x4_f32 (three k steps for dim_head 10): lane (g, m) holds S^T[key 16 jt + 4 g + r][query m], so a
+//   query's scores of the key block sit in the four lanes of its column — block maximum in registers + two cross-row swaps, then
+//   p = exp2(s - m_new), the running sum and the O^T accumulator rescaled by exp2(m_old - m_new) (the online softmax of the VALU
+//   kernel, per key block instead of per key), and O^T += V^T P^T with the SAME registers as the B operand (k-step (jt, r) contracts
+//   over the keys {16 jt + 4 g + r}).  Seven MFMAs per (query tile, key tile); nothing passes through LDS after the staging.
+// RAT_m0's joint sequences (231 tokens at the north-star shape): 15 x 15 tiles, 96 % full.
+#ifndef RAT_CM_KB
+#define RAT_CM_KB 4
+#endif
+constexpr int CM_THREADS = 256, CM_WAVES = 4, CM_LD = 12, CM_DH = 10, CM_KB = RAT_CM_KB;      // CM_KB: 16-key tiles per trip of the key loop
+__device__ __forceinline__ float cm_rows_max(float v) {
+#ifdef RAT_EMU
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+#else
+    auto r = __builtin_amdgcn_permlane16_swap(rat_fbits(v), rat_fbits(v), false, false);
+    v = fmaxf(rat_bitsf(r[0]), rat_bitsf(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(rat_fbits(v), rat_fbits(v), false, false);
+    return fmaxf(rat_bitsf(r[0]), rat_bitsf(r[1]));
+#endif
+}
+__device__ __forceinline__ float cm_rows_sum(float v) {
+#ifdef RAT_EMU
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+#else
+    auto r = __builtin_amdgcn_permlane16_swap(rat_fbits(v), rat_fbits(v), false, false);
+    v = rat_bitsf(r[0]) + rat_bitsf(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(rat_fbits(v), rat_fbits(v), false, false);
+    return rat_bitsf(r[0]) + rat_bitsf(r[1]);
+#endif
+}
+__global__ void __launch_bounds__(CM_THREADS) core_fwd_mfma_kernel(CoreArgs a) {
+    RAT_DYN_SMEM(smem);
+    const int L = a.L, I = a.heads * CM_DH, L16 = (L + 15) / 16 * 16, NT = L16 / 16;
+    constexpr int SPARE = 16 * (CM_KB - 1);              // zero rows past the sequence: the last trip's tiles beyond it
+    float* ks = reinterpret_cast<float*>(smem);          // [L16 + SPARE][12]: rows >= L and columns 10, 11 are zero
+    float* vs = ks + (size_t)(L16 + SPARE) * CM_LD;
+    const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
+    const float sl2 = a.scale * RAT_LOG2E;
+    const int64_t ntask = a.nseq * a.heads;
+    for (int e = threadIdx.x; e < 2 * (L16 + SPARE) * CM_LD; e += CM_THREADS) ks[e] = 0.f;
+    __syncthreads();
+    for (int64_t task = blockIdx.x; task < ntask; task += gridDim.x) {
+        const int64_t sq = task / a.heads;
+        const int h = (int)(task - sq * a.heads);
+        for (int e = threadIdx.x; e < L * (CM_DH / 2); e += CM_THREADS) {       // K, V rows of the pair -> LDS (8-byte pieces)
+            const int j = e / (CM_DH / 2), c2 = e - j * (CM_DH / 2);
+            const float* row = a.qkv + core_token(a, sq, j) * (3 * I) + h * CM_DH + 2 * c2;
+            *reinterpret_cast<float2*>(ks + j * CM_LD + 2 * c2) = *reinterpret_cast<const float2*>(row + I);
+            *reinterpret_cast<float2*>(vs + j * CM_LD + 2 * c2) = *reinterpret_cast<const float2*>(row + 2 * I);
+        }
+        __syncthreads();
+        for (int qt = w; qt < NT; qt += CM_WAVES) {
+            const int qi = 16 * qt + m;
+            const bool qok = qi < L;
+            const int64_t tok = core_token(a, sq, qok ? qi : 0);
+            float bq[3];
+#pragma unroll
+            for (int ks_ = 0; ks_ < 3; ++ks_) {
+                const int c = 4 * ks_ + g;
+                bq[ks_] = (qok && c < CM_DH) ? a.qkv[tok * (3 * I) + h * CM_DH + c] : 0.f;
+            }
+            float mx = -INFINITY, lsum = 0.f;
+            f32x4 ot = rat_zero4(), ot2 = rat_zero4();
+            for (int kt0 = 0; kt0 < NT; kt0 += CM_KB) {                         // (a second tile past the sequence reads the spare zero rows)
+                float ak[3][CM_KB], av[4][CM_KB];
+#pragma unroll
+                for (int jt = 0; jt < CM_KB; ++jt) {
+#pragma unroll
+                    for (int ks_ = 0; ks_ < 3; ++ks_) ak[ks_][jt] = ks[(16 * (kt0 + jt) + m) * CM_LD + 4 * ks_ + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = vs[(16 * (kt0 + jt) + 4 * g + r) * CM_LD + (m < CM_LD ? m : 0)];
+                        av[r][jt] = m < CM_DH ? t : 0.f;
+                    }
+                }
+                f32x4 st[CM_KB];
+#pragma unroll
+                for (int jt = 0; jt < CM_KB; ++jt) st[jt] = rat_zero4();
+#pragma unroll
+                for (int ks_ = 0; ks_ < 3; ++ks_)
+#pragma unroll
+                    for (int jt = 0; jt < CM_KB; ++jt) st[jt] = RAT_MFMA16(ak[ks_][jt], bq[ks_], st[jt]);
+                float bm = -INFINITY;
+#pragma unroll
+                for (int jt = 0; jt < CM_KB; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[jt][r] = 16 * (kt0 + jt) + 4 * g + r < L ? st[jt][r] * sl2 : -INFINITY;
+                        bm = fmaxf(bm, st[jt][r]);
+                    }
+                const float mn = fmaxf(mx, cm_rows_max(bm));                    // (finite: the block's first key exists)
+                const float corr = rat_exp2(mx - mn);
+                lsum *= corr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ot[r] *= corr;
+                    ot2[r] *= corr;
+                }
+#pragma unroll
+                for (int jt = 0; jt < CM_KB; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[jt][r] = rat_exp2(st[jt][r] - mn);
+                        lsum += st[jt][r];
+                    }
+#pragma unroll
+                for (int jt = 0; jt < CM_KB; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                               // two accumulators: two independent MFMA chains
+                        if ((jt & 1) == 0) ot = RAT_MFMA16(av[r][jt], st[jt][r], ot);
+                        else ot2 = RAT_MFMA16(av[r][jt], st[jt][r], ot2);
+                    }
+                mx = mn;
+            }
+            const float lt = cm_rows_sum(lsum);
+            if (qok) {
+                const float inv = 1.0f / lt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < CM_DH) a.o_out[tok * I + h * CM_DH + 4 * g + r] = (ot[r] + ot2[r]) * inv;
+                if (g == 0 && a.lse_out != nullptr) a.lse_out[tok * a.heads + h] = mx + rat_log2(lt);
+            }
+        }
+        __syncthreads();                                                        // (the next pair's rows overwrite the tiles)
+    }
+}
+// dispatch: dim_head 10, sequences of 48 ... 1024 tokens (tiles at least three quarters full; the tiles fit LDS), 8-byte aligned rows
+bool core_fwd_mfma_ok(const CoreArgs& a) {
+    return a.dh == CM_DH && a.L >= 48 && a.L <= 1024 && (reinterpret_cast<uintptr_t>(a.qkv) & 7) == 0 && rat_knob(RAT_KNOB_ATTN_FWD_CORE_MFMA) != 3;
+}
+
 template <template <int, bool> class Launch, bool MULTI>
 int core_dispatch_dh(int dh, const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
     switch (dh) {
@@ -320,6 +456,12 @@ extern "C" int rat_attn_core_fwd_map(const float* qkv, float* o, float* lse, con
     a.heads = heads;
     a.dh = dim_head;
     a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
+    if (core_fwd_mfma_ok(a)) {
+        const int L16 = (L + 15) / 16 * 16;
+        const int64_t tasks = nseq * heads, cap = (int64_t)rat_max_blocks() * 8;
+        RAT_LAUNCH(core_fwd_mfma_kernel, (unsigned)(tasks < cap ? tasks : cap), CM_THREADS, (size_t)2 * (L16 + 16 * (CM_KB - 1)) * CM_LD * sizeof(float), stream, a);
+        return rat_check_launch("rat_attn_core_fwd (matrix pipe)");
+    }
     return core_dispatch<LaunchFwd>(dim_head, a, core_grid((nseq * heads + core_pairs(L) - 1) / core_pairs(L)), core_threads(L), smem, stream);
 }
 
