@@ -118,7 +118,14 @@ def parse(argv=None):
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo process group, the host-emulation build of the kernels (tests/emu), "
                          "workload `dryrun`; the printed numbers mean nothing")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    # The guards of the N > 1 regions must fire BEFORE the process group's own collective timeout (= --init-timeout: RCCL's watchdog
+    # aborts a rank that sits in a collective that long, SIGABRT, and the launcher then discards rank 0's line): a rank that raised
+    # has left, the others wait in a collective, and only their own timer can still get the finished weak-scaling line out.
+    limit = 0.8 * args.init_timeout
+    args.region_timeout = min(args.region_timeout, limit)
+    args.graph_attempt_timeout = min(args.graph_attempt_timeout, limit)
+    return args
 
 
 # ------------------------------------------------------------------------------------------------- self-launch

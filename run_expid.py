@@ -90,10 +90,10 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
             # stored next to the data in the data's own format: retrieval_{K}_{split}.h5 — the reference's file name and keys
             # (data_generator.py:106-113) — when the split is an HDF5 file, .npz otherwise
             rpath = os.path.join(data_dir, "retrieval_%d_%s%s" % (topk, split, ".h5" if dpath.endswith(".h5") else ".npz"))
-            failed = rpath + ".failed"
+            # the marker is this JOB's (rendezvous port in its name): a poller can never mistake what an earlier, failed run left
+            # behind for rank 0's verdict on this one
+            failed = rpath + ".failed.%s" % os.environ.get("MASTER_PORT", "0")
             if shard[0] == 0:                                   # one rank computes and writes the file (atomically), the others wait
-                if os.path.exists(failed):
-                    os.remove(failed)                           # (a marker of an earlier, failed run)
                 try:
                     precompute_retrieval_file(dpath, pool, rpath, rcfg, feature_map, params)
                 except BaseException as exc:                    # tell the pollers before dying: they must not wait for a file that will never come
@@ -110,6 +110,9 @@ def build_sources(params, feature_map, synthetic_rows, shard=(0, 1)):
     return out
 
 
+_PROCESS_START = __import__("time").time()      # a failure marker older than this process belongs to an earlier job
+
+
 def _wait_for_file(path, leader, poll_s=2.0, failed_marker=None, max_wait_s=None):
     """The top-K pre-computation of a large split can take longer than a collective's timeout (10 minutes by default), so the other ranks
     do not sit in a barrier: they poll for the finished file (written under a temporary name and renamed, so existence means complete)
@@ -122,7 +125,8 @@ def _wait_for_file(path, leader, poll_s=2.0, failed_marker=None, max_wait_s=None
             max_wait_s = float(os.environ.get("RAT_RETRIEVAL_WAIT_S", 6 * 3600))
         t_end = time.monotonic() + max_wait_s
         while not os.path.exists(path):
-            if failed_marker is not None and os.path.exists(failed_marker):
+            # (a marker older than this process is a previous job's that happened to use the same port)
+            if failed_marker is not None and os.path.exists(failed_marker) and os.path.getmtime(failed_marker) >= _PROCESS_START - 5.0:
                 with open(failed_marker) as f:
                     raise SystemExit("rank 0 could not write %s: %s" % (path, f.read().strip()))
             if time.monotonic() > t_end:

@@ -271,3 +271,37 @@ def test_grouped_heads_mode_is_selected_for_wide_heads():
     model = mc.build_model(gc.case_by_name("tmall_real_heads"), gpu=0, seed=1)
     assert model._attn_mode(ops.intra_map(4, 7, 9)) == ("grouped", 8)
     assert model._attn_mode(ops.cross_map(4, 7, 9)) == ("grouped", 8)
+
+
+def test_evaluate_generator_on_device_tuples_keeps_every_batchs_labels_under_the_eval_graph():
+    """base_model.py:232-247 keeps each batch's y_true until the end of the pass.  Once a shape's inference graph is captured,
+    rat_batch_prepare writes the labels into the graph's static inputs: forward() must hand out a copy, not that view
+    (ADVICE r5, high).  Seven same-shape CUDA 4-tuples with different labels: graph on == graph off, batch by batch."""
+    import golden_cases as gc
+    case = gc.case_by_name("tiny_seq_bn")
+    X, y, rv, rl = mc.batch_of(case)
+    rng = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(7):
+        perm = torch.randperm(X.shape[0], generator=rng)
+        yi = y[perm].clone()
+        yi[:, 0] = (torch.rand(X.shape[0], generator=rng) < 0.5).to(y.dtype)
+        batches.append(tuple(t.cuda() for t in (X[perm], yi, rv[perm], rl[perm])))
+    out = {}
+    for graph in (True, False):
+        model = mc.build_model(case, gpu=0, seed=1)
+        mc.load_weights(model, case)
+        model.eval_graph = graph
+        model.eval()
+        with torch.no_grad():
+            per_batch = [model.forward(b) for b in batches]
+        torch.cuda.synchronize()
+        assert bool(model.__dict__.get("_eval_graphs")) == graph
+        out[graph] = ([o["y_true"].cpu() for o in per_batch], [o["y_pred"].cpu() for o in per_batch], model.evaluate_generator(batches))
+    for i, b in enumerate(batches):
+        assert torch.equal(out[True][0][i].reshape(-1), b[1][:, 0].float().cpu()), i
+        assert torch.equal(out[True][0][i], out[False][0][i]), i
+        assert float((out[True][1][i] - out[False][1][i]).abs().max()) < 1e-6
+    assert len({tuple(t.reshape(-1).tolist()) for t in out[True][0]}) > 1       # the labels really differ from batch to batch
+    for k, v in out[False][2].items():
+        assert abs(out[True][2][k] - v) < 1e-6, (k, out[True][2], out[False][2])

@@ -236,6 +236,10 @@ def test_waiting_ranks_give_up_when_rank0_fails_or_takes_too_long(tmp_path, monk
     open(marker, "w").write("MemoryError: top-K\n")
     with pytest.raises(SystemExit, match="MemoryError: top-K"):
         run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=5)
+    # a marker older than this process is an EARLIER job's: it must not end this one
+    os.utime(marker, (run_expid._PROCESS_START - 3600, run_expid._PROCESS_START - 3600))
+    with pytest.raises(SystemExit, match="gave up waiting"):
+        run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=0.05)
     open(target, "w").write("x")
     run_expid._wait_for_file(target, leader=False, poll_s=0.01, failed_marker=marker, max_wait_s=5)       # the file wins
     run_expid._wait_for_file(target, leader=True)

@@ -1178,7 +1178,10 @@ class RAT_m2(BaseModel):
                 y_pred = graph.run(batch)
             else:
                 y_pred, _, _, _ = self._run_forward(batch, save=False, with_reg=False)
-        return {"y_true": batch[2].unsqueeze(-1), "y_pred": y_pred}
+        # `ready` means batch[2] IS the captured graph's static input: the next same-shape batch overwrites it, and evaluate_generator
+        # keeps every batch's y_true until the end of the pass (base_model.py:232-251) - hand out a copy, never the static view
+        y_true = batch[2].clone() if ready is not None else batch[2]
+        return {"y_true": y_true.unsqueeze(-1), "y_pred": y_pred}
 
     # The inference forward as a hipGraph (graph.EvalGraph): used for batches of at most `eval_graph_max_batch` samples — where the
     # forward is short enough for its ~25 launches to be the limit (measured: bench.py `inference`) — after `graph_warmup` eager
@@ -1315,9 +1318,11 @@ class RAT_m2(BaseModel):
     use_graph = True           # capture the fused iteration into a hipGraph (CUDA devices only)
     # Under data parallelism the captured step is a chain of graph segments with the collectives between them as eager closures
     # (graph.py): proven on one GPU with two gloo ranks (tests/test_gpu_dp.py) and with one RCCL rank (tests/test_gpu_rccl.py,
-    # bench.py --dp-rehearsal); on by default since round 5 (the owner exchange no longer needs a host read-back mid-step).  A capture
-    # that fails leaves that batch shape on the eager step (_step_graph_for); `graph_under_dp=False` / bench.py --no-graph-dp turns it off.
-    graph_under_dp = True
+    # bench.py --dp-rehearsal).  OFF by default on the model: no run with more than one RCCL rank exists yet, and fit_generator has no
+    # watchdog that could take a stalled segmented-graph collective back to the eager step.  bench.py opts in — it measures
+    # the eager form first and runs the graph form under a timer; `graph_under_dp=True` in the model's kwargs opts a training run in.
+    # A capture that fails leaves that batch shape on the eager step (_step_graph_for).
+    graph_under_dp = False
     group_loop = True          # wide heads (heads = G x 8 at d = 64): the forward of a layer as ONE launch that loops over the head groups
                                # (rat_attn_fwd_groups) instead of G launches; False: the per-group launches (A/B, tests)
     graph_warmup = 2           # eager fused steps of a batch shape before it is captured
@@ -1478,12 +1483,15 @@ class RAT_m2(BaseModel):
     def _dropout_state_init(self, base=None, counter=0):
         """(base seed, step counter) of the device-side dropout generator.  The base is drawn ONCE from torch's CPU generator
         (seed_everything governs it) and — under data parallelism, where every rank draws the same number — mixed with the rank, so that
-        the ranks mask their different shards with different masks, like the reference's per-process generators would."""
+        the ranks mask their different shards with different masks, like the reference's per-process generators would.  The UNMIXED
+        draw is what a checkpoint stores (only rank 0 writes one): every rank re-applies its own mix on load, so a resumed run draws
+        the masks the uninterrupted run would have drawn."""
         if base is None:
             base = int(torch.randint(0, 2 ** 62, (1,)))
-            if self._dp():
-                import torch.distributed as dist
-                base = (base ^ (0x9E3779B97F4A7C15 * (dist.get_rank() + 1))) & (2 ** 62 - 1)
+        self._drop_base_unmixed = int(base)
+        if self._dp():
+            import torch.distributed as dist
+            base = (base ^ (0x9E3779B97F4A7C15 * (dist.get_rank() + 1))) & (2 ** 62 - 1)
         dev = self._flat.device
         self._drop_base = int(base)
         self._drop_words = torch.zeros(self._DROP_WORDS, dtype=torch.int64, device=dev)
@@ -1491,11 +1499,12 @@ class RAT_m2(BaseModel):
 
     def dropout_state(self):
         """-> {"base", "counter"} or None when no training forward with dropout has run: what a checkpoint needs to continue the mask
-        sequence.  The reference's `.model` file is the bare state_dict and must stay loadable by it, so the state travels with the
-        optimizer's state_dict (`rat_dropout`, next to the moments and the step count — the resume state the reference does not have)"""
+        sequence (`base` is the draw before the rank is mixed in).  The reference's `.model` file is the bare state_dict and must stay
+        loadable by it, so the state travels with the optimizer's state_dict (`rat_dropout`, next to the moments and the step count —
+        the resume state the reference does not have)"""
         if self.__dict__.get("_drop_words") is None:
             return None
-        return {"base": int(self._drop_base), "counter": int(self._drop_counter.cpu()[0])}
+        return {"base": int(self._drop_base_unmixed), "counter": int(self._drop_counter.cpu()[0])}
 
     def load_dropout_state(self, state):
         if state:
