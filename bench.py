@@ -341,7 +341,8 @@ def algorithmic_work(spec, batch, model="RAT_m2"):
         bwd = 2 if "_bwd" in name else 1
         if name in KernelTimer.ATTN_ARGS:                                # fused kernel: projections of `heads` heads + core
             L, h = [int(v) for v in tag[1:].split("h")]
-            inner = h * dh
+            # RAT_m3 launches heads / 2 heads of width 2 * dim_head (RAT_m3.py:181): the tag's h counts THOSE heads
+            inner = h * (2 * dh if model == "RAT_m3" else dh)
             return "mfma", bwd * tokens_of(L) * (8 * d * inner + 4 * inner * L)
         if name.startswith("rat_attn_core"):                             # core only (fp32 VALU, priced against the fp32 peak)
             L = int(tag[1:])

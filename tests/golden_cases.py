@@ -98,6 +98,20 @@ CASES += [
          batch_norm=False, use_wide=True, embedding_regularizer=0.03, net_regularizer=0),
 ]
 
+# Round 6: RAT_m3 outside the one geometry its fused kernel serves.  (a) the head geometry of the README's RAT_PA-on-Tmall run
+# (configs/RAT_m2/tmall_x1_002/model_config.yaml:23 — 32 heads x 10 at d = 10 -> RAT_m3 runs 16 heads of width 20, inner 320): head
+# groups; (b) dim_head 16 -> heads of width 32, wider than any fused instantiation: the composed path.
+CASES += [
+    dict(name="m3_tmall_real_heads", model="RAT_m3", batch=4, topk=6, init_seed=2021, data_seed=161, weight_seed=162, full_limit=2048,
+         fields=[_cat("f%d" % i, 11 + 2 * i) for i in range(8)],
+         embedding_dim=10, num_heads=32, dim_head=10, depth=2, scale_dim=2, dnn_hidden_units=[20, 8],
+         batch_norm=True, use_wide=True, embedding_regularizer=0.07, net_regularizer=0),
+    dict(name="m3_wide_dim_head", model="RAT_m3", batch=5, topk=4, init_seed=2021, data_seed=171, weight_seed=172, full_limit=2048,
+         fields=[_cat("a", 7), _cat("b", 5), _seq("c", 6), _cat("e", 9, padding_idx=8)],
+         embedding_dim=16, num_heads=4, dim_head=16, depth=2, scale_dim=2, dnn_hidden_units=[16, 8],
+         batch_norm=False, use_wide=True, embedding_regularizer=0.01, net_regularizer=0),
+]
+
 # RAT_m0 (one Transformer over the joint (t n) sequence of a sample — RAT_m0.py)
 CASES += [
     dict(name="m0_tiny_seq", model="RAT_m0", batch=6, topk=3, init_seed=2021, data_seed=131, weight_seed=132, full_limit=1 << 20,

@@ -238,15 +238,18 @@ def test_wide_heads_forward_group_loop_equals_the_per_group_launches(heads, drop
 def test_variants_with_the_shipped_tmall_heads(variant):
     """32 heads x 10 at d = 10 in the other model variants: RAT_m1's transformers run the wide-head layers through the same one-launch
     forward / backward as RAT_m2 (equal to the per-group launches), RAT_m0's joint sequences take the composed path whatever the head
-    count, RAT_m3's shared-query attention has only the fused form and says so"""
+    count, RAT_m3's shared-query attention (16 heads of width 20) runs as four head groups of the fused kernel — against the golden
+    vectors of the real RAT_m3 class at this geometry (m3_tmall_real_heads); heads of width 32 take the composed path (m3_wide_dim_head)"""
     import golden_cases as gc
     case = dict(gc.case_by_name("tmall_real_heads"), name="tm_" + variant, model=variant, batch_norm=False)
     if variant == "RAT_m3":
-        model = mc.build_model(case, gpu=0, seed=1)
-        mc.load_weights(model, case)
-        model.train()
-        with pytest.raises(NotImplementedError, match="RAT_m3 with num_heads"):
-            model.get_total_loss(tuple(t.to(model.device) for t in mc.batch_of(case)))
+        from rat_amd import ops
+        model = mc.build_model(gc.case_by_name("m3_tmall_real_heads"), gpu=0, seed=1)
+        assert model._m3_mode(ops.intra_map(4, 7, 9)) == ("grouped", 4) and model._m3_mode(ops.cross_map(4, 7, 9)) == ("grouped", 4)
+        mc.check_training("m3_tmall_real_heads", gpu=0)
+        model = mc.build_model(gc.case_by_name("m3_wide_dim_head"), gpu=0, seed=1)
+        assert model._m3_mode(ops.intra_map(5, 5, 5))[0] == "composed"
+        mc.check_training("m3_wide_dim_head", gpu=0)
         return
     out = {}
     for loop in (True, False):

@@ -31,7 +31,8 @@ def test_init_matches_reference_bit_for_bit(name):
 
 
 # the emulator runs one OS thread per GPU thread: keep the CPU suite to the small cases (the GPU suite runs them all)
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m3_tiny_seq", "m0_tiny_seq"])
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "mltag_shape", "m1_tiny_seq", "m3_tiny_seq", "m0_tiny_seq",
+                                  "m3_tmall_real_heads", "m3_wide_dim_head"])
 def test_eval_forward(name):
     mc.check_eval(name, gpu=-1)
 
@@ -74,7 +75,9 @@ def test_constructor_options_through_the_fused_step(name):
 # (RAT_m0 shares RAT_m1's transformer-stack code; its long-sequence composed path is exercised by
 # test_m2_composed_attention_path here and by the m0_northstar_shape golden case on the GPU)
 # one case per variant on the emulator (35-40 s each); the GPU suite runs every case of golden_cases.CASES
-@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m3_tiny_seq"])
+# m3_wide_dim_head: RAT_m3's composed attention (heads of width 32); its grouped form (m3_tmall_real_heads, 33 s here) trains in the GPU
+# suite and in the dropout probe below
+@pytest.mark.parametrize("name", ["tiny_seq_bn", "bare_no_proj", "m1_tiny_seq", "m3_tiny_seq", "m3_wide_dim_head"])
 def test_two_training_steps(name):
     mc.check_training(name, gpu=-1)
 
@@ -215,9 +218,11 @@ def _dropout_gradient_probe(case_name, model_kw, param_name=None):
     assert abs(l_eval - float(loss)) > 1e-6
 
 
-def test_attention_dropout_of_the_parallel_variant():
-    """RAT_m3: each of the two parallel attentions has its own Dropout behind to_out (missing until round 4)"""
-    _dropout_gradient_probe("m3_tiny_seq", dict(dropout=0.3))
+@pytest.mark.parametrize("name", ["m3_tiny_seq", "m3_tmall_real_heads", "m3_wide_dim_head"], ids=["fused", "grouped", "composed"])
+def test_attention_dropout_of_the_parallel_variant(name):
+    """RAT_m3: each of the two parallel attentions has its own Dropout behind to_out (missing until round 4) — in all three forms of
+    the layer (round 6: head groups share the mask of the one Dropout they feed; the composed form masks between to_out and the mean)"""
+    _dropout_gradient_probe(name, dict(dropout=0.3))
 
 
 def test_attention_dropout_on_the_composed_path(monkeypatch):
