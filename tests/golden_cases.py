@@ -316,5 +316,11 @@ def check_summary(store, key, arr, rtol, atol):
     return float(np.max(np.abs(got[6:] - ref[6:])))
 
 
+def summary_scale(store, key):
+    """largest |element| the fixture holds for `key` (the whole tensor, or the sampled elements of a summary)"""
+    ref = store[key] if key in store else store[key + "#summary"][6:]
+    return float(np.max(np.abs(np.asarray(ref, dtype=np.float64)))) if np.size(ref) else 0.0
+
+
 def has(store, key):
     return key in store or (key + "#summary") in store

@@ -61,6 +61,10 @@ def check_eval(name, gpu):
         out = model.forward(batch_of(case))
     np.testing.assert_allclose(out["y_pred"].cpu().numpy(), gold["eval/y_pred"], rtol=0, atol=2e-6)
     np.testing.assert_array_equal(out["y_true"].cpu().numpy(), gold["eval/y_true"])
+    if gpu >= 0:
+        import margins
+        margins.record("check_eval", name, "y_pred, absolute", float(np.abs(out["y_pred"].cpu().numpy() - gold["eval/y_pred"]).max()), 2e-6,
+                       arith=model.arith)
 
 
 def noise_step(case):
@@ -79,6 +83,17 @@ def eval_after_atol(case):
     return 2e-3 * max(1.0, noise_step(case) / 1e-3) * (4.0 if case.get("task") == "regression" else 1.0)
 
 
+# Gates on the MEASURED quantity: the worst error of a gradient tensor relative to the largest element the fixture
+# stores for it, on the MI355X box (profiles/round6/r6_parity_margins.txt; <= 5 x the worst seen, rounded).  The elementwise comparison
+# of check_summary (rtol 3e-4 + atol 3e-6 per element) stays as it was; this one is the tighter of the two wherever a tensor has
+# elements of very different size.  Default: every case but the three below landed at or under 4.4e-6.
+TRAINING_GRAD_GATE = 2.5e-5
+TRAINING_GRAD_GATES = {"kkbox_shape": 6e-5,                  # 1.1e-5 (LayerNorm bias of the cross phase)
+                       "m1_northstar_shape": 1e-4,           # 2.0e-5 (a table row)
+                       "m0_northstar_shape": 3e-4}           # 1.4e-4: the output layer's bias, a 3-sample sum that cancels to ~1e-3 of its terms
+LOSS_GATE = 2e-6                                             # x max(1, |loss|): losses of 5-9 (regularised tables) have ulps of 4.8e-7
+
+
 def check_training(name, gpu):
     case = gc.case_by_name(name)
     gold = np.load(os.path.join(GOLD, name + ".npz"))
@@ -87,11 +102,13 @@ def check_training(name, gpu):
     batch = batch_of(case)
     model.train()
     noise = noise_tensors(model)
+    worst_grad, worst_post, worst_loss = (0.0, None), (0.0, None), 0.0
     for step in (1, 2):
         before = {k: v.detach().clone() for k, v in model.state_dict().items()}
         model.optimizer.zero_grad()
         loss = model.get_total_loss(batch)
-        assert abs(float(loss) - float(gold["train%d/loss" % step])) < 2e-6
+        assert abs(float(loss.detach()) - float(gold["train%d/loss" % step])) < LOSS_GATE * max(1.0, abs(float(gold["train%d/loss" % step])))
+        worst_loss = max(worst_loss, abs(float(loss.detach()) - float(gold["train%d/loss" % step])))
         loss.backward()
         n = 0
         for k, p in model.named_parameters():
@@ -100,8 +117,11 @@ def check_training(name, gpu):
                 continue
             # a bias feeding BatchNorm has the exact gradient 0: both sides hold cancellation noise of sum(dz) there, whose size
             # scales with |dz| (1/sqrt(var) of a 3-row batch can be large) — only bound it
-            gc.check_summary(gold, "train%d/grad/%s" % (step, k), p.grad.detach().cpu().numpy(), rtol=3e-4,
-                             atol=3e-5 if k in noise else 3e-6)
+            err = gc.check_summary(gold, "train%d/grad/%s" % (step, k), p.grad.detach().cpu().numpy(), rtol=3e-4,
+                                   atol=3e-5 if k in noise else 3e-6)
+            if k not in noise:
+                rel = err / max(gc.summary_scale(gold, "train%d/grad/%s" % (step, k)), 1e-30)
+                worst_grad = max(worst_grad, (rel, "step %d %s" % (step, k)), key=lambda t: t[0])
             n += 1
         assert n == sum(1 for k in gold.files if k.startswith("train%d/grad/" % step))
         norm_sq = model.optimizer.clip_and_step(10.0)
@@ -116,7 +136,18 @@ def check_training(name, gpu):
                 assert float((v - before[k]).abs().max()) <= 1.0001 * noise_step(case)
                 continue
             atol = 3e-6 if not k.endswith("running_mean") else 3e-6 + step * 0.1 * noise_step(case) * 1.01
-            gc.check_summary(gold, "train%d/post/%s" % (step, k), v.detach().cpu().numpy(), rtol=3e-4, atol=atol)
+            err = gc.check_summary(gold, "train%d/post/%s" % (step, k), v.detach().cpu().numpy(), rtol=3e-4, atol=atol)
+            if not k.endswith("running_mean"):                # (running_mean carries the noise tensors' bound, see atol above)
+                rel = err / max(gc.summary_scale(gold, "train%d/post/%s" % (step, k)), 1e-30)
+                worst_post = max(worst_post, (rel, "step %d %s" % (step, k)), key=lambda t: t[0])
+    if gpu >= 0:
+        import margins
+        gate = TRAINING_GRAD_GATES.get(name, TRAINING_GRAD_GATE)
+        margins.record("check_training", name, "gradient, relative to the fixture's largest stored element", worst_grad[0], gate, arith=model.arith,
+                       where=worst_grad[1])
+        margins.record("check_training", name, "post-step weight, relative", worst_post[0], 3e-4, arith=model.arith, where=worst_post[1])
+        margins.record("check_training", name, "loss, absolute", worst_loss, LOSS_GATE * max(1.0, abs(float(gold["train2/loss"]))), arith=model.arith)
+        assert worst_grad[0] < gate, (name, worst_grad, gate)
     model.eval()
     with torch.no_grad():
         yp = model.forward(batch)["y_pred"].cpu().numpy()

@@ -102,15 +102,6 @@ def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
     kc.check_attn_dropout(emu, "cpu", (1, 3, 5, 40, 8, 10, True), "cross", arith="bf16x3")
 
 
-@pytest.mark.parametrize("case,mode", [pytest.param((1, 11, 4, 64, 8, 10, True), "cross", id="L11"), twin((1, 2, 33, 64, 8, 10, True), "intra", id="L33"),
-                                       twin((3, 16, 2, 64, 8, 10, True), "cross", id="L16")])
-def test_attn_fwd_bf16x3_matrix_core_lengths(emu, case, mode, two_blocks, knob):
-    """attn_fwd3m_kernel (QK^T and PV on the bf16 MFMA as well; opt-in: measured slower than the VALU core): one key
-    block with masked keys (L = 11), exactly one block (16), three blocks with one sequence per chunk (33)"""
-    knob(emu, "attn_fwd_core_mfma", 1)
-    kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
-
-
 @pytest.mark.parametrize("case,mode", [pytest.param((2, 3, 21, 64, 8, 10, True), "intra", id="L21_two_tiles"),
                                        pytest.param((3, 11, 4, 64, 8, 10, True), "cross", id="L11_one_tile"),
                                        twin((1, 31, 2, 64, 8, 10, True), "cross", id="L31")])
@@ -120,12 +111,6 @@ def test_attn_fwd_exact_fp32_matrix_pipe_core(emu, case, mode, two_blocks, knob)
     ragged second one (L = 21), one ragged tile (L = 11); L = 31 is where the host selects it by itself"""
     knob(emu, "attn_fwd_core_mfma", 2)
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
-
-
-@gpu_twin
-def test_attn_fwd_bf16x3_matrix_core_at_the_north_star_intra_length(emu, two_blocks, knob):
-    knob(emu, "attn_fwd_core_mfma", 1)
-    kc.check_attn(emu, "cpu", (2, 6, 21, 64, 8, 10, True), "intra", arith="bf16x3")
 
 
 @pytest.mark.parametrize("case,mode,nq,arith", [pytest.param((2, 6, 21, 64, 8, 10, True), "intra", 1, "bf16x3", id="b3_intra_L21"),

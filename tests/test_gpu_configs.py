@@ -29,7 +29,27 @@ CASES = [
     ("tmall_like_F8_K30_d64_h32_B4096", 384),
     ("kkbox_real_F13_K5_d40_B4096", 768),
 ]
-GRAD_RTOL = 3e-4          # gradients 3e-4 relative (to the tensor's largest element)
+GRAD_RTOL = 3e-4          # gradients 3e-4 relative (to the tensor's largest element) — the ceiling; per workload below
+# Per-workload gates = <= 5 x the worst error MEASURED on the MI355X box (tests/margins.py -> profiles/round6/r6_parity_margins.txt,
+# table in DESIGN.md §2); a workload without an entry keeps the ceiling.
+GRAD_GATES = {"mltag_like_K10_d16_B256": 1e-5,               # measured worst 1.9e-6 (f32)
+              "synthetic_F20_V1M_K10_d64_B4096": 1e-5,       # 2.0e-6 (bf16x3), 1.8e-6 (f32)
+              "kkbox_like_F13_K10_d64_B4096": 5e-6,          # 9.7e-7, 8.5e-7
+              "tmall_like_F8_K30_d64_h32_B4096": 1e-5,       # 1.8e-6, 2.0e-6
+              "kkbox_real_F13_K5_d40_B4096": 4.5e-5}         # 8.9e-6, 8.8e-6 (to_qkv.weight of the d = 40 layer: 40-wide rows, smaller maxima)
+GRAD_GATES_BN = {"synthetic_F20_V1M_K10_d64_B4096": 7.5e-6,  # 1.5e-6
+                 "tmall_like_F8_K30_d64_h32_B4096": 1e-5}    # 1.9e-6
+LOSS_GATE = 1.5e-6                                           # absolute, x max(1, |loss|): the worst seen is 3.6e-7 on losses of 0.6-0.7
+
+
+def _record(name, model, kind, loss, ref_loss, worst):
+    import margins
+    k, (err, scale) = max(worst.items(), key=lambda kv: kv[1][0])
+    gates = GRAD_GATES_BN if kind.endswith("batchnorm") else GRAD_GATES
+    margins.record("test_gpu_configs." + kind, name, "gradient, relative to the tensor's largest element", err, gates.get(name, GRAD_RTOL),
+                   arith=model.arith, where=k)
+    margins.record("test_gpu_configs." + kind, name, "loss, absolute", abs(float(loss) - float(ref_loss)),
+                   LOSS_GATE * max(1.0, abs(float(ref_loss))), arith=model.arith)
 
 
 def _oracle_cfg(orc, spec, fm, **over):
@@ -81,6 +101,8 @@ def test_full_batch_forward_matches_oracle(fwd_setup):
         ref = orc.forward(w, batch[0][rows], batch[1][rows], _oracle_cfg(orc, spec, fm), training=False).reshape(-1).double()
     np.testing.assert_allclose(full[rows].numpy(), ref.numpy(), rtol=0, atol=2e-6)
     model.check_id_errors()
+    import margins
+    margins.record("test_gpu_configs.full_batch_forward", name, "y_pred, absolute", float((full[rows] - ref).abs().max()), 2e-6, arith=model.arith)
 
 
 def test_auc_and_logloss_match_the_oracle_within_1e4(fwd_setup):
@@ -99,6 +121,9 @@ def test_auc_and_logloss_match_the_oracle_within_1e4(fwd_setup):
     mine = evaluate_metrics(y_true, full[rows].numpy(), ["AUC", "logloss"])
     want = evaluate_metrics(y_true, ref, ["AUC", "logloss"])
     assert abs(mine["AUC"] - want["AUC"]) < 1e-4 and abs(mine["logloss"] - want["logloss"]) < 1e-4, (mine, want)
+    import margins
+    for k in ("AUC", "logloss"):
+        margins.record("test_gpu_configs.auc_and_logloss", name, k + ", absolute", abs(mine[k] - want[k]), 1e-4, arith=model.arith)
 
 
 def _relu_margins(orc, w, X, y, cfg):
@@ -160,6 +185,29 @@ def _chunks_per_group(n, T, S):
     return intra, cross
 
 
+def _grad_errors(model, sub, ref_grads, skip=()):
+    """one training forward / backward of the slice -> ({parameter: (worst error / the reference tensor's largest element, that
+    element)}, loss)"""
+    model.train()
+    model.optimizer.zero_grad()
+    loss = model.get_total_loss(sub)
+    loss.backward()
+    torch.cuda.synchronize()
+    model.check_id_errors()
+    worst = {}
+    for k, p in model.named_parameters():
+        if k.startswith("query_proj"):
+            assert p.grad is None
+            continue
+        if k in skip:
+            continue
+        got, ref = p.grad.detach().cpu().double(), ref_grads[k].double()
+        scale = float(ref.abs().max())
+        assert scale > 0, k
+        worst[k] = (float((got - ref).abs().max()) / scale, scale)
+    return worst, loss.detach()
+
+
 @pytest.mark.parametrize("name,nslice", CASES, ids=[c[0] for c in CASES])
 def test_gradients_of_a_full_size_slice_match_the_oracle(name, nslice):
     from oracle import rat_m2_oracle as orc
@@ -177,25 +225,22 @@ def test_gradients_of_a_full_size_slice_match_the_oracle(name, nslice):
         intra, cross = _chunks_per_group(int(keep.numel()), T, S)
         assert intra >= 4 and cross >= 4, "slice too small: every work-group must loop over >= 4 chunks (%s)" % ((intra, cross),)
     sub = tuple(t[keep] for t in batch)
-    model.train()
-    model.optimizer.zero_grad()
-    loss = model.get_total_loss(sub)
-    loss.backward()
-    torch.cuda.synchronize()
-    model.check_id_errors()
     ref_loss, _ref_pred, ref_grads, _ = orc.loss_and_grads(w, sub[0], sub[1], cfg, training=True)
-    assert abs(float(loss) - float(ref_loss)) < 2e-6, (float(loss), float(ref_loss))
-    worst = {}
-    for k, p in model.named_parameters():
-        if k.startswith("query_proj"):
-            assert p.grad is None
-            continue
-        got, ref = p.grad.detach().cpu().double(), ref_grads[k].double()
-        scale = float(ref.abs().max())
-        assert scale > 0, k
-        worst[k] = (float((got - ref).abs().max()) / scale, scale)
-    bad = {k: v for k, v in worst.items() if not v[0] < GRAD_RTOL}
-    assert not bad, "gradients outside %g of their tensor's largest element: %s" % (GRAD_RTOL, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
+    default = model.arith
+    # the default arithmetic last: its result is the one asserted below; the other arithmetic the library offers for this geometry
+    # (exact fp32 beside bf16x3) goes through the same comparison first, at the same gate
+    for arith in [m for m in model.arith_modes() if m != default] + [default]:
+        model.set_arith(arith)
+        worst, loss = _grad_errors(model, sub, ref_grads)
+        assert abs(float(loss) - float(ref_loss)) < LOSS_GATE * max(1.0, abs(float(ref_loss))), (arith, float(loss), float(ref_loss))
+        if arith != default:
+            _record(name, model, "full_size_slice", loss, ref_loss, worst)
+            gate = GRAD_GATES.get(name, GRAD_RTOL)
+            assert all(v[0] < gate for v in worst.values()), (arith, max(worst.items(), key=lambda kv: kv[1][0]))
+    _record(name, model, "full_size_slice", loss, ref_loss, worst)
+    gate = GRAD_GATES.get(name, GRAD_RTOL)
+    bad = {k: v for k, v in worst.items() if not v[0] < gate}
+    assert not bad, "gradients outside %g of their tensor's largest element: %s" % (gate, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
     assert len(worst) >= 20
 
 
@@ -223,7 +268,7 @@ def test_gradients_of_a_full_size_slice_match_the_oracle_with_batchnorm(name, ns
     torch.cuda.synchronize()
     model.check_id_errors()
     ref_loss, _ref_pred, ref_grads, bn_state = orc.loss_and_grads(w, sub[0], sub[1], cfg, training=True)
-    assert abs(float(loss) - float(ref_loss)) < 2e-6, (float(loss), float(ref_loss))
+    assert abs(float(loss) - float(ref_loss)) < LOSS_GATE * max(1.0, abs(float(ref_loss))), (float(loss), float(ref_loss))
     noise = mc.noise_tensors(model)
     assert len(noise) == len(spec["dnn_hidden_units"])
     worst = {}
@@ -237,8 +282,10 @@ def test_gradients_of_a_full_size_slice_match_the_oracle_with_batchnorm(name, ns
         scale = float(ref.abs().max())
         assert scale > 0, k
         worst[k] = (float((got - ref).abs().max()) / scale, scale)
-    bad = {k: v for k, v in worst.items() if not v[0] < GRAD_RTOL}
-    assert not bad, "gradients outside %g of their tensor's largest element: %s" % (GRAD_RTOL, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
+    _record(name, model, "full_size_slice_batchnorm", loss, ref_loss, worst)
+    gate = GRAD_GATES_BN.get(name, GRAD_RTOL)
+    bad = {k: v for k, v in worst.items() if not v[0] < gate}
+    assert not bad, "gradients outside %g of their tensor's largest element: %s" % (gate, sorted(bad.items(), key=lambda kv: -kv[1][0])[:12])
     assert sum(1 for k in worst if k.startswith("dnn.")) >= 2 * len(spec["dnn_hidden_units"]) + 2      # W, gamma, beta per layer + out
     sd = model.state_dict()
     for k, v in bn_state.items():                                   # running statistics after this one training forward

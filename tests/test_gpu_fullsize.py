@@ -53,6 +53,9 @@ def test_slice_of_full_batch_matches_oracle(setup):
     ref = orc.forward(w, batch[0][rows], batch[1][rows], cfg, training=False)
     ref = (ref[0] if isinstance(ref, (tuple, list)) else ref).reshape(-1).double()
     np.testing.assert_allclose(full[rows].numpy(), ref.numpy(), rtol=0, atol=2e-6)      # tolerance of DESIGN.md §2 (y_pred 2e-6 abs)
+    import margins
+    margins.record("test_gpu_fullsize.slice_of_full_batch", "synthetic_F20_V1M_K10_d64_B4096/" + which, "y_pred, absolute",
+                   float((full[rows] - ref).abs().max()), 2e-6, arith=model.arith)
 
 
 def test_prediction_is_per_sample_and_chunking_independent(setup):
@@ -137,6 +140,10 @@ def test_auc_and_logloss_match_the_oracle_within_1e4(setup):
     mine = evaluate_metrics(y_true, full[rows].numpy(), ["AUC", "logloss"])
     want = evaluate_metrics(y_true, ref, ["AUC", "logloss"])
     assert abs(mine["AUC"] - want["AUC"]) < 1e-4 and abs(mine["logloss"] - want["logloss"]) < 1e-4, (mine, want)
+    import margins
+    for k in ("AUC", "logloss"):
+        margins.record("test_gpu_fullsize.auc_and_logloss", "synthetic_F20_V1M_K10_d64_B4096/" + which, k + ", absolute", abs(mine[k] - want[k]),
+                       1e-4, arith=model.arith)
 
 
 def test_dead_token_pruning_at_the_full_size(setup):

@@ -119,14 +119,6 @@ def test_attn_with_a_subset_of_query_positions(lib, case, mode, nq, arith):
     kc.check_attn_queries(lib, "cuda", case, mode, nq=nq, arith=arith)
 
 
-@pytest.mark.parametrize("case", B3_CASES, ids=str)
-@pytest.mark.parametrize("mode", ["intra", "cross"])
-def test_attn_fwd_bf16x3_matrix_core(lib, case, mode, knob):
-    """the opt-in forward kernel with QK^T / PV on the bf16 MFMA as well (attn_fwd3m_kernel; DESIGN.md §9: correct, measured slower)"""
-    knob(lib, "attn_fwd_core_mfma", 1)
-    kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
-
-
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None),
                                                            (5, 48, 3, 10, 0.3), (3, 900, 2, 10, None), (300, 60, 32, 10, None)])
 def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale, knob):

@@ -437,22 +437,6 @@ __global__ void __launch_bounds__(FFN_THREADS) ffn_bwd_kernel(FfnArgs a) {
 }
 
 
-// ======================================================================================================================
-// Fast path (D, H multiples of 16; D <= 64): "token-on-lanes" formulation.  Every product is computed TRANSPOSED,
-//     h^T = W1 x^T,   y^T = W2 g^T,   dh^T = W2^T dy^T,   dx^T = W1^T dhp^T,
-// with the weights as the MFMA A operand and a 16-token tile as the B operand: lane (g, n) = (lane >> 4, lane & 15)
-// holds x[token n][16 kb + 4 g + j] — one 16-byte global load per k-block.  The accumulator of such a product (rows =
-// output features 4 g + r, column = token n) IS the B operand of the next product (rat_device.h k-permutation), and its four
-// registers are four CONTIGUOUS features of one token: activations never pass through LDS between the GEMMs, results
-// are stored straight from the accumulators with 16-byte stores, and a wave needs no barrier to run the whole chain.
-// ======================================================================================================================
-__device__ __forceinline__ f32x4 mfma4(const float4& a, const float4& b, f32x4 c) {
-    c = RAT_MFMA16(a.x, b.x, c);
-    c = RAT_MFMA16(a.y, b.y, c);
-    c = RAT_MFMA16(a.z, b.z, c);
-    c = RAT_MFMA16(a.w, b.w, c);
-    return c;
-}
 __device__ __forceinline__ float4 as_f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ f32x4 as_v4(const float4& v) {
     f32x4 r = {v.x, v.y, v.z, v.w};
@@ -470,6 +454,15 @@ struct FfnTGeom {
     static constexpr size_t fwd_smem = (size_t)(H * LDW1 + D * LDW2 + H + D) * 4;
 };
 
+// ======================================================================================================================
+// Fast path (D, H multiples of 16; D <= 64): "token-on-lanes" formulation.  Every product is computed TRANSPOSED,
+//     h^T = W1 x^T,   y^T = W2 g^T,   dh^T = W2^T dy^T,   dx^T = W1^T dhp^T,
+// with the weights as the MFMA A operand and a 16-token tile as the B operand: lane (g, n) = (lane >> 4, lane & 15)
+// holds x[token n][16 kb + 4 g + j] — one 16-byte global load per k-block.  The accumulator of such a product (rows =
+// output features 4 g + r, column = token n) IS the B operand of the next product (rat_device.h k-permutation), and its four
+// registers are four CONTIGUOUS features of one token: activations never pass through LDS between the GEMMs, results
+// are stored straight from the accumulators with 16-byte stores, and a wave needs no barrier to run the whole chain.
+// ======================================================================================================================
 // two independent accumulator chains (M tiles `a0`, `a1` against the same B fragment), MFMAs issued alternately so that a
 // wave alone sustains the 32-cycle issue rate (dependent-accumulator latency is 40 cycles)
 __device__ __forceinline__ void mfma4x2(const float4& a0, const float4& a1, const float4& b, f32x4& c0, f32x4& c1) {
@@ -814,13 +807,6 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t_kernel(FfnArgs a) {
         f32x4 hp0 = rat_zero4(), hp1 = rat_zero4();
         auto epilogue = [&](int i, const f32x4& hacc, const f32x4& dacc) {
             float4 gv, dp;
-#ifdef RAT_FFN_PK
-            rat_f2 g01, d01, g23, d23;
-            rat_gelu_both2(rat_f2_make(hacc[0], hacc[1]), g01, d01);
-            rat_gelu_both2(rat_f2_make(hacc[2], hacc[3]), g23, d23);
-            gv = make_float4(g01.x, g01.y, g23.x, g23.y);
-            dp = make_float4(dacc[0] * d01.x, dacc[1] * d01.y, dacc[2] * d23.x, dacc[3] * d23.y);
-#else
             float dg;
             rat_gelu_both(hacc[0], gv.x, dg);
             dp.x = dacc[0] * dg;
@@ -830,7 +816,6 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t_kernel(FfnArgs a) {
             dp.z = dacc[2] * dg;
             rat_gelu_both(hacc[3], gv.w, dg);
             dp.w = dacc[3] * dg;
-#endif
             const int col = 16 * (HT * half + i) + 4 * g;
             st4(gs + row * G::LDH + col, gv);
             st4(dhs + row * G::LDH + col, dp);
@@ -1006,13 +991,6 @@ __device__ __forceinline__ HalfPieces f3_split4(const float4& v) {
     rat_split2(v.x, v.y, p.h0, p.m0, p.l0);
     rat_split2(v.z, v.w, p.h1, p.m1, p.l1);
     return p;
-}
-__device__ __forceinline__ RatB3 f3_stack(const HalfPieces& lo, const HalfPieces& hi) {     // k slots 0..3 | 4..7
-    rat_u4 h, m, l;
-    h.x = lo.h0; h.y = lo.h1; h.z = hi.h0; h.w = hi.h1;
-    m.x = lo.m0; m.y = lo.m1; m.z = hi.m0; m.w = hi.m1;
-    l.x = lo.l0; l.y = lo.l1; l.z = hi.l0; l.w = hi.l1;
-    return RatB3{rat_as_bf16x8(h), rat_as_bf16x8(m), rat_as_bf16x8(l)};
 }
 
 template <bool DPAD = false>
@@ -1329,11 +1307,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t4_kernel(FfnArgs a, Ffn3W
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
-#ifdef RAT_FFN_BWD_NT                                             // (A/B knob: x and dy of this layer are read exactly once)
-            tN[q] = (ok && (!DPAD || c < dr)) ? rat_ld4_stream(src + tk * dr + c) : zero4;
-#else
             tN[q] = (ok && (!DPAD || c < dr)) ? ld4(src + tk * dr + c) : zero4;
-#endif
         }
     }
     RAT_PROF_DECL
@@ -1426,11 +1400,7 @@ __global__ void __launch_bounds__(FB_THREADS) ffn_bwd_t4_kernel(FfnArgs a, Ffn3W
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = 32 * (q >> 1) + 8 * g + 4 * (q & 1);
-    #ifdef RAT_FFN_BWD_NT                                             // (A/B knob: x and dy of this layer are read exactly once)
-            tN[q] = (ok && (!DPAD || c < dr)) ? rat_ld4_stream(src + tk * dr + c) : zero4;
-#else
             tN[q] = (ok && (!DPAD || c < dr)) ? ld4(src + tk * dr + c) : zero4;
-#endif
             }
         }
         // ---- dx^T (d tile md, token tiles t0, t0 + 1) = W1^T dh'^T over the four K steps of the hidden dimension; W1^T's planes carry

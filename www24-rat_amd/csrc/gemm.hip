@@ -176,9 +176,6 @@ __global__ void __launch_bounds__(256) sgemm_reduce_kernel(GemmArgs g) {
 typedef RatPlanes<80, 0, 64 * 80> GmPlanesR;           // [64 r][32 k]
 typedef RatPlanes<128, 7, 32 * 128> GmPlanesK;         // [32 k][64 r]
 constexpr int GM3_OPERAND = 3 * 64 * 80;               // bytes per operand (the larger of the two images)
-#ifndef RAT_SGEMM_KSUB
-#define RAT_SGEMM_KSUB 1
-#endif
 
 template <bool KMAJOR>
 struct Tile3 {
@@ -215,7 +212,7 @@ struct Tile3 {
     }
 };
 
-// KSUB: 32-wide k sub-tiles per trip.  KSUB = 2 (-DRAT_SGEMM_KSUB=2: 48 MFMAs per wave between a request and its use, half the barriers
+// KSUB: 32-wide k sub-tiles per trip.  KSUB = 2 (48 MFMAs per wave between a request and its use, half the barriers
 // per k, 61 KB of LDS) was built in round 5 on the theory that the loads of the next sub-tile arrive late at the head's small grids —
 // measured: no shape faster, the 1280-tile input-gradient product 0.047 -> 0.088 ms (occupancy), profiles/round5/r5_sgemm_ksub_ab.txt.
 // The product runs KSUB = 1.
@@ -327,13 +324,7 @@ static int sgemm_launch(int trans_a, int trans_b, int M, int N, int K, const flo
     if (arith == RAT_ARITH_BF16X3 && g.veca && g.vecb && K >= 2 * GM_K && M >= 16 && N >= 16) {
         const size_t smem3 = (size_t)2 * GM3_OPERAND;
         const bool ka = g.ta != 0, kb = g.tb == 0;
-        const bool two = RAT_SGEMM_KSUB == 2 && g.slices == 1 && K >= 4 * GM_K;       // (split products keep their occupancy: one sub-tile per trip)
-        if (two) {
-            if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
-            else if (ka) RAT_LAUNCH((sgemm3_kernel<true, false, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
-            else if (kb) RAT_LAUNCH((sgemm3_kernel<false, true, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
-            else RAT_LAUNCH((sgemm3_kernel<false, false, 2>), tiles, GM_THREADS, 2 * smem3, stream, g);
-        } else if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
+        if (ka && kb) RAT_LAUNCH((sgemm3_kernel<true, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
         else if (ka) RAT_LAUNCH((sgemm3_kernel<true, false>), tiles * g.slices, GM_THREADS, smem3, stream, g);
         else if (kb) RAT_LAUNCH((sgemm3_kernel<false, true>), tiles * g.slices, GM_THREADS, smem3, stream, g);
         else RAT_LAUNCH((sgemm3_kernel<false, false>), tiles * g.slices, GM_THREADS, smem3, stream, g);

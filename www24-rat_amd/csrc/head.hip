@@ -317,11 +317,7 @@ __device__ __forceinline__ float4 st_block_sum(float4 v, float* scratch) {
 }
 
 __device__ __forceinline__ int st_column_group(int ngroups, int per_xcd) {
-#ifdef RAT_ST_NOMAP
-    const int g = blockIdx.x;
-#else
     const int g = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-#endif
     return g < ngroups ? g : -1;
 }
 
