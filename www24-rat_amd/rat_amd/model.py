@@ -21,6 +21,7 @@ from . import ops
 from ._lib import get_lib
 from .base_model import BaseModel, parse_regularizer
 from .data import DeviceBatch
+from .dp import DataParallelExchange
 from .features import field_infos
 
 
@@ -93,55 +94,6 @@ class _Encoder(nn.Module):
     def __init__(self, dim, heads, dim_head, dropout, depth, hidden):
         super().__init__()
         self.encoder = nn.ModuleList([_Block(dim, heads, dim_head, dropout, hidden) for _ in range(depth)])
-
-
-class _AttentionM3(nn.Module):
-    """RAT_m3's Attention (RAT_m3.py:164-178): the three projections are modules OWNED BY THE BLOCK and only referenced here
-    (so state_dict lists them again under fn.W_q / fn.W_k / fn.W_v); the output projection is its own."""
-
-    def __init__(self, W_q, W_k, W_v, dim, inner_dim, heads, dim_head, dropout):
-        super().__init__()
-        self.inner_dim = inner_dim
-        project_out = not (heads == 1 and dim_head == dim)
-        self.W_q, self.W_k, self.W_v = W_q, W_k, W_v
-        self.heads, self.scale = heads, dim_head ** -0.5
-        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
-
-
-class _BlockM3(nn.Module):
-    """CrossIntraEncoderBlock of RAT_m3 (RAT_m3.py:191-213): registration order W_q, W_k_s, W_v_s, W_k_t, W_v_t,
-    intra_attention, cross_attention, mlp."""
-
-    def __init__(self, dim, heads, dim_head, dropout, hidden):
-        super().__init__()
-        self.inner_dim = heads * dim_head
-        self.W_q = nn.Linear(dim, self.inner_dim, bias=False)
-        self.W_k_s = nn.Linear(dim, self.inner_dim, bias=False)
-        self.W_v_s = nn.Linear(dim, self.inner_dim, bias=False)
-        self.W_k_t = nn.Linear(dim, self.inner_dim, bias=False)
-        self.W_v_t = nn.Linear(dim, self.inner_dim, bias=False)
-        self.intra_attention = _PreNorm(dim, _AttentionM3(self.W_q, self.W_k_s, self.W_v_s, dim, self.inner_dim, heads, dim_head, dropout))
-        self.cross_attention = _PreNorm(dim, _AttentionM3(self.W_q, self.W_k_t, self.W_v_t, dim, self.inner_dim, heads, dim_head, dropout))
-        self.mlp = _FeedForward(dim, hidden)
-
-
-class _EncoderM3(nn.Module):
-    def __init__(self, dim, heads, dim_head, dropout, depth, hidden):
-        super().__init__()
-        self.encoder = nn.ModuleList([_BlockM3(dim, heads, dim_head, dropout, hidden) for _ in range(depth)])
-
-
-class _Transformer(nn.Module):
-    """RAT_m1's Transformer (RAT_m1.py:194-203): `layers` is registered before `norm`; layers[i] = [PreNorm(Attention),
-    PreNorm(FeedForward)]."""
-
-    def __init__(self, dim, depth, heads, dim_head, hidden, dropout):
-        super().__init__()
-        self.layers = nn.ModuleList([])
-        self.norm = nn.LayerNorm(dim)
-        for _ in range(depth):
-            self.layers.append(nn.ModuleList([_PreNorm(dim, _Attention(dim, heads, dim_head, dropout)),
-                                              _PreNorm(dim, _FeedForward(dim, hidden))]))
 
 
 def _activation_module(name):
@@ -228,7 +180,7 @@ class _RATFunction(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
-class RAT_m2(BaseModel):
+class RAT_m2(DataParallelExchange, BaseModel):
     def __init__(self, feature_map, model_id="RAT_m2", gpu=-1, task="binary_classification", learning_rate=1e-3,
                  embedding_dim=10, dnn_hidden_units=[64, 64, 64], dnn_activations="ReLU", attention_layers=2,
                  num_heads=1, attention_dim=8, net_dropout=0, batch_norm=False, layer_norm=False, use_scale=False,
@@ -804,321 +756,6 @@ class RAT_m2(BaseModel):
             if self._params[n].grad is not None:
                 self._gflat_view(g, n).copy_(self._params[n].grad)
         return g
-
-    def _exchange_gradients(self, g=None):
-        """Data parallelism.  C1: all-reduce (RCCL over xGMI) of the dense-net slice of the flat gradient bucket —
-        started inside backward, only waited for here.  Tables: in sparse mode, and in the dense modes whenever the fused training
-        step asked backward for row lists (`_table_lists`), C2: all-gather of (row ids, gradient rows, count) + the same
-        deterministic plan + segmented reduction on every rank (28.8 MB per rank at the north-star strong-scaling shape instead of
-        a 257 MB all-reduce; the regulariser's lambda*W is replica-identical and never travels); otherwise one dense all-reduce.
-        `g`: the flat gradient buffer when the caller holds it (the fused step; p.grad is not populated there)."""
-        if not self._dp():
-            return
-        explicit = g is not None
-        if g is None:
-            g = self._gather_flat_grad()
-        pending, self._pending_reduce = self._pending_reduce, None
-        lists, self._table_lists = self._table_lists, None
-        world = self._world_size()
-        ring = lambda nbytes: int(2 * nbytes * (world - 1) / world)      # noqa: E731  (an all-reduce moves ~2 (N-1)/N of its size per rank)
-        if g is not None:
-            n0 = self._n_emb - self._n_sparse                      # [0, n0): "embedding_layer" tensors with a dense gradient
-            form = ("owner_lists" if self._owner_state is not None else "gathered_lists") if lists is not None else \
-                ("owner_lists(sparse)" if self._owner_state is not None else "gathered_lists(sparse)") if self._sparse is not None else \
-                "dense_allreduce"
-            self._exchange_info = dict(form=form, world=world, dense_net_bytes=ring(4 * (g.numel() - n0)),
-                                       table_bytes=ring(4 * n0) if form == "dense_allreduce" else None)
-            if pending is not None and pending[1] is g:            # the dense-net part is already on its way
-                if lists is not None:
-                    if self._owner_state is not None:              # (the label table's partial gradients ride in the lists' headers)
-                        self._exchange_lists_owner(g, lists)
-                    else:
-                        for part in lists:                         # into the zeroed table block
-                            rows, grads, count, width, _t, _b = self._merge_sparse(part)
-                            ops.scatter_rows(g[part[5]:], rows, grads, count, width, lib=self._lib)
-                        if n0 > self._n_tab:
-                            self._all_reduce_sum(g[self._n_tab:n0])    # the label table (3 x d floats)
-                elif n0 > 0:
-                    self._all_reduce_sum(g[:n0])
-                self._collective(lambda: pending[0][0].wait())
-            else:
-                if pending is not None:
-                    pending[0][0].wait()
-                    raise RuntimeError("gradient buffers were replaced between backward and the exchange: the in-flight all-reduce "
-                                       "of the dense-net gradients would be summed twice (gradient accumulation under data "
-                                       "parallelism is not supported on this path)")
-                assert lists is None
-                self._all_reduce_sum(g)
-            if not explicit and g is not self._last_gflat:
-                for n in self._dense_names():
-                    self._params[n].grad = self._gflat_view(g, n)
-                self._last_gflat = g
-        if self._sparse is not None and not self._sparse_is_global:      # (a second call must not merge global lists again)
-            if self._owner_state is not None and g is not None:
-                self._sparse = self._exchange_lists_owner(g, self._sparse)
-            else:
-                self._sparse = [self._merge_sparse(part) for part in self._sparse]
-            self._sparse_is_global = True
-        self._owner_state = None
-        info = self.__dict__.get("_exchange_info")
-        if info is not None and info["table_bytes"] is None:
-            if info["form"].startswith("owner"):
-                info["table_bytes"] = (self.__dict__.get("_owner_stats") or {}).get("wire_bytes")
-            elif lists is not None:                                # all-gather at capacity: my lists to every peer
-                info["table_bytes"] = sum(4 * (p[0].numel() * (1 + p[3]) + 1) for p in lists) * (world - 1)
-
-    # Owner-partitioned exchange of the table-gradient lists: rank k owns the rows [k R/N, (k+1) R/N) of a table family; every rank sends
-    # each owner ITS rows of the local (sorted, unique) lists — an all-to-all of exactly the pairs that exist — the owner sorts / reduces
-    # only what it received (1/N of the union instead of the whole union on every rank) and the reduced lists are all-gathered.  Same
-    # sums in the same (rank) order as the all-gather form, so the replicas stay bit-identical.
-    #
-    # Round 5: no host stall, three collectives per step instead of twelve.  The split sizes of the all-to-all are the per-owner counts
-    # of the local lists — a function of the batch's IDS alone.  `_owner_prepare` therefore builds the sort plans and the counts at
-    # the START of the step (rat_owner_counts), all-gathers the N x N matrix and starts its copy to pinned host memory; the host reads
-    # it when the backward has been enqueued — long after the copy has landed.  Both table families and the label table's partial
-    # gradient share ONE wire buffer per peer (rat_owner_pack / rat_owner_unpack) and ONE all-gathered list per rank
-    # (rat_owner_scatter).  Under a captured step the exchange is one eager closure between two graph segments (its buffer sizes
-    # change from step to step; its inputs and outputs — the local lists, the gradient bucket — are static).
-    owner_exchange = True
-    _OWNER_BUCKET = 4096                 # list capacities are rounded up to this many rows (few distinct plan sizes)
-
-    def _merge_sparse(self, part):
-        """one family's local (rows, grads, count) -> the global list as ONE (rows, grads, count, width, total_rows, base) record
-        (all-gather at capacity + merge of the union on every rank: the form without owners)"""
-        return self._merge_sparse_gather(part)
-
-    def _use_owner_exchange(self):
-        # (sparse mode inside a captured step: the optimizer's row kernels are recorded with the list pointers baked in — the
-        # all-gather form has static capacities)
-        return bool(self.owner_exchange) and not (self._tape is not None and self._grad_mode == "sparse")
-
-    def _raw_all_to_all(self, out, inp, out_splits, in_splits):
-        """uneven all-to-all along dim 0 (RCCL on device tensors; gloo on host tensors, staged through the host for device tensors)"""
-        import torch.distributed as dist
-        if self._staged(inp):
-            ho = torch.empty(out.shape, dtype=out.dtype)
-            dist.all_to_all_single(ho, inp.detach().cpu().contiguous(), out_splits, in_splits)
-            out.copy_(ho)
-        else:
-            dist.all_to_all_single(out, inp, out_splits, in_splits)
-
-    def _raw_all_gather(self, out, t):
-        import torch.distributed as dist
-        world = self._world_size()
-        if self._staged(t):
-            parts = [torch.empty(t.numel(), dtype=t.dtype) for _ in range(world)]
-            dist.all_gather(parts, t.detach().reshape(-1).cpu())
-            out.copy_(torch.cat(parts))
-        elif t.is_cuda:
-            dist.all_gather_into_tensor(out, t)
-        else:
-            dist.all_gather(list(out.view(world, -1).unbind(0)), t)
-
-    def _build_plans(self, idx, dims):
-        """the sort plans of a batch's table rows (feature tables; LR tables): functions of the ids alone"""
-        c, lib = self._cfg, self._lib
-        B, T, L, S = dims
-        d, F = c["d"], c["nf"]
-        if self._col2field is None or self._col2field.numel() != L:
-            self._col2field = ops.col2field_table(self._fields, L, idx.device)
-        rows_feat = self._n_feat // d
-        # one plan per batch size, kept for the model's life: captured steps point into its workspace (see _merge_sparse_gather)
-        plan = ops.sparse_plan_ids(idx, self._ftab, self._col2field, F, self._flat, d, rows_feat, B, T, L,
-                                   plan=self._ws.get(("plan", 0, B * T * L)), lib=lib)
-        self._ws[("plan", 0, B * T * L)] = plan
-        plan_lr = None
-        if c["use_wide"]:
-            rows_lr = self._n_tab - self._n_feat
-            plan_lr = ops.sparse_plan_ids(idx, self._lr_ftab, self._col2field, F, self._flat[self._n_feat:], 1, rows_lr, B, T, L,
-                                          target_only=True, plan=self._ws.get(("plan", 1, B * L)), lib=lib)
-            self._ws[("plan", 1, B * L)] = plan_lr
-        return plan, plan_lr
-
-    def _owner_prepare(self, idx, dims):
-        """Start of a fused iteration whose table gradients will travel as row lists: plans, per-owner counts, the N x N count matrix
-        on every rank and — asynchronously — on every host."""
-        c, lib = self._cfg, self._lib
-        world, dev = self._world_size(), idx.device
-        d = c["d"]
-        plans = self._build_plans(idx, dims)
-        per_a = -(-(self._n_feat // d) // world)
-        per_b = -(-(self._n_tab - self._n_feat) // world) if plans[1] is not None else 1
-        cnt = self._ws.get(("owner-counts", world))
-        if cnt is None or cnt.device != dev:
-            cnt = self._ws[("owner-counts", world)] = torch.zeros(2 * world, dtype=torch.int32, device=dev)
-        ops.owner_counts(plans[0], per_a, world, cnt[:world], lib=lib)
-        if plans[1] is not None:
-            ops.owner_counts(plans[1], per_b, world, cnt[world:], lib=lib)
-        self._owner_publish(cnt, plans, (per_a, per_b))
-
-    def _owner_publish(self, cnt, plans, per):
-        """cnt: int32 [2][world] on the device, this rank's pairs per (family, owner) -> `_owner_state`"""
-        import torch.distributed as dist
-        world, rank, dev = self._world_size(), dist.get_rank(), cnt.device
-        mat = torch.empty(2 * world * world, dtype=torch.int32, device=dev)
-        host = self._ws.get(("owner-host", world))
-        if host is None:
-            host = torch.empty(2 * world * world, dtype=torch.int32)
-            host = self._ws[("owner-host", world)] = host.pin_memory() if dev.type == "cuda" else host
-        event = torch.cuda.Event() if dev.type == "cuda" else None
-
-        def run():
-            self._raw_all_gather(mat, cnt)
-            host.copy_(mat, non_blocking=True)
-            if event is not None:
-                event.record()
-        self._collective(run)
-        self._owner_state = dict(plans=plans, mat=mat, host=host, event=event, per=per, rank=rank, world=world)
-
-    def _exchange_lists_owner(self, g, lists):
-        """lists: this backward's [(rows, grads, count, width, total_rows, base)] per table family (feature tables[, LR tables]) ->
-        dense modes: the global gradient rows land in the zeroed table block of `g` and the label table's gradient is summed over
-        the ranks; sparse mode: returns the global lists as records for the row optimizer."""
-        st, self._owner_state = self._owner_state, None
-        c, lib = self._cfg, self._lib
-        d, world, rank = c["d"], st["world"], st["rank"]
-        mat, host, event = st["mat"], st["host"], st["event"]
-        rows_a, grads_a, _ca, _wa, total_a, base_a = lists[0]
-        rows_b, vals_b, _cb, _wb, total_b, base_b = lists[1] if len(lists) > 1 else (None, None, None, 1, 0, 0)
-        dev = rows_a.device
-        sparse_mode = self._grad_mode == "sparse"
-        # the label table's slot (the "embedding_layer" tensor without a row list): its partial gradients ride in the lists' headers
-        # (sparse mode: it is part of the dense slice _exchange_gradients all-reduces)
-        n_label = 0 if sparse_mode else self._n_emb - self._n_tab
-        label = g[self._n_tab:self._n_emb] if n_label > 0 else None
-        pad4 = lambda n: (n + 3) // 4 * 4                              # noqa: E731
-        chunk = lambda na, nb: pad4(na) + na * d + 2 * pad4(nb)        # noqa: E731
-        bucket = lambda n: max(self._OWNER_BUCKET, -(-n // self._OWNER_BUCKET) * self._OWNER_BUCKET)      # noqa: E731
-        out = {}
-
-        def run():
-            recording = self._tape is not None        # graph capture: nothing has executed, the matrix is not there yet — issue the
-            if recording:                              # same collectives on token buffers and launch nothing that reads it
-                S = torch.zeros((world, 2, world), dtype=torch.int64)
-            else:
-                if event is not None:
-                    event.synchronize()
-                S = host.view(world, 2, world).to(torch.int64)
-            in_splits = [chunk(int(S[rank, 0, k]), int(S[rank, 1, k])) if not recording else 4 for k in range(world)]
-            out_splits = [chunk(int(S[k, 0, rank]), int(S[k, 1, rank])) if not recording else 4 for k in range(world)]
-            n_send, n_recv = sum(in_splits), sum(out_splits)
-            cap_a = bucket(int(S[:, 0, :].sum(0).max()))
-            cap_b = bucket(int(S[:, 1, :].sum(0).max())) if rows_b is not None else 0
-            max_pairs = int(S.sum(1).max())
-            send = torch.empty(max(n_send, 4), dtype=torch.float32, device=dev)
-            recv = torch.empty(max(n_recv, 4), dtype=torch.float32, device=dev)
-            if not recording:
-                ops.owner_pack(mat, world, rank, d, rows_a, grads_a, rows_b, vals_b, max_pairs, send, lib=lib)
-            self._raw_all_to_all(recv[:n_recv], send[:n_send], out_splits, in_splits)
-            stride = 4 + pad4(n_label) + cap_a * (1 + d) + 2 * cap_b
-            mine = torch.empty(stride, dtype=torch.float32, device=dev)
-            mine_i = mine.view(torch.int32)
-            o_ra = 4 + pad4(n_label)
-            o_ga, o_rb = o_ra + cap_a, o_ra + cap_a * (1 + d)
-            o_vb = o_rb + cap_b
-            if not recording:
-                got_ra = torch.empty(cap_a, dtype=torch.int32, device=dev)
-                got_ga = torch.empty((cap_a, d), dtype=torch.float32, device=dev)
-                got_rb = torch.empty(cap_b, dtype=torch.int32, device=dev) if cap_b else None
-                got_vb = torch.empty(cap_b, dtype=torch.float32, device=dev) if cap_b else None
-                totals = torch.empty(2, dtype=torch.int32, device=dev)
-                if not cap_b:
-                    mine_i[1:2].zero_()
-                ops.owner_unpack(mat, world, rank, d, recv, max_pairs, got_ra, got_ga, got_rb, got_vb, totals,
-                                 extra_src=label, extra_dst=mine[4:4 + n_label] if n_label > 0 else None, lib=lib)
-                # the owner's merge: sort + fixed-order reduction of what it received (sources in rank order), written straight into
-                # the list this rank contributes to the all-gather
-                key = ("merge-owner", 0, cap_a)
-                plan = ops.sparse_plan_rows(got_ra, totals[0:1], cap_a, 1, total_a, plan=self._ws.get(key), count_out=mine_i[0:1], lib=lib)
-                self._ws[key] = plan
-                ops.sparse_reduce_rows(plan, got_ga, cap_a, 1, d, mine_i[o_ra:o_ga], mine[o_ga:o_rb].view(cap_a, d), count=mine_i[0:1], lib=lib)
-                if cap_b:
-                    key = ("merge-owner", 1, cap_b)
-                    plan = ops.sparse_plan_rows(got_rb, totals[1:2], cap_b, 1, total_b, plan=self._ws.get(key), count_out=mine_i[1:2], lib=lib)
-                    self._ws[key] = plan
-                    ops.sparse_reduce_rows(plan, got_vb.view(cap_b, 1), cap_b, 1, 1, mine_i[o_rb:o_vb], mine[o_vb:].view(cap_b, 1),
-                                           count=mine_i[1:2], lib=lib)
-            everyone = torch.empty(world * stride, dtype=torch.float32, device=dev)
-            self._raw_all_gather(everyone, mine)
-            self._owner_stats = dict(sent=int(S[rank].sum()), received=int(S[:, :, rank].sum()), capacity=(cap_a, cap_b),
-                                     local_capacity=rows_a.numel(), floats_sent=n_send, floats_gathered=world * stride, collectives=3,
-                                     # what this rank puts on the links: its chunks for the other owners + its reduced list to every peer
-                                     wire_bytes=4 * ((n_send - in_splits[rank]) + stride * (world - 1)))
-            if recording:
-                return
-            if sparse_mode:
-                ev_i = everyone.view(torch.int32).view(world, stride)
-                ev_f = everyone.view(world, stride)
-                recs = []
-                for k in range(world):
-                    recs.append((ev_i[k, o_ra:o_ga], ev_f[k, o_ga:o_rb].view(cap_a, d), ev_i[k, 0:1], d, total_a, base_a))
-                    if cap_b:
-                        recs.append((ev_i[k, o_rb:o_vb], ev_f[k, o_vb:].view(cap_b, 1), ev_i[k, 1:2], 1, total_b, base_b))
-                out["records"] = recs
-            else:
-                ops.owner_scatter(g[base_a:], g[base_b:] if cap_b else None, label, everyone, stride, world, cap_a, cap_b, d, n_label, lib=lib)
-        self._collective(run)
-        return out.get("records")
-
-    def _merge_sparse_gather(self, part):
-        """all-gather one family's (rows, grads, count) at capacity and reduce the union: -> the same record, global"""
-        lib, world = self._lib, self._world_size()
-        rows, grads, count, width, total_rows, base_off = part
-        cap = rows.numel()
-        all_rows = self._all_gather_flat(rows)
-        all_grads = self._all_gather_flat(grads.reshape(-1))
-        all_counts = self._all_gather_flat(count)
-        # plans are cached PER SIZE and never dropped: a captured step (graph.StepGraph) has the plan's workspace / count
-        # pointers baked in, and a second batch shape (an epoch's tail batch) must not hand that memory back to the allocator
-        pkey = ("merge", width, cap * world)
-        plan = ops.sparse_plan_rows(all_rows, all_counts, cap, world, total_rows, plan=self._ws.get(pkey), lib=lib)
-        self._ws[pkey] = plan
-        ncap = min(cap * world, total_rows)
-        out_rows = torch.empty(ncap, dtype=torch.int32, device=rows.device)
-        out_grads = torch.empty((ncap, width), dtype=torch.float32, device=rows.device)
-        ops.sparse_reduce_rows(plan, all_grads, cap, world, width, out_rows, out_grads, lib=lib)
-        return (out_rows, out_grads, plan.count.clone(), width, total_rows, base_off)
-
-    def _collective(self, fn):
-        """Every communication call of the step goes through here as a closure over tensors that already exist.  Normally it just
-        runs; while the step is being captured into hipGraphs (graph.StepGraph) the capture is suspended around it and the closure is
-        kept, to be run again between the graph segments of every replay."""
-        return self._tape.between_segments(fn) if self._tape is not None else fn()
-
-    def _staged(self, t):
-        """device tensors under the gloo backend (GPU tests that run two ranks on ONE device, where RCCL refuses): the collective
-        goes through host copies.  RCCL ("nccl") and CPU tensors are used directly."""
-        import torch.distributed as dist
-        return t.is_cuda and dist.get_backend() == "gloo"
-
-    def _all_gather_flat(self, t):
-        """[n] -> [world * n], ranks in order (RCCL all-gather on the GPU, gloo in the CPU tests)."""
-        import torch.distributed as dist
-        world = self._world_size()
-        out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
-        if self._staged(t):
-            def run():
-                parts = [torch.empty(t.numel(), dtype=t.dtype) for _ in range(world)]
-                dist.all_gather(parts, t.detach().reshape(-1).cpu())
-                out.copy_(torch.cat(parts))
-            self._collective(run)
-        elif t.is_cuda:
-            self._collective(lambda: dist.all_gather_into_tensor(out, t))
-        else:
-            self._collective(lambda: dist.all_gather(list(out.view(world, -1).unbind(0)), t))
-        return out
-
-    def _all_reduce_sum(self, t):
-        import torch.distributed as dist
-        if self._staged(t):
-            def run():
-                h = t.detach().cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                t.copy_(h)
-            self._collective(run)
-        else:
-            self._collective(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM))
-        return t
 
     def check_id_errors(self):
         """nn.Embedding raises IndexError on an out-of-vocabulary id (embedding.py:158-178); the kernels clamp for memory safety
@@ -1712,354 +1349,3 @@ class RAT_m2(BaseModel):
                 sparse.append((rows, vals, plan_lr.count.clone(), 1, rows_lr, self._n_feat))
         self._sparse = sparse if mode in ("sparse", "lists") else None
         self._sparse_is_global = False
-
-
-class RAT_m1(RAT_m2):
-    """RAT_m1 (fuxictr/pytorch/models/RAT_m1.py:24-130): the cascaded variant.  Every sample's S = F+1 tokens go through
-    an intra `Transformer` (depth x [PreNorm attention + residual, PreNorm feed-forward + residual], final LayerNorm);
-    the label token of each of the T samples is kept, the [B, T, d] result goes through a second, cross `Transformer`,
-    and the target's row feeds `fc`.  Same constructor, batch layout, head, loss, optimizer and C-ABI as RAT_m2; the
-    encoder is K2a (attention) + K2c (LayerNorm) + K2b with a separate residual (rat_ffn_fwd_res)."""
-
-    def __init__(self, feature_map, model_id="RAT_m1", **kwargs):
-        super().__init__(feature_map, model_id=model_id, **kwargs)
-
-    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
-        self.intra_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:71
-        self.cross_transformer = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)     # RAT_m1.py:72
-
-    def _build_encoder_descriptors(self):
-        self._stacks = {}
-        for t in ("intra_transformer", "cross_transformer"):
-            layers = []
-            for i in range(self._cfg["depth"]):
-                p = "%s.layers.%d." % (t, i)
-                layers.append(dict(attn=self._attn_descriptor(p + "0."), ln=[p + "1.norm.weight", p + "1.norm.bias"],
-                                   ffn=[p + "1.fn.net.0.weight", p + "1.fn.net.0.bias", p + "1.fn.net.3.weight", p + "1.fn.net.3.bias"]))
-            self._stacks[t] = (layers, [t + ".norm.weight", t + ".norm.bias"])
-
-    def _stack_forward(self, which, x, smap, ntok, cls_stride, ncls, save, saved):
-        """One Transformer (RAT_m1.py:205-209) on `ntok` tokens; the final LayerNorm is applied to token 0 of every
-        sequence only (the sole rows read afterwards, RAT_m1.py:125,128) -> [ncls, d]."""
-        c, lib = self._cfg, self._lib
-        d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
-        layers, norm = self._stacks[which]
-        rec = []
-        for lay in layers:
-            xa, att = self._attn_layer_forward(lay["attn"], x, smap, save)                            # attn(norm(x)) + x
-            xn = ops.layernorm_fwd(xa, d, ntok, self._p(lay["ln"][0]), self._p(lay["ln"][1]), d, lib=lib)
-            w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
-            # FeedForward(dim, mlp_dim, dropout) carries two Dropout layers of the same rate (RAT_m1.py:151-161,202; RAT_m0.py:150-160,201)
-            fdrop = (c["attn_dropout"], self._dropout_word(), self._dropout_word()) if (self.training and c["attn_dropout"] > 0) else None
-            xb = ops.ffn_fwd_res(xn, xa, w1, b1, w2, b2, d, H, arith=self.arith, dropout=fdrop, lib=lib)   # ff(norm(x)) + x
-            if save:
-                rec.append((x, att, xa, xn, fdrop))
-            x = xb
-        out = ops.layernorm_fwd(x, cls_stride, ncls, self._p(norm[0]), self._p(norm[1]), d, lib=lib)
-        if save:
-            saved[which] = (rec, x)
-        return out
-
-    def _stack_backward(self, which, saved, dcls, smap, cls_stride, shape, G):
-        c, lib = self._cfg, self._lib
-        d, H, heads, dh = c["d"], c["hidden"], c["heads"], c["dh"]
-        layers, norm = self._stacks[which]
-        rec, x_last = saved[which]
-        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
-        dx = torch.zeros(shape, dtype=torch.float32, device=dcls.device)          # only the class-token rows get a gradient
-        ops.layernorm_bwd(x_last, cls_stride, dcls, self._p(norm[0]), dx, cls_stride, G(norm[0]), G(norm[1]), d, lib=lib)
-        for lay, (x_in, att, xa, xn, fdrop) in zip(reversed(layers), reversed(rec)):
-            w1, b1, w2, b2 = [self._p(n) for n in lay["ffn"]]
-            gw = [G(n) for n in lay["ffn"]]
-            dxn, _ = ops.ffn_bwd_res(xn, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
-                                     arith=self.arith, dropout=fdrop, lib=lib)
-            dxa = ops.layernorm_bwd(xa, d, dxn, self._p(lay["ln"][0]), dxn, d, G(lay["ln"][0]), G(lay["ln"][1]), d, add=dx, lib=lib)
-            dx = self._attn_layer_backward(lay["attn"], x_in, dxa, att, smap, G)
-        return dx
-
-    def _encoder_forward(self, x, x0, dims, save, saved):
-        B, T, L, S = dims
-        d = self._cfg["d"]
-        xi = self._stack_forward("intra_transformer", x, ops.intra_map(B, T, S), B * T * S, S * d, B * T, save, saved)
-        xc = self._stack_forward("cross_transformer", xi, ops.intra_map(B, 1, T), B * T, T * d, B, save, saved)
-        return xc, d
-
-    def _encoder_backward(self, saved, dx, G):
-        B, T, L, S = saved["dims"]
-        d = self._cfg["d"]
-        dxi = self._stack_backward("cross_transformer", saved, dx, ops.intra_map(B, 1, T), T * d, (B, T, d), G)
-        return self._stack_backward("intra_transformer", saved, dxi, ops.intra_map(B, T, S), S * d, (B, T, S, d), G)
-
-
-class RAT_m3(RAT_m2):
-    """RAT_m3 (fuxictr/pytorch/models/RAT_m3.py:27-243): intra and cross attention run IN PARALLEL on the block input,
-    share the query projection, use heads/2 heads of width 2*dim_head (softmax scale still dim_head^-0.5), carry no
-    residual of their own; their mean goes through the MLP, whose residual is the block input.  On the HIP path:
-        out  = 0.5 * intra(x)                 rat_attn_fwd_ex(res = NULL,  out_scale = 0.5)
-        out += 0.5 * cross(x)                 rat_attn_fwd_ex(res = out,   out_scale = 0.5)   (same memory, strided sequences)
-        x'   = FFN(out) + x                   rat_ffn_fwd_res(x = out, res = x)
-    The stacked [W_q; W_k; W_v] operand of each attention is assembled per step from the block's five projections."""
-
-    def __init__(self, feature_map, model_id="RAT_m3", **kwargs):
-        super().__init__(feature_map, model_id=model_id, **kwargs)
-
-    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
-        if num_heads < 2:
-            raise ValueError("RAT_m3 splits the projections into num_heads/2 heads (RAT_m3.py:181): num_heads must be >= 2")
-        self.encoder = _EncoderM3(d, num_heads, dim_head, dropout, depth, hidden)
-
-    def _build_encoder_descriptors(self):
-        c = self._cfg
-        inner = c["heads"] * c["dh"]
-        self._m3_heads = int(c["heads"] / 2)
-        self._m3_dh = inner // self._m3_heads
-        self._m3_scale = float(c["dh"]) ** -0.5
-        self._blocks = []
-        for i in range(c["depth"]):
-            p = "encoder.encoder.%d." % i
-            blk = {"proj": [p + n + ".weight" for n in ("W_q", "W_k_s", "W_v_s", "W_k_t", "W_v_t")],
-                   "ffn": [p + "mlp.net.%s" % n for n in ("0.weight", "0.bias", "3.weight", "3.bias")]}
-            for which in ("intra", "cross"):
-                q = p + which + "_attention."
-                has_out = (q + "fn.to_out.0.weight") in self._params
-                blk[which] = [q + "norm.weight", q + "norm.bias", q + "fn.to_out.0.weight" if has_out else None,
-                              q + "fn.to_out.0.bias" if has_out else None]
-            # stacked projection operands, refreshed from the parameters at every forward
-            blk["w_s"] = torch.empty((3 * inner, c["d"]), dtype=torch.float32, device=self.device)
-            blk["w_t"] = torch.empty((3 * inner, c["d"]), dtype=torch.float32, device=self.device)
-            self._blocks.append(blk)
-
-    def _m3_params(self, blk, which, w_qkv, source):
-        ln_g, ln_b, w_out, b_out = [source(n) if n else None for n in blk[which]]
-        return ops.attn_params(ln_g, ln_b, w_qkv, w_out, b_out)
-
-    # ---- one of the block's two attentions, y = 0.5 * Dropout(to_out(softmax(Q K^T dim_head^-0.5) V)) (+ res), at ANY head geometry
-    #      (RAT_m3.py:164-189 takes any num_heads x dim_head; the README's RAT_PA-on-Tmall run is 32 x 10 at d = 10).  The same three
-    #      forms as RAT_m2._attn_mode, on heads/2 heads of width 2 * dim_head:
-    #        fused     one rat_attn_fwd_ex / rat_attn_bwd_ex launch;
-    #        grouped   heads * dim_head too wide for the fused kernels' LDS tile: the heads only meet in to_out, so the layer is G
-    #                  launches on `per` heads each — group g gets its rows of W_q | W_k | W_v and its columns of to_out, the first one
-    #                  the bias, every later one accumulates onto the output of the one before (res = y; backward: add = dx);
-    #        composed  heads wider than any fused instantiation (2 * dim_head > 20) or sequences above 64 tokens: LayerNorm ->
-    #                  rat_sgemm -> rat_attn_core_*_map -> rat_sgemm.
-    def _m3_mode(self, smap):
-        key = ("m3", int(smap.L), self.FUSED_MAX_L)
-        hit = self._fused_cache.get(key)
-        if hit is None:
-            c, L, h, dh = self._cfg, int(smap.L), self._m3_heads, self._m3_dh
-            ok = lambda n: L <= self.FUSED_MAX_L and ops.attn_fused_supported(c["d"], n, dh, L, lib=self._lib)   # noqa: E731
-            if ok(h):
-                hit = ("fused", h)
-            else:
-                per = next((n for n in (8, 4, 2, 1) if h % n == 0 and n < h and ok(n)), None)
-                hit = ("grouped", per) if per else ("composed", None)
-            self._fused_cache[key] = hit
-        return hit
-
-    def _m3_group_params(self, blk, which, w_stack, per):
-        """per-group (RatAttnParams, w_qkv_g, w_out_g): contiguous copies of group g's rows of each of the Q | K | V blocks and of its
-        columns of to_out; the bias rides with group 0"""
-        d, dh, groups = self._cfg["d"], self._m3_dh, self._m3_heads // per
-        ig = per * dh
-        ln_g, ln_b, w_out, b_out = [self._p(n) if n else None for n in blk[which]]
-        if w_out is None:
-            raise NotImplementedError("grouped attention needs an output projection")
-        wq = w_stack.view(3, groups, ig, d).permute(1, 0, 2, 3).contiguous()
-        wo = w_out.view(d, groups, ig).permute(1, 0, 2).contiguous()
-        zero_bias = torch.zeros_like(b_out)
-        return [(ops.attn_params(ln_g, ln_b, wq[g].view(3 * ig, d), wo[g], b_out if g == 0 else zero_bias), wq[g], wo[g], zero_bias)
-                for g in range(groups)]
-
-    def _m3_attn_forward(self, blk, which, w_stack, x, res, smap, save, drop, out=None):
-        """-> (y, what the backward needs); y = 0.5 * attention(LayerNorm(x)) + res (res None: no addend; res may be `out` itself)"""
-        c, lib = self._cfg, self._lib
-        d, h, dh, sc = c["d"], self._m3_heads, self._m3_dh, self._m3_scale
-        mode, per = self._m3_mode(smap)
-        if mode == "fused":
-            y, o, l = ops.attn_fwd_ex(x, res, self._m3_params(blk, which, w_stack, self._p), smap, d, h, dh, sc, 0.5, save=save, out=out,
-                                      dropout=drop, lib=lib)
-            return y, (o, l)
-        if mode == "grouped":
-            y, kept = out, []
-            for g, (params_g, w_g, wo_g, zb) in enumerate(self._m3_group_params(blk, which, w_stack, per)):
-                # Dropout(sum of the groups' partial projections + bias) = the sum of the equally masked partials: same seed everywhere
-                y, o, l = ops.attn_fwd_ex(x, res if g == 0 else y, params_g, smap, d, per, dh, sc, 0.5, save=save, out=y, dropout=drop, lib=lib)
-                kept.append((params_g, w_g, wo_g, zb, o, l))
-            return y, (kept if save else None)
-        inner, ntok = h * dh, x.numel() // d
-        ln_g, ln_b, w_out, b_out = [self._p(n) if n else None for n in blk[which]]
-        if w_out is None:
-            raise NotImplementedError("attention without an output projection is only implemented in the fused kernel")
-        xn = ops.layernorm_fwd(x, d, ntok, ln_g, ln_b, d, lib=lib)
-        qkv = torch.empty((ntok, 3 * inner), dtype=torch.float32, device=x.device)
-        ops.sgemm(0, 1, ntok, 3 * inner, d, xn, d, w_stack, d, qkv, 3 * inner, arith=self.gemm_arith, lib=lib)
-        o, lse = ops.attn_core_fwd_map(qkv, smap, h, dh, softmax_scale=sc, save=True, lib=lib)
-        t = torch.empty((ntok, d), dtype=torch.float32, device=x.device)
-        ops.sgemm(0, 1, ntok, d, inner, o, inner, w_out, inner, t, d, bias=b_out, arith=self.gemm_arith, lib=lib)
-        if drop[0] > 0:
-            ops.dropout(t, drop[0], drop[1], out=t, lib=lib)
-        t = t.view_as(x)
-        y = torch.mul(t, 0.5, out=out) if res is None else torch.add(res, t, alpha=0.5, out=out)
-        return y, ((qkv, o, lse) if save else None)
-
-    def _m3_attn_backward(self, blk, which, w_stack, g_stack, x_in, dy, add, att, smap, G, ws, drop, out=None):
-        """dx = add + d/dx [0.5 * attention(LayerNorm(x))] (add: a grid laid out like x; may be `out`); the gradients of the stacked
-        [W_q; W_k; W_v] operand go to g_stack, the layer's own (LayerNorm, to_out) through G"""
-        c, lib = self._cfg, self._lib
-        d, h, dh, sc = c["d"], self._m3_heads, self._m3_dh, self._m3_scale
-        mode, per = self._m3_mode(smap)
-        if mode == "fused":
-            dx, _ = ops.attn_bwd_ex(x_in, dy, add, att[0], att[1], self._m3_params(blk, which, w_stack, self._p),
-                                    self._m3_params(blk, which, g_stack, G), smap, d, h, dh, sc, 0.5, workspace=ws, out=out, dropout=drop, lib=lib)
-            return dx
-        names = blk[which]
-        if mode == "grouped":
-            groups, ig = h // per, per * dh
-            wsg = self._workspace("attn_m3g", lib.size("rat_attn_bwd_workspace", d, per, dh))
-            g_lng, g_lnb, g_wout, g_bout = [G(n) for n in names]
-            t_ln = torch.empty((2, groups, g_lng.numel()), dtype=torch.float32, device=dy.device)
-            t_b = torch.empty_like(g_bout)
-            t_w = torch.empty((groups, 3 * ig, d), dtype=torch.float32, device=dy.device)
-            t_wo = torch.empty((groups, d, ig), dtype=torch.float32, device=dy.device)
-            dx = out
-            for g, (params_g, w_g, wo_g, zb, o, l) in enumerate(att):
-                grads_g = ops.attn_params(t_ln[0, g], t_ln[1, g], t_w[g], t_wo[g], g_bout if g == 0 else t_b)
-                dx, _ = ops.attn_bwd_ex(x_in, dy, add if g == 0 else dx, o, l, params_g, grads_g, smap, d, per, dh, sc, 0.5, workspace=wsg,
-                                        out=dx, dropout=drop, lib=lib)
-            g_stack.view(3, groups, ig, d).copy_(t_w.view(groups, 3, ig, d).permute(1, 0, 2, 3))
-            g_wout.view(d, groups, ig).copy_(t_wo.permute(1, 0, 2))
-            torch.sum(t_ln[0], 0, out=g_lng)
-            torch.sum(t_ln[1], 0, out=g_lnb)
-            return dx
-        inner, ntok = h * dh, x_in.numel() // d
-        ln_g, ln_b, w_out, b_out = [self._p(n) if n else None for n in names]
-        qkv, o, lse = att
-        dev = dy.device
-        xn = ops.layernorm_fwd(x_in, d, ntok, ln_g, ln_b, d, lib=lib)                                    # recomputed, not stored
-        dyp = dy.reshape(ntok, d) if drop[0] == 0 else ops.dropout(dy.reshape(ntok, d), drop[0], drop[1], lib=lib)
-        dyp = dyp * 0.5                                                                                   # the mean of the two attentions
-        do = torch.empty((ntok, inner), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, inner, d, dyp, d, w_out, inner, do, inner, arith=self.gemm_arith, lib=lib)                 # dO = dy W_out
-        ops.sgemm(1, 0, d, inner, ntok, dyp, d, o, inner, G(names[2]), inner, arith=self.gemm_arith, lib=lib)            # dW_out = dy^T O
-        ops.colsum(dyp, d, G(names[3]), ntok, d, lib=lib)
-        dqkv = ops.attn_core_bwd_map(qkv, o, lse, do, smap, h, dh, softmax_scale=sc, lib=lib)
-        dxn = torch.empty((ntok, d), dtype=torch.float32, device=dev)
-        ops.sgemm(0, 0, ntok, d, 3 * inner, dqkv, 3 * inner, w_stack, d, dxn, d, arith=self.gemm_arith, lib=lib)         # d(norm(x)) = dQKV W
-        ops.sgemm(1, 0, 3 * inner, d, ntok, dqkv, 3 * inner, xn, d, g_stack, d, arith=self.gemm_arith, lib=lib)          # dW = dQKV^T norm(x)
-        dx = ops.layernorm_bwd(x_in, d, dxn, ln_g, dxn, d, G(names[0]), G(names[1]), d, add=add, lib=lib).view_as(x_in)
-        if out is not None and out.data_ptr() != dx.data_ptr():
-            out.copy_(dx)
-            dx = out
-        return dx
-
-    def _encoder_forward(self, x, x0, dims, save, saved):
-        c, lib = self._cfg, self._lib
-        B, T, L, S = dims
-        d, H = c["d"], c["hidden"]
-        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
-        # (the composed form runs LayerNorm and the projections over the whole grid: nothing to gain from the last block's row maps)
-        prune = self.prune_dead_tokens and "composed" not in (self._m3_mode(imap)[0], self._m3_mode(cmap)[0])
-        last = len(self._blocks) - 1
-        for bi, blk in enumerate(self._blocks):
-            wq, wks, wvs, wkt, wvt = [self._p(n) for n in blk["proj"]]
-            torch.cat([wq, wks, wvs], dim=0, out=blk["w_s"])
-            torch.cat([wq, wkt, wvt], dim=0, out=blk["w_t"])
-            # each of the two attentions has its own nn.Dropout behind to_out (RAT_m3.py:186-189 via Attention): y = 0.5 * Dropout(..)
-            drop_on = self.training and c["attn_dropout"] > 0
-            dr_s = (c["attn_dropout"], self._dropout_word()) if drop_on and blk["intra"][2] else (0.0, 0)
-            dr_t = (c["attn_dropout"], self._dropout_word()) if drop_on and blk["cross"][2] else (0.0, 0)
-            if bi == last and prune:
-                # Dead-token pruning (RAT_m2._encoder_forward): the head reads x[:, 0][:, 0] only (RAT_m3.py:128-129), and in
-                # the LAST block that token needs the intra-sample attention of the target sample's sequence and the cross-sample
-                # attention of token position 0's sequence — B sequences each instead of B T and B S — and the MLP on one token.
-                im0, cm0 = ops.intra_map_target_sample(B, T, S), ops.cross_map_label_token(B, T, S)
-                out, a_s = self._m3_attn_forward(blk, "intra", blk["w_s"], x, None, im0, save, dr_s)
-                out, a_t = self._m3_attn_forward(blk, "cross", blk["w_t"], x, out, cm0, save, dr_t, out=out)
-                out_cls = out.view(B, T, S, d)[:, 0, 0, :].contiguous()
-                x_cls = x.view(B, T, S, d)[:, 0, 0, :].contiguous()
-                w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-                xc = ops.ffn_fwd_res(out_cls, x_cls, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)
-                if save:
-                    saved["blocks"].append((x, a_s, a_t, out_cls, dr_s, dr_t))
-                    saved["pruned"] = True
-                return xc, d
-            out, a_s = self._m3_attn_forward(blk, "intra", blk["w_s"], x, None, imap, save, dr_s)                 # 0.5 * intra(x)
-            out, a_t = self._m3_attn_forward(blk, "cross", blk["w_t"], x, out, cmap, save, dr_t, out=out)         # += 0.5 * cross(x)
-            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            xn = ops.ffn_fwd_res(out, x, w1, b1, w2, b2, d, H, arith=self.arith, lib=lib)                         # mlp(out) + x
-            if save:
-                saved["blocks"].append((x, a_s, a_t, out, dr_s, dr_t))
-            x = xn
-        return x, T * S * d
-
-    def _encoder_backward(self, saved, dx, G):
-        c, lib = self._cfg, self._lib
-        B, T, L, S = saved["dims"]
-        d, H = c["d"], c["hidden"]
-        inner = c["heads"] * c["dh"]
-        h, dh = self._m3_heads, self._m3_dh
-        imap, cmap = ops.intra_map(B, T, S), ops.cross_map(B, T, S)
-        ws_attn = self._workspace("attn", lib.size("rat_attn_bwd_workspace", d, h, dh))
-        ws_ffn = self._workspace("ffn", lib.size("rat_ffn_bwd_workspace", d, H))
-        g_s = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
-        g_t = torch.empty((3 * inner, d), dtype=torch.float32, device=dx.device)
-        pruned = bool(saved.get("pruned"))
-        for bi, (blk, (x_in, a_s, a_t, out, dr_s, dr_t)) in enumerate(zip(reversed(self._blocks), reversed(saved["blocks"]))):
-            w1, b1, w2, b2 = [self._p(n) for n in blk["ffn"]]
-            gw = [G(n) for n in blk["ffn"]]
-            dout, _ = ops.ffn_bwd_res(out, dx, w1, b1, w2, b2, gw[0], gw[1], gw[2], gw[3], d, H, add_dy=False, workspace=ws_ffn,
-                                      arith=self.arith, lib=lib)
-            amap, bmap = cmap, imap
-            if bi == 0 and pruned:        # the last block (see _encoder_forward): `out`, dx, dout are the class tokens' [B, d] rows
-                dgrid = torch.zeros((B, T, S, d), dtype=torch.float32, device=dx.device)
-                dgrid[:, 0, 0, :] = dx                              # the residual of x' = mlp(out) + x
-                dog = torch.zeros((B, T, S, d), dtype=torch.float32, device=dx.device)
-                dog[:, 0, 0, :] = dout
-                dx, dout = dgrid, dog
-                amap, bmap = ops.cross_map_label_token(B, T, S), ops.intra_map_target_sample(B, T, S)
-                # in place: the rows of the two B-sequence maps receive their gradient, every other row stays zero
-                dxn = self._m3_attn_backward(blk, "cross", blk["w_t"], g_t, x_in, dout, dx, a_t, amap, G, ws_attn, dr_t, out=dx)
-            else:
-                # dx = dy (the MLP residual) + cross backward + intra backward, accumulated in place
-                dxn = self._m3_attn_backward(blk, "cross", blk["w_t"], g_t, x_in, dout, dx, a_t, amap, G, ws_attn, dr_t)
-            dxn = self._m3_attn_backward(blk, "intra", blk["w_s"], g_s, x_in, dout, dxn, a_s, bmap, G, ws_attn, dr_s, out=dxn)
-            gq, gks, gvs, gkt, gvt = [G(n) for n in blk["proj"]]
-            torch.add(g_s[:inner], g_t[:inner], out=gq)                    # W_q is used by both attentions
-            gks.copy_(g_s[inner:2 * inner])
-            gvs.copy_(g_s[2 * inner:])
-            gkt.copy_(g_t[inner:2 * inner])
-            gvt.copy_(g_t[2 * inner:])
-            dx = dxn
-        return dx
-
-
-class RAT_m0(RAT_m1):
-    """RAT_m0 (fuxictr/pytorch/models/RAT_m0.py:24-141): ONE Transformer over the joint sequence of all T*S tokens of a sample
-    ('b t n d -> b (t n) d'), class token = token (t=0, n=0).  Sequences of up to 64 tokens run on the fused attention kernel
-    (K2a); longer ones (231 at the north-star shape) do not fit its LDS tile and take the composed path of
-    RAT_m2._attn_layer_forward (K2c LayerNorm -> rat_sgemm -> K2d attention core -> rat_sgemm + bias + residual)."""
-
-    def __init__(self, feature_map, model_id="RAT_m0", **kwargs):
-        super().__init__(feature_map, model_id=model_id, **kwargs)
-
-    def _make_encoder(self, d, num_heads, dim_head, dropout, depth, hidden):
-        self.encoder = _Transformer(d, depth, num_heads, dim_head, hidden, dropout)               # RAT_m0.py:70
-
-    def _build_encoder_descriptors(self):
-        layers = []
-        for i in range(self._cfg["depth"]):
-            p = "encoder.layers.%d." % i
-            layers.append(dict(attn=self._attn_descriptor(p + "0."), ln=[p + "1.norm.weight", p + "1.norm.bias"],
-                               ffn=[p + "1.fn.net.0.weight", p + "1.fn.net.0.bias", p + "1.fn.net.3.weight", p + "1.fn.net.3.bias"]))
-        self._stacks = {"encoder": (layers, ["encoder.norm.weight", "encoder.norm.bias"])}
-
-    def _encoder_forward(self, x, x0, dims, save, saved):
-        B, T, L, S = dims
-        d = self._cfg["d"]
-        xc = self._stack_forward("encoder", x, ops.intra_map(B, 1, T * S), B * T * S, T * S * d, B, save, saved)
-        return xc, d
-
-    def _encoder_backward(self, saved, dx, G):
-        B, T, L, S = saved["dims"]
-        d = self._cfg["d"]
-        return self._stack_backward("encoder", saved, dx, ops.intra_map(B, 1, T * S), T * S * d, (B, T, S, d), G)
