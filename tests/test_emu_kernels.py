@@ -140,13 +140,18 @@ def test_persistent_kernels_loop_over_several_chunks(emu, two_blocks):
 # (1, 70, 1, 10) and (3, 49, 2, 10): dim_head 10 with 48+ tokens — the forward on the matrix pipe (core_fwd_mfma_kernel): five key tiles = an odd
 # count (the second tile of the last key block is the spare zero tile), a ragged last tile; several pairs per work-group with RAT_MAX_BLOCKS
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (1, 70, 1, 10, None), (2, 33, 2, 7, 0.3), (3, 49, 2, 10, 0.4)])
-def test_attn_core_fwd_bwd(emu, nseq, L, heads, dh, softmax_scale):
+def test_attn_core_fwd_bwd(emu, nseq, L, heads, dh, softmax_scale, knob):
+    """dim_head 10 with 48+ tokens: the backward is the hybrid kernel (core_bwd_hybrid_kernel: dQ on the matrix pipe beside dK / dV on the
+    VALU); the attn_bwd_core_mfma knob's value 0 keeps the two VALU passes — both forms"""
     kc.check_attn_core(emu, "cpu", nseq, L, heads, dh, softmax_scale)
+    if dh == 10 and L >= 48:
+        knob(emu, "attn_bwd_core_mfma", 0)
+        kc.check_attn_core(emu, "cpu", nseq, L, heads, dh, softmax_scale)
 
 
 def test_attn_core_matrix_pipe_forward_several_pairs_per_work_group(emu, knob):
     """core_fwd_mfma_kernel with fewer work-groups than (sequence, head) pairs: the K / V tiles are re-staged per pair"""
-    knob(emu, "max_blocks", 1)                                   # 8 work-groups for 10 pairs
+    knob(emu, "max_blocks", 1)                                   # 8 work-groups for 10 pairs (backward: 4 — every one re-stages its tiles)
     kc.check_attn_core(emu, "cpu", 5, 50, 2, 10, None)
 
 

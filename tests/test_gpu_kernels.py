@@ -122,16 +122,24 @@ def test_attn_with_a_subset_of_query_positions(lib, case, mode, nq, arith):
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None),
                                                            (5, 48, 3, 10, 0.3), (3, 900, 2, 10, None), (300, 60, 32, 10, None)])
 def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale, knob):
-    """(dim_head 10 with 48 ... 1024 tokens: the forward runs on the matrix pipe — core_fwd_mfma_kernel; the knob's value 3 keeps the VALU kernel)"""
+    """(dim_head 10 with 48 ... 1024 tokens: the forward runs on the matrix pipe — core_fwd_mfma_kernel; the knob's value 3 keeps the VALU kernel;
+    up to ~800 tokens the backward is the hybrid kernel — core_bwd_hybrid_kernel: dQ on the matrix pipe beside dK / dV on the VALU — and
+    attn_bwd_core_mfma = 0 keeps the two VALU passes: every case with the knobs both ways)"""
     kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)
     if dh == 10 and L >= 48:
         knob(lib, "attn_fwd_core_mfma", 3)
+        knob(lib, "attn_bwd_core_mfma", 0)
         kc.check_attn_core(lib, "cuda", nseq, L, heads, dh, softmax_scale)
 
 
-@pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (64, 31, 9, 32, 10), (16, 11, 21, 8, 10), (6, 61, 5, 8, 10)])
-def test_attn_core_strided(lib, B, T, S, heads, dh):
+@pytest.mark.parametrize("B,T,S,heads,dh", [(2, 3, 4, 2, 4), (64, 31, 9, 32, 10), (16, 11, 21, 8, 10), (6, 61, 5, 8, 10), (40, 231, 3, 8, 10)])
+def test_attn_core_strided(lib, B, T, S, heads, dh, knob):
+    """(T = 61 / 231 at dim_head 10: the matrix-pipe forward and the hybrid backward through a strided RatSeqMap; more pairs than work-groups
+    with max_blocks = 1)"""
     kc.check_attn_core_strided(lib, "cuda", B, T, S, heads, dh)
+    if T >= 48:
+        knob(lib, "max_blocks", 1)
+        kc.check_attn_core_strided(lib, "cuda", B, T, S, heads, dh)
 
 
 @pytest.mark.parametrize("case,mode,res_mode,dropout", [pytest.param((40, 11, 21, 64, 16, 10, True), "intra", "x", 0.0, id="G2_intra_L21"),

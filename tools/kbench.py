@@ -138,6 +138,18 @@ def main():
                 ms = timeit(run, args.reps)
                 fl = 2 * tok * 4 * d * H
                 print("ffn_bwd %-6s %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (arith, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
+    if "core" in args.which:
+        # RAT_m0's joint attention core at the headline shape: B sequences of T * S tokens (rat_attn_core_*_map's contiguous form)
+        Lc = T * S
+        qkv = rn(B * Lc, 3 * I)
+        dout = rn(B * Lc, I)
+        o, lse = ops.attn_core_fwd(qkv, B, Lc, heads, dh)
+        fl = B * Lc * 4 * I * Lc
+        ms = timeit(lambda: ops.attn_core_fwd(qkv, B, Lc, heads, dh), args.reps)
+        print("core_fwd L%-3d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (Lc, ms, fl / ms / 1e9, 100 * fl / ms / 1e9 / PEAK))
+        ms = timeit(lambda: ops.attn_core_bwd(qkv, o, lse, dout, B, Lc, heads, dh), args.reps)
+        print("core_bwd L%-3d %.4f ms  %.1f TFLOP/s  (%.1f %%)" % (Lc, ms, 2 * fl / ms / 1e9, 100 * 2 * fl / ms / 1e9 / PEAK))
+        del qkv, dout, o, lse
     if any(w.startswith("attn") for w in args.which):
         ln_g, ln_b = 1 + rn(d, sc=0.1), rn(d, sc=0.1)
         w_qkv, w_out, b_out = rn(3 * I, d, sc=d ** -0.5), rn(d, I, sc=I ** -0.5), rn(d, sc=0.1)

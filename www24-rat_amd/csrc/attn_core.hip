@@ -377,6 +377,216 @@ bool core_fwd_mfma_ok(const CoreArgs& a) {
     return a.dh == CM_DH && a.L >= 48 && a.L <= 1024 && (reinterpret_cast<uintptr_t>(a.qkv) & 7) == 0 && rat_knob(RAT_KNOB_ATTN_FWD_CORE_MFMA) != 3;
 }
 
+// ---- the backward core for LONG sequences at dim_head 10 on the matrix pipe, exact fp32 (round 6) ------------------------------------------
+// The backward is two independent passes over the (query, key) pairs of a (sequence, head): dQ_i = sum_j dS_ij K_j and
+// (dK_j, dV_j) = sum_i (dS_ij Q_i, P_ij dO_i), both from P_ij = exp2(s_ij - lse_i) and dP_ij = dO_i . V_j.  core_bwd_kernel runs them on
+// the VALU at ~38 instructions per 64 pairs; here both run on v_mfma_f32_16x16x4_f32, each in the orientation whose ACCUMULATORS are
+// directly the operand of its next product, so nothing is transposed, nothing passes through LDS after the staging, and no wave
+// needs another wave's data (every output element is written once: bit-reproducible).  A 512-thread work-group owns one pair, its Q, K, V,
+// dO rows staged in LDS ([L16 + 16][12], zero padded), lse / delta beside them:
+//   pass A (a wave owns 16-query tiles; the forward kernel's construction): S^T = K Q^T, dP^T = V dO^T (three k steps each, Q / dO of the
+//       tile are the B operands, in registers across the key loop); lane (g, m) holds keys 4 g + r of query m, so lse_i and delta_i are
+//       per-lane scalars; dS^T = p (dP^T - delta) on the accumulators, which then ARE the B operand of dQ^T += K^T dS^T (k step (jt, r)
+//       contracts over the keys {16 jt + 4 g + r}): ten MFMAs per (query tile, key tile);
+//   pass B (a wave owns CB_KT consecutive 16-key tiles, their K / V operands and dK / dV accumulators in registers across the query
+//       loop): S = Q K^T, dP = dO V^T with the QUERY rows as the A operand — lane (g, m) holds queries 4 g + r of key m — and P, dS on
+//       the accumulators are the A operand (rows = keys, k = those queries) of dV += P^T dO and dK += dS^T Q: fourteen MFMAs per pair of tiles.
+// 24 MFMAs of 32 cycles per 256 (query, key) pairs against ~150 VALU instructions; the elementwise work (exp2, masks) is ~70 instructions.
+// Measured at RAT_m0's shape (4096 sequences of 231 tokens, 8 heads): profiles/round6/r6_attn_core_bwd_ab.txt.  The first form of the
+// round — dQ on the matrix pipe BESIDE the VALU (dK, dV) pass — was no faster than the VALU kernel (tools/experiments/attn_core_bwd_hybrid.hip.txt).
+// Work-group shape by same-box A/B at L = 231 (profiles/round6/r6_attn_core_bwd_ab.txt): 8 waves, 3 key tiles per trip of pass A, groups of
+// 2 key tiles in pass B: 4.00-4.05 ms; 4 / 5 waves per work-group 4.7-6.4 ms (the kernel lives on waves in flight), 16 waves 4.8 ms (one
+// work-group per CU: staging no longer overlaps), register caps for 5 / 6 waves per SIMD: no change.
+constexpr int CB_THREADS = 512, CB_WAVES = CB_THREADS / 64, CB_LD = 12, CB_DH = 10, CB_KB = 3, CB_KT = 2;
+__global__ void __launch_bounds__(CB_THREADS) core_bwd_mfma_kernel(CoreArgs a) {
+    RAT_DYN_SMEM(smem);
+    const int L = a.L, I = a.heads * CB_DH, L16 = (L + 15) / 16 * 16, NT = L16 / 16;
+    constexpr int SPARE = 16 * ((CB_KB > CB_KT ? CB_KB : CB_KT) - 1);   // zero rows past the sequence: a trip's / a group's tiles beyond it
+    const int LR = L16 + SPARE;
+    float* qs = reinterpret_cast<float*>(smem);             // [LR][12] each: rows >= L and columns 10, 11 are zero
+    float* ks = qs + (size_t)LR * CB_LD;
+    float* vs = ks + (size_t)LR * CB_LD;
+    float* gs = vs + (size_t)LR * CB_LD;                    // dO
+    float* ls = gs + (size_t)LR * CB_LD;                    // [L16] lse (+inf beyond the sequence: p = 0 there)
+    float* ds = ls + L16;                                   // [L16] delta = dO . O
+    const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
+    const int mc = m < CB_LD ? m : 0;                       // this lane's column of a [.][dim_head] operand (masked by cm below)
+    const bool cm = m < CB_DH;
+    const float sl2 = a.scale * RAT_LOG2E;
+    const int64_t ntask = a.nseq * a.heads;
+    for (int e = threadIdx.x; e < 4 * LR * CB_LD; e += CB_THREADS) qs[e] = 0.f;
+    __syncthreads();
+    for (int64_t task = blockIdx.x; task < ntask; task += gridDim.x) {
+        const int64_t sq = task / a.heads;
+        const int h = (int)(task - sq * a.heads);
+        for (int e = threadIdx.x; e < L * (CB_DH / 2); e += CB_THREADS) {       // the pair's rows -> LDS (8-byte pieces)
+            const int j = e / (CB_DH / 2), c2 = e - j * (CB_DH / 2);
+            const int64_t tok = core_token(a, sq, j);
+            const float* row = a.qkv + tok * (3 * I) + h * CB_DH + 2 * c2;
+            *reinterpret_cast<float2*>(qs + j * CB_LD + 2 * c2) = *reinterpret_cast<const float2*>(row);
+            *reinterpret_cast<float2*>(ks + j * CB_LD + 2 * c2) = *reinterpret_cast<const float2*>(row + I);
+            *reinterpret_cast<float2*>(vs + j * CB_LD + 2 * c2) = *reinterpret_cast<const float2*>(row + 2 * I);
+            *reinterpret_cast<float2*>(gs + j * CB_LD + 2 * c2) = *reinterpret_cast<const float2*>(a.dout + tok * I + h * CB_DH + 2 * c2);
+        }
+        for (int i = threadIdx.x; i < L16; i += CB_THREADS) {
+            float lse = INFINITY, dsum = 0.f;
+            if (i < L) {
+                const int64_t tok = core_token(a, sq, i);
+                lse = a.lse_in[tok * a.heads + h];
+                const float* go = a.dout + tok * I + h * CB_DH;
+                const float* oo = a.o + tok * I + h * CB_DH;
+#pragma unroll
+                for (int c = 0; c < CB_DH; ++c) dsum = fmaf(go[c], oo[c], dsum);
+            }
+            ls[i] = lse;
+            ds[i] = dsum;
+        }
+        __syncthreads();
+        // ---- pass A: dQ, one 16-query tile at a time
+        for (int qt = w; qt < NT; qt += CB_WAVES) {
+            const int qi = 16 * qt + m;
+            float bq[3], bg[3];
+#pragma unroll
+            for (int k_ = 0; k_ < 3; ++k_) {
+                bq[k_] = qs[qi * CB_LD + 4 * k_ + g];                             // (columns 10, 11 and rows >= L are zero in LDS)
+                bg[k_] = gs[qi * CB_LD + 4 * k_ + g];
+            }
+            const float lse_i = ls[qi], delta_i = ds[qi];
+            f32x4 dq = rat_zero4(), dq2 = rat_zero4();
+            for (int kt0 = 0; kt0 < NT; kt0 += CB_KB) {                          // (a second tile past the sequence reads the spare zero rows)
+                // (requesting the operands of trip t + 1 before the MFMAs of trip t by hand: 145 VGPRs, and 4.33 ms against 4.02 at 128)
+                float ak[3][CB_KB], av[3][CB_KB], akc[4][CB_KB];
+#pragma unroll
+                for (int jt = 0; jt < CB_KB; ++jt) {
+#pragma unroll
+                    for (int k_ = 0; k_ < 3; ++k_) {
+                        ak[k_][jt] = ks[(16 * (kt0 + jt) + m) * CB_LD + 4 * k_ + g];
+                        av[k_][jt] = vs[(16 * (kt0 + jt) + m) * CB_LD + 4 * k_ + g];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) akc[r][jt] = ks[(16 * (kt0 + jt) + 4 * g + r) * CB_LD + mc];
+                }
+                f32x4 st[CB_KB], dp[CB_KB];
+#pragma unroll
+                for (int jt = 0; jt < CB_KB; ++jt) st[jt] = dp[jt] = rat_zero4();
+#pragma unroll
+                for (int k_ = 0; k_ < 3; ++k_)
+#pragma unroll
+                    for (int jt = 0; jt < CB_KB; ++jt) {
+                        st[jt] = RAT_MFMA16(ak[k_][jt], bq[k_], st[jt]);        // S^T[key 16 jt + 4 g + r][query m]
+                        dp[jt] = RAT_MFMA16(av[k_][jt], bg[k_], dp[jt]);        // dP^T, same layout
+                    }
+#pragma unroll
+                for (int jt = 0; jt < CB_KB; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = 16 * (kt0 + jt) + 4 * g + r < L ? rat_exp2(st[jt][r] * sl2 - lse_i) : 0.f;
+                        st[jt][r] = pr * (dp[jt][r] - delta_i);                  // dS^T
+                    }
+#pragma unroll
+                for (int jt = 0; jt < CB_KB; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                                // dQ^T[c][query] += K[key][c] dS^T[key][query]; two independent chains
+                        const float kc = cm ? akc[r][jt] : 0.f;
+                        if ((jt & 1) == 0) dq = RAT_MFMA16(kc, st[jt][r], dq);
+                        else dq2 = RAT_MFMA16(kc, st[jt][r], dq2);
+                    }
+            }
+            if (qi < L) {                                                        // dq[r] = dQ[query 16 qt + m][c = 4 g + r]
+                float* out = a.dqkv + core_token(a, sq, qi) * (3 * I) + h * CB_DH + 4 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < CB_DH) out[r] = (dq[r] + dq2[r]) * a.scale;
+            }
+        }
+        // ---- pass B: dK, dV, CB_KT key tiles at a time (their operands and accumulators stay in registers across the query loop)
+        for (int kg = w; kg * CB_KT < NT; kg += CB_WAVES) {
+            float bk[3][CB_KT], bv[3][CB_KT];
+            f32x4 adk[CB_KT], adv[CB_KT];
+#pragma unroll
+            for (int t = 0; t < CB_KT; ++t) {
+                const int kj = 16 * (kg * CB_KT + t) + m;                        // (a tile past the sequence: the spare zero rows)
+#pragma unroll
+                for (int k_ = 0; k_ < 3; ++k_) {
+                    bk[k_][t] = ks[kj * CB_LD + 4 * k_ + g];
+                    bv[k_][t] = vs[kj * CB_LD + 4 * k_ + g];
+                }
+                adk[t] = adv[t] = rat_zero4();
+            }
+            for (int it = 0; it < NT; ++it) {
+                const int i0 = 16 * it;
+                float aq[3], ag[3], cq[4], cg[4];
+#pragma unroll
+                for (int k_ = 0; k_ < 3; ++k_) {
+                    aq[k_] = qs[(i0 + m) * CB_LD + 4 * k_ + g];                   // A of S:  Q[query i0 + m][c = 4 k + g]
+                    ag[k_] = gs[(i0 + m) * CB_LD + 4 * k_ + g];                   // A of dP: dO, same layout
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    cq[r] = qs[(i0 + 4 * g + r) * CB_LD + mc];                    // B of dK: Q[query i0 + 4 g + r][c = m]
+                    cg[r] = gs[(i0 + 4 * g + r) * CB_LD + mc];                    // B of dV: dO, same layout
+                }
+                const float4 lse4 = *reinterpret_cast<const float4*>(ls + i0 + 4 * g);     // queries i0 + 4 g + r (+inf past the sequence)
+                const float4 dl4 = *reinterpret_cast<const float4*>(ds + i0 + 4 * g);
+                const float lse_r[4] = {lse4.x, lse4.y, lse4.z, lse4.w}, dl_r[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+                f32x4 sa[CB_KT], da[CB_KT];
+#pragma unroll
+                for (int t = 0; t < CB_KT; ++t) sa[t] = da[t] = rat_zero4();
+#pragma unroll
+                for (int k_ = 0; k_ < 3; ++k_)
+#pragma unroll
+                    for (int t = 0; t < CB_KT; ++t) {
+                        sa[t] = RAT_MFMA16(aq[k_], bk[k_][t], sa[t]);           // S[query i0 + 4 g + r][key m of tile t]
+                        da[t] = RAT_MFMA16(ag[k_], bv[k_][t], da[t]);           // dP, same layout
+                    }
+                // (keys past the sequence have zero K / V rows: their columns hold p = exp2(-lse_i), which only reaches dK / dV rows
+                //  that are never stored; queries past it have lse = +inf: p = 0)
+#pragma unroll
+                for (int t = 0; t < CB_KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = rat_exp2(sa[t][r] * sl2 - lse_r[r]);
+                        sa[t][r] = pr;
+                        da[t][r] = pr * (da[t][r] - dl_r[r]);                    // dS
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float bq_ = cm ? cq[r] : 0.f, bg_ = cm ? cg[r] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < CB_KT; ++t) {
+                        adv[t] = RAT_MFMA16(sa[t][r], bg_, adv[t]);             // dV[key 4 g' + r'][c m] += P[query][key] dO[query][c]
+                        adk[t] = RAT_MFMA16(da[t][r], bq_, adk[t]);             // dK += dS[query][key] Q[query][c]
+                    }
+                }
+            }
+            if (cm)
+#pragma unroll
+                for (int t = 0; t < CB_KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * (kg * CB_KT + t) + 4 * g + r;
+                        if (j < L) {
+                            float* drow = a.dqkv + core_token(a, sq, j) * (3 * I) + h * CB_DH + m;
+                            drow[I] = adk[t][r] * a.scale;
+                            drow[2 * I] = adv[t][r];
+                        }
+                    }
+        }
+        __syncthreads();                                                        // (the next pair's rows overwrite the tiles)
+    }
+}
+size_t core_bwd_mfma_smem(int L) {
+    const int L16 = (L + 15) / 16 * 16, spare = 16 * ((CB_KB > CB_KT ? CB_KB : CB_KT) - 1);
+    return ((size_t)4 * (L16 + spare) * CB_LD + 2 * (size_t)L16) * sizeof(float);
+}
+// dispatch: dim_head 10, sequences of 48+ tokens whose four row tiles fit the LDS (<= ~800 tokens), 8-byte aligned rows; the
+// attn_bwd_core_mfma knob's value 0 (RAT_ATTN_BWD_CORE=valu) keeps the two VALU passes
+bool core_bwd_mfma_ok(const CoreArgs& a) {
+    const int I = a.heads * a.dh;
+    return a.dh == CB_DH && a.L >= 48 && core_bwd_mfma_smem(a.L) <= 160 * 1024 && I % 2 == 0 &&
+           ((reinterpret_cast<uintptr_t>(a.qkv) | reinterpret_cast<uintptr_t>(a.dout)) & 7) == 0 && rat_knob(RAT_KNOB_ATTN_BWD_CORE_MFMA) != 0;
+}
+
 template <template <int, bool> class Launch, bool MULTI>
 int core_dispatch_dh(int dh, const CoreArgs& a, unsigned grid, int threads, size_t smem, void* stream) {
     switch (dh) {
@@ -490,5 +700,10 @@ extern "C" int rat_attn_core_bwd_map(const float* qkv, const float* o, const flo
     a.heads = heads;
     a.dh = dim_head;
     a.scale = softmax_scale > 0.f ? softmax_scale : 1.0f / sqrtf((float)dim_head);
+    if (core_bwd_mfma_ok(a)) {
+        const int64_t tasks = nseq * heads, cap = (int64_t)rat_max_blocks() * 4;
+        RAT_LAUNCH(core_bwd_mfma_kernel, (unsigned)(tasks < cap ? tasks : cap), CB_THREADS, core_bwd_mfma_smem(L), stream, a);
+        return rat_check_launch("rat_attn_core_bwd (matrix pipe)");
+    }
     return core_dispatch<LaunchBwd>(dim_head, a, core_grid((nseq * heads + core_pairs(L) - 1) / core_pairs(L)), core_threads(L), smem, stream);
 }
