@@ -251,9 +251,12 @@ int core_check(int64_t nseq, int L, int heads, int dh, size_t smem) {
 //   over the keys {16 jt + 4 g + r}).  Seven MFMAs per (query tile, key tile); nothing passes through LDS after the staging.
 // RAT_m0's joint sequences (231 tokens at the north-star shape): 15 x 15 tiles, 96 % full.
 #ifndef RAT_CM_KB
-#define RAT_CM_KB 4
+#define RAT_CM_KB 3
 #endif
-constexpr int CM_THREADS = 256, CM_WAVES = 4, CM_LD = 12, CM_DH = 10, CM_KB = RAT_CM_KB;      // CM_KB: 16-key tiles per trip of the key loop
+#ifndef RAT_CM_THREADS
+#define RAT_CM_THREADS 512      // round 6, same-box A/B at L = 231 (profiles/round6/r6_attn_core_fwd_ab.txt): 8 waves x 3 key tiles per trip 1.58-1.61 ms,
+#endif                          // 4 waves x 4 tiles (round 5) 1.78-1.79 ms — like the backward, the kernel lives on waves in flight
+constexpr int CM_THREADS = RAT_CM_THREADS, CM_WAVES = CM_THREADS / 64, CM_LD = 12, CM_DH = 10, CM_KB = RAT_CM_KB;      // CM_KB: 16-key tiles per trip of the key loop
 __device__ __forceinline__ float cm_rows_max(float v) {
 #ifdef RAT_EMU
     v = fmaxf(v, __shfl_xor(v, 16, 64));
