@@ -36,11 +36,12 @@ for p in (ROOT, os.path.join(ROOT, "www24-rat_amd")):
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense, exact fp32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the sparsity figures are never used)
 PEAK_HBM_GBS = 8000.0             # HBM3E spec
-ROCPROF_NOTE = "profiles/round5/r5_bench_kernel_stats.csv (in the step), r5_gather_V100M_kernel_stats.csv (25.6 GB table)"
+ROCPROF_NOTE = "profiles/round6/r6_bench_kernel_stats.csv (in the step), r6_gather_V100M_kernel_stats.csv (25.6 GB table)"
 NBATCH = 4                        # distinct batches rotated through the timed loop
 # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), collected with rocprofv3 in
 # separate runs (bench.py cannot host the profiler) and committed next to the kernel stats; valid for the north-star shapes only
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "round5", "r5_traffic_pmc.json"),
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "round6", "r6_traffic_pmc.json"),
+                 os.path.join(ROOT, "profiles", "round5", "r5_traffic_pmc.json"),
                  os.path.join(ROOT, "profiles", "round4", "r4_traffic_pmc.json"),
                  os.path.join(ROOT, "profiles", "round3", "r3_traffic_pmc.json"),
                  os.path.join(ROOT, "profiles", "round2", "r2_traffic_pmc.json"),

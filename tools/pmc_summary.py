@@ -12,7 +12,8 @@ import json
 import os
 import sys
 
-ENTRY = [("attn_bwd_wide_kernel", "rat_attn_bwd_groups"), ("attn_fwd_wide_kernel", "rat_attn_fwd_groups"), ("attn_bwd3_kernel", "rat_attn_bwd_ex"), ("attn_fwd3_kernel", "rat_attn_fwd_ex"), ("ffn_bwd_t4_kernel", "rat_ffn_bwd_res"), ("ffn_bwd_t3_kernel", "rat_ffn_bwd_res:t3"),
+ENTRY = [("core_bwd_mfma_kernel", "rat_attn_core_bwd_map"), ("core_fwd_mfma_kernel", "rat_attn_core_fwd_map"), ("core_bwd_kernel", "rat_attn_core_bwd_map:valu"),
+         ("attn_bwd_wide_kernel", "rat_attn_bwd_groups"), ("attn_fwd_wide_kernel", "rat_attn_fwd_groups"), ("attn_bwd3_kernel", "rat_attn_bwd_ex"), ("attn_fwd3_kernel", "rat_attn_fwd_ex"), ("ffn_bwd_t4_kernel", "rat_ffn_bwd_res"), ("ffn_bwd_t3_kernel", "rat_ffn_bwd_res:t3"),
          ("ffn_fwd_t3_kernel", "rat_ffn_fwd_res"), ("attn_bwd_kernel", "rat_attn_bwd"), ("attn_fwd_kernel", "rat_attn_fwd"),
          ("ffn_bwd_t_kernel", "rat_ffn_bwd"), ("ffn_fwd_t_kernel", "rat_ffn_fwd")]
 
