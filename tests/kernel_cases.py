@@ -224,7 +224,7 @@ def check_attn_dropout(lib, dev, case, mode, p=0.25, seed=123456789, arith="f32"
         close(g, w.grad, 1e-4, 1e-4 * scale, name)
 
 
-def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed=5):
+def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed=5, arith="f32"):
     """rat_attn_fwd_ex / rat_attn_bwd_ex: y = out_scale * attention(LN(x)) + res with res in {none, a second tensor, the output
     itself}, an explicit softmax scale; backward with the matching `add` term."""
     B, T, S, d, heads, dh, proj = case
@@ -251,21 +251,21 @@ def check_attn_ex(lib, dev, case, mode, res_mode, out_scale, softmax_scale, seed
     smap = ops.intra_map(B, T, S) if mode == "intra" else ops.cross_map(B, T, S)
     if res_mode == "acc":                                   # accumulate onto a tensor that already holds `other`
         y = od.clone()
-        y, o_save, lse = ops.attn_fwd_ex(xd, y, params, smap, d, heads, dh, softmax_scale or 0.0, out_scale, save=True, out=y, lib=lib)
+        y, o_save, lse = ops.attn_fwd_ex(xd, y, params, smap, d, heads, dh, softmax_scale or 0.0, out_scale, save=True, out=y, arith=arith, lib=lib)
     else:
         y, o_save, lse = ops.attn_fwd_ex(xd, od if res_mode == "other" else None, params, smap, d, heads, dh, softmax_scale or 0.0,
-                                         out_scale, save=True, lib=lib)
+                                         out_scale, save=True, arith=arith, lib=lib)
     close(y, ref, 2e-5, 2e-5, "y")
     gs = [torch.zeros_like(t) if t is not None else None for t in wd]
     grads = ops.attn_params(*gs)
     add = rnd(rs, B, T, S, d)
     if res_mode == "none":
-        dx, _ = ops.attn_bwd_ex(xd, dyd, None, o_save, lse, params, grads, smap, d, heads, dh, softmax_scale or 0.0, out_scale, lib=lib)
+        dx, _ = ops.attn_bwd_ex(xd, dyd, None, o_save, lse, params, grads, smap, d, heads, dh, softmax_scale or 0.0, out_scale, arith=arith, lib=lib)
         want = xr.grad
     else:                                                   # dx = add + ..., written in place over `add`
         buf = add.clone().to(dev)             # .to("cpu") would alias `add`, which the in-place kernel overwrites
         dx, _ = ops.attn_bwd_ex(xd, dyd, buf, o_save, lse, params, grads, smap, d, heads, dh, softmax_scale or 0.0, out_scale,
-                                out=buf, lib=lib)
+                                out=buf, arith=arith, lib=lib)
         want = xr.grad + add.double()
     scale = max(1.0, (B * T * S) ** 0.5 / 4)
     close(dx, want, 1e-4, 1e-4, "dx")

@@ -189,6 +189,13 @@ def test_attn_ex_fwd_bwd(emu, case, mode, res_mode, out_scale, softmax_scale):
     kc.check_attn_ex(emu, "cpu", case, mode, res_mode, out_scale, softmax_scale)
 
 
+@pytest.mark.parametrize("case,mode,res_mode", [((2, 3, 21, 64, 4, 20, True), "intra", "none"), ((3, 11, 4, 64, 4, 20, True), "cross", "acc")], ids=str)
+def test_attn_ex_fwd_bwd_bf16x3_four_heads(emu, case, mode, res_mode, two_blocks):
+    """round 6: attn_fwd3_kernel / attn_bwd3_kernel<.., NH = 4> (RAT_m3 at the north-star config): two work-groups over several chunks with a
+    ragged last one; L = 21 recomputes P in pass 2, L = 11 hands it over"""
+    kc.check_attn_ex(emu, "cpu", case, mode, res_mode, 0.5, 10 ** -0.5, arith="bf16x3")
+
+
 def test_ffn_bf16x3_narrower_layer(emu, two_blocks):
     """(40, 80) — the shipped KKBox feed-forward — inside the (64, 128) tiles of the bf16x3 kernels: zero-padded weight planes / staged
     weights, guarded token fragments, (hidden, d)-shaped gradient slabs"""

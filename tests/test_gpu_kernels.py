@@ -177,6 +177,18 @@ def test_attn_ex_fwd_bwd(lib, case, mode, res_mode, out_scale, softmax_scale):
     kc.check_attn_ex(lib, "cuda", case, mode, res_mode, out_scale, softmax_scale)
 
 
+# round 6: the bf16x3 kernels' 4-head instantiation (attn_fwd3_kernel / attn_bwd3_kernel<.., NH = 4>): RAT_m3's heads / 2 heads of width
+# 2 dim_head at the north-star config — every residual form, both phases, many chunks per work-group, a ragged last chunk, P handed to
+# pass 2 (L = 11: it fits) and recomputed (L = 21)
+@pytest.mark.parametrize("case,mode,res_mode", [((40, 11, 21, 64, 4, 20, True), "intra", "none"), ((40, 11, 21, 64, 4, 20, True), "cross", "acc"),
+                                                ((7, 11, 21, 64, 4, 20, True), "cross", "other"), ((3, 5, 31, 64, 4, 20, True), "intra", "acc"),
+                                                ((600, 11, 2, 64, 4, 20, True), "cross", "none")], ids=str)
+def test_attn_ex_fwd_bwd_bf16x3_four_heads(lib, case, mode, res_mode, knob):
+    kc.check_attn_ex(lib, "cuda", case, mode, res_mode, 0.5, 10 ** -0.5, arith="bf16x3")
+    knob(lib, "attn_bwd_ph", 0)
+    kc.check_attn_ex(lib, "cuda", case, mode, res_mode, 0.5, 10 ** -0.5, arith="bf16x3")
+
+
 @pytest.mark.parametrize("ntok,d,hidden", [(70, 8, 16), (33, 10, 40), (64, 64, 128), (100000, 64, 128), (5000, 40, 80),
                                            (20011, 10, 40), (20011, 10, 20)])          # (the shipped d = 10 geometries: weights in LDS, one-sweep loads)
 def test_ffn_fwd_bwd(lib, ntok, d, hidden):

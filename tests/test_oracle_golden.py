@@ -101,7 +101,9 @@ def test_two_training_steps(name):
     for step in (1, 2):
         new_w, loss, y_pred, grads, gnorm = orc.train_step(w, X, y, cfg, state, step)
         np.testing.assert_allclose(y_pred.numpy(), gold["train%d/y_pred" % step], rtol=0, atol=1e-6)
-        assert abs(float(loss) - float(gold["train%d/loss" % step])) < 1e-6
+        # (relative above 1: the regularised-table cases have losses of 5-9, where an fp32 ulp is 4.8e-7 and the order in which the
+        #  per-tensor penalties are added already moves the sum by 2-3 of them — m3_tmall_real_heads: 1.4e-6 at 5.85)
+        assert abs(float(loss) - float(gold["train%d/loss" % step])) < 1e-6 * max(1.0, abs(float(gold["train%d/loss" % step])))
         assert abs(float(gnorm) - float(gold["train%d/gnorm" % step])) < 1e-5 * max(1.0, float(gnorm))
         seen = 0
         for k, g in grads.items():

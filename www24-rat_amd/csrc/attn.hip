@@ -1186,12 +1186,15 @@ extern "C" int rat_attn_fwd(const float* x, float* y, float* o_save, float* lse_
 // embedding_dim 40 / 48 / 56 with the same heads (DPAD: the shipped KKBox config is d = 40); every other shape runs the exact-fp32
 // kernels whatever `arith` says
 static bool b3_dim(int d) { return d == B3_D || d == 40 || d == 48 || d == 56; }
-static bool b3_geom(int d, int heads, int dim_head) { return b3_dim(d) && heads == B3_H && dim_head == B3_DH; }
+// (round 6: also 4 heads x 20 at embedding_dim 64 — what RAT_m3 runs at the north-star config: the same projections and planes, NH = 4)
+static bool b3_geom(int d, int heads, int dim_head) {
+    return (b3_dim(d) && heads == B3_H && dim_head == B3_DH) || (d == B3_D && heads == 4 && dim_head == 2 * B3_DH);
+}
 static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
     return b3_geom(d, heads, dim_head) && w->w_out != nullptr;
 }
 // PH instantiation of attn_bwd3_kernel: P of a chunk inside the dy planes' 24 KB
-static bool b3_ph_fits(int L, int nsq_chunk) { return (size_t)nsq_chunk * B3_H * L * L * 4 <= (size_t)3 * B3_XP; }
+static bool b3_ph_fits(int L, int nsq_chunk, int heads = B3_H) { return (size_t)nsq_chunk * heads * L * L * 4 <= (size_t)3 * B3_XP; }
 // the matrix-pipe backward core (b3_bwd_core_mfma) by sequence length — see its comment for the measurements behind the rule; the
 // attn_bwd_core_mfma knob forces it on (1, any L <= 32) or off (0)
 static bool b3_matrix_core(int L) {
@@ -1290,6 +1293,10 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(p_qkv), 2};
         W.out = RatWPlanes{reinterpret_cast<const rat_u4*>(p_out), 3};
         const unsigned b3_blocks = (unsigned)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
+        if (heads == 4) {                                        // 4 heads x 20 (RAT_m3): one general instantiation
+            RAT_LAUNCH((attn_fwd3_kernel<true, false, false, false, 0, 4>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+            return rat_check_launch("rat_attn_fwd (bf16x3, 4 heads)");
+        }
         if (dpad) {
             if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
             else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false, false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
@@ -1556,7 +1563,11 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
         W.qkv = RatWPlanes{reinterpret_cast<const rat_u4*>(ws), 2};
         W.outT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV), 2};
         W.qkvT = RatWPlanes{reinterpret_cast<const rat_u4*>(ws + B3_W_QKV + B3_W_OUTT), 8};
-        if (dpad) {
+        if (heads == 4) {                                        // 4 heads x 20 (RAT_m3): the general form, P handed to pass 2 where it fits
+            if (b3_ph_fits(a.L, a.nsq_chunk, 4) && b3_ph_enabled())
+                RAT_LAUNCH((attn_bwd3_kernel<true, false, false, true, 0, 4>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+            else RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 0, 4>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        } else if (dpad) {
             if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
             else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_bwd3_kernel<true, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);

@@ -309,8 +309,13 @@ __device__ __forceinline__ void b3_fwd_core_mfma(float* qkv, float* lse_s, int L
 // Group g's fragment planes are W.qkv / W.out + g x B3_GRP_PLANES; W_out's come from L2 (four groups' planes do not fit the LDS).
 // MCF (1 / 2 = 16-row tiles per sequence): the attention core on the matrix pipe (b3_fwd_core_mfma) instead of the VALU loop; every position
 // a query, sequences of at most 32 tokens
-template <bool EX, bool QSUB = false, bool DPAD = false, bool GRP = false, int MCF = 0>
+// NH (round 6): heads of the layer, 8 (x 10) or 4 (x 20) — RAT_m3 at the north-star config runs heads / 2 heads of width 2 dim_head
+// (RAT_m3.py:181): the same projections and planes (inner = 80), a different slicing of Q | K | V in the VALU core.  NH = 4 has no matrix
+// core, group loop or narrower-embedding instantiation (nothing asks for them).
+template <bool EX, bool QSUB = false, bool DPAD = false, bool GRP = false, int MCF = 0, int NH = B3_H>
 __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn3W W) {
+    constexpr int NDH = B3_I / NH;
+    static_assert(NH == B3_H || (NH == 4 && MCF == 0 && !GRP && !DPAD), "the matrix cores, the group loop and DPAD are written for 8 heads x 10");
     static_assert(!GRP || (EX && !QSUB && !DPAD), "the group loop is written for the general (EX) form at embedding_dim 64");
     static_assert(MCF == 0 || !QSUB, "the matrix core computes every query");
     RAT_DYN_SMEM(smem);
@@ -370,7 +375,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         const RatWPlanes wq = GRP ? RatWPlanes{W.qkv.base + (size_t)grp * (B3_GRP_PLANES / 16), W.qkv.steps} : W.qkv;
         const RatWPlanes wo = GRP ? RatWPlanes{W.out.base + (size_t)grp * (B3_GRP_PLANES / 16), W.out.steps} : W.out;
         float* const o_save = (GRP && a.o_save != nullptr) ? a.o_save + (int64_t)grp * a.group_tok * B3_I : a.o_save;
-        float* const lse_save = (GRP && a.lse_save != nullptr) ? a.lse_save + (int64_t)grp * a.group_tok * B3_H : a.lse_save;
+        float* const lse_save = (GRP && a.lse_save != nullptr) ? a.lse_save + (int64_t)grp * a.group_tok * NH : a.lse_save;
         // Q|K|V = LN(x) W_qkv^T
         b3_gemm_rows<2>(xp, wq, B3_Q3 / 16, [&](int mt, int nt, const f32x4& acc) {
             const int col = rat_acc_col(nt);
@@ -388,30 +393,30 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
         //  maximum, no rescaling, independent keys): +-0 / +3 % — tools/experiments/attn_fwd3_core_variants.hip.txt.)
         if ((int)threadIdx.x < ATT_ROWS * 2 && chunk + gridDim.x < a.nchunks && (!GRP || grp == ngroups - 1))   // (no prefetch: +2-3 %, same-box A/B)
             pf = prefetch_lines_map((rowtok0 + (parity ^ 1) * ATT_ROWS), threadIdx.x, 2, a.x, dreal);
-        typedef HeadVec<B3_DH> HV;
+        typedef HeadVec<NDH> HV;
         const int nq = QSUB ? a.nq : L;                          // queries that matter per sequence (RatSeqMap.queries; normally L)
-        const int ntasks = MCF ? 0 : nsq * B3_H * nq;
+        const int ntasks = MCF ? 0 : nsq * NH * nq;
         const float sl2 = a.scale * RAT_LOG2E;
         if (MCF) b3_fwd_core_mfma<(MCF > 0 ? MCF : 1)>(qkv, lse_s, L, nsq, a.scale);
         for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
             const int i = task % nq;
-            const int h = (task / nq) % B3_H;
-            const int sq = task / (nq * B3_H);
+            const int h = (task / nq) % NH;
+            const int sq = task / (nq * NH);
             const int row_i = sq * L + i;
-            float* qp = qkv + (size_t)row_i * B3_LDQ + h * B3_DH;
+            float* qp = qkv + (size_t)row_i * B3_LDQ + h * NDH;
             HV q, o, kv;
-            q.load(qp, B3_DH);
+            q.load(qp, NDH);
             o.zero();
             float m = -INFINITY, l = 0.f;
-            const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + h * B3_DH;
+            const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + h * NDH;
             int j = 0;
             for (; j + CORE_UNROLL <= L; j += CORE_UNROLL) {
                 HV kk[CORE_UNROLL], vv[CORE_UNROLL];
 #pragma unroll
                 for (int u = 0; u < CORE_UNROLL; ++u) {
                     const float* kp = kbase + (size_t)(j + u) * B3_LDQ;
-                    kk[u].load(kp, B3_DH);
-                    vv[u].load(kp + B3_I, B3_DH);
+                    kk[u].load(kp, NDH);
+                    vv[u].load(kp + B3_I, NDH);
                 }
                 float sc[CORE_UNROLL];
 #pragma unroll
@@ -428,27 +433,27 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
             }
             for (; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * B3_LDQ;
-                kv.load(kp, B3_DH);
+                kv.load(kp, NDH);
                 const float sv = q.dot(kv) * sl2;
                 const float mn = fmaxf(m, sv);
                 const float corr = rat_exp2(m - mn);
                 const float p = rat_exp2(sv - mn);
                 l = l * corr + p;
-                kv.load(kp + B3_I, B3_DH);
+                kv.load(kp + B3_I, NDH);
                 o.scale_axpy(corr, p, kv);
                 m = mn;
             }
             const float inv = 1.0f / l;
-            o.store(qp, B3_DH, inv);
-            lse_s[row_i * B3_H + h] = m + rat_log2(l);
+            o.store(qp, NDH, inv);
+            lse_s[row_i * NH + h] = m + rat_log2(l);
         }
         if (QSUB && nq < L) {                                    // the positions nobody asked for: O = 0, lse = 0 (defined, never used)
-            for (int e = threadIdx.x; e < rows * B3_H; e += ATT_THREADS) {
-                const int r = e / B3_H, h = e - r * B3_H;
+            for (int e = threadIdx.x; e < rows * NH; e += ATT_THREADS) {
+                const int r = e / NH, h = e - r * NH;
                 if (r % L < nq) continue;
                 HV z;
                 z.zero();
-                z.store(qkv + (size_t)r * B3_LDQ + h * B3_DH, B3_DH, 1.0f);
+                z.store(qkv + (size_t)r * B3_LDQ + h * NDH, NDH, 1.0f);
                 lse_s[e] = 0.f;
             }
         }
@@ -470,10 +475,10 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_fwd3_kernel(AttnArgs a, Attn
                 rat_st4_stream(o_save + tok * B3_I + 8 * o8 + 4, v1);
             }
         }
-        if (lse_save != nullptr && (int)threadIdx.x < 2 * ATT_ROWS) {
-            const int r = threadIdx.x >> 1, part = threadIdx.x & 1;
+        if (lse_save != nullptr && (int)threadIdx.x < (NH / 4) * ATT_ROWS) {       // a row's NH values as NH / 4 16-byte pieces
+            const int r = threadIdx.x / (NH / 4), part = threadIdx.x % (NH / 4);
             const int64_t tok = rowtok[r];
-            if (tok >= 0) rat_st4_stream(lse_save + tok * B3_H + 4 * part, *reinterpret_cast<const float4*>(lse_s + r * B3_H + 4 * part));
+            if (tok >= 0) rat_st4_stream(lse_save + tok * NH + 4 * part, *reinterpret_cast<const float4*>(lse_s + r * NH + 4 * part));
         }
         __syncthreads();
         RAT_PROF_MARK(3);
@@ -732,8 +737,10 @@ static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP, "the 
 // and are handed to pass 2, which then needs neither the q . k product nor the exponential again
 // MC (1 / 2 = 16-row tiles per sequence): the attention core on the matrix pipe (b3_bwd_core_mfma) instead of the two VALU passes;
 // sequences of at most 32 tokens, every position a query
-template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false, int MC = 0>
+template <bool EX, bool QSUB = false, bool DPAD = false, bool PH = false, int MC = 0, int NH = B3_H>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn3W W) {
+    constexpr int NDH = B3_I / NH;
+    static_assert(NH == B3_H || (NH == 4 && MC == 0 && !DPAD), "the matrix core and DPAD are written for 8 heads x 10");
     static_assert(MC == 0 || (!QSUB && !PH), "the matrix core computes every query and hands nothing over");   // MC = 16-row tiles per sequence (1 / 2)
     RAT_DYN_SMEM(smem);
     const PlanesX xp{smem};                                                  // LayerNorm(x)
@@ -746,8 +753,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
     float* mu = reinterpret_cast<float*>(smem + B3_OFF_MISC);
     float* rs = mu + ATT_ROWS;
     float* lses = rs + ATT_ROWS;                                             // [64][8]
-    float* dlt = lses + ATT_ROWS * B3_H;                                     // [64][8]
-    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(dlt + ATT_ROWS * B3_H);
+    float* dlt = lses + ATT_ROWS * NH;                                     // [64][8]
+    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(dlt + ATT_ROWS * NH);
     const int L = a.L;
     const int r_own = threadIdx.x >> 3, sub = threadIdx.x & 7;               // this thread's (row slot, 8-column piece)
     const int dreal = DPAD ? a.d : B3_D;                                     // DPAD: embedding_dim 40 / 48 / 56 inside the 64-wide tiles
@@ -794,7 +801,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             float4 x0 = b3_ld4(a.x, po), x1 = b3_ld4(a.x, po + 16u);
             float4 d0 = b3_ld4(a.dy, po), d1 = b3_ld4(a.dy, po + 16u);
             fo.issue(a.o_save, rowtok);
-            float lsen = b3_ld1(a.lse_save, (uint32_t)(tok_own >= 0 ? tok_own : 0) * (uint32_t)(B3_H * 4) + 4u * sub);
+            float lsen = b3_ld1(a.lse_save, (uint32_t)(tok_own >= 0 ? tok_own : 0) * (uint32_t)(NH * 4) + 4u * (sub < NH ? sub : 0));
             RAT_SCHED_FENCE();                                               // every request is out before anything is consumed
             b3_zero_unless(valid, x0);
             b3_zero_unless(valid, x1);
@@ -824,7 +831,7 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
             rat_split8(d0, d1, h, m, l);
             dyp.store(r_own, sub, h, m, l);
             fo.stash(ob, B3_LDT);
-            lses[threadIdx.x] = lsen;                                        // 512 threads = 64 rows x 8 heads
+            if (sub < NH) lses[r_own * NH + sub] = lsen;                     // (NH = 8: 512 threads = 64 rows x 8 heads)
         }
         if (chunk + gridDim.x < a.nchunks) {
             int nsq1, rows1;
@@ -884,76 +891,76 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         // different row per lane, while in both passes below all lanes of a group read the SAME row (an LDS broadcast).
         // RatSeqMap.queries < L: the dy rows of the other positions are zero by contract, so their dQ is zero and they add nothing to
         // dK / dV — pass 1 runs for nq queries per sequence, pass 2 sums over them.
-        typedef HeadVec<B3_DH> HV;
+        typedef HeadVec<NDH> HV;
         const int nq = QSUB ? a.nq : L;
-        const int ntasks = nsq * B3_H * L, nqtasks = QSUB ? nsq * B3_H * nq : ntasks;
+        const int ntasks = nsq * NH * L, nqtasks = QSUB ? nsq * NH * nq : ntasks;
         const float sl2 = a.scale * RAT_LOG2E;
         if (MC) b3_bwd_core_mfma<(MC > 0 ? MC : 1)>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);   // (the dy planes are dead since P2b: the wave-private tiles go there)
         for (int task = threadIdx.x; !MC && task < nqtasks; task += ATT_THREADS) {
             const int i = task % nq;
-            const int h = (task / nq) % B3_H;
-            const int sq = task / (nq * B3_H);
+            const int h = (task / nq) % NH;
+            const int sq = task / (nq * NH);
             const int row_i = sq * L + i;
-            const int ho = h * B3_DH;
+            const int ho = h * NDH;
             float* opp = ob + (size_t)row_i * B3_LDT + ho;
             HV q, go, dq, kv;
-            q.load(qkv + (size_t)row_i * B3_LDQ + ho, B3_DH);
-            go.load(dob + (size_t)row_i * B3_LDT + ho, B3_DH);
-            kv.load(opp, B3_DH);
+            q.load(qkv + (size_t)row_i * B3_LDQ + ho, NDH);
+            go.load(dob + (size_t)row_i * B3_LDT + ho, NDH);
+            kv.load(opp, NDH);
             const float delta = go.dot(kv);
             dq.zero();
-            dlt[row_i * B3_H + h] = delta;
-            const float lse = lses[row_i * B3_H + h];
+            dlt[row_i * NH + h] = delta;
+            const float lse = lses[row_i * NH + h];
             const float* kbase = qkv + (size_t)(sq * L) * B3_LDQ + B3_I + ho;
-            float* const prow = PH ? dxn + ((sq * B3_H + h) * L + i) * L : nullptr;     // P[(sequence, head)][query i][key j]
+            float* const prow = PH ? dxn + ((sq * NH + h) * L + i) * L : nullptr;     // P[(sequence, head)][query i][key j]
             for (int j = 0; j < L; ++j) {
                 const float* kp = kbase + (size_t)j * B3_LDQ;
-                kv.load(kp + B3_I, B3_DH);
+                kv.load(kp + B3_I, NDH);
                 const float dp = go.dot(kv);
-                kv.load(kp, B3_DH);
+                kv.load(kp, NDH);
                 const float p = rat_exp2(q.dot(kv) * sl2 - lse);
                 if (PH) prow[j] = p;
                 dq.axpy(p * (dp - delta), kv);
             }
-            dq.store(opp, B3_DH, a.scale);
+            dq.store(opp, NDH, a.scale);
         }
         if (QSUB && nq < L) {
-            for (int e = threadIdx.x; e < nsq * L * B3_H; e += ATT_THREADS) {
-                const int r = e / B3_H, h = e - r * B3_H;
+            for (int e = threadIdx.x; e < nsq * L * NH; e += ATT_THREADS) {
+                const int r = e / NH, h = e - r * NH;
                 if (r % L < nq) continue;
                 HV z;
                 z.zero();
-                z.store(ob + (size_t)r * B3_LDT + h * B3_DH, B3_DH, 1.0f);    // dQ of a position that is no query
+                z.store(ob + (size_t)r * B3_LDT + h * NDH, NDH, 1.0f);    // dQ of a position that is no query
             }
         }
         __syncthreads();
         RAT_PROF_MARK(4);
         for (int task = threadIdx.x; !MC && task < ntasks; task += ATT_THREADS) {
             const int j = task % L;
-            const int h = (task / L) % B3_H;
-            const int sq = task / (L * B3_H);
-            const int ho = h * B3_DH;
+            const int h = (task / L) % NH;
+            const int sq = task / (L * NH);
+            const int ho = h * NDH;
             float* kp = qkv + (size_t)(sq * L + j) * B3_LDQ + B3_I + ho;
             HV kk, vv, dk, dv, t;
-            kk.load(kp, B3_DH);
-            vv.load(kp + B3_I, B3_DH);
+            kk.load(kp, NDH);
+            vv.load(kp + B3_I, NDH);
             dk.zero();
             dv.zero();
             for (int i = 0; i < nq; ++i) {
                 const int row_i = sq * L + i;
-                t.load(dob + (size_t)row_i * B3_LDT + ho, B3_DH);
+                t.load(dob + (size_t)row_i * B3_LDT + ho, NDH);
                 const float dp = t.dot(vv);
-                const float delta = dlt[row_i * B3_H + h];
+                const float delta = dlt[row_i * NH + h];
                 HV qv;
-                qv.load(qkv + (size_t)row_i * B3_LDQ + ho, B3_DH);
+                qv.load(qkv + (size_t)row_i * B3_LDQ + ho, NDH);
                 float p;
-                if (PH) p = dxn[((sq * B3_H + h) * L + i) * L + j];           // consecutive lanes = consecutive keys: conflict-free
-                else p = rat_exp2(qv.dot(kk) * sl2 - lses[row_i * B3_H + h]);
+                if (PH) p = dxn[((sq * NH + h) * L + i) * L + j];           // consecutive lanes = consecutive keys: conflict-free
+                else p = rat_exp2(qv.dot(kk) * sl2 - lses[row_i * NH + h]);
                 dv.axpy(p, t);
                 dk.axpy(p * (dp - delta), qv);
             }
-            dk.store(kp, B3_DH, a.scale);
-            dv.store(kp + B3_I, B3_DH, 1.0f);
+            dk.store(kp, NDH, a.scale);
+            dv.store(kp + B3_I, NDH, 1.0f);
         }
         __syncthreads();
         RAT_PROF_MARK(5);

@@ -188,6 +188,14 @@ class RAT_m3(RAT_m2):
     #                  the bias, every later one accumulates onto the output of the one before (res = y; backward: add = dx);
     #        composed  heads wider than any fused instantiation (2 * dim_head > 20) or sequences above 64 tokens: LayerNorm ->
     #                  rat_sgemm -> rat_attn_core_*_map -> rat_sgemm.
+    def _m3_arith(self):
+        """the arithmetic of the fused attention launches: the model's, where the library has a bf16x3 instantiation for heads / 2 heads of
+        width 2 * dim_head (round 6: 4 x 20 at embedding_dim 64, the north-star config), else exact fp32"""
+        v = self.__dict__.get("_m3_b3")
+        if v is None:
+            v = self._m3_b3 = self._lib.size("rat_attn_fwd_workspace", self._cfg["d"], self._m3_heads, self._m3_dh) > 0
+        return self.arith if v else "f32"
+
     def _m3_mode(self, smap):
         key = ("m3", int(smap.L), self.FUSED_MAX_L)
         hit = self._fused_cache.get(key)
@@ -223,7 +231,7 @@ class RAT_m3(RAT_m2):
         mode, per = self._m3_mode(smap)
         if mode == "fused":
             y, o, l = ops.attn_fwd_ex(x, res, self._m3_params(blk, which, w_stack, self._p), smap, d, h, dh, sc, 0.5, save=save, out=out,
-                                      dropout=drop, lib=lib)
+                                      arith=self._m3_arith(), dropout=drop, lib=lib)
             return y, (o, l)
         if mode == "grouped":
             y, kept = out, []
@@ -256,7 +264,8 @@ class RAT_m3(RAT_m2):
         mode, per = self._m3_mode(smap)
         if mode == "fused":
             dx, _ = ops.attn_bwd_ex(x_in, dy, add, att[0], att[1], self._m3_params(blk, which, w_stack, self._p),
-                                    self._m3_params(blk, which, g_stack, G), smap, d, h, dh, sc, 0.5, workspace=ws, out=out, dropout=drop, lib=lib)
+                                    self._m3_params(blk, which, g_stack, G), smap, d, h, dh, sc, 0.5, workspace=ws, out=out,
+                                    arith=self._m3_arith(), dropout=drop, lib=lib)
             return dx
         names = blk[which]
         if mode == "grouped":
