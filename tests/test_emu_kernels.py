@@ -104,7 +104,8 @@ def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
 
 @pytest.mark.parametrize("case,mode", [pytest.param((2, 3, 21, 64, 8, 10, True), "intra", id="L21_two_tiles"),
                                        pytest.param((3, 11, 4, 64, 8, 10, True), "cross", id="L11_one_tile"),
-                                       twin((1, 31, 2, 64, 8, 10, True), "cross", id="L31")])
+                                       twin((1, 31, 2, 64, 8, 10, True), "cross", id="L31"),
+                                       pytest.param((1, 3, 41, 64, 8, 10, True), "intra", id="L41_three_tiles")])
 def test_attn_fwd_exact_fp32_matrix_pipe_core(emu, case, mode, two_blocks, knob):
     """attn_fwd3_kernel<.., MCF>: the forward core on v_mfma_f32_16x16x4_f32 (S^T = K Q^T, the row softmax in the accumulators, which then
     ARE the B operand of O^T = V^T P^T) — forced on by the knob at lengths the host would leave to the VALU loop: two 16-row tiles with a

@@ -53,7 +53,10 @@ def test_attn_fwd_bwd(lib, case, mode):
 # lengths of the north star, the KKBox-like S = 14 and Tmall-like T = 31 lengths — same tolerances as the exact-fp32 kernels, plus
 # agreement of the two arithmetic variants to 4e-6 of each tensor's largest element
 B3_CASES = [(3, 11, 21, 64, 8, 10, True), (300, 11, 21, 64, 8, 10, True), (37, 11, 14, 64, 8, 10, True), (29, 31, 9, 64, 8, 10, True),
-            (1, 2, 64, 64, 8, 10, True)]
+            (1, 2, 64, 64, 8, 10, True),
+            # one sequence per chunk (33 ... 48 tokens; BASELINE configs[3]: F = 40 -> 41): one chunk, many chunks per work-group with a ragged
+            # last round, both phases; forward core on the matrix pipe from 40 tokens on (three 16-row tiles), backward on the VALU
+            (1, 33, 41, 64, 8, 10, True), (130, 11, 41, 64, 8, 10, True), (7, 48, 33, 64, 8, 10, True)]
 
 
 @pytest.mark.parametrize("case", B3_CASES, ids=str)
@@ -91,8 +94,10 @@ def test_attn_bwd_bf16x3_matrix_pipe_core(lib, case, mode, knob):
 
 
 @pytest.mark.parametrize("case,mode", [((40, 6, 21, 64, 8, 10, True), "intra"), ((30, 11, 4, 64, 8, 10, True), "cross"), ((9, 31, 9, 64, 8, 10, True), "cross"),
-                                       ((9, 31, 16, 64, 8, 10, True), "intra"), ((5, 28, 3, 64, 8, 10, True), "cross"), ((7, 3, 32, 64, 8, 10, True), "intra")],
-                         ids=["L21", "L11", "L31", "L16", "L28", "L32"])
+                                       ((9, 31, 16, 64, 8, 10, True), "intra"), ((5, 28, 3, 64, 8, 10, True), "cross"), ((7, 3, 32, 64, 8, 10, True), "intra"),
+                                       ((60, 11, 41, 64, 8, 10, True), "intra"), ((5, 48, 3, 64, 8, 10, True), "cross"), ((4, 40, 2, 64, 8, 10, True), "cross"),
+                                       ((3, 2, 33, 64, 8, 10, True), "intra")],
+                         ids=["L21", "L11", "L31", "L16", "L28", "L32", "L41_three_tiles", "L48", "L40", "L33_forced"])
 def test_attn_fwd_exact_fp32_matrix_pipe_core(lib, case, mode, knob):
     """the forward core on the matrix pipe (attn_fwd3_kernel<.., MCF>): forced on at every length class, forced off, and by the host's own
     rule (L 28 ... 32); also through the entry point with a residual of its own (the EX instantiation) and with dropout"""

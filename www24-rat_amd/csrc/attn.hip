@@ -1199,16 +1199,18 @@ static bool b3_ph_fits(int L, int nsq_chunk, int heads = B3_H) { return (size_t)
 // attn_bwd_core_mfma knob forces it on (1, any L <= 32) or off (0)
 static bool b3_matrix_core(int L) {
     const int k = rat_knob(RAT_KNOB_ATTN_BWD_CORE_MFMA);
-    if (L > 32 || k == 0) return false;
-    return k == 1 || L >= 28;
+    if (L > 32 || k == 0) return false;                 // (three tiles — 33 ... 48 tokens, round 6 — were built and measured SLOWER than the VALU passes:
+    return k == 1 || L >= 28;                           //  64-66 spilled VGPRs beside the kernel's persistent accumulators; profiles/round6/r6_attn_L41_ab.txt)
 }
-// the matrix-pipe FORWARD core (b3_fwd_core_mfma): attn_fwd_core_mfma knob 0 = by length (28 ... 32 tokens), 2 = forced on (L <= 32), 3 = off
+// the matrix-pipe FORWARD core (b3_fwd_core_mfma): attn_fwd_core_mfma knob 0 = by length (28 ... 32 and 40 ... 48 tokens), 2 = forced on (L <= 48), 3 = off
 // (1 selected round 3's bf16x3 core until round 6 — tools/experiments/attn_fwd3m_kernel.hip.txt — and now means 0)
 static int b3_fwd_matrix_core(int L, int nq) {
     const int k = rat_knob(RAT_KNOB_ATTN_FWD_CORE_MFMA);
-    if (L > 32 || nq < L || k == 3) return 0;
-    if (k != 2 && L < 28) return 0;
-    return L > 16 ? 2 : 1;
+    if (L > 48 || nq < L || k == 3) return 0;
+    // by length: 28 ... 32 tokens (two 16-row tiles, >= 88 % full) and — round 6 — 40 ... 48 (three tiles, one sequence per chunk: the VALU loop
+    // leaves 36 % of the lanes idle there and walks 41 keys per lane; BASELINE configs[3]'s intra-sample sequences, F = 40)
+    if (k != 2 && !((L >= 28 && L <= 32) || L >= 40)) return 0;
+    return L > 32 ? 3 : (L > 16 ? 2 : 1);
 }
 static bool b3_ph_enabled() {                          // on unless the attn_bwd_ph knob is 0 (same-box A/B: L = 11 1.2477 -> 1.2322 ms, -1.2 %)
     return rat_knob(RAT_KNOB_ATTN_BWD_PH) != 0;
@@ -1302,12 +1304,16 @@ extern "C" int rat_attn_fwd_ex(const float* x, const float* res, float* y, float
             else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false, false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_fwd3_kernel<true, false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         } else if (plain && a.nq < a.L) RAT_LAUNCH((attn_fwd3_kernel<false, true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else if (plain && b3_fwd_matrix_core(a.L, a.nq) == 3)
+            RAT_LAUNCH((attn_fwd3_kernel<false, false, false, false, 3>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else if (plain && b3_fwd_matrix_core(a.L, a.nq) == 2)
             RAT_LAUNCH((attn_fwd3_kernel<false, false, false, false, 2>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else if (plain && b3_fwd_matrix_core(a.L, a.nq) == 1)      // (sequences of at most 16 tokens: only when the knob forces it)
             RAT_LAUNCH((attn_fwd3_kernel<false, false, false, false, 1>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else if (plain) RAT_LAUNCH((attn_fwd3_kernel<false>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
-        else if (b3_fwd_matrix_core(a.L, a.L) == 2)                // (EX computes every position whatever `queries` says)
+        else if (b3_fwd_matrix_core(a.L, a.L) == 3)                // (EX computes every position whatever `queries` says)
+            RAT_LAUNCH((attn_fwd3_kernel<true, false, false, false, 3>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
+        else if (b3_fwd_matrix_core(a.L, a.L) == 2)
             RAT_LAUNCH((attn_fwd3_kernel<true, false, false, false, 2>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);
         else RAT_LAUNCH((attn_fwd3_kernel<true>), b3_blocks, ATT_THREADS, b3_fwd_smem(), stream, a, W);   // (computes every position)
         return rat_check_launch("rat_attn_fwd (bf16x3)");

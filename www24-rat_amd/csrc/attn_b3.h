@@ -576,10 +576,14 @@ __device__ __forceinline__ void b3_gemm_rows_longk(const PA& A, const RatWPlanes
 template <int NIT>
 __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const float* dob, const float* lses, float* scratch, int L, int nsq,
                                                  float scale) {
-    constexpr int SCR = 16 * 33 + 16;
+    constexpr int SLD = 16 * NIT + 1, SCR = 16 * SLD + 16;          // wave-private [16 queries][16 NIT keys (+ 1)] tile + 16 deltas
     const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
-    float* scr = scratch + w * SCR;
-    float* dl = scr + 16 * 33;
+    // NIT = 3 (round 6: one 33 ... 48-token sequence per chunk; built, parity-green, measured slower than the VALU passes and NOT dispatched —
+    // attn.hip b3_matrix_core): eight 3 200-byte tiles are 1 KB more than the dead dy planes hold — the last
+    // wave's goes to rows 48 ... 51 of the Q|K|V tile, which such a chunk never uses (zeros from the padded projection), and is cleared
+    // again at the end (those rows feed the padded rows of d(Q|K|V)'s planes)
+    float* scr = (NIT == 3 && w == ATT_WAVES - 1) ? qkv + (size_t)48 * B3_LDQ : scratch + w * SCR;
+    float* dl = scr + 16 * SLD;
     const float sl2 = scale * RAT_LOG2E;
     const int npairs = nsq * B3_H;
     const bool cm = m < B3_DH;                                // this lane's column of a [.][dim_head] operand exists
@@ -654,7 +658,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                     for (int r = 0; r < 4; ++r) {
                         const bool ok = 4 * g + r < irows && 16 * jt + m < L;
                         const float p = ok ? rat_exp2(aS[jt][r] * sl2 - lse4[r]) : 0.f;
-                        scr[(4 * g + r) * 33 + 16 * jt + m] = p;
+                        scr[(4 * g + r) * SLD + 16 * jt + m] = p;
                         dS[jt][r] = p * (aP[jt][r] - d4[r]);
                     }
             }
@@ -667,7 +671,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                     const int ii = 4 * ks + g;
                     bdo[ks] = dob[(size_t)(r0 + i0 + ii) * B3_LDT + cq + mc];
 #pragma unroll
-                    for (int jt = 0; jt < NIT; ++jt) ap[ks][jt] = scr[ii * 33 + 16 * jt + m];
+                    for (int jt = 0; jt < NIT; ++jt) ap[ks][jt] = scr[ii * SLD + 16 * jt + m];
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -680,7 +684,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
 #pragma unroll
             for (int jt = 0; jt < NIT; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) scr[(4 * g + r) * 33 + 16 * jt + m] = dS[jt][r];
+                for (int r = 0; r < 4; ++r) scr[(4 * g + r) * SLD + 16 * jt + m] = dS[jt][r];
             RAT_WAVE_FENCE();
             // dK[j][c] += sum_i dS[i][j] Q[i][c]   (A = dS^T, B = Q);   dQ[i][c] = sum_j dS[i][j] K[j][c]   (A = dS, B = K)
             {
@@ -690,7 +694,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                     const int ii = 4 * ks + g;
                     bq[ks] = qkv[(size_t)(r0 + i0 + ii) * B3_LDQ + cq + mc];
 #pragma unroll
-                    for (int jt = 0; jt < NIT; ++jt) at[ks][jt] = scr[ii * 33 + 16 * jt + m];
+                    for (int jt = 0; jt < NIT; ++jt) at[ks][jt] = scr[ii * SLD + 16 * jt + m];
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -707,7 +711,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                 for (int ks = 0; ks < 4; ++ks) {
                     const int jj = 16 * half + 4 * ks + g;
                     bkk[ks] = qkv[(size_t)(r0 + jj) * B3_LDQ + ck + mc];
-                    as[ks] = scr[m * 33 + jj];
+                    as[ks] = scr[m * SLD + jj];
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) adQ = RAT_MFMA16(as[ks], (cm && 16 * half + 4 * ks + g < L) ? bkk[ks] : 0.f, adQ);
@@ -730,8 +734,13 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                     }
                 }
     }
+    if (NIT == 3 && w == ATT_WAVES - 1) {
+        RAT_WAVE_FENCE();
+        for (int e = l; e < SCR; e += 64) scr[e] = 0.f;
+    }
 }
-static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP, "the matrix core's wave-private tiles live in the dead dy planes");
+static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP && (size_t)(ATT_WAVES - 1) * (16 * 49 + 16) * 4 <= (size_t)3 * B3_XP,
+              "the matrix core's wave-private tiles live in the dead dy planes (three-tile sequences: all but the last wave's)");
 
 // PH: sequences of at most 12 tokens — the probabilities P of pass 1 fit the (then dead) dy planes (64 rows x L x 8 heads x 4 B <= 24 KB)
 // and are handed to pass 2, which then needs neither the q . k product nor the exponential again
