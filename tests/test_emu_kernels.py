@@ -97,6 +97,12 @@ def test_attn_bwd_bf16x3_matrix_pipe_core(emu, case, mode, two_blocks, knob):
     kc.check_attn(emu, "cpu", case, mode, arith="bf16x3")
 
 
+def test_attn_bwd_bf16x3_matrix_pipe_core_three_tiles(emu, two_blocks):
+    """41 tokens: one sequence per chunk, the backward core's key-tile-inner form on three 16-row tiles (the host's rule from 40 tokens on),
+    the forward core on three tiles as well; two work-groups over three chunks"""
+    kc.check_attn(emu, "cpu", (1, 3, 41, 64, 8, 10, True), "intra", arith="bf16x3")
+
+
 def test_attn_narrower_embedding_with_queries_and_dropout(emu, two_blocks):
     kc.check_attn_queries(emu, "cpu", (2, 3, 7, 40, 8, 10, True), "intra", nq=1, arith="bf16x3")
     kc.check_attn_dropout(emu, "cpu", (1, 3, 5, 40, 8, 10, True), "cross", arith="bf16x3")

@@ -93,6 +93,16 @@ def test_attn_bwd_bf16x3_matrix_pipe_core(lib, case, mode, knob):
     kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
 
 
+@pytest.mark.parametrize("case,mode", [((60, 11, 41, 64, 8, 10, True), "intra"), ((5, 48, 3, 64, 8, 10, True), "cross"), ((3, 2, 33, 64, 8, 10, True), "intra")],
+                         ids=["L41", "L48", "L33"])
+def test_attn_bwd_bf16x3_matrix_pipe_core_three_tiles(lib, case, mode, knob):
+    """33 ... 48 tokens (one sequence per chunk, three 16-row tiles): the key-tile-inner form of the matrix core (b3_bwd_core_mfma_kt), forced by
+    the knob (the host's own rule takes it from 40 tokens on: test_attn_fwd_bwd_bf16x3's 41-token cases run it by default)"""
+    knob(lib, "attn_bwd_core_mfma", 1)
+    kc.check_attn(lib, "cuda", case, mode, arith="bf16x3")
+    kc.check_attn_dropout(lib, "cuda", case, mode, arith="bf16x3")
+
+
 @pytest.mark.parametrize("case,mode", [((40, 6, 21, 64, 8, 10, True), "intra"), ((30, 11, 4, 64, 8, 10, True), "cross"), ((9, 31, 9, 64, 8, 10, True), "cross"),
                                        ((9, 31, 16, 64, 8, 10, True), "intra"), ((5, 28, 3, 64, 8, 10, True), "cross"), ((7, 3, 32, 64, 8, 10, True), "intra"),
                                        ((60, 11, 41, 64, 8, 10, True), "intra"), ((5, 48, 3, 64, 8, 10, True), "cross"), ((4, 40, 2, 64, 8, 10, True), "cross"),

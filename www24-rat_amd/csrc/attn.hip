@@ -1197,10 +1197,14 @@ static bool b3_shape(int d, int heads, int dim_head, const RatAttnParams* w) {
 static bool b3_ph_fits(int L, int nsq_chunk, int heads = B3_H) { return (size_t)nsq_chunk * heads * L * L * 4 <= (size_t)3 * B3_XP; }
 // the matrix-pipe backward core (b3_bwd_core_mfma) by sequence length — see its comment for the measurements behind the rule; the
 // attn_bwd_core_mfma knob forces it on (1, any L <= 32) or off (0)
-static bool b3_matrix_core(int L) {
+static int b3_matrix_core(int L) {                     // -> 0 (VALU passes) | NIT (all key tiles of a query tile at once) | 13 (three tiles, key tiles inner)
     const int k = rat_knob(RAT_KNOB_ATTN_BWD_CORE_MFMA);
-    if (L > 32 || k == 0) return false;                 // (three tiles — 33 ... 48 tokens, round 6 — were built and measured SLOWER than the VALU passes:
-    return k == 1 || L >= 28;                           //  64-66 spilled VGPRs beside the kernel's persistent accumulators; profiles/round6/r6_attn_L41_ab.txt)
+    if (L > 48 || k == 0) return 0;
+    // 33 ... 48 tokens (round 6; one sequence per chunk): three tiles at once spill 64-66 VGPRs and lose to the VALU passes (1.24 against
+    // 1.17 ms at L = 41); with the key tiles as the inner loop (b3_bwd_core_mfma_kt) the core wins by 4 % from 40 tokens on — r6_attn_L41_ab.txt.
+    // At one and two tiles that form is SLOWER than the all-at-once form (L 31: 1.77 against 1.72 ms; L 21 / 11: x 1.2) and is not built in.
+    if (L > 32) return (k == 1 || L >= 40) ? 13 : 0;
+    return (k == 1 || L >= 28) ? (L > 16 ? 2 : 1) : 0;
 }
 // the matrix-pipe FORWARD core (b3_fwd_core_mfma): attn_fwd_core_mfma knob 0 = by length (28 ... 32 and 40 ... 48 tokens), 2 = forced on (L <= 48), 3 = off
 // (1 selected round 3's bf16x3 core until round 6 — tools/experiments/attn_fwd3m_kernel.hip.txt — and now means 0)
@@ -1578,14 +1582,16 @@ extern "C" int rat_attn_bwd_ex(const float* x, const float* dy, const float* add
             else if (a.add_lds) RAT_LAUNCH((attn_bwd3_kernel<false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
             else RAT_LAUNCH((attn_bwd3_kernel<true, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         } else if (a.add_lds && a.nq < a.L) RAT_LAUNCH((attn_bwd3_kernel<false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.add_lds && a.L > 16)
-            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 2>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.L > 16)
-            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 2>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-        else if (b3_matrix_core(a.L) && a.nq >= a.L && a.add_lds)          // (sequences of at most 16 tokens: only when the knob forces it)
-            RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
-        else if (b3_matrix_core(a.L) && a.nq >= a.L)
-            RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
+        else if (b3_matrix_core(a.L) && a.nq >= a.L) {
+            switch (b3_matrix_core(a.L) * 2 + (a.add_lds ? 0 : 1)) {   // (code, EX)
+                case 2: RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W); break;
+                case 3: RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 1>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W); break;
+                case 4: RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 2>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W); break;
+                case 5: RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 2>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W); break;
+                case 26: RAT_LAUNCH((attn_bwd3_kernel<false, false, false, false, 13>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W); break;
+                default: RAT_LAUNCH((attn_bwd3_kernel<true, false, false, false, 13>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W); break;
+            }
+        }
         else if (a.add_lds && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())
             RAT_LAUNCH((attn_bwd3_kernel<false, false, false, true>), blocks, ATT_THREADS, b3_bwd_smem(), stream, a, W);
         else if (a.nq >= a.L && b3_ph_fits(a.L, a.nsq_chunk) && b3_ph_enabled())      // (wide heads: groups 1 ... G - 1 add onto dx, not dy)

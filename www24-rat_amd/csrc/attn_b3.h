@@ -579,7 +579,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
     constexpr int SLD = 16 * NIT + 1, SCR = 16 * SLD + 16;          // wave-private [16 queries][16 NIT keys (+ 1)] tile + 16 deltas
     const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
     // NIT = 3 (round 6: one 33 ... 48-token sequence per chunk; built, parity-green, measured slower than the VALU passes and NOT dispatched —
-    // attn.hip b3_matrix_core): eight 3 200-byte tiles are 1 KB more than the dead dy planes hold — the last
+    // attn.hip b3_matrix_core; b3_bwd_core_mfma_kt below serves three tiles): eight 3 200-byte tiles are 1 KB more than the dead dy planes hold — the last
     // wave's goes to rows 48 ... 51 of the Q|K|V tile, which such a chunk never uses (zeros from the padded projection), and is cleared
     // again at the end (those rows feed the padded rows of d(Q|K|V)'s planes)
     float* scr = (NIT == 3 && w == ATT_WAVES - 1) ? qkv + (size_t)48 * B3_LDQ : scratch + w * SCR;
@@ -737,6 +737,154 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
     if (NIT == 3 && w == ATT_WAVES - 1) {
         RAT_WAVE_FENCE();
         for (int e = l; e < SCR; e += 64) scr[e] = 0.f;
+    }
+}
+// ---- the same core with the KEY tiles as the inner loop (round 6) ------------------------------------------------------------------------------
+// b3_bwd_core_mfma keeps S, dP and dS of ALL key tiles of a query tile in registers at once (3 NIT accumulator quads + 6 NIT operands on
+// top of the 2 NIT dK / dV accumulators): beside attn_bwd3_kernel's 48 persistent weight-gradient VGPRs that spills 18 registers at NIT = 2
+// and 64-66 at NIT = 3.  Here one (query tile, key tile) pair is finished — S, dP, p, dS, dV += P^T dO, dK += dS^T Q, dQ += dS K — before the
+// next key tile starts: one accumulator quad each for S / dP / dS, a [16][17] wave-private tile whatever NIT is (9 KB for eight waves), the
+// query tile's operands loaded once per query tile.  Three wave fences per pair of tiles instead of four per query tile.
+template <int NIT>
+__device__ __forceinline__ void b3_bwd_core_mfma_kt(float* qkv, float* ob, const float* dob, const float* lses, float* scratch, int L, int nsq,
+                                                    float scale) {
+    constexpr int SLD = 17, SCR = 16 * SLD + 16;
+    const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
+    float* scr = scratch + w * SCR;
+    float* dl = scr + 16 * SLD;
+    const float sl2 = scale * RAT_LOG2E;
+    const int npairs = nsq * B3_H;
+    const bool cm = m < B3_DH;                                // this lane's column of a [.][dim_head] operand exists
+    for (int pair = w; pair < npairs; pair += ATT_WAVES) {
+        const int h = pair % B3_H, sq = pair / B3_H;
+        const int r0 = sq * L, cq = h * B3_DH, ck = B3_I + h * B3_DH, cv = 2 * B3_I + h * B3_DH;
+        f32x4 adK[NIT], adV[NIT];
+#pragma unroll
+        for (int jt = 0; jt < NIT; ++jt) adK[jt] = adV[jt] = rat_zero4();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i0 = 16 * it;
+            if (i0 >= L) break;                               // (wave-uniform)
+            const int irows = L - i0 < 16 ? L - i0 : 16;
+            {                                                 // delta_i = dO_i . O_i for the tile's rows
+                const int rr = r0 + i0 + m;
+                const float* a_ = dob + (size_t)rr * B3_LDT + cq;
+                const float* b_ = ob + (size_t)rr * B3_LDT + cq;
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < B3_DH; c += 2) {
+                    const float2 x = *reinterpret_cast<const float2*>(a_ + c), y = *reinterpret_cast<const float2*>(b_ + c);
+                    d = fmaf(x.x, y.x, d);
+                    d = fmaf(x.y, y.y, d);
+                }
+                if (l < 16) dl[l] = m < irows ? d : 0.f;
+            }
+            // the query tile's operands, once: A of S / dP (lane: [row m][k g]) and B of dK / dV (lane: [k = query 4 ks + g][col m])
+            float aq[3], ao[3], bq[4], bdo[4];
+            const int ri = r0 + i0 + m;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const int cc = 4 * ks + g;
+                const bool oki = cc < B3_DH && m < irows;
+                const float q_ = qkv[(size_t)ri * B3_LDQ + cq + cc], o_ = dob[(size_t)ri * B3_LDT + cq + cc];
+                aq[ks] = oki ? q_ : 0.f;
+                ao[ks] = oki ? o_ : 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ii = 4 * ks + g;
+                const bool ok = cm && ii < irows;
+                const float q_ = qkv[(size_t)(r0 + i0 + ii) * B3_LDQ + cq + m], o_ = dob[(size_t)(r0 + i0 + ii) * B3_LDT + cq + m];
+                bq[ks] = ok ? q_ : 0.f;
+                bdo[ks] = ok ? o_ : 0.f;
+            }
+            RAT_WAVE_FENCE();                                 // (dl is written above, read below)
+            float lse4[4], d4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lse4[r] = lses[(r0 + i0 + 4 * g + r) * B3_H + h];
+                d4[r] = dl[4 * g + r];
+            }
+            f32x4 adQ = rat_zero4();
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt) {
+                const int j0 = 16 * jt;
+                if (j0 >= L) break;                           // (wave-uniform)
+                float bk[3], bv[3], bkk[4];
+                const int rj = r0 + j0 + m;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const int cc = 4 * ks + g;
+                    const bool okj = cc < B3_DH && j0 + m < L;
+                    const float k_ = qkv[(size_t)rj * B3_LDQ + ck + cc], v_ = qkv[(size_t)rj * B3_LDQ + cv + cc];
+                    bk[ks] = okj ? k_ : 0.f;
+                    bv[ks] = okj ? v_ : 0.f;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int jj = j0 + 4 * ks + g;
+                    const float k_ = qkv[(size_t)(r0 + jj) * B3_LDQ + ck + m];
+                    bkk[ks] = (cm && jj < L) ? k_ : 0.f;
+                }
+                f32x4 aS = rat_zero4(), aP = rat_zero4();
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    aS = RAT_MFMA16(aq[ks], bk[ks], aS);
+                    aP = RAT_MFMA16(ao[ks], bv[ks], aP);
+                }
+                // p and dS on the accumulators (C layout: column m = key, rows 4 g + r = query)
+                f32x4 dS;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = 4 * g + r < irows && j0 + m < L;
+                    const float p = ok ? rat_exp2(aS[r] * sl2 - lse4[r]) : 0.f;
+                    scr[(4 * g + r) * SLD + m] = p;
+                    dS[r] = p * (aP[r] - d4[r]);
+                }
+                RAT_WAVE_FENCE();
+                {                                             // dV[j][c] += sum_i P[i][j] dO[i][c]   (A = P^T from the tile, B = dO)
+                    float ap[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) ap[ks] = scr[(4 * ks + g) * SLD + m];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) adV[jt] = RAT_MFMA16(ap[ks], bdo[ks], adV[jt]);
+                }
+                RAT_WAVE_FENCE();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(4 * g + r) * SLD + m] = dS[r];
+                RAT_WAVE_FENCE();
+                {                                             // dK[j][c] += sum_i dS[i][j] Q[i][c] (A = dS^T, B = Q);  dQ[i][c] += sum_j dS[i][j] K[j][c] (A = dS, B = K)
+                    float at[4], as[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        at[ks] = scr[(4 * ks + g) * SLD + m];
+                        as[ks] = scr[m * SLD + 4 * ks + g];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        adK[jt] = RAT_MFMA16(at[ks], bq[ks], adK[jt]);
+                        adQ = RAT_MFMA16(as[ks], bkk[ks], adQ);
+                    }
+                }
+                RAT_WAVE_FENCE();                             // (the next key tile overwrites the private tile)
+            }
+            if (cm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r < irows) ob[(size_t)(r0 + i0 + 4 * g + r) * B3_LDT + cq + m] = adQ[r] * scale;
+            RAT_WAVE_FENCE();
+        }
+        if (cm)
+#pragma unroll
+            for (int jt = 0; jt < NIT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * jt + 4 * g + r;
+                    if (j < L) {
+                        qkv[(size_t)(r0 + j) * B3_LDQ + ck + m] = adK[jt][r] * scale;
+                        qkv[(size_t)(r0 + j) * B3_LDQ + cv + m] = adV[jt][r];
+                    }
+                }
     }
 }
 static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP && (size_t)(ATT_WAVES - 1) * (16 * 49 + 16) * 4 <= (size_t)3 * B3_XP,
@@ -904,7 +1052,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd3_kernel(AttnArgs a, Attn
         const int nq = QSUB ? a.nq : L;
         const int ntasks = nsq * NH * L, nqtasks = QSUB ? nsq * NH * nq : ntasks;
         const float sl2 = a.scale * RAT_LOG2E;
-        if (MC) b3_bwd_core_mfma<(MC > 0 ? MC : 1)>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);   // (the dy planes are dead since P2b: the wave-private tiles go there)
+        if (MC >= 10) b3_bwd_core_mfma_kt<(MC >= 10 ? MC % 10 : 1)>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);   // MC = 10 + NIT: key tiles as the inner loop
+        else if (MC) b3_bwd_core_mfma<(MC > 0 && MC < 10 ? MC : 1)>(qkv, ob, dob, lses, dxn, L, nsq, a.scale);   // (the dy planes are dead since P2b: the wave-private tiles go there)
         for (int task = threadIdx.x; !MC && task < nqtasks; task += ATT_THREADS) {
             const int i = task % nq;
             const int h = (task / nq) % NH;
