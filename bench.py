@@ -837,7 +837,7 @@ def worker(args):
             per = B // world
             batches = [make(2000 + i, rank * per, (rank + 1) * per) for i in range(NBATCH)]
             guard = None
-            if weak is not None and not dry:
+            if weak is not None and (not dry or (args.fault or "").endswith(":strong")):      # (dry runs: only for the injected fault's test)
                 keep = assemble(weak, None, dict(region_info), mode) if rank == 0 else None
 
                 def give_up(why):

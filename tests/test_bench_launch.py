@@ -66,6 +66,25 @@ def test_bench_launcher_ends_the_job_when_one_rank_dies(where, tmp_path):
         assert took < 60.0, took
 
 
+def test_a_rank_that_fails_in_the_strong_region_does_not_cost_the_weak_scaling_line(tmp_path):
+    """rank 1 raises inside the strong-scaling region and leaves; rank 0 sits in a collective whose own timeout is
+    --init-timeout.  The region guard must fire BEFORE that (bench.py clamps --region-timeout to 0.8 x --init-timeout; here 600 -> 32 s):
+    every rank exits 0 and rank 0's line comes out with the weak-scaling value and `strong_scaling_error` instead of `strong_scaling`."""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1",
+                        "--fault", "1:strong", "--log-dir", str(tmp_path), "--init-timeout", "40", "--region-timeout", "600"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env())
+    took = time.monotonic() - t0
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert "strong_scaling" not in out and "strong_scaling_error" in out, sorted(out)
+    assert took < 400, took
+
+
 def test_bench_launcher_deadline(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1",
                         "--launch-timeout", "1", "--log-dir", str(tmp_path)],
