@@ -115,7 +115,8 @@ def parse(argv=None):
     ap.add_argument("--fault", default=None,
                     help="test hook RANK:WHERE — that rank exits with code 17 at `init` (before the rendezvous), `barrier` (after the "
                          "first barrier) or `step` (inside the timed region): the launcher must notice and end the job; `strong`: that rank "
-                         "raises inside the strong-scaling region: the line must still come out, without `strong_scaling`")
+                         "raises inside the strong-scaling region: the line must still come out, without `strong_scaling`; `strongexit`: that "
+                         "rank DIES there: rank 0 writes its last complete measurement when the launcher stops it, the job returns 17")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: gloo process group, the host-emulation build of the kernels (tests/emu), "
                          "workload `dryrun`; the printed numbers mean nothing")
@@ -191,6 +192,13 @@ def self_launch(args):
         sys.stdout.write(text)
         sys.stdout.flush()
         return 0
+    # a rank died AFTER rank 0 had a complete measurement (e.g. inside the strong-scaling region, once the weak one was done): rank 0's
+    # termination handler wrote that line with a `terminated` note — relay it; the exit code still says that the job lost a rank
+    # (or its strong-region guard did, when the dead peer surfaced as an exception in rank 0's collective first)
+    salvaged = [ln for ln in text.splitlines() if ln.startswith("{") and ('"terminated"' in ln or '"strong_scaling_error"' in ln)]
+    if salvaged:
+        sys.stdout.write(salvaged[-1] + "\n")
+        sys.stdout.flush()
     who = "the %d s launch timeout" % args.launch_timeout if failed[0] < 0 else "rank %d (exit code %d)" % failed
     print("bench.py: %s ended the job; the other ranks were stopped.  Log tails:" % who, file=sys.stderr)
     for r in range(args.gpus):
@@ -495,6 +503,27 @@ def big_table_gather(lib, device, rows_per_field=2_500_000, F=40, d=64, K=10, B=
 
 # ------------------------------------------------------------------------------------------------- the worker
 def worker(args):
+    # The last COMPLETE measurement of a data-parallel run (rank 0): when a peer dies later (the launcher / torchrun then sends SIGTERM to
+    # the survivors) a watcher thread writes it out with a `terminated` note before the process ends.  SIGTERM is blocked HERE, before
+    # torch (and with it every helper thread, which inherits the mask) exists, and taken with sigwait by the watcher — so that it is
+    # served even while the main thread sits inside a collective or a device synchronisation.
+    last_complete = {"line": None, "why": None, "emit": None}
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+        import signal
+        import threading
+        signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})
+
+        def _on_sigterm():
+            signal.sigwait({signal.SIGTERM})
+            try:
+                if last_complete["line"] is not None and last_complete["emit"] is not None:
+                    d = dict(last_complete["line"])
+                    d["terminated"] = ("SIGTERM %s: a peer rank failed or the job was stopped; this is the last complete measurement"
+                                       % last_complete["why"])
+                    last_complete["emit"](json.dumps(d))
+            finally:
+                os._exit(143)
+        threading.Thread(target=_on_sigterm, daemon=True).start()
     import torch
     import torch.distributed as dist
     from rat_amd import models, synthetic
@@ -526,6 +555,7 @@ def worker(args):
             sys.stdout.flush()
         else:
             os.write(result_fd, (line + "\n").encode())
+    last_complete["emit"] = emit
 
     def fault(where):
         if args.fault and args.fault == "%d:%s" % (rank, where):
@@ -642,6 +672,8 @@ def worker(args):
                 fault("step")
                 if label == "strong" and args.fault == "%d:strong" % rank:
                     raise RuntimeError("--fault %s: injected into the strong-scaling region" % args.fault)
+                if label == "strong" and args.fault == "%d:strongexit" % rank:        # (a rank that DIES there: segfault, OOM kill)
+                    os._exit(17)
         sync()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
@@ -837,8 +869,11 @@ def worker(args):
             per = B // world
             batches = [make(2000 + i, rank * per, (rank + 1) * per) for i in range(NBATCH)]
             guard = None
-            if weak is not None and (not dry or (args.fault or "").endswith(":strong")):      # (dry runs: only for the injected fault's test)
+            if weak is not None and (not dry or ":strong" in (args.fault or "")):      # (dry runs: only for the injected faults' tests)
                 keep = assemble(weak, None, dict(region_info), mode) if rank == 0 else None
+                if rank == 0 and last_complete["line"] is None:
+                    last_complete.update(line=dict(keep, strong_scaling_error="the job ended inside the strong-scaling region"),
+                                         why="inside the strong-scaling region")
 
                 def give_up(why):
                     if rank == 0:
@@ -873,6 +908,8 @@ def worker(args):
         weak_e, strong_e = run_regions(False)
         info_e = dict(region_info)
         fallback = assemble(weak_e, strong_e, info_e, False) if rank == 0 else None
+        if rank == 0:
+            last_complete.update(line=fallback, why="during the segmented-graph attempt (these are the eager numbers)")
 
         def bail():
             if rank == 0:

@@ -85,6 +85,21 @@ def test_a_rank_that_fails_in_the_strong_region_does_not_cost_the_weak_scaling_l
     assert took < 400, took
 
 
+def test_a_rank_that_dies_in_the_strong_region_leaves_the_weak_scaling_line_behind(tmp_path):
+    """a rank that DIES (exit code 17, like a segfault / OOM kill) inside the strong-scaling region: the launcher stops the others and returns
+    17 — and rank 0, whose weak-scaling measurement was complete, writes that line with a `terminated` note when it is stopped (a watcher
+    thread takes SIGTERM with sigwait, so it is served even while the main thread sits in a collective); the launcher relays it"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1",
+                        "--fault", "1:strongexit", "--log-dir", str(tmp_path), "--init-timeout", "120"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env())
+    assert r.returncode == 17, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and "strong_scaling" not in out
+    assert "strong_scaling_error" in out          # (+ `terminated` when the launcher's SIGTERM got there before the dead peer surfaced in a collective)
+
+
 def test_bench_launcher_deadline(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "1",
                         "--launch-timeout", "1", "--log-dir", str(tmp_path)],
