@@ -320,8 +320,9 @@ __global__ void __launch_bounds__(CM_THREADS) core_fwd_mfma_kernel(CoreArgs a) {
                     for (int ks_ = 0; ks_ < 3; ++ks_) ak[ks_][jt] = ks[(16 * (kt0 + jt) + m) * CM_LD + 4 * ks_ + g];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float t = vs[(16 * (kt0 + jt) + 4 * g + r) * CM_LD + (m < CM_LD ? m : 0)];
-                        av[r][jt] = m < CM_DH ? t : 0.f;
+                        // (lanes m >= 10 hold a column that is no head column — zeros in 10, 11, column 0 again from 12 on: as the A operand they
+                        //  only produce output ROWS c >= 10 of O^T, which are never stored: no select needed)
+                        av[r][jt] = vs[(16 * (kt0 + jt) + 4 * g + r) * CM_LD + (m < CM_LD ? m : 0)];
                     }
                 }
                 f32x4 st[CM_KB];
@@ -479,20 +480,27 @@ __global__ void __launch_bounds__(CB_THREADS) core_bwd_mfma_kernel(CoreArgs a) {
                         st[jt] = RAT_MFMA16(ak[k_][jt], bq[k_], st[jt]);        // S^T[key 16 jt + 4 g + r][query m]
                         dp[jt] = RAT_MFMA16(av[k_][jt], bg[k_], dp[jt]);        // dP^T, same layout
                     }
+                if (16 * (kt0 + CB_KB) <= L) {                                   // (wave-uniform: every key of the trip exists — no masks)
 #pragma unroll
-                for (int jt = 0; jt < CB_KB; ++jt)
+                    for (int jt = 0; jt < CB_KB; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pr = 16 * (kt0 + jt) + 4 * g + r < L ? rat_exp2(st[jt][r] * sl2 - lse_i) : 0.f;
-                        st[jt][r] = pr * (dp[jt][r] - delta_i);                  // dS^T
-                    }
+                        for (int r = 0; r < 4; ++r) st[jt][r] = rat_exp2(st[jt][r] * sl2 - lse_i) * (dp[jt][r] - delta_i);   // dS^T
+                } else {
+#pragma unroll
+                    for (int jt = 0; jt < CB_KB; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = 16 * (kt0 + jt) + 4 * g + r < L ? rat_exp2(st[jt][r] * sl2 - lse_i) : 0.f;
+                            st[jt][r] = pr * (dp[jt][r] - delta_i);
+                        }
+                }
 #pragma unroll
                 for (int jt = 0; jt < CB_KB; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                                // dQ^T[c][query] += K[key][c] dS^T[key][query]; two independent chains
-                        const float kc = cm ? akc[r][jt] : 0.f;
-                        if ((jt & 1) == 0) dq = RAT_MFMA16(kc, st[jt][r], dq);
-                        else dq2 = RAT_MFMA16(kc, st[jt][r], dq2);
+                        // (akc of a lane m >= 10 is no head column: it only reaches rows c >= 10 of dQ^T, which are never stored)
+                        if ((jt & 1) == 0) dq = RAT_MFMA16(akc[r][jt], st[jt][r], dq);
+                        else dq2 = RAT_MFMA16(akc[r][jt], st[jt][r], dq2);
                     }
             }
             if (qi < L) {                                                        // dq[r] = dQ[query 16 qt + m][c = 4 g + r]
@@ -554,11 +562,11 @@ __global__ void __launch_bounds__(CB_THREADS) core_bwd_mfma_kernel(CoreArgs a) {
                     }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float bq_ = cm ? cq[r] : 0.f, bg_ = cm ? cg[r] : 0.f;
+                    // (cq / cg of a lane m >= 10 are no head column: as the B operand they only reach COLUMNS c >= 10 of dK / dV: never stored)
 #pragma unroll
                     for (int t = 0; t < CB_KT; ++t) {
-                        adv[t] = RAT_MFMA16(sa[t][r], bg_, adv[t]);             // dV[key 4 g' + r'][c m] += P[query][key] dO[query][c]
-                        adk[t] = RAT_MFMA16(da[t][r], bq_, adk[t]);             // dK += dS[query][key] Q[query][c]
+                        adv[t] = RAT_MFMA16(sa[t][r], cg[r], adv[t]);           // dV[key 4 g' + r'][c m] += P[query][key] dO[query][c]
+                        adk[t] = RAT_MFMA16(da[t][r], cq[r], adk[t]);           // dK += dS[query][key] Q[query][c]
                     }
                 }
             }
