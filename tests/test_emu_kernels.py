@@ -176,7 +176,8 @@ def test_attn_wide_heads_group_loop(emu, case, mode, res_mode, dropout, two_bloc
 
 @pytest.mark.parametrize("case,mode,res_mode,dropout", [pytest.param((2, 3, 5, 10, 32, 10, True), "intra", "x", 0.0, id="tmall_G4_intra"),
                                                         pytest.param((1, 4, 3, 10, 16, 10, True), "cross", "other", 0.25, id="G2_cross_dropout"),
-                                                        twin((1, 3, 2, 16, 24, 10, True), "intra", "x", 0.0, id="G3_d16")])
+                                                        twin((1, 3, 2, 16, 24, 10, True), "intra", "x", 0.0, id="G3_d16"),
+                                                        pytest.param((2, 3, 5, 10, 16, 20, True), "cross", "other", 0.2, id="m3_tmall_G4_4x20")])
 def test_attn_wide_heads_small_d_one_launch_per_direction(emu, case, mode, res_mode, dropout, two_blocks):
     """attn_fwd_wide_kernel / attn_bwd_wide_kernel: the shipped Tmall head geometry (32 x 10 at d = 10) with the head groups looped inside"""
     kc.check_attn_groups_small_d(emu, "cpu", case, mode, res_mode=res_mode, dropout=dropout)

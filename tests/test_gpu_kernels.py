@@ -171,7 +171,12 @@ def test_attn_wide_heads_group_loop(lib, case, mode, res_mode, dropout):
                                                         pytest.param((300, 6, 10, 10, 32, 10, True), "cross", "x", 0.0, id="tmall_G4_cross_L6"),
                                                         pytest.param((40, 13, 5, 10, 16, 10, True), "cross", "other", 0.25, id="G2_cross_L13_dropout"),
                                                         pytest.param((40, 5, 21, 16, 24, 10, True), "intra", "other", 0.1, id="G3_d16_L21_dropout"),
-                                                        pytest.param((9, 3, 64, 12, 64, 10, True), "intra", "x", 0.0, id="G8_forward_only")])
+                                                        pytest.param((9, 3, 64, 12, 64, 10, True), "intra", "x", 0.0, id="G8_forward_only"),
+                                                        # round 6: groups of 4 heads x 20 — RAT_m3 at the Tmall geometry (16 heads of width 20)
+                                                        pytest.param((300, 6, 10, 10, 16, 20, True), "intra", "x", 0.0, id="m3_tmall_G4_intra_L10"),
+                                                        pytest.param((300, 6, 10, 10, 16, 20, True), "cross", "other", 0.0, id="m3_tmall_G4_cross_L6"),
+                                                        pytest.param((40, 13, 5, 16, 8, 20, True), "cross", "other", 0.25, id="m3_G2_d16_dropout"),
+                                                        pytest.param((9, 3, 31, 12, 32, 20, True), "intra", "x", 0.0, id="m3_G8_forward_only")])
 def test_attn_wide_heads_small_d_one_launch_per_direction(lib, case, mode, res_mode, dropout):
     """attn_fwd_wide_kernel / attn_bwd_wide_kernel: the shipped Tmall head geometry (32 x 10 at d = 10) with the head groups looped inside"""
     kc.check_attn_groups_small_d(lib, "cuda", case, mode, res_mode=res_mode, dropout=dropout)

@@ -1348,8 +1348,11 @@ static int b3_groups(int d, int heads, int dim_head) {
     return (d == B3_D && dim_head == B3_DH && heads > B3_H && heads % B3_H == 0 && heads / B3_H <= 8) ? heads / B3_H : 0;
 }
 // ... and at a small embedding dimension (the shipped Tmall geometry, d = 10): exact-fp32 kernels, weights addressed in place (no planes)
+// heads per group: 8 x 10, or (round 6: RAT_m3's heads / 2 heads of width 2 dim_head) 4 x 20 — a group's inner width is 80 either way
+static int wide_heads(int dim_head) { return dim_head == WG_DH ? WG_H : (dim_head == 2 * WG_DH ? WG_H / 2 : 0); }
 static int wide_groups(int d, int heads, int dim_head) {
-    return (d >= 1 && d <= 16 && dim_head == WG_DH && heads > WG_H && heads % WG_H == 0 && heads / WG_H <= 8) ? heads / WG_H : 0;
+    const int wh = wide_heads(dim_head);
+    return (d >= 1 && d <= 16 && wh > 0 && heads > wh && heads % wh == 0 && heads / wh <= 8) ? heads / wh : 0;
 }
 // bit 0: rat_attn_fwd_groups serves these dimensions; bit 1: rat_attn_bwd_groups does too
 extern "C" int rat_attn_groups_supported(int d, int heads, int dim_head) {
@@ -1385,11 +1388,12 @@ extern "C" int rat_attn_fwd_groups(const float* x, const float* res, float* y, f
                                    uint64_t dropout_seed, void* stream) {
     const int Gw = wide_groups(d, heads, dim_head);
     if (Gw > 0) {                                                // small embedding_dim: exact fp32, weights in place, `planes` unused
-        if (check_dims(map_host, d, WG_H, dim_head, false)) return -1;
+        const int wh = wide_heads(dim_head);
+        if (check_dims(map_host, d, wh, dim_head, false)) return -1;
         RAT_REQUIRE(x && y && w_host && w_host->ln_g && w_host->ln_b && w_host->w_qkv && w_host->w_out && w_host->b_out, "null pointer");
         RAT_REQUIRE((o_save == nullptr) == (lse_save == nullptr) && ntok > 0, "o_save and lse_save come together, [G][ntok][.]");
         AttnArgs a{};
-        fill_common(a, w_host, map_host, d, WG_H, dim_head, ln_eps);
+        fill_common(a, w_host, map_host, d, wh, dim_head, ln_eps);
         a.vec_wout = ((heads * dim_head) % 4 == 0) && aligned16(w_host->w_out);
         a.vec_wqkv = (aligned8(x) && aligned16(w_host->w_out)) ? 1 : 0;   // (read by the kernel as "aligned for the one-round-trip loads")
         if (softmax_scale > 0.f) a.scale = softmax_scale;
@@ -1405,15 +1409,17 @@ extern "C" int rat_attn_fwd_groups(const float* x, const float* res, float* y, f
         RAT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "dropout_p must be in [0, 1)");
         if (dropout_p > 0.f)
             a.drop = RatDrop{dropout_seed, (uint32_t)((double)dropout_p * 4294967296.0), 1.0f / (1.0f - dropout_p), w_host->drop_seed_dev};
-        const size_t smem = AttnGeom(d, WG_H, dim_head).fwd_smem() + (size_t)WG_WO_FLOATS * 4;
+        const size_t smem = AttnGeom(d, wh, dim_head).fwd_smem() + (size_t)WG_WO_FLOATS * 4;
         const int per_cu = (int)((160 * 1024) / smem) >= 2 ? 2 : 1;
         const unsigned blocks = (unsigned)(a.nchunks < rat_max_blocks() * per_cu ? a.nchunks : rat_max_blocks() * per_cu);
-        if (d == 10) RAT_LAUNCH((attn_fwd_wide_kernel<10>), blocks, ATT_THREADS, smem, stream, a);
+        if (wh == 4 && d == 10) RAT_LAUNCH((attn_fwd_wide_kernel<10, 4>), blocks, ATT_THREADS, smem, stream, a);
+        else if (wh == 4) RAT_LAUNCH((attn_fwd_wide_kernel<0, 4>), blocks, ATT_THREADS, smem, stream, a);
+        else if (d == 10) RAT_LAUNCH((attn_fwd_wide_kernel<10>), blocks, ATT_THREADS, smem, stream, a);
         else RAT_LAUNCH((attn_fwd_wide_kernel<0>), blocks, ATT_THREADS, smem, stream, a);
         return rat_check_launch("rat_attn_fwd_groups (small d)");
     }
     const int G = b3_groups(d, heads, dim_head);
-    RAT_REQUIRE(G > 0, "rat_attn_fwd_groups serves dim_head 10 and 16 ... 64 heads in groups of 8 at embedding_dim 64 or <= 16");
+    RAT_REQUIRE(G > 0, "rat_attn_fwd_groups serves dim_head 10 and 16 ... 64 heads in groups of 8 at embedding_dim 64 or <= 16 (there also 8 ... 32 heads of width 20)");
     if (check_dims(map_host, d, B3_H, dim_head, false)) return -1;
     RAT_REQUIRE(x && y && planes && w_host && w_host->ln_g && w_host->ln_b && w_host->b_out, "null pointer");
     RAT_REQUIRE((o_save == nullptr) == (lse_save == nullptr) && ntok > 0, "o_save and lse_save come together, [G][ntok][.]");
@@ -1456,14 +1462,15 @@ extern "C" int rat_attn_bwd_groups(const float* x, const float* dy, const float*
                                    size_t workspace_bytes, const RatSeqMap* map_host, int d, int heads, int dim_head, float softmax_scale,
                                    float out_scale, float ln_eps, float dropout_p, uint64_t dropout_seed, void* stream) {
     const int G = wide_groups(d, heads, dim_head);
-    RAT_REQUIRE(G > 0 && G <= WG_MAXG, "rat_attn_bwd_groups serves embedding_dim <= 16, dim_head 10 and 16 ... 32 heads in groups of 8");
-    if (check_dims(map_host, d, WG_H, dim_head, true)) return -1;
+    RAT_REQUIRE(G > 0 && G <= WG_MAXG, "rat_attn_bwd_groups serves embedding_dim <= 16 and 2 ... 4 head groups of 8 x 10 or 4 x 20");
+    const int wh = wide_heads(dim_head);
+    if (check_dims(map_host, d, wh, dim_head, true)) return -1;
     RAT_REQUIRE(x && dy && o_save && lse_save && dx && w_host && grads_host && workspace && ntok > 0, "null pointer");
     RAT_REQUIRE(w_host->ln_g && w_host->ln_b && w_host->w_qkv && w_host->w_out && w_host->b_out, "null parameter");
     RAT_REQUIRE(grads_host->ln_g && grads_host->ln_b && grads_host->w_qkv && grads_host->w_out && grads_host->b_out, "null gradient");
     RAT_REQUIRE(workspace_bytes >= rat_attn_bwd_groups_workspace(d, heads, dim_head), "workspace too small");
     AttnArgs a{};
-    fill_common(a, w_host, map_host, d, WG_H, dim_head, ln_eps);
+    fill_common(a, w_host, map_host, d, wh, dim_head, ln_eps);
     if (softmax_scale > 0.f) a.scale = softmax_scale;
     a.out_scale = out_scale;
     a.add = add;
@@ -1485,8 +1492,10 @@ extern "C" int rat_attn_bwd_groups(const float* x, const float* dy, const float*
     a.slabs = workspace;
     a.slab_stride = gfull.slab_floats();
     const int blocks = (int)(a.nchunks < rat_max_blocks() ? a.nchunks : rat_max_blocks());
-    const size_t smem = AttnGeom(d, WG_H, dim_head).bwd_smem(WG_H) + (size_t)(WG_WQ_FLOATS + WG_WO_FLOATS) * 4;
-    if (d == 10) RAT_LAUNCH((attn_bwd_wide_kernel<10>), blocks, ATT_THREADS, smem, stream, a);
+    const size_t smem = AttnGeom(d, wh, dim_head).bwd_smem(wh) + (size_t)(WG_WQ_FLOATS + WG_WO_FLOATS) * 4;
+    if (wh == 4 && d == 10) RAT_LAUNCH((attn_bwd_wide_kernel<10, 4>), blocks, ATT_THREADS, smem, stream, a);
+    else if (wh == 4) RAT_LAUNCH((attn_bwd_wide_kernel<0, 4>), blocks, ATT_THREADS, smem, stream, a);
+    else if (d == 10) RAT_LAUNCH((attn_bwd_wide_kernel<10>), blocks, ATT_THREADS, smem, stream, a);
     else RAT_LAUNCH((attn_bwd_wide_kernel<0>), blocks, ATT_THREADS, smem, stream, a);
     if (rat_check_launch("rat_attn_bwd_groups")) return -1;
     const int D = d, I = heads * dim_head;

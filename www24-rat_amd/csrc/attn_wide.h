@@ -72,6 +72,7 @@ __device__ __forceinline__ void wide_stage_wo(float* wo_s, const float* w_out, i
 // The same two copies plus the chunk's O / lse / x / dy tiles with EVERY request issued before anything is stored (compile-time trip
 // counts): one memory round trip per group instead of one per loop trip — the run-time loops above compile to load -> wait -> LDS store
 // chains, 11 serial L2 round trips per group at the Tmall shape.  d = 10 with 8-byte aligned rows / 16-byte aligned O and W_out only.
+template <int WH>
 struct WideGroupFetch {
     static constexpr int NO = (ATT_ROWS * (WG_I / 4) + ATT_THREADS - 1) / ATT_THREADS;      // float4 pieces of the O tile per thread (3)
     static constexpr int NQ = (WG_Q3 * 5 + ATT_THREADS - 1) / ATT_THREADS;                   // float2 pieces of the group's W_qkv rows (3)
@@ -88,14 +89,15 @@ struct WideGroupFetch {
                 const int e = threadIdx.x + ATT_THREADS * it;
                 tok[it] = e < ATT_ROWS * W4 ? rowtok[e / W4] : -1;
             }
-            const int64_t tl = rowtok[threadIdx.x / WG_H];
+            const bool lt = (int)threadIdx.x < ATT_ROWS * WH;        // (WH = 8: every thread owns one lse element; 4: the first 256)
+            const int64_t tl = lt ? rowtok[threadIdx.x / WH] : -1;
 #pragma unroll
             for (int it = 0; it < NO; ++it) {
                 const int e = threadIdx.x + ATT_THREADS * it;
                 o[it] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (tok[it] >= 0) o[it] = *reinterpret_cast<const float4*>(o_g + tok[it] * WG_I + 4 * (e % W4));
             }
-            lse = tl >= 0 ? lse_g[tl * WG_H + threadIdx.x % WG_H] : 0.f;
+            lse = tl >= 0 ? lse_g[tl * WH + threadIdx.x % WH] : 0.f;
         }
 #pragma unroll
         for (int it = 0; it < NQ; ++it) {
@@ -120,7 +122,7 @@ struct WideGroupFetch {
                 const int e = threadIdx.x + ATT_THREADS * it;
                 if (e < ATT_ROWS * W4) *reinterpret_cast<float4*>(ob + (size_t)(e / W4) * WG_LDT + 4 * (e % W4)) = o[it];
             }
-            lses[threadIdx.x] = lse;
+            if ((int)threadIdx.x < ATT_ROWS * WH) lses[threadIdx.x] = lse;
         }
         if (wq_s != nullptr) {
 #pragma unroll
@@ -132,7 +134,7 @@ struct WideGroupFetch {
         if ((int)threadIdx.x < 10 * W4) *reinterpret_cast<float4*>(wo_s + 4 * threadIdx.x) = wo;
     }
 };
-static_assert(ATT_ROWS * WG_H == ATT_THREADS, "one lse element per thread");
+static_assert(ATT_ROWS * WG_H == ATT_THREADS, "at most one lse element per thread");
 // this thread's 8-byte piece of a [tokens][10] row (threads < 64 * 5)
 __device__ __forceinline__ float2 wide_row_piece(const float* src, const int64_t* rowtok) {
     float2 v = make_float2(0.f, 0.f);
@@ -157,8 +159,11 @@ __device__ __forceinline__ float wide_touch(const int64_t* rt, int& t, const flo
 }
 
 // GD: the embedding dimension as a compile-time constant (10: the shipped geometry; 0: run-time, any d <= 16)
-template <int GD>
+// WH (round 6): heads per group, 8 (x 10) or 4 (x 20) — RAT_m3 runs heads / 2 heads of width 2 dim_head (RAT_m3.py:181); a group's inner width is 80
+// either way, so the weight slices, the GEMM phases and the LDS map are the same; the VALU core slices Q | K | V differently and lse is WH wide
+template <int GD, int WH = WG_H>
 __global__ void __launch_bounds__(ATT_THREADS, 4) attn_fwd_wide_kernel(AttnArgs a) {   // (4 waves per SIMD: two work-groups per CU)
+    constexpr int WDH = WG_I / WH;
     RAT_DYN_SMEM(smem);
     const int D = GD > 0 ? GD : a.d, L = a.L, G = a.groups, itot = G * WG_I;
     float* xs = reinterpret_cast<float*>(smem);                  // [64][20] LayerNorm(x), read by every group; at the end the y tile
@@ -200,7 +205,7 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attn_fwd_wide_kernel(AttnArgs 
         float pf = 0.f;
         for (int grp = 0; grp < G; ++grp) {
             if (fast) {                                          // (read two barriers from here)
-                WideGroupFetch gf;
+                WideGroupFetch<WH> gf;
                 gf.issue(nullptr, nullptr, rowtok, nullptr, a.w_out, itot, grp, false);
                 gf.stash(nullptr, nullptr, nullptr, wo_s, false);
             } else {
@@ -222,30 +227,30 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attn_fwd_wide_kernel(AttnArgs 
                 pf += wide_touch(rowtok_next, t, a.x, D);
             }
             // softmax(Q K^T * scale) V, one lane per (sequence, head, query) — attn_fwd_kernel's loop at compile-time dim_head 10
-            typedef HeadVec<WG_DH> HV;
+            typedef HeadVec<WDH> HV;
             float* const o_save = a.o_save != nullptr ? a.o_save + (int64_t)grp * a.group_tok * WG_I : nullptr;
-            float* const lse_save = a.lse_save != nullptr ? a.lse_save + (int64_t)grp * a.group_tok * WG_H : nullptr;
-            const int ntasks = nsq * WG_H * L;
+            float* const lse_save = a.lse_save != nullptr ? a.lse_save + (int64_t)grp * a.group_tok * WH : nullptr;
+            const int ntasks = nsq * WH * L;
             const float sl2 = a.scale * RAT_LOG2E;
             for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
                 const int i = task % L;
-                const int h = (task / L) % WG_H;
-                const int sq = task / (L * WG_H);
+                const int h = (task / L) % WH;
+                const int sq = task / (L * WH);
                 const int row_i = sq * L + i;
-                float* qp = qkv + (size_t)row_i * WG_LDQ + h * WG_DH;
+                float* qp = qkv + (size_t)row_i * WG_LDQ + h * WDH;
                 HV q, o, kv;
-                q.load(qp, WG_DH);
+                q.load(qp, WDH);
                 o.zero();
                 float m = -INFINITY, l = 0.f;
-                const float* kbase = qkv + (size_t)(sq * L) * WG_LDQ + WG_I + h * WG_DH;
+                const float* kbase = qkv + (size_t)(sq * L) * WG_LDQ + WG_I + h * WDH;
                 int j = 0;
                 for (; j + CORE_UNROLL <= L; j += CORE_UNROLL) {
                     HV kk[CORE_UNROLL], vv[CORE_UNROLL];
 #pragma unroll
                     for (int u = 0; u < CORE_UNROLL; ++u) {
                         const float* kp = kbase + (size_t)(j + u) * WG_LDQ;
-                        kk[u].load(kp, WG_DH);
-                        vv[u].load(kp + WG_I, WG_DH);
+                        kk[u].load(kp, WDH);
+                        vv[u].load(kp + WG_I, WDH);
                     }
                     float sc[CORE_UNROLL];
 #pragma unroll
@@ -262,21 +267,21 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attn_fwd_wide_kernel(AttnArgs 
                 }
                 for (; j < L; ++j) {
                     const float* kp = kbase + (size_t)j * WG_LDQ;
-                    kv.load(kp, WG_DH);
+                    kv.load(kp, WDH);
                     const float s = q.dot(kv) * sl2;
                     const float mn = fmaxf(m, s);
                     const float corr = rat_exp2(m - mn);
                     const float p = rat_exp2(s - mn);
                     l = l * corr + p;
-                    kv.load(kp + WG_I, WG_DH);
+                    kv.load(kp + WG_I, WDH);
                     o.scale_axpy(corr, p, kv);
                     m = mn;
                 }
                 const float inv = 1.0f / l;
-                o.store(qp, WG_DH, inv);
+                o.store(qp, WDH, inv);
                 const int64_t tok = rowtok[row_i];
-                if (o_save != nullptr) o.store(o_save + tok * WG_I + h * WG_DH, WG_DH, inv);
-                if (lse_save != nullptr) lse_save[tok * WG_H + h] = m + rat_log2(l);
+                if (o_save != nullptr) o.store(o_save + tok * WG_I + h * WDH, WDH, inv);
+                if (lse_save != nullptr) lse_save[tok * WH + h] = m + rat_log2(l);
             }
             __syncthreads();
             // partial output projection O_g W_out[:, group]^T into the accumulators of waves 0-3 (B from the staged LDS copy)
@@ -304,8 +309,9 @@ __global__ void __launch_bounds__(ATT_THREADS, 4) attn_fwd_wide_kernel(AttnArgs 
     }
 }
 
-template <int GD>
+template <int GD, int WH = WG_H>
 __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) {
+    constexpr int WDH = WG_I / WH;
     RAT_DYN_SMEM(smem);
     const int D = GD > 0 ? GD : a.d, L = a.L, G = a.groups, itot = G * WG_I;
     float* xs = reinterpret_cast<float*>(smem);                  // [64][20] LayerNorm(x)            (every group)
@@ -316,8 +322,8 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
     float* mu = dob + (size_t)ATT_ROWS * WG_LDT;
     float* rs = mu + ATT_ROWS;
     float* lses = rs + ATT_ROWS;                                 // [64][8]
-    float* dlt = lses + (size_t)ATT_ROWS * WG_H;                 // [64][8]
-    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(dlt + (size_t)ATT_ROWS * WG_H);
+    float* dlt = lses + (size_t)ATT_ROWS * WH;                 // [64][8]
+    int64_t* const rowtok0 = reinterpret_cast<int64_t*>(dlt + (size_t)ATT_ROWS * WH);
     float* const wq_s = reinterpret_cast<float*>(rowtok0 + 2 * ATT_ROWS);   // [240][12] the current group's rows of to_qkv.weight (wide_stage_wq)
     float* const wo_s = wq_s + WG_WQ_FLOATS;                                // [16][80]  ... and its columns of to_out.weight
     const bool lds_w = D <= 10;                                  // (embedding_dim 11 ... 16: the fragments' k-quads would not fit 12-float rows)
@@ -388,18 +394,18 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
         RAT_PROF_MARK(0);
         for (int grp = 0; grp < G; ++grp) {
             const float* const o_g = a.o_save + (int64_t)grp * a.group_tok * WG_I;
-            const float* const lse_g = a.lse_save + (int64_t)grp * a.group_tok * WG_H;
+            const float* const lse_g = a.lse_save + (int64_t)grp * a.group_tok * WH;
             if (fast) {                                          // O, lse and the group's weight slices: one round trip
-                WideGroupFetch gf;
+                WideGroupFetch<WH> gf;
                 gf.issue(o_g, lse_g, rowtok, a.w_qkv, a.w_out, itot, grp, true);
                 gf.stash(ob, lses, wq_s, wo_s, true);
             } else {
                 load_rows(ob, WG_LDT, o_g, rowtok, WG_I, false);
                 if (lds_w) wide_stage_wq(wq_s, a.w_qkv, itot, grp, D);
                 wide_stage_wo(wo_s, a.w_out, itot, grp, D);
-                for (int e = threadIdx.x; e < ATT_ROWS * WG_H; e += ATT_THREADS) {
-                    const int64_t tok = rowtok[e / WG_H];
-                    lses[e] = tok >= 0 ? lse_g[tok * WG_H + e % WG_H] : 0.f;
+                for (int e = threadIdx.x; e < ATT_ROWS * WH; e += ATT_THREADS) {
+                    const int64_t tok = rowtok[e / WH];
+                    lses[e] = tok >= 0 ? lse_g[tok * WH + e % WH] : 0.f;
                 }
             }
             __syncthreads();                                     // (also: LayerNorm of xs, the dy tile — first group)
@@ -435,73 +441,73 @@ __global__ void __launch_bounds__(ATT_THREADS) attn_bwd_wide_kernel(AttnArgs a) 
             __syncthreads();
             RAT_PROF_MARK(2);
             // (4) attention backward on the VALU: attn_bwd_kernel's two passes at compile-time dim_head 10
-            typedef HeadVec<WG_DH> HV;
-            const int ntasks = nsq * WG_H * L;
+            typedef HeadVec<WDH> HV;
+            const int ntasks = nsq * WH * L;
             const float sl2 = a.scale * RAT_LOG2E;
             {   // both passes touch LDS only: the lines this block loads next travel HBM -> L2 meanwhile
                 int t = threadIdx.x;
                 if (grp + 1 < G) {
                     pf += wide_touch(rowtok, t, o_g + a.group_tok * WG_I, WG_I);
-                    pf += wide_touch(rowtok, t, lse_g + a.group_tok * WG_H, WG_H);
+                    pf += wide_touch(rowtok, t, lse_g + a.group_tok * WH, WH);
                 } else if (more) {
                     pf += wide_touch(rowtok_next, t, a.x, D);
                     pf += wide_touch(rowtok_next, t, a.dy, D);
                     pf += wide_touch(rowtok_next, t, a.o_save, WG_I);
-                    pf += wide_touch(rowtok_next, t, a.lse_save, WG_H);
+                    pf += wide_touch(rowtok_next, t, a.lse_save, WH);
                 }
             }
             for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
                 const int i = task % L;
-                const int h = (task / L) % WG_H;
-                const int sq = task / (L * WG_H);
+                const int h = (task / L) % WH;
+                const int sq = task / (L * WH);
                 const int row_i = sq * L + i;
-                const int ho = h * WG_DH;
+                const int ho = h * WDH;
                 float* op = ob + (size_t)row_i * WG_LDT + ho;
                 HV q, go, dq, kv;
-                q.load(qkv + (size_t)row_i * WG_LDQ + ho, WG_DH);
-                go.load(dob + (size_t)row_i * WG_LDT + ho, WG_DH);
-                kv.load(op, WG_DH);
+                q.load(qkv + (size_t)row_i * WG_LDQ + ho, WDH);
+                go.load(dob + (size_t)row_i * WG_LDT + ho, WDH);
+                kv.load(op, WDH);
                 const float delta = go.dot(kv);
                 dq.zero();
-                dlt[row_i * WG_H + h] = delta;
-                const float lse = lses[row_i * WG_H + h];
+                dlt[row_i * WH + h] = delta;
+                const float lse = lses[row_i * WH + h];
                 const float* kbase = qkv + (size_t)(sq * L) * WG_LDQ + WG_I + ho;
                 for (int j = 0; j < L; ++j) {
                     const float* kp = kbase + (size_t)j * WG_LDQ;
-                    kv.load(kp + WG_I, WG_DH);
+                    kv.load(kp + WG_I, WDH);
                     const float dp = go.dot(kv);
-                    kv.load(kp, WG_DH);
+                    kv.load(kp, WDH);
                     const float p = rat_exp2(q.dot(kv) * sl2 - lse);
                     dq.axpy(p * (dp - delta), kv);
                 }
-                dq.store(op, WG_DH, a.scale);
+                dq.store(op, WDH, a.scale);
             }
             __syncthreads();
             RAT_PROF_MARK(3);
             for (int task = threadIdx.x; task < ntasks; task += ATT_THREADS) {
                 const int j = task % L;
-                const int h = (task / L) % WG_H;
-                const int sq = task / (L * WG_H);
-                const int ho = h * WG_DH;
+                const int h = (task / L) % WH;
+                const int sq = task / (L * WH);
+                const int ho = h * WDH;
                 float* kp = qkv + (size_t)(sq * L + j) * WG_LDQ + WG_I + ho;
                 HV kk, vv, dk, dv, t;
-                kk.load(kp, WG_DH);
-                vv.load(kp + WG_I, WG_DH);
+                kk.load(kp, WDH);
+                vv.load(kp + WG_I, WDH);
                 dk.zero();
                 dv.zero();
                 for (int i = 0; i < L; ++i) {
                     const int row_i = sq * L + i;
-                    t.load(dob + (size_t)row_i * WG_LDT + ho, WG_DH);
+                    t.load(dob + (size_t)row_i * WG_LDT + ho, WDH);
                     const float dp = t.dot(vv);
-                    const float lse = lses[row_i * WG_H + h], delta = dlt[row_i * WG_H + h];
+                    const float lse = lses[row_i * WH + h], delta = dlt[row_i * WH + h];
                     HV qv;
-                    qv.load(qkv + (size_t)row_i * WG_LDQ + ho, WG_DH);
+                    qv.load(qkv + (size_t)row_i * WG_LDQ + ho, WDH);
                     const float p = rat_exp2(qv.dot(kk) * sl2 - lse);
                     dv.axpy(p, t);
                     dk.axpy(p * (dp - delta), qv);
                 }
-                dk.store(kp, WG_DH, a.scale);
-                dv.store(kp + WG_I, WG_DH, 1.0f);
+                dk.store(kp, WDH, a.scale);
+                dv.store(kp + WG_I, WDH, 1.0f);
             }
             __syncthreads();
             RAT_PROF_MARK(4);

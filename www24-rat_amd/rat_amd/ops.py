@@ -378,16 +378,18 @@ def attn_bwd_groups(x, dy, add, o_save, lse, params, grads, seqmap, d, heads, di
 
 def attn_fwd_groups(x, res, params, planes, seqmap, d, heads, dim_head, softmax_scale=0.0, out_scale=1.0, save=False, eps=1e-5, out=None,
                     dropout=(0.0, 0), lib=None):
-    """Wide heads (heads = G x 8) in ONE launch: y = out_scale * Dropout(to_out(attention(LayerNorm(x)))) + res, the head groups looped
-    over inside each chunk.  -> (y, o_save [G, ntok, 80], lse [G, ntok, 8]); slice g is what attn_bwd_ex takes for group g."""
+    """Wide heads (heads = G x 8 of width 10; at small embedding dimensions also G x 4 of width 20) in ONE launch: y = out_scale *
+    Dropout(to_out(attention(LayerNorm(x)))) + res, the head groups looped over inside each chunk.  -> (y, o_save [G, ntok, 80],
+    lse [G, ntok, heads per group]); slice g is what attn_bwd_ex takes for group g."""
     lib = lib or get_lib()
     _chk(x, name="x"), _chk(planes, torch.uint8, "planes")                    # planes: None at small embedding dimensions
     y = out if out is not None else torch.empty_like(x)
-    ntok, G = x.numel() // d, heads // 8
+    per = 80 // dim_head                                     # heads per group: 8 x 10, or 4 x 20 (RAT_m3's halved head count; small d only)
+    ntok, G = x.numel() // d, heads // per
     o_save = lse = None
     if save:
-        o_save = torch.empty((G, ntok, 8 * dim_head), dtype=torch.float32, device=x.device)
-        lse = torch.empty((G, ntok, 8), dtype=torch.float32, device=x.device)
+        o_save = torch.empty((G, ntok, 80), dtype=torch.float32, device=x.device)
+        lse = torch.empty((G, ntok, per), dtype=torch.float32, device=x.device)
     drop_p, drop_seed = _drop_args(params, dropout)
     lib.call("rat_attn_fwd_groups", _p(x), _p(res), _p(y), _p(o_save), _p(lse), ntok, ctypes.byref(params), _p(planes),
              ctypes.byref(seqmap), d, heads, dim_head, float(softmax_scale), float(out_scale), eps, drop_p, drop_seed, _stream(x))

@@ -196,6 +196,13 @@ class RAT_m3(RAT_m2):
             v = self._m3_b3 = self._lib.size("rat_attn_fwd_workspace", self._cfg["d"], self._m3_heads, self._m3_dh) > 0
         return self.arith if v else "f32"
 
+    def _m3_groups_supported(self):
+        """rat_attn_groups_supported for heads / 2 heads of width 2 * dim_head (bit 0: one-launch forward, bit 1: one-launch backward)"""
+        v = self.__dict__.get("_m3_groups_sup")
+        if v is None:
+            v = self._m3_groups_sup = ops.attn_groups_supported(self._cfg["d"], self._m3_heads, self._m3_dh, lib=self._lib) if self.group_loop else 0
+        return v
+
     def _m3_mode(self, smap):
         key = ("m3", int(smap.L), self.FUSED_MAX_L)
         hit = self._fused_cache.get(key)
@@ -233,6 +240,12 @@ class RAT_m3(RAT_m2):
             y, o, l = ops.attn_fwd_ex(x, res, self._m3_params(blk, which, w_stack, self._p), smap, d, h, dh, sc, 0.5, save=save, out=out,
                                       arith=self._m3_arith(), dropout=drop, lib=lib)
             return y, (o, l)
+        if mode == "grouped" and (self._m3_groups_supported() & (3 if save else 1)) == (3 if save else 1) and blk[which][2] is not None:
+            # small embedding dimension (the Tmall geometry): the whole layer in ONE launch that loops over the head groups inside a chunk
+            # (rat_attn_fwd_groups, exact fp32, weights addressed in place) — and the backward in one launch too (rat_attn_bwd_groups)
+            y, o, l = ops.attn_fwd_groups(x, res, self._m3_params(blk, which, w_stack, self._p), None, smap, d, h, dh, sc, 0.5, save=save,
+                                          out=out, dropout=drop, lib=lib)
+            return y, (("loop", o, l) if save else None)
         if mode == "grouped":
             y, kept = out, []
             for g, (params_g, w_g, wo_g, zb) in enumerate(self._m3_group_params(blk, which, w_stack, per)):
@@ -268,6 +281,12 @@ class RAT_m3(RAT_m2):
                                     arith=self._m3_arith(), dropout=drop, lib=lib)
             return dx
         names = blk[which]
+        if mode == "grouped" and att[0] == "loop":
+            wsl = self._workspace("attn_m3_groups", lib.size("rat_attn_bwd_groups_workspace", d, h, dh))
+            dx, _ = ops.attn_bwd_groups(x_in, dy, add, att[1], att[2], self._m3_params(blk, which, w_stack, self._p),
+                                        self._m3_params(blk, which, g_stack, G), smap, d, h, dh, sc, 0.5, workspace=wsl, out=out, dropout=drop,
+                                        lib=lib)
+            return dx
         if mode == "grouped":
             groups, ig = h // per, per * dh
             wsg = self._workspace("attn_m3g", lib.size("rat_attn_bwd_workspace", d, per, dh))
