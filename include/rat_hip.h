@@ -206,6 +206,8 @@ int rat_attn_bwd_ex(const float* x, const float* dy, const float* add, const flo
  * 16-wide column tile the weight-gradient accumulators of four head groups fit the registers that one group needs at embedding_dim 64.
  * Gradients arrive in the layer's full-width layout (grads_host = [3*heads*dim_head][d], [d][heads*dim_head], [d], [d], [d]); dx = add +
  * LayerNorm-backward(...) as rat_attn_bwd_ex; workspace: rat_attn_bwd_groups_workspace() bytes (0: not served).
+ * Round 6 (same signatures): at embedding_dim <= 16 the groups may also be 4 heads x dim_head 20 (heads = G x 4; RAT_m3 runs num_heads / 2
+ * heads of width 2 * dim_head, RAT_m3.py:181): a group's inner width is 80 either way; lse_save is then [G][ntok][4].
  * rat_attn_groups_supported: bit 0 = rat_attn_fwd_groups serves these dimensions, bit 1 = rat_attn_bwd_groups does. */
 int rat_attn_groups_supported(int d, int heads, int dim_head);
 size_t rat_attn_bwd_groups_workspace(int d, int heads, int dim_head);
