@@ -211,6 +211,43 @@ def check_wide_heads_group_loop(gpu, batch=3, topk=2, nfields=2, heads=16, depth
 CHECKPOINT_CASES = ["tiny_seq_bn", "m0_tiny_seq", "m1_tiny_seq", "m3_tiny_seq"]
 
 
+def check_variant_against_oracle(gpu, variant, base="northstar_shape", gate=1e-4, **over):
+    """a model VARIANT on a golden case's fields / seeds with some hyper-parameters changed (no fixture exists for the combination): loss,
+    predictions and every gradient of one training forward / backward against the reference-pinned oracle run on the same weights and batch.
+    -> (model, worst gradient error relative to the tensor's largest element)"""
+    from oracle import rat_m2_oracle as orc
+    case = dict(gc.case_by_name(base), name="variant_probe", model=variant, batch_norm=False, embedding_regularizer=0.0)
+    case.update(over)
+    model = build_model(case, gpu=gpu, seed=1)
+    load_weights(model, case)
+    batch = batch_of(case)
+    w = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = orc.Config(fields=orc.fields_from_specs(gc.feature_specs(case)), embedding_dim=case["embedding_dim"], num_heads=case["num_heads"],
+                     dim_head=case["dim_head"], depth=case["depth"], scale_dim=case["scale_dim"],
+                     dnn_hidden_units=tuple(case["dnn_hidden_units"]), batch_norm=False, use_wide=case["use_wide"], embedding_regularizer=0.0,
+                     variant={"RAT_m2": "m2", "RAT_m1": "m1", "RAT_m3": "m3", "RAT_m0": "m0"}[variant])
+    ref_loss, ref_pred, ref_grads, _ = orc.loss_and_grads(w, batch[0], batch[1], cfg, training=True)
+    model.train()
+    model.optimizer.zero_grad()
+    loss = model.get_total_loss(batch)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss)) < 2e-6 * max(1.0, abs(float(ref_loss))), (float(loss.detach()), float(ref_loss))
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        if k.startswith("query_proj"):
+            continue
+        ref = ref_grads[k].double()
+        err = float((p.grad.detach().cpu().double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        worst = max(worst, (err, k), key=lambda t: t[0])
+    assert worst[0] < gate, worst
+    model.eval()
+    with torch.no_grad():
+        yp = model.forward(batch)["y_pred"].reshape(-1).cpu()
+        want = orc.forward(w, batch[0], batch[1], cfg, training=False).reshape(-1)
+    assert float((yp - want).abs().max()) < 2e-6
+    return model, worst[0]
+
+
 def check_checkpoint(name, gpu, tmpdir):
     """On-disk format of `.model` files (base_model.py:275-284): tests/golden/ckpt_<case>.model was written by the REFERENCE class's
     own save_weights after two training steps (tests/golden/make_golden_checkpoints.py).  load_weights must take it as is and the

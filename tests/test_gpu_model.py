@@ -267,6 +267,15 @@ def test_variants_with_the_shipped_tmall_heads(variant):
         assert float((g1[k] - g0[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-30) < 1e-4, k
 
 
+def test_parallel_variant_with_wide_heads_at_the_north_star_embedding_dimension():
+    """RAT_m3 with 16 x 10 heads at d = 64 (8 heads of width 20, inner 160: too wide for one launch): two head groups of 4 x 20, each on the
+    bf16x3 kernels' 4-head instantiation (round 6) — loss, predictions and every gradient against the oracle"""
+    from rat_amd import ops
+    model, worst = mc.check_variant_against_oracle(0, "RAT_m3", num_heads=16, batch=5, topk=4, depth=2)
+    assert model._m3_mode(ops.intra_map(5, 5, 21)) == ("grouped", 4) and model._m3_arith(4) == "bf16x3"
+    assert worst < 2e-5, worst
+
+
 def test_grouped_heads_mode_is_selected_for_wide_heads():
     """32 heads x 10: four launches of the fused kernel on 8 heads each (model._attn_mode)"""
     import golden_cases as gc

@@ -188,12 +188,15 @@ class RAT_m3(RAT_m2):
     #                  the bias, every later one accumulates onto the output of the one before (res = y; backward: add = dx);
     #        composed  heads wider than any fused instantiation (2 * dim_head > 20) or sequences above 64 tokens: LayerNorm ->
     #                  rat_sgemm -> rat_attn_core_*_map -> rat_sgemm.
-    def _m3_arith(self):
-        """the arithmetic of the fused attention launches: the model's, where the library has a bf16x3 instantiation for heads / 2 heads of
-        width 2 * dim_head (round 6: 4 x 20 at embedding_dim 64, the north-star config), else exact fp32"""
-        v = self.__dict__.get("_m3_b3")
+    def _m3_arith(self, heads=None):
+        """the arithmetic of a fused attention launch on `heads` (default: all heads / 2) heads of width 2 * dim_head: the model's, where the
+        library has a bf16x3 instantiation for that geometry (round 6: 4 x 20 at embedding_dim 64 — the north-star config, and the head
+        groups of a wider layer at that embedding_dim), else exact fp32"""
+        heads = self._m3_heads if heads is None else heads
+        cache = self.__dict__.setdefault("_m3_b3", {})
+        v = cache.get(heads)
         if v is None:
-            v = self._m3_b3 = self._lib.size("rat_attn_fwd_workspace", self._cfg["d"], self._m3_heads, self._m3_dh) > 0
+            v = cache[heads] = self._lib.size("rat_attn_fwd_workspace", self._cfg["d"], heads, self._m3_dh) > 0
         return self.arith if v else "f32"
 
     def _m3_groups_supported(self):
@@ -250,7 +253,8 @@ class RAT_m3(RAT_m2):
             y, kept = out, []
             for g, (params_g, w_g, wo_g, zb) in enumerate(self._m3_group_params(blk, which, w_stack, per)):
                 # Dropout(sum of the groups' partial projections + bias) = the sum of the equally masked partials: same seed everywhere
-                y, o, l = ops.attn_fwd_ex(x, res if g == 0 else y, params_g, smap, d, per, dh, sc, 0.5, save=save, out=y, dropout=drop, lib=lib)
+                y, o, l = ops.attn_fwd_ex(x, res if g == 0 else y, params_g, smap, d, per, dh, sc, 0.5, save=save, out=y,
+                                          arith=self._m3_arith(per), dropout=drop, lib=lib)
                 kept.append((params_g, w_g, wo_g, zb, o, l))
             return y, (kept if save else None)
         inner, ntok = h * dh, x.numel() // d
@@ -299,7 +303,7 @@ class RAT_m3(RAT_m2):
             for g, (params_g, w_g, wo_g, zb, o, l) in enumerate(att):
                 grads_g = ops.attn_params(t_ln[0, g], t_ln[1, g], t_w[g], t_wo[g], g_bout if g == 0 else t_b)
                 dx, _ = ops.attn_bwd_ex(x_in, dy, add if g == 0 else dx, o, l, params_g, grads_g, smap, d, per, dh, sc, 0.5, workspace=wsg,
-                                        out=dx, dropout=drop, lib=lib)
+                                        out=dx, arith=self._m3_arith(per), dropout=drop, lib=lib)
             g_stack.view(3, groups, ig, d).copy_(t_w.view(groups, 3, ig, d).permute(1, 0, 2, 3))
             g_wout.view(d, groups, ig).copy_(t_wo.permute(1, 0, 2))
             torch.sum(t_ln[0], 0, out=g_lng)
