@@ -203,8 +203,8 @@ class RAT_m3(RAT_m2):
         """rat_attn_groups_supported for heads / 2 heads of width 2 * dim_head (bit 0: one-launch forward, bit 1: one-launch backward)"""
         v = self.__dict__.get("_m3_groups_sup")
         if v is None:
-            v = self._m3_groups_sup = ops.attn_groups_supported(self._cfg["d"], self._m3_heads, self._m3_dh, lib=self._lib) if self.group_loop else 0
-        return v
+            v = self._m3_groups_sup = ops.attn_groups_supported(self._cfg["d"], self._m3_heads, self._m3_dh, lib=self._lib)
+        return v if self.group_loop else 0                       # (`group_loop = False`: the per-group launches, A/B and tests)
 
     def _m3_mode(self, smap):
         key = ("m3", int(smap.L), self.FUSED_MAX_L)
