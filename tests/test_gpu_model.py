@@ -250,7 +250,7 @@ def test_variants_with_the_shipped_tmall_heads(variant):
         model = mc.build_model(gc.case_by_name("m3_wide_dim_head"), gpu=0, seed=1)
         assert model._m3_mode(ops.intra_map(5, 5, 5))[0] == "composed"
         mc.check_training("m3_wide_dim_head", gpu=0)
-        return
+        # (and, below: the one-launch form of the head groups against the per-group launches, like the other variants)
     out = {}
     for loop in (True, False):
         model = mc.build_model(case, gpu=0, seed=1)
