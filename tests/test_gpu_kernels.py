@@ -135,7 +135,10 @@ def test_attn_with_a_subset_of_query_positions(lib, case, mode, nq, arith):
 
 
 @pytest.mark.parametrize("nseq,L,heads,dh,softmax_scale", [(2, 5, 2, 4, None), (7, 231, 8, 10, None), (64, 84, 8, 10, None), (3, 400, 2, 20, 0.2), (5, 33, 2, 7, 0.3), (2, 600, 1, 16, None),
-                                                           (5, 48, 3, 10, 0.3), (3, 900, 2, 10, None), (300, 60, 32, 10, None)])
+                                                           (5, 48, 3, 10, 0.3), (3, 900, 2, 10, None), (300, 60, 32, 10, None),
+                                                           # round 6 (the matrix-pipe backward): 7 key tiles = odd against 3 per trip / 2 per group, a
+                                                           # ragged last tile; 32 full tiles; the longest sequence whose four row tiles fit the LDS
+                                                           (3, 97, 2, 10, None), (4, 512, 3, 10, None), (2, 799, 1, 10, 0.2)])
 def test_attn_core_fwd_bwd(lib, nseq, L, heads, dh, softmax_scale, knob):
     """(dim_head 10 with 48 ... 1024 tokens: the forward runs on the matrix pipe — core_fwd_mfma_kernel; the knob's value 3 keeps the VALU kernel;
     up to ~800 tokens the backward is the hybrid kernel — core_bwd_hybrid_kernel: dQ on the matrix pipe beside dK / dV on the VALU — and
