@@ -578,11 +578,9 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                                                  float scale) {
     constexpr int SLD = 16 * NIT + 1, SCR = 16 * SLD + 16;          // wave-private [16 queries][16 NIT keys (+ 1)] tile + 16 deltas
     const int w = rat_wave(), l = rat_lane(), g = l >> 4, m = l & 15;
-    // NIT = 3 (round 6: one 33 ... 48-token sequence per chunk; built, parity-green, measured slower than the VALU passes and NOT dispatched —
-    // attn.hip b3_matrix_core; b3_bwd_core_mfma_kt below serves three tiles): eight 3 200-byte tiles are 1 KB more than the dead dy planes hold — the last
-    // wave's goes to rows 48 ... 51 of the Q|K|V tile, which such a chunk never uses (zeros from the padded projection), and is cleared
-    // again at the end (those rows feed the padded rows of d(Q|K|V)'s planes)
-    float* scr = (NIT == 3 && w == ATT_WAVES - 1) ? qkv + (size_t)48 * B3_LDQ : scratch + w * SCR;
+    // (three tiles — 33 ... 48 tokens — in this all-at-once form were built in round 6 and lost to the VALU passes: 64-66 spilled VGPRs;
+    //  b3_bwd_core_mfma_kt below serves them.  tools/experiments/attn_bwd_core_three_tiles_at_once.txt)
+    float* scr = scratch + w * SCR;
     float* dl = scr + 16 * SLD;
     const float sl2 = scale * RAT_LOG2E;
     const int npairs = nsq * B3_H;
@@ -734,10 +732,6 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                     }
                 }
     }
-    if (NIT == 3 && w == ATT_WAVES - 1) {
-        RAT_WAVE_FENCE();
-        for (int e = l; e < SCR; e += 64) scr[e] = 0.f;
-    }
 }
 // ---- the same core with the KEY tiles as the inner loop (round 6) ------------------------------------------------------------------------------
 // b3_bwd_core_mfma keeps S, dP and dS of ALL key tiles of a query tile in registers at once (3 NIT accumulator quads + 6 NIT operands on
@@ -887,8 +881,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma_kt(float* qkv, float* ob, const
                 }
     }
 }
-static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP && (size_t)(ATT_WAVES - 1) * (16 * 49 + 16) * 4 <= (size_t)3 * B3_XP,
-              "the matrix core's wave-private tiles live in the dead dy planes (three-tile sequences: all but the last wave's)");
+static_assert((size_t)ATT_WAVES * (16 * 33 + 16) * 4 <= (size_t)3 * B3_XP, "the matrix core's wave-private tiles live in the dead dy planes");
 
 // PH: sequences of at most 12 tokens — the probabilities P of pass 1 fit the (then dead) dy planes (64 rows x L x 8 heads x 4 B <= 24 KB)
 // and are handed to pass 2, which then needs neither the q . k product nor the exponential again
