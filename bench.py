@@ -84,7 +84,9 @@ def parse(argv=None):
     ap.add_argument("--dp-rehearsal", action="store_true",
                     help="with one rank: run the N > 1 code path anyway (RCCL process group of one rank, the model's data-parallel "
                          "path with every collective issued, barriers, weak and strong regions) — the 1-GPU rehearsal of the scaling job")
-    ap.add_argument("--graph-dp", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--graph-dp", action="store_true",
+                    help="N > 1: ALSO time hipGraph segments with the collectives between them (after the eager measurement, under a watchdog) "
+                         "and report the faster form; default since round 6: the eager fused step only")
     ap.add_argument("--no-eager-first", action="store_true",
                     help="N > 1 with graphs: skip the eager measurement that is taken first as the fall-back of a stalled graph attempt")
     ap.add_argument("--graph-attempt-timeout", type=float, default=240.0,
@@ -93,8 +95,7 @@ def parse(argv=None):
     ap.add_argument("--region-timeout", type=float, default=600.0,
                     help="N > 1: seconds the strong-scaling region may take once the weak region's line is ready; after that every rank "
                          "exits 0 and rank 0 prints the line without `strong_scaling`")
-    ap.add_argument("--no-graph-dp", action="store_true",
-                    help="N > 1: eager launches instead of graph segments with the collectives between them (the default)")
+    ap.add_argument("--no-graph-dp", action="store_true", help="(the default since round 6; kept so that older command lines still parse)")
     ap.add_argument("--no-group-loop", action="store_true",
                     help="diagnostic (wide heads: heads = G x 8 at d = 64): G forward launches per layer instead of the one that loops over "
                          "the head groups (rat_attn_fwd_groups)")
@@ -625,9 +626,13 @@ def worker(args):
         model.prune_dead_tokens = bool(args.prune)
     if args.no_group_loop:
         model.group_loop = False
-    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or not args.no_graph_dp)
+    # Under data parallelism the segmented-graph form (graph segments with the collectives between them) is OPT-IN since round 6
+    # (`--graph-dp`): measured with one RCCL rank it buys 0.4 % at B = 4096 (19.79 against 19.86 ms) and 4 % at the per-rank shape — and no
+    # run with more than one RCCL rank exists yet, so the default N > 1 line is the eager fused step, the form with the fewest moving parts.
+    graph_under_dp = bool(args.graph_dp) and not args.no_graph_dp
+    graph_mode = bool(getattr(model, "use_graph", False)) and not dry and not args.no_graph and (not dp or graph_under_dp)
     model.use_graph = graph_mode
-    model.graph_under_dp = not args.no_graph_dp
+    model.graph_under_dp = graph_under_dp
     model.graph_shapes = 8                       # weak / strong / per-rank shapes and both arithmetics each get their own graph
     region_info = {}
 

@@ -121,7 +121,7 @@ def test_bench_rehearsal_measures_eager_first_then_graphs_and_reports_the_exchan
     """bench.py's N > 1 path on one RCCL rank: the eager regions are measured first, then the segmented-graph regions; the line carries
     both attempts, the world size, the exchange form with what it put on the links and the per-phase HIP-event times"""
     import json
-    r, lines = _bench(["--dp-rehearsal", "--workload", "tiny", "--steps", "3", "--warmup", "2"])
+    r, lines = _bench(["--dp-rehearsal", "--graph-dp", "--workload", "tiny", "--steps", "3", "--warmup", "2"])      # (--graph-dp: opt-in since round 6)
     if "RCCL" in r.stderr and r.returncode != 0 and "init_process_group" in r.stderr:
         pytest.skip("RCCL could not bring up a one-rank communicator here")
     assert r.returncode == 0, r.stderr[-3000:]
@@ -141,13 +141,25 @@ def test_bench_rehearsal_measures_eager_first_then_graphs_and_reports_the_exchan
 def test_bench_rehearsal_survives_a_stalled_graph_attempt():
     """the watchdog around the graph attempt: with a timeout it cannot meet, every rank exits 0 and rank 0 prints the EAGER line with a note"""
     import json
-    r, lines = _bench(["--dp-rehearsal", "--workload", "tiny", "--steps", "3", "--warmup", "2", "--graph-attempt-timeout", "0.001"])
+    r, lines = _bench(["--dp-rehearsal", "--graph-dp", "--workload", "tiny", "--steps", "3", "--warmup", "2", "--graph-attempt-timeout", "0.001"])
     if r.returncode != 0 and "init_process_group" in r.stderr:
         pytest.skip("RCCL could not bring up a one-rank communicator here")
     assert r.returncode == 0, r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert "abandoned" in out["step_mode"]["graph_attempt"] and out["step_mode"]["graph"] is False and out["value"] > 0
+
+
+def test_bench_rehearsal_default_is_the_eager_step():
+    """round 6: without --graph-dp the N > 1 line is the eager fused step only (no graph attempt, nothing to abandon)"""
+    import json
+    r, lines = _bench(["--dp-rehearsal", "--workload", "tiny", "--steps", "3", "--warmup", "2"])
+    if r.returncode != 0 and "init_process_group" in r.stderr:
+        pytest.skip("RCCL could not bring up a one-rank communicator here")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["step_mode"]["graph"] is False and "attempts" not in out["step_mode"] and out["value"] > 0 and "strong_scaling" in out
 
 
 def test_bench_rehearsal_keeps_the_headline_when_the_strong_region_fails():
