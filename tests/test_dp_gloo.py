@@ -79,10 +79,13 @@ def _worker(rank, world, port, case_name, emu_path, out_dir, batch_norm=False, r
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("batch_norm,row_lists,owner", [twin(False, True, True, id="bn_off"), pytest.param(True, True, True, id="sync_bn"),
-                                                        twin(True, True, False, id="sync_bn_gather_at_capacity"),
-                                                        pytest.param(True, False, True, id="sync_bn_dense_tables")])
-def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
+@pytest.mark.parametrize("batch_norm,row_lists,owner,case_name", [
+    twin(False, True, True, "tiny_seq_bn", id="bn_off"), pytest.param(True, True, True, "tiny_seq_bn", id="sync_bn"),
+    twin(True, True, False, "tiny_seq_bn", id="sync_bn_gather_at_capacity"), pytest.param(True, False, True, "tiny_seq_bn", id="sync_bn_dense_tables"),
+    # round 6: a VARIANT under data parallelism — RAT_m3 at the Tmall head geometry (16 heads of width 20 at d = 10: the one-launch head-group
+    # kernels), SyncBN; table rows of 40 bytes cannot travel as row lists (the sort / reduce kernels need 16-byte rows): dense all-reduce
+    pytest.param(True, False, True, "m3_tmall_real_heads", id="RAT_m3_tmall_heads_sync_bn")])
+def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner, case_name):
     _setup_paths()
     import build_emu
     import rat_amd._lib as L
@@ -90,7 +93,7 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
     old = L._default
     L._default = L.RatLib(emu_path)
     try:
-        case, model, batch = _make("tiny_seq_bn", batch_norm)
+        case, model, batch = _make(case_name, batch_norm)
         model.train()
         for _ in range(2):
             full_loss = model.train_step(batch)
@@ -108,7 +111,7 @@ def test_two_rank_step_equals_full_batch_step(batch_norm, row_lists, owner):
         L._default = old
     port = 29500 + (os.getpid() % 2000)
     with tempfile.TemporaryDirectory() as out_dir:
-        mp.spawn(_worker, args=(2, port, "tiny_seq_bn", emu_path, out_dir, batch_norm, row_lists, owner), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, case_name, emu_path, out_dir, batch_norm, row_lists, owner), nprocs=2, join=True)
         r0 = torch.load(os.path.join(out_dir, "rank0.pt"))
         r1 = torch.load(os.path.join(out_dir, "rank1.pt"))
     assert torch.equal(r0["flat"], r1["flat"]), "replicas diverged"
