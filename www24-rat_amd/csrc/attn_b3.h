@@ -241,13 +241,10 @@ __device__ __forceinline__ void b3_fwd_core_mfma(float* qkv, float* lse_s, int L
 #pragma unroll
             for (int r = 0; r < 4; ++r) av[r][jt] = qkv[(size_t)(r0 + 16 * jt + 4 * g + r) * B3_LDQ + cv + m];
         }
-#pragma unroll
-        for (int jt = 0; jt < NIT; ++jt) {
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) ak[ks][jt] = (4 * ks + g < B3_DH && 16 * jt + m < L) ? ak[ks][jt] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) av[r][jt] = (m < B3_DH && 16 * jt + 4 * g + r < L) ? av[r][jt] : 0.f;
-        }
+        // (no selects on these operands — round 6: K columns 10, 11 of the k dimension meet Q's, which ARE masked to zero below; key rows past
+        //  the sequence only reach scores that are masked to -inf before the softmax, and V rows past it meet p = 0; V "columns" m >= 10 only
+        //  produce output rows c >= 10 of O^T, which are never stored.  Everything read is finite: rows of a neighbouring sequence or the
+        //  zero rows the padded projection writes)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i0 = 16 * it;
@@ -630,13 +627,16 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
             for (int jt = 0; jt < NIT; ++jt) aS[jt] = aP[jt] = rat_zero4();
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
+                // (round 6: the selects on the K / V / Q operands of the B side went — the k columns 10, 11 are masked on the A side; key rows
+                //  past the sequence only reach (i, j) pairs whose p is forced to 0 below; operand "columns" m >= 10 only reach output
+                //  columns c >= 10, which are never stored; and what those loads can read past the Q|K|V tile is the O tile: finite.  The
+                //  dO-side selects STAY: rows past the dO tile are the never-written tail of the kernel's LDS)
                 const bool okc = 4 * ks + g < B3_DH, oki = okc && m < irows;
                 const float xq = oki ? aq[ks] : 0.f, xo = oki ? ao[ks] : 0.f;
 #pragma unroll
                 for (int jt = 0; jt < NIT; ++jt) {
-                    const bool okj = okc && 16 * jt + m < L;
-                    aS[jt] = RAT_MFMA16(xq, okj ? bk[ks][jt] : 0.f, aS[jt]);
-                    aP[jt] = RAT_MFMA16(xo, okj ? bv[ks][jt] : 0.f, aP[jt]);
+                    aS[jt] = RAT_MFMA16(xq, bk[ks][jt], aS[jt]);
+                    aP[jt] = RAT_MFMA16(xo, bv[ks][jt], aP[jt]);
                 }
             }
             RAT_WAVE_FENCE();
@@ -696,7 +696,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const float b = (cm && 4 * ks + g < irows) ? bq[ks] : 0.f;
+                    const float b = bq[ks];
 #pragma unroll
                     for (int jt = 0; jt < NIT; ++jt) adK[jt] = RAT_MFMA16(at[ks][jt], b, adK[jt]);
                 }
@@ -712,7 +712,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma(float* qkv, float* ob, const fl
                     as[ks] = scr[m * SLD + jj];
                 }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) adQ = RAT_MFMA16(as[ks], (cm && 16 * half + 4 * ks + g < L) ? bkk[ks] : 0.f, adQ);
+                for (int ks = 0; ks < 4; ++ks) adQ = RAT_MFMA16(as[ks], bkk[ks], adQ);
             }
             if (cm)
 #pragma unroll
@@ -779,7 +779,7 @@ __device__ __forceinline__ void b3_bwd_core_mfma_kt(float* qkv, float* ob, const
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
                 const int cc = 4 * ks + g;
-                const bool oki = cc < B3_DH && m < irows;
+                const bool oki = cc < B3_DH && m < irows;     // (which selects stay and which went: see b3_bwd_core_mfma)
                 const float q_ = qkv[(size_t)ri * B3_LDQ + cq + cc], o_ = dob[(size_t)ri * B3_LDT + cq + cc];
                 aq[ks] = oki ? q_ : 0.f;
                 ao[ks] = oki ? o_ : 0.f;
@@ -787,10 +787,9 @@ __device__ __forceinline__ void b3_bwd_core_mfma_kt(float* qkv, float* ob, const
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int ii = 4 * ks + g;
-                const bool ok = cm && ii < irows;
-                const float q_ = qkv[(size_t)(r0 + i0 + ii) * B3_LDQ + cq + m], o_ = dob[(size_t)(r0 + i0 + ii) * B3_LDT + cq + m];
-                bq[ks] = ok ? q_ : 0.f;
-                bdo[ks] = ok ? o_ : 0.f;
+                bq[ks] = qkv[(size_t)(r0 + i0 + ii) * B3_LDQ + cq + m];
+                const float o_ = dob[(size_t)(r0 + i0 + ii) * B3_LDT + cq + m];
+                bdo[ks] = (cm && ii < irows) ? o_ : 0.f;
             }
             RAT_WAVE_FENCE();                                 // (dl is written above, read below)
             float lse4[4], d4[4];
@@ -809,16 +808,13 @@ __device__ __forceinline__ void b3_bwd_core_mfma_kt(float* qkv, float* ob, const
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
                     const int cc = 4 * ks + g;
-                    const bool okj = cc < B3_DH && j0 + m < L;
-                    const float k_ = qkv[(size_t)rj * B3_LDQ + ck + cc], v_ = qkv[(size_t)rj * B3_LDQ + cv + cc];
-                    bk[ks] = okj ? k_ : 0.f;
-                    bv[ks] = okj ? v_ : 0.f;
+                    bk[ks] = qkv[(size_t)rj * B3_LDQ + ck + cc];
+                    bv[ks] = qkv[(size_t)rj * B3_LDQ + cv + cc];
                 }
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int jj = j0 + 4 * ks + g;
-                    const float k_ = qkv[(size_t)(r0 + jj) * B3_LDQ + ck + m];
-                    bkk[ks] = (cm && jj < L) ? k_ : 0.f;
+                    bkk[ks] = qkv[(size_t)(r0 + jj) * B3_LDQ + ck + m];
                 }
                 f32x4 aS = rat_zero4(), aP = rat_zero4();
 #pragma unroll
